@@ -1,0 +1,186 @@
+/*
+ * ppg.h -- C ABI of libppg_hip.so: a batched Predator-Prey-Grass environment
+ * whose per-step transition runs as hand-written HIP on MI355X (gfx950).
+ *
+ * The reference (doesburg11/PredPreyGrass) is pure Python and has no FFI; this
+ * is the boundary a maintainer would bind with ctypes to put
+ * the HIP path behind the reference's own class
+ *   predpreygrass/non_evolutionary/base_environment/predpreygrass_rllib_env.py
+ * ("BASE" below).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - extern "C", POD structs, fixed-width ints, no torch / C++ types.
+ *  - every function returns 0 on success or a negative PPG_E* code and never
+ *    throws; ppg_last_error() gives the message for the last failure.
+ *  - all device buffers are allocated and owned by the caller (PyTorch-ROCm
+ *    tensors); the library borrows the raw pointers for the handle's lifetime
+ *    and never frees them.  Library-owned scratch is freed by ppg_destroy().
+ *  - all work is asynchronous on the caller's HIP stream (`stream` is a
+ *    hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream).
+ *  - one handle belongs to one device and one host thread.
+ *
+ * State layout (one "row" = one agent slot, kept in the order of the dict that
+ * the reference's step() returns, per type):
+ *   rows [0, pred_capacity)                       predators
+ *   rows [pred_capacity, pred_capacity+prey_cap)  prey
+ * Within a type the rows are [survivors in self.agents order..., newborns of
+ * the last call in birth order...]; agents that died in the last call keep
+ * their row (flag PPG_ROW_DIED) until the next call, exactly like
+ * self.agents / _pending_removal in the reference (BASE:222-225,383).
+ */
+#ifndef PPG_H
+#define PPG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPG_ABI_VERSION 1
+
+/* error codes */
+#define PPG_OK 0
+#define PPG_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define PPG_ENOMEM (-2)
+#define PPG_EHIP (-3)     /* a HIP runtime call failed */
+#define PPG_ENODEV (-4)   /* no usable gfx950 device */
+
+/* row_flags bits (uint8 per row) */
+#define PPG_ROW_DIED 0x01u     /* terminations[agent] == True in the last call (BASE:289,332) */
+#define PPG_ROW_OWNS 0x02u     /* grid[type, pos] currently holds this agent's energy */
+#define PPG_ROW_NEWBORN 0x04u  /* created by the last call (BASE:396-414) */
+#define PPG_ROW_ATE 0x08u      /* agent in self.agents_just_ate (BASE:319,362) */
+#define PPG_ROW_TRUNC 0x10u    /* truncations[agent] == True in the last call (BASE:232) */
+
+/* env_state words (int32 per env) */
+#define PPG_ENV_WORDS 16
+#define PPG_ENV_N_PRED_ROWS 0   /* rows in use incl. agents that died in the last call */
+#define PPG_ENV_N_PREY_ROWS 1
+#define PPG_ENV_N_PRED_NEW 2    /* trailing rows that are newborns of the last call */
+#define PPG_ENV_N_PREY_NEW 3
+#define PPG_ENV_NEXT_PRED_ID 4  /* _next_predator_idx */
+#define PPG_ENV_NEXT_PREY_ID 5  /* _next_prey_idx */
+#define PPG_ENV_STEP 6          /* current_step */
+#define PPG_ENV_N_PRED_ALIVE 7  /* current_num_predators */
+#define PPG_ENV_N_PREY_ALIVE 8  /* current_num_prey */
+#define PPG_ENV_FLAGS 9
+#define PPG_ENV_STATUS 10       /* sticky anomaly bits, see PPG_STATUS_* */
+#define PPG_ENV_EPISODE 11
+#define PPG_ENV_FALLBACK_SPAWNS 12 /* count of BASE:759-764 events this episode */
+#define PPG_ENV_CALLS 13        /* step calls served (diagnostic) */
+
+/* env_state[PPG_ENV_FLAGS] bits */
+#define PPG_ENVF_TERM_ALL 0x01   /* terminations["__all__"] of the last call (BASE:466) */
+#define PPG_ENVF_TRUNC_ALL 0x02  /* truncations["__all__"] of the last call (BASE:236) */
+#define PPG_ENVF_DONE 0x04       /* episode over: the next auto-reset call resets */
+#define PPG_ENVF_WAS_RESET 0x08  /* the last call was a reset, not a transition */
+#define PPG_ENVF_LIST_IS_ROW_ORDER 0x10 /* self.agents == row order, not yet sorted (after reset, BASE:143) */
+
+/* env_state[PPG_ENV_STATUS] bits */
+#define PPG_STATUS_PRED_OVERFLOW 0x01  /* a birth was dropped: predator rows exhausted */
+#define PPG_STATUS_PREY_OVERFLOW 0x02
+#define PPG_STATUS_FALLBACK_SPAWN 0x04 /* BASE:759-764 reached (reference is non-deterministic there) */
+#define PPG_STATUS_FAILED_SPAWN 0x08   /* BASE:766 reached (reference raises TypeError) */
+#define PPG_STATUS_BAD_ACTION 0x10     /* action outside -1..8 (reference: KeyError at BASE:502) */
+
+/* ppg_step flags */
+#define PPG_STEP_RANDOM_ACTIONS 0x1u /* ignore `actions`; draw uniform actions with Philox4x32-10 on device */
+#define PPG_STEP_AUTO_RESET 0x2u     /* envs whose last call ended the episode are reset instead of stepped */
+
+#define PPG_ACTION_NONE (-1) /* agent absent from the action dict: no decay, no move (BASE:244,259) */
+
+/* The config dict of the reference (BASE:20-61; defaults CFG = config_env.py:1-38)
+ * plus the capacities of this implementation. */
+typedef struct ppg_config {
+    int32_t abi_version;          /* PPG_ABI_VERSION */
+    int32_t grid_size;            /* BASE:53, 2..128 */
+    int32_t predator_obs_range;   /* BASE:55, 1..15 */
+    int32_t prey_obs_range;       /* BASE:56, 1..15 */
+    int32_t max_steps;            /* BASE:26 */
+    int32_t n_possible_predators; /* BASE:44, <= 999999 */
+    int32_t n_possible_prey;      /* BASE:45, <= 999999 */
+    int32_t n_initial_predators;  /* BASE:46 */
+    int32_t n_initial_prey;       /* BASE:47 */
+    int32_t n_grass;              /* BASE:59 */
+    int32_t pred_capacity;        /* predator rows per env: 64 */
+    int32_t prey_capacity;        /* prey rows per env: 64, 128 or 256 */
+    int32_t grass_capacity;       /* >= n_grass, multiple of 64 */
+    int32_t obs_dtype;            /* 0: float64 (bit-exact with the reference), 1: float32 */
+    double reward_predator_catch_prey;  /* BASE:29 */
+    double reward_prey_eat_grass;       /* BASE:30 */
+    double reward_predator_step;        /* BASE:31 */
+    double reward_prey_step;            /* BASE:32 */
+    double penalty_prey_caught;         /* BASE:33 */
+    double reproduction_reward_predator;/* BASE:34 */
+    double reproduction_reward_prey;    /* BASE:35 */
+    double energy_loss_per_step_predator; /* BASE:38 */
+    double energy_loss_per_step_prey;     /* BASE:39 */
+    double predator_creation_energy_threshold; /* BASE:40 */
+    double prey_creation_energy_threshold;     /* BASE:41 */
+    double initial_energy_predator;     /* BASE:49 */
+    double initial_energy_prey;         /* BASE:50 */
+    double initial_energy_grass;        /* BASE:60 (also the regrowth cap, BASE:254) */
+    double energy_gain_per_step_grass;  /* BASE:61 */
+} ppg_config;
+
+/* Caller-owned device buffers.  B = batch, S = pred_capacity + prey_capacity,
+ * NG = grass_capacity, Rp/Rq = predator/prey obs range. */
+typedef struct ppg_buffers {
+    uint16_t *row_xy;      /* [B,S]  (x << 8) | y          agent_positions (BASE:111) */
+    double *row_energy;    /* [B,S]                        agent_energies (BASE:116) */
+    int32_t *row_id;       /* [B,S]  k of "predator_k"/"prey_k" (BASE:71-72) */
+    uint32_t *row_key;     /* [B,S]  ppg_lexkey(row_id): order of list.sort() on the id strings (BASE:468) */
+    double *row_cumrew;    /* [B,S]                        cumulative_rewards (BASE:63) */
+    uint8_t *row_flags;    /* [B,S]  PPG_ROW_* */
+    double *row_reward;    /* [B,S]  rewards[agent] of the last call */
+    int32_t *env_state;    /* [B,PPG_ENV_WORDS] */
+    uint64_t *env_seed;    /* [B]    Philox key of each env (reset placement, random actions, spawn fallback) */
+    uint16_t *grass_xy;    /* [B,NG] grass_positions (BASE:114), static after reset */
+    double *grass_energy;  /* [B,NG] grass_energies (BASE:117) */
+    void *obs_pred;        /* [B,pred_capacity,4,Rp,Rp] float64|float32: observations (BASE:511-526) */
+    void *obs_prey;        /* [B,prey_capacity,4,Rq,Rq] */
+} ppg_buffers;
+
+typedef struct ppg_handle ppg_handle;
+
+int ppg_abi_version(void);
+
+/* Validates cfg and binds the buffers.  Replaces PredPreyGrass.__init__ (BASE:18-127). */
+int ppg_create(const ppg_config *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out);
+int ppg_destroy(ppg_handle *h);
+
+/* reset() (BASE:129-217) for every env: unique random placement (Philox
+ * Fisher-Yates keyed by env_seed -- distributionally, not bitwise, the
+ * reference's PCG64 + set-order placement), initial energies, observations.
+ * seeds: optional device pointer [B]; copied into env_seed first.  episode is
+ * the Philox episode counter to start from (normally 0). */
+int ppg_reset(ppg_handle *h, const uint64_t *seeds, uint32_t episode, void *stream);
+
+/* Observations for all live rows from the state currently in the buffers
+ * (reset() tail BASE:215; _get_observation BASE:511; used after the host wrote
+ * a captured placement or restored a snapshot, BASE:788-804). */
+int ppg_observe(ppg_handle *h, void *stream);
+
+/* step(action_dict) (BASE:219-473) for every env.
+ * actions: device int8 [B,S], indexed by the row an agent had in the previous
+ * call's output (PPG_ACTION_NONE = not in the dict); may be NULL with
+ * PPG_STEP_RANDOM_ACTIONS.  The movement phase applies actions in row order,
+ * which is the order of the previous observation dict (RLlib's protocol). */
+int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream);
+
+/* grid_world_state (BASE:124): dense float64 [B,4,G,G] rebuilt from the rows. */
+int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream);
+
+/* Sort key of the decimal string of `id` (digits d: sum (d+1)*11^(5-pos)); host helper. */
+uint32_t ppg_lexkey(uint32_t id);
+
+/* Dynamic LDS bytes per wavefront the step kernel uses for this handle (diagnostic). */
+int32_t ppg_lds_bytes(const ppg_handle *h);
+
+const char *ppg_last_error(const ppg_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPG_H */

@@ -1,0 +1,100 @@
+"""ctypes view of include/ppg.h and the loader of libppg_hip.so.
+
+The product path has exactly one implementation: the HIP library built for gfx950.
+If it is missing or cannot be loaded this module raises -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libppg_hip.so")
+
+ABI_VERSION = 1
+
+# row_flags bits
+ROW_DIED, ROW_OWNS, ROW_NEWBORN, ROW_ATE, ROW_TRUNC = 0x01, 0x02, 0x04, 0x08, 0x10
+# env_state words
+ENV_WORDS = 16
+(ENV_N_PRED_ROWS, ENV_N_PREY_ROWS, ENV_N_PRED_NEW, ENV_N_PREY_NEW, ENV_NEXT_PRED_ID, ENV_NEXT_PREY_ID,
+ ENV_STEP, ENV_N_PRED_ALIVE, ENV_N_PREY_ALIVE, ENV_FLAGS, ENV_STATUS, ENV_EPISODE, ENV_FALLBACK_SPAWNS,
+ ENV_CALLS) = range(14)
+ENVF_TERM_ALL, ENVF_TRUNC_ALL, ENVF_DONE, ENVF_WAS_RESET, ENVF_LIST_IS_ROW_ORDER = 0x01, 0x02, 0x04, 0x08, 0x10
+(STATUS_PRED_OVERFLOW, STATUS_PREY_OVERFLOW, STATUS_FALLBACK_SPAWN, STATUS_FAILED_SPAWN,
+ STATUS_BAD_ACTION) = 0x01, 0x02, 0x04, 0x08, 0x10
+STEP_RANDOM_ACTIONS, STEP_AUTO_RESET = 0x1, 0x2
+ACTION_NONE = -1
+
+_INT_FIELDS = [
+    "abi_version", "grid_size", "predator_obs_range", "prey_obs_range", "max_steps", "n_possible_predators",
+    "n_possible_prey", "n_initial_predators", "n_initial_prey", "n_grass", "pred_capacity", "prey_capacity",
+    "grass_capacity", "obs_dtype",
+]
+_DBL_FIELDS = [
+    "reward_predator_catch_prey", "reward_prey_eat_grass", "reward_predator_step", "reward_prey_step",
+    "penalty_prey_caught", "reproduction_reward_predator", "reproduction_reward_prey",
+    "energy_loss_per_step_predator", "energy_loss_per_step_prey", "predator_creation_energy_threshold",
+    "prey_creation_energy_threshold", "initial_energy_predator", "initial_energy_prey", "initial_energy_grass",
+    "energy_gain_per_step_grass",
+]
+_BUF_FIELDS = [
+    "row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "env_state", "env_seed",
+    "grass_xy", "grass_energy", "obs_pred", "obs_prey",
+]
+
+
+class PpgConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS]
+
+
+class PpgBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _BUF_FIELDS]
+
+
+EXPORTED_SYMBOLS = [
+    "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_reset", "ppg_observe", "ppg_step", "ppg_export_grid",
+    "ppg_lexkey", "ppg_lds_bytes", "ppg_last_error",
+]
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    """Declare the prototypes of include/ppg.h on a loaded library."""
+    lib.ppg_abi_version.restype = C.c_int
+    lib.ppg_create.restype = C.c_int
+    lib.ppg_create.argtypes = [C.POINTER(PpgConfig), C.c_int32, C.c_int32, C.POINTER(PpgBuffers), C.POINTER(C.c_void_p)]
+    lib.ppg_destroy.restype = C.c_int
+    lib.ppg_destroy.argtypes = [C.c_void_p]
+    lib.ppg_reset.restype = C.c_int
+    lib.ppg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ppg_observe.restype = C.c_int
+    lib.ppg_observe.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ppg_step.restype = C.c_int
+    lib.ppg_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ppg_export_grid.restype = C.c_int
+    lib.ppg_export_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ppg_lexkey.restype = C.c_uint32
+    lib.ppg_lexkey.argtypes = [C.c_uint32]
+    lib.ppg_lds_bytes.restype = C.c_int32
+    lib.ppg_lds_bytes.argtypes = [C.c_void_p]
+    lib.ppg_last_error.restype = C.c_char_p
+    lib.ppg_last_error.argtypes = [C.c_void_p]
+    if lib.ppg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libppg ABI {lib.ppg_abi_version()} != {ABI_VERSION}: rebuild with __graft_entry__.build()")
+    return lib
+
+
+_lib = None
+
+
+def load_hip_library() -> C.CDLL:
+    """Load libppg_hip.so (HIP, gfx950).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+            )
+        _lib = bind(C.CDLL(LIB_PATH))
+    return _lib

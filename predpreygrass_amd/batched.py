@@ -1,0 +1,283 @@
+"""BatchedPredPreyGrass: B independent PredPreyGrass grids stepped in lockstep on one MI355X.
+
+Host code is plumbing only: it owns the PyTorch-ROCm tensors (state, actions, observations),
+hands their raw pointers to libppg_hip.so through the C ABI of include/ppg.h and launches one
+HIP kernel per call on torch's current stream.  All environment logic
+(predpreygrass_rllib_env.py:219-473 of the reference) runs in predpreygrass_amd/csrc/ppg_kernel.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from .config import resolve_config
+
+PREDATOR, PREY = 0, 1
+PRED_CAPACITY = 64
+
+
+def lexkey(ids) -> np.ndarray:
+    """Sort key of the decimal id strings: same order as list.sort() on "prey_<id>"
+    (predpreygrass_rllib_env.py:468); mirrors ppg_lexkey() in include/ppg.h."""
+    ids = np.asarray(ids, dtype=np.int64)
+    out = np.zeros(ids.shape, dtype=np.int64)
+    flat, o = ids.reshape(-1), out.reshape(-1)
+    for n, v in enumerate(flat):
+        s = str(int(v))
+        o[n] = sum((ord(ch) - 48 + 1) * 11 ** (5 - i) for i, ch in enumerate(s))
+    return out.astype(np.int32)
+
+
+def agent_name(type_: int, id_: int) -> str:
+    return ("predator_%d" if type_ == PREDATOR else "prey_%d") % int(id_)
+
+
+class BatchedPredPreyGrass:
+    """Tensor API.
+
+    Rows: ``[0, 64)`` predators, ``[64, 64 + prey_capacity)`` prey.  Within a type the rows of
+    the last call are ordered like the dict the reference's ``step()`` returns:
+    survivors (incl. agents that died in that call) followed by newborns.  ``actions[b, row]``
+    answers the observation in the same row of the previous call; rows that are dead, unused or
+    deliberately left out of the action dict hold ``ACTION_NONE`` (-1).
+    """
+
+    def __init__(self, config=None, batch_size=1, device=None, obs_dtype=torch.float64,
+                 prey_capacity=128, seed=0, _library=None):
+        cfg = resolve_config(config)
+        self.config = cfg
+        self.batch_size = int(batch_size)
+        self._emulated = _library is not None
+        if _library is None:
+            # the product path: HIP on a real GPU, or an exception
+            self._lib = _abi.load_hip_library()
+            if not torch.cuda.is_available():
+                raise RuntimeError("predpreygrass_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False")
+            self.device = torch.device(device if device is not None else "cuda:0")
+            if self.device.type != "cuda":
+                raise RuntimeError(f"device must be a cuda (ROCm) device, got {self.device}")
+            if self.device.index is None:
+                self.device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            # test hook (tests/wave_emu): the same kernel source compiled for the CPU wave emulator
+            self._lib = _library
+            self.device = torch.device("cpu")
+        if obs_dtype not in (torch.float64, torch.float32):
+            raise ValueError("obs_dtype must be torch.float64 or torch.float32")
+        self.obs_dtype = obs_dtype
+        self.grid_size = int(cfg["grid_size"])
+        self.Rp, self.Rq = int(cfg["predator_obs_range"]), int(cfg["prey_obs_range"])
+        self.P0, self.Q0 = int(cfg["n_initial_active_predator"]), int(cfg["n_initial_active_prey"])
+        self.n_grass = int(cfg["initial_num_grass"])
+        self.pred_capacity = PRED_CAPACITY
+        self.prey_capacity = int(prey_capacity)
+        self.S = self.pred_capacity + self.prey_capacity
+        self.grass_capacity = max(64, (self.n_grass + 63) // 64 * 64)
+        B, S, NG, dev = self.batch_size, self.S, self.grass_capacity, self.device
+
+        def z(shape, dtype):
+            return torch.zeros(shape, dtype=dtype, device=dev)
+
+        self.row_xy = z((B, S), torch.int16)
+        self.row_energy = z((B, S), torch.float64)
+        self.row_id = z((B, S), torch.int32)
+        self.row_key = z((B, S), torch.int32)
+        self.row_cumrew = z((B, S), torch.float64)
+        self.row_flags = z((B, S), torch.uint8)
+        self.row_reward = z((B, S), torch.float64)
+        self.env_state = z((B, _abi.ENV_WORDS), torch.int32)
+        self.env_seed = z((B,), torch.int64)
+        self.grass_xy = z((B, NG), torch.int16)
+        self.grass_energy = z((B, NG), torch.float64)
+        self.obs_pred = z((B, self.pred_capacity, 4, self.Rp, self.Rp), obs_dtype)
+        self.obs_prey = z((B, self.prey_capacity, 4, self.Rq, self.Rq), obs_dtype)
+        self.actions = torch.full((B, S), _abi.ACTION_NONE, dtype=torch.int8, device=dev)
+
+        c = _abi.PpgConfig()
+        c.abi_version = _abi.ABI_VERSION
+        c.grid_size, c.predator_obs_range, c.prey_obs_range = self.grid_size, self.Rp, self.Rq
+        c.max_steps = int(cfg["max_steps"])
+        c.n_possible_predators, c.n_possible_prey = int(cfg["n_possible_predators"]), int(cfg["n_possible_prey"])
+        c.n_initial_predators, c.n_initial_prey, c.n_grass = self.P0, self.Q0, self.n_grass
+        c.pred_capacity, c.prey_capacity, c.grass_capacity = self.pred_capacity, self.prey_capacity, NG
+        c.obs_dtype = 0 if obs_dtype == torch.float64 else 1
+        for k_cfg, k_abi in [
+            ("reward_predator_catch_prey",) * 2, ("reward_prey_eat_grass",) * 2, ("reward_predator_step",) * 2,
+            ("reward_prey_step",) * 2, ("penalty_prey_caught",) * 2, ("reproduction_reward_predator",) * 2,
+            ("reproduction_reward_prey",) * 2, ("energy_loss_per_step_predator",) * 2,
+            ("energy_loss_per_step_prey",) * 2, ("predator_creation_energy_threshold",) * 2,
+            ("prey_creation_energy_threshold",) * 2, ("initial_energy_predator",) * 2,
+            ("initial_energy_prey",) * 2, ("initial_energy_grass",) * 2, ("energy_gain_per_step_grass",) * 2,
+        ]:
+            setattr(c, k_abi, float(cfg[k_cfg]))
+        bufs = _abi.PpgBuffers()
+        for name in _abi._BUF_FIELDS:
+            setattr(bufs, name, getattr(self, name).data_ptr())
+        self._handle = C.c_void_p()
+        dev_index = self.device.index if self.device.type == "cuda" else 0
+        rc = self._lib.ppg_create(C.byref(c), B, dev_index, C.byref(bufs), C.byref(self._handle))
+        if rc != 0:
+            msg = self._lib.ppg_last_error(None).decode()
+            self._handle = None
+            if rc == -1:
+                raise ValueError(msg)  # e.g. "Cannot place more unique positions than grid cells."
+            raise RuntimeError(f"ppg_create failed ({rc}): {msg}")
+        self.lds_bytes = int(self._lib.ppg_lds_bytes(self._handle))
+        self.set_seeds(seed)
+
+    # ------------------------------------------------------------------
+    def close(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            self._lib.ppg_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self._lib.ppg_last_error(self._handle).decode()}")
+
+    # ------------------------------------------------------------------
+    def set_seeds(self, seed):
+        """Env b gets Philox key ``seed + b`` (or the given per-env array)."""
+        if np.isscalar(seed):
+            seeds = (np.arange(self.batch_size, dtype=np.uint64) + np.uint64(int(seed) & (2 ** 64 - 1)))
+        else:
+            seeds = np.asarray(seed).astype(np.uint64).reshape(self.batch_size)
+        self.env_seed.copy_(torch.from_numpy(seeds.view(np.int64)))
+
+    def reset(self, seed=None, episode=0):
+        """reset() of every env with on-device Philox placement (predpreygrass_rllib_env.py:129-217)."""
+        if seed is not None:
+            self.set_seeds(seed)
+        self._check(self._lib.ppg_reset(self._handle, None, int(episode), self._stream()), "ppg_reset")
+        return self
+
+    def set_placement(self, pred_xy, prey_xy, grass_xy, episode=0):
+        """reset() with a given placement (arrays [B,P0,2], [B,Q0,2], [B,n_grass,2] of (x, y)):
+        writes the initial state (predpreygrass_rllib_env.py:138-212) and computes the observations."""
+        B, G = self.batch_size, self.grid_size
+        pred = np.asarray(pred_xy, dtype=np.int64).reshape(B, self.P0, 2)
+        prey = np.asarray(prey_xy, dtype=np.int64).reshape(B, self.Q0, 2)
+        grass = np.asarray(grass_xy, dtype=np.int64).reshape(B, self.n_grass, 2)
+        for a in (pred, prey, grass):
+            if a.size and (a.min() < 0 or a.max() >= G):
+                raise ValueError("position outside the grid")
+        gcell = grass[..., 0] * G + grass[..., 1]
+        for b in range(B):
+            if len(np.unique(gcell[b])) != self.n_grass:
+                raise ValueError("grass positions must be unique")
+        S, cp = self.S, self.pred_capacity
+        xy = np.zeros((B, S), dtype=np.int16)
+        en = np.zeros((B, S), dtype=np.float64)
+        ids = np.zeros((B, S), dtype=np.int32)
+        keys = np.zeros((B, S), dtype=np.int32)
+        fl = np.zeros((B, S), dtype=np.uint8)
+        xy[:, : self.P0] = (pred[..., 0] << 8 | pred[..., 1]).astype(np.int16)
+        xy[:, cp: cp + self.Q0] = (prey[..., 0] << 8 | prey[..., 1]).astype(np.int16)
+        en[:, : self.P0] = float(self.config["initial_energy_predator"])
+        en[:, cp: cp + self.Q0] = float(self.config["initial_energy_prey"])
+        ids[:, : self.P0] = np.arange(self.P0)
+        ids[:, cp: cp + self.Q0] = np.arange(self.Q0)
+        keys[:, : self.P0] = lexkey(np.arange(self.P0))
+        keys[:, cp: cp + self.Q0] = lexkey(np.arange(self.Q0))
+        # grid[type, pos] = energy in id order (predpreygrass_rllib_env.py:190-200): the last agent
+        # written to a cell owns it
+        for b in range(B):
+            for lo, arr in ((0, pred[b]), (cp, prey[b])):
+                owner = {}
+                for i, (x, y) in enumerate(arr):
+                    owner[(int(x), int(y))] = i
+                for i in owner.values():
+                    fl[b, lo + i] = _abi.ROW_OWNS
+        es = np.zeros((B, _abi.ENV_WORDS), dtype=np.int32)
+        es[:, _abi.ENV_N_PRED_ROWS] = self.P0
+        es[:, _abi.ENV_N_PREY_ROWS] = self.Q0
+        es[:, _abi.ENV_NEXT_PRED_ID] = self.P0
+        es[:, _abi.ENV_NEXT_PREY_ID] = self.Q0
+        es[:, _abi.ENV_N_PRED_ALIVE] = self.P0
+        es[:, _abi.ENV_N_PREY_ALIVE] = self.Q0
+        es[:, _abi.ENV_FLAGS] = _abi.ENVF_WAS_RESET | _abi.ENVF_LIST_IS_ROW_ORDER
+        es[:, _abi.ENV_EPISODE] = int(episode)
+        gxy = np.zeros((B, self.grass_capacity), dtype=np.int16)
+        ge = np.zeros((B, self.grass_capacity), dtype=np.float64)
+        gxy[:, : self.n_grass] = (grass[..., 0] << 8 | grass[..., 1]).astype(np.int16)
+        ge[:, : self.n_grass] = float(self.config["initial_energy_grass"])
+        for t, a in ((self.row_xy, xy), (self.row_energy, en), (self.row_id, ids), (self.row_key, keys),
+                     (self.row_flags, fl), (self.env_state, es), (self.grass_xy, gxy), (self.grass_energy, ge)):
+            t.copy_(torch.from_numpy(a))
+        self.row_cumrew.zero_()
+        self.row_reward.zero_()
+        self.observe()
+        return self
+
+    def observe(self):
+        """Recompute the observations of all live rows from the current state tensors."""
+        self._check(self._lib.ppg_observe(self._handle, self._stream()), "ppg_observe")
+        return self
+
+    def step(self, actions=None, random_actions=False, auto_reset=False):
+        """One transition of every env (predpreygrass_rllib_env.py:219-473)."""
+        flags = 0
+        ptr = None
+        if random_actions:
+            flags |= _abi.STEP_RANDOM_ACTIONS
+        else:
+            if actions is None:
+                actions = self.actions
+            if actions.dtype != torch.int8 or tuple(actions.shape) != (self.batch_size, self.S) or \
+                    actions.device != self.device or not actions.is_contiguous():
+                raise ValueError(f"actions must be a contiguous int8 tensor [{self.batch_size},{self.S}] on {self.device}")
+            ptr = C.c_void_p(actions.data_ptr())
+        if auto_reset:
+            flags |= _abi.STEP_AUTO_RESET
+        self._check(self._lib.ppg_step(self._handle, ptr, flags, self._stream()), "ppg_step")
+        return self
+
+    def export_grid(self):
+        """grid_world_state of every env: float64 [B,4,G,G] (predpreygrass_rllib_env.py:124)."""
+        G = self.grid_size
+        out = torch.empty((self.batch_size, 4, G, G), dtype=torch.float64, device=self.device)
+        self._check(self._lib.ppg_export_grid(self._handle, C.c_void_p(out.data_ptr()), self._stream()), "ppg_export_grid")
+        return out
+
+    # ------------------------------------------------------------------
+    # host views (one device->host copy each; used by the dict API and by tests)
+    def host_tables(self, b=None):
+        """Small per-env tables copied to the host as numpy arrays."""
+        sl = slice(None) if b is None else slice(b, b + 1)
+        names = ["row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state",
+                 "grass_xy", "grass_energy"]
+        return {n: getattr(self, n)[sl].cpu().numpy() for n in names}
+
+    def records(self, b, tables=None):
+        """The returned dicts of env b's last call as an ordered list of
+        (name, type, row, reward, terminated, truncated) in the reference's dict order:
+        predator survivors, prey survivors, predator newborns, prey newborns."""
+        t = tables if tables is not None else self.host_tables(b)
+        i = 0 if tables is None else b
+        es = t["env_state"][i]
+        nP, nQ = int(es[_abi.ENV_N_PRED_ROWS]), int(es[_abi.ENV_N_PREY_ROWS])
+        newP, newQ = int(es[_abi.ENV_N_PRED_NEW]), int(es[_abi.ENV_N_PREY_NEW])
+        cp = self.pred_capacity
+        order = [(PREDATOR, r) for r in range(nP - newP)] + [(PREY, r) for r in range(nQ - newQ)] + \
+                [(PREDATOR, r) for r in range(nP - newP, nP)] + [(PREY, r) for r in range(nQ - newQ, nQ)]
+        out = []
+        for ty, r in order:
+            s = r if ty == PREDATOR else cp + r
+            fl = int(t["row_flags"][i, s])
+            out.append((agent_name(ty, t["row_id"][i, s]), ty, r, float(t["row_reward"][i, s]),
+                        bool(fl & _abi.ROW_DIED), bool(fl & _abi.ROW_TRUNC)))
+        return out

@@ -1,0 +1,62 @@
+// ppg_hip.hip -- libppg_hip.so: the gfx950 kernels and the HIP backend of include/ppg.h.
+//
+// Build (see __graft_entry__.build):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -o libppg_hip.so ppg_hip.hip
+// -ffp-contract=off: energies are IEEE float64 sums that must round exactly like CPython's.
+#include <hip/hip_runtime.h>
+
+#include "ppg_host.h"
+
+#define PPG_DEFINE_KERNELS(NQ)                                                                         \
+    PPG_KERNEL(ppg_step_q##NQ)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP>(P, lds); }       \
+    PPG_KERNEL(ppg_reset_q##NQ)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_RESET>(P, lds); }     \
+    PPG_KERNEL(ppg_observe_q##NQ)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_OBSERVE>(P, lds); } \
+    PPG_KERNEL(ppg_grid_q##NQ)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_EXPORT_GRID>(P, lds); }
+
+PPG_DEFINE_KERNELS(1)
+PPG_DEFINE_KERNELS(2)
+PPG_DEFINE_KERNELS(4)
+
+typedef void (*ppg_kernel_fn)(const ppg::KParams);
+
+static ppg_kernel_fn pick_kernel(int nq, int mode) {
+    static const ppg_kernel_fn table[3][4] = {
+        {ppg_step_q1, ppg_reset_q1, ppg_observe_q1, ppg_grid_q1},
+        {ppg_step_q2, ppg_reset_q2, ppg_observe_q2, ppg_grid_q2},
+        {ppg_step_q4, ppg_reset_q4, ppg_observe_q4, ppg_grid_q4},
+    };
+    return table[nq == 1 ? 0 : nq == 2 ? 1 : 2][mode];
+}
+
+#define PPG_HIP_TRY(h, call)                                                                   \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return ppg_fail(h, PPG_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static int backend_init(ppg_handle *h, int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ppg_fail(h, PPG_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return ppg_fail(h, PPG_ENODEV, "device %d not in 0..%d", device, n - 1);
+    hipDeviceProp_t prop;
+    PPG_HIP_TRY(h, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return ppg_fail(h, PPG_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    PPG_HIP_TRY(h, hipSetDevice(device));
+    PPG_HIP_TRY(h, hipMalloc((void **)&h->lut_dev, h->lut_host.size() * sizeof(uint32_t)));
+    PPG_HIP_TRY(h, hipMemcpy(h->lut_dev, h->lut_host.data(), h->lut_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return PPG_OK;
+}
+
+static void backend_release(ppg_handle *h) {
+    if (h->lut_dev) (void)hipFree(h->lut_dev);
+    h->lut_dev = nullptr;
+}
+
+static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream) {
+    // one workgroup = one wavefront = one environment
+    hipLaunchKernelGGL(pick_kernel(h->nq, mode), dim3((unsigned)h->batch), dim3(64), (size_t)P.lds_bytes,
+                       (hipStream_t)stream, P);
+    PPG_HIP_TRY(h, hipGetLastError());
+    return PPG_OK;
+}

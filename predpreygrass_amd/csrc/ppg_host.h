@@ -1,0 +1,214 @@
+// ppg_host.h -- host side of the C ABI in include/ppg.h that does not depend on how the
+// kernels are launched.  The including translation unit provides three functions:
+//   static int  backend_init(ppg_handle *h, int device);            // device check + upload h->lut_host
+//   static void backend_release(ppg_handle *h);
+//   static int  backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream);
+// predpreygrass_amd/csrc/ppg_hip.hip is the product backend (hipLaunchKernelGGL on gfx950);
+// tests/wave_emu/ppg_emu.cpp is a test-only backend that runs the same kernel source on the
+// CPU under a lockstep wave emulator.
+#pragma once
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "ppg_kernel.h"
+
+struct ppg_handle {
+    ppg_config cfg;
+    ppg_buffers bufs;
+    int32_t batch;
+    int32_t device;
+    int32_t nq;  // prey row registers
+    ppg::KParams base;
+    std::vector<uint32_t> lut_host;
+    uint32_t *lut_dev;
+    void *backend;
+    char err[256];
+};
+
+static char g_ppg_create_error[256] = "";
+
+static int ppg_fail(ppg_handle *h, int code, const char *fmt, ...) {
+    char *dst = h ? h->err : g_ppg_create_error;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static uint32_t ppg_host_lexkey(uint32_t id) {
+    char s[16];
+    snprintf(s, sizeof s, "%u", id);
+    static const uint32_t pw[6] = {161051u, 14641u, 1331u, 121u, 11u, 1u};
+    uint32_t key = 0;
+    for (int i = 0; s[i] && i < 6; ++i) key += (uint32_t)(s[i] - '0' + 1) * pw[i];
+    return key;
+}
+
+// Observation element descriptors (see Env::obs_row): for type t, chunk ch, lane l the word
+// describes elements e = ch*128 + 2l and e+1 of the (4,R,R) block in C order.
+static void ppg_build_lut(int R, uint32_t *out) {
+    const int blk = 4 * R * R;
+    const int W = 2 * ((R - 1) / 2) + 1;  // BASE:532-539: window is x-off..x+off
+    for (int w = 0; w < ppg::LUT_WORDS_PER_TYPE; ++w) {
+        uint32_t word = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int e = 2 * w + h;
+            uint32_t d = 0;
+            if (e < blk) {
+                const int c = e / (R * R), rem = e % (R * R), i = rem / R, j = rem % R;
+                d = 1u | ((uint32_t)c << 1) | ((uint32_t)i << 3) | ((uint32_t)j << 7) |
+                    ((i < W && j < W) ? 0x800u : 0u);
+            }
+            word |= d << (12 * h);
+        }
+        out[w] = word;
+    }
+}
+
+static int ppg_validate_and_layout(ppg_handle *h) {
+    const ppg_config &c = h->cfg;
+    if (c.abi_version != PPG_ABI_VERSION) return ppg_fail(h, PPG_EINVAL, "abi_version %d != %d", c.abi_version, PPG_ABI_VERSION);
+    if (h->batch < 1) return ppg_fail(h, PPG_EINVAL, "batch must be >= 1");
+    if (c.grid_size < 2 || c.grid_size > 88) return ppg_fail(h, PPG_EINVAL, "grid_size %d outside 2..88", c.grid_size);
+    if (c.predator_obs_range < 1 || c.predator_obs_range > 15 || c.prey_obs_range < 1 || c.prey_obs_range > 15)
+        return ppg_fail(h, PPG_EINVAL, "obs ranges must be in 1..15");
+    if (c.pred_capacity != 64) return ppg_fail(h, PPG_EINVAL, "pred_capacity must be 64");
+    if (c.prey_capacity != 64 && c.prey_capacity != 128 && c.prey_capacity != 256)
+        return ppg_fail(h, PPG_EINVAL, "prey_capacity must be 64, 128 or 256");
+    if (c.n_grass < 0 || c.grass_capacity < c.n_grass || c.grass_capacity % 64 != 0 || c.grass_capacity > 4096)
+        return ppg_fail(h, PPG_EINVAL, "grass_capacity must be a multiple of 64, >= n_grass, <= 4096");
+    if (c.n_initial_predators < 0 || c.n_initial_predators > c.pred_capacity || c.n_initial_prey < 0 ||
+        c.n_initial_prey > c.prey_capacity)
+        return ppg_fail(h, PPG_EINVAL, "initial agent counts exceed the row capacities");
+    if (c.n_initial_predators + c.n_initial_prey + c.n_grass > c.grid_size * c.grid_size)
+        return ppg_fail(h, PPG_EINVAL, "Cannot place more unique positions than grid cells.");  // BASE:167-168
+    if (c.n_possible_predators < 0 || c.n_possible_predators > 999999 || c.n_possible_prey < 0 || c.n_possible_prey > 999999)
+        return ppg_fail(h, PPG_EINVAL, "n_possible_* must be in 0..999999");
+    if (c.obs_dtype != 0 && c.obs_dtype != 1) return ppg_fail(h, PPG_EINVAL, "obs_dtype must be 0 (f64) or 1 (f32)");
+    if (c.max_steps < 0) return ppg_fail(h, PPG_EINVAL, "max_steps < 0");
+    const ppg_buffers &b = h->bufs;
+    if (!b.row_xy || !b.row_energy || !b.row_id || !b.row_key || !b.row_cumrew || !b.row_flags || !b.row_reward ||
+        !b.env_state || !b.env_seed || !b.grass_xy || !b.grass_energy || !b.obs_pred || !b.obs_prey)
+        return ppg_fail(h, PPG_EINVAL, "a buffer pointer is NULL");
+
+    ppg::KParams &P = h->base;
+    memset(&P, 0, sizeof P);
+    P.G = c.grid_size; P.Rp = c.predator_obs_range; P.Rq = c.prey_obs_range; P.max_steps = c.max_steps;
+    P.npos_pred = c.n_possible_predators; P.npos_prey = c.n_possible_prey;
+    P.n_init_pred = c.n_initial_predators; P.n_init_prey = c.n_initial_prey; P.n_grass = c.n_grass;
+    P.cap_pred = c.pred_capacity; P.cap_prey = c.prey_capacity; P.cap_grass = c.grass_capacity;
+    P.S = c.pred_capacity + c.prey_capacity;
+    P.obs_f32 = c.obs_dtype;
+    P.g_magic = (uint32_t)((0x100000000ull + (uint64_t)c.grid_size - 1) / (uint64_t)c.grid_size);
+    P.r_catch = c.reward_predator_catch_prey; P.r_eat = c.reward_prey_eat_grass;
+    P.r_pstep = c.reward_predator_step; P.r_qstep = c.reward_prey_step; P.r_caught = c.penalty_prey_caught;
+    P.r_repro_p = c.reproduction_reward_predator; P.r_repro_q = c.reproduction_reward_prey;
+    P.loss_p = c.energy_loss_per_step_predator; P.loss_q = c.energy_loss_per_step_prey;
+    P.thr_p = c.predator_creation_energy_threshold; P.thr_q = c.prey_creation_energy_threshold;
+    P.e0_p = c.initial_energy_predator; P.e0_q = c.initial_energy_prey; P.e0_g = c.initial_energy_grass;
+    P.gain_g = c.energy_gain_per_step_grass;
+    h->nq = c.prey_capacity / 64;
+
+    // LDS layout, every region 16-byte aligned
+    const int n = c.grid_size * c.grid_size;
+    P.map_n = (n + 7) / 8 * 8;
+    int off = 0;
+    P.off_map = off; off += 4 * P.map_n * 2;
+    off = (off + 15) / 16 * 16;
+    P.off_val = off; off += (1 + P.S + P.cap_grass) * 8;
+    off = (off + 15) / 16 * 16;
+    P.off_scr = off; off += (P.S * 8 > 1024 ? P.S * 8 : 1024);
+    P.off_lut = off; off += 2 * ppg::LUT_WORDS_PER_TYPE * 4;
+    P.lds_bytes = off;
+    if (P.lds_bytes > 64 * 1024) return ppg_fail(h, PPG_EINVAL, "configuration needs %d bytes of LDS per wave (> 64 KiB)", P.lds_bytes);
+
+    P.row_xy = b.row_xy; P.row_e = b.row_energy; P.row_id = b.row_id; P.row_key = b.row_key;
+    P.row_cum = b.row_cumrew; P.row_flags = b.row_flags; P.row_reward = b.row_reward;
+    P.env_state = b.env_state; P.env_seed = b.env_seed; P.grass_xy = b.grass_xy; P.grass_e = b.grass_energy;
+    P.obs_pred = b.obs_pred; P.obs_prey = b.obs_prey;
+    P.batch = h->batch;
+
+    h->lut_host.assign(2 * ppg::LUT_WORDS_PER_TYPE, 0u);
+    ppg_build_lut(P.Rp, h->lut_host.data());
+    ppg_build_lut(P.Rq, h->lut_host.data() + ppg::LUT_WORDS_PER_TYPE);
+    return PPG_OK;
+}
+
+static int backend_init(ppg_handle *h, int device);
+static void backend_release(ppg_handle *h);
+static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream);
+
+extern "C" {
+
+int ppg_abi_version(void) { return PPG_ABI_VERSION; }
+
+uint32_t ppg_lexkey(uint32_t id) { return ppg_host_lexkey(id); }
+
+int ppg_create(const ppg_config *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out) {
+    if (!cfg || !bufs || !out) return ppg_fail(nullptr, PPG_EINVAL, "null argument");
+    ppg_handle *h = new (std::nothrow) ppg_handle();
+    if (!h) return ppg_fail(nullptr, PPG_ENOMEM, "out of host memory");
+    h->cfg = *cfg; h->bufs = *bufs; h->batch = batch; h->device = device;
+    h->lut_dev = nullptr; h->backend = nullptr; h->err[0] = 0;
+    int rc = ppg_validate_and_layout(h);
+    if (rc == PPG_OK) rc = backend_init(h, device);
+    if (rc != PPG_OK) {
+        memcpy(g_ppg_create_error, h->err, sizeof g_ppg_create_error);
+        backend_release(h);
+        delete h;
+        return rc;
+    }
+    h->base.obs_lut = h->lut_dev;
+    *out = h;
+    return PPG_OK;
+}
+
+int ppg_destroy(ppg_handle *h) {
+    if (!h) return PPG_OK;
+    backend_release(h);
+    delete h;
+    return PPG_OK;
+}
+
+int ppg_reset(ppg_handle *h, const uint64_t *seeds, uint32_t episode, void *stream) {
+    if (!h) return PPG_EINVAL;
+    ppg::KParams P = h->base;
+    P.mode = ppg::MODE_RESET; P.seeds = seeds; P.reset_episode = episode;
+    return backend_launch(h, ppg::MODE_RESET, P, stream);
+}
+
+int ppg_observe(ppg_handle *h, void *stream) {
+    if (!h) return PPG_EINVAL;
+    ppg::KParams P = h->base;
+    P.mode = ppg::MODE_OBSERVE;
+    return backend_launch(h, ppg::MODE_OBSERVE, P, stream);
+}
+
+int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
+    if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
+    ppg::KParams P = h->base;
+    P.mode = ppg::MODE_STEP; P.actions = actions; P.flags = flags;
+    return backend_launch(h, ppg::MODE_STEP, P, stream);
+}
+
+int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!grid_out) return ppg_fail(h, PPG_EINVAL, "grid_out is NULL");
+    ppg::KParams P = h->base;
+    P.mode = ppg::MODE_EXPORT_GRID; P.grid_out = grid_out;
+    return backend_launch(h, ppg::MODE_EXPORT_GRID, P, stream);
+}
+
+int32_t ppg_lds_bytes(const ppg_handle *h) { return h ? h->base.lds_bytes : 0; }
+
+const char *ppg_last_error(const ppg_handle *h) { return h ? h->err : g_ppg_create_error; }
+
+}  // extern "C"

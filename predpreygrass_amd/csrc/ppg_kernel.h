@@ -1,0 +1,1040 @@
+// ppg_kernel.h -- the PredPreyGrass transition as hand-written HIP for gfx950 (MI355X).
+//
+// ONE 64-LANE WAVEFRONT STEPS ONE ENVIRONMENT.  Lane l holds agent row l of each row
+// register (register 0: predator rows 0..63; register 1+q: prey rows 64q..64q+63), so the
+// whole agent table lives in VGPRs and the per-agent flags live in 64-bit SGPR masks.
+// Order-dependent phases of the reference (movement in action order, engagement in
+// self.agents order, spawning) run as wave-uniform scalar loops over mask bits that read
+// a row with v_readlane and test cell occupancy with one v_cmp + ballot; order-free
+// phases (decay, grass regrowth, observation extraction, reward assembly) are lane-parallel.
+//
+// The reference's dense float64 grid (4,G,G) is never materialised.  Every non-zero write
+// the reference makes to grid[1|2] stores the writer's *current* energy at the writer's
+// own cell, and every energy change is followed by such a write (BASE:247-250,269-273,
+// 325,368,405-406), so   grid[type][cell] == energy[owner(cell)]  or 0.   The kernel
+// therefore carries one OWNS bit per row ("my cell's grid value is mine") and reproduces
+// the reference's ghost-cell behaviour exactly through that bit.  LDS only
+// holds an acceleration structure for observation extraction: u16 cell->value-index maps
+// per channel plus a float64 value table.
+//
+// "BASE:n" = line n of predpreygrass/non_evolutionary/base_environment/predpreygrass_rllib_env.py
+// in the reference.  Correctness is checked bit-for-bit against oracle/ppg_oracle.c.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/ppg.h"
+
+#ifndef PPG_WAVE_EMU
+#include "wave.h"
+#endif
+
+namespace ppg {
+
+enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3 };
+
+// event bits of a row during one call
+enum { EV_STARVED = 1, EV_CAUGHT = 2, EV_ATE = 4, EV_PARENT = 8, EV_BORN = 16, EV_TRUNC = 32 };
+
+constexpr uint32_t TAG_ACT = 0x41435431u;  // Philox key domains (see oracle/ppg_oracle.c)
+constexpr uint32_t TAG_RST = 0x52535431u;
+constexpr uint32_t TAG_SPW = 0x53505731u;
+
+constexpr int LUT_WORDS_PER_TYPE = 8 * 64;  // up to 8 chunks of 128 elements (R <= 15)
+
+struct KParams {
+    // config
+    int32_t G, Rp, Rq, max_steps;
+    int32_t npos_pred, npos_prey, n_init_pred, n_init_prey, n_grass;
+    int32_t cap_pred, cap_prey, cap_grass, S;
+    int32_t obs_f32;
+    uint32_t g_magic;  // ceil(2^32 / G): cell / G == mulhi(cell, g_magic) for cell < G*G
+    double r_catch, r_eat, r_pstep, r_qstep, r_caught, r_repro_p, r_repro_q;
+    double loss_p, loss_q, thr_p, thr_q, e0_p, e0_q, e0_g, gain_g;
+    // LDS layout (bytes from the start of dynamic LDS)
+    int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
+    int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
+    int32_t off_val;  // float64 value table: [0]=0, 1+row predators, 1+cap_pred+row prey, then grass
+    int32_t off_scr;  // 8-byte scratch per row (permutation / reset random words)
+    int32_t off_lut;  // observation element descriptors, 2 types x LUT_WORDS_PER_TYPE u32
+    int32_t lds_bytes;
+    // buffers (caller-owned)
+    uint16_t *row_xy;
+    double *row_e;
+    int32_t *row_id;
+    uint32_t *row_key;
+    double *row_cum;
+    uint8_t *row_flags;
+    double *row_reward;
+    int32_t *env_state;
+    uint64_t *env_seed;
+    uint16_t *grass_xy;
+    double *grass_e;
+    void *obs_pred;
+    void *obs_prey;
+    const uint32_t *obs_lut;  // library-owned, [2][LUT_WORDS_PER_TYPE]
+    // per-launch
+    const int8_t *actions;
+    const uint64_t *seeds;
+    double *grid_out;
+    uint32_t flags;
+    uint32_t reset_episode;
+    int32_t mode;
+    int32_t batch;
+};
+
+// ---------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------
+
+PPG_DEVICE uint64_t bit64(int k) { return 1ull << k; }
+PPG_DEVICE uint64_t lowmask(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull)); }
+
+PPG_DEVICE double readlane_f64(double v, int k) {
+    long long b = __double_as_longlong(v);
+    uint32_t lo = wv::readlane((uint32_t)b, k), hi = wv::readlane((uint32_t)((uint64_t)b >> 32), k);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+PPG_DEVICE double writelane_f64(double v, int k, double s) {
+    long long b = __double_as_longlong(v), sb = __double_as_longlong(s);
+    uint32_t lo = wv::writelane((uint32_t)b, k, (uint32_t)sb);
+    uint32_t hi = wv::writelane((uint32_t)((uint64_t)b >> 32), k, (uint32_t)((uint64_t)sb >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+PPG_DEVICE double first_f64(double v) {
+    long long b = __double_as_longlong(v);
+    uint32_t lo = wv::first((uint32_t)b), hi = wv::first((uint32_t)((uint64_t)b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// Order of Python's list.sort() on "prey_<id>" strings (BASE:468): decimal digits compared
+// left to right, a shorter string that is a prefix sorts first.  digit d -> d+1, absent -> 0,
+// base 11, six positions.
+PPG_DEVICE uint32_t lexkey(uint32_t id) {
+    uint32_t L = 1 + (id >= 10u) + (id >= 100u) + (id >= 1000u) + (id >= 10000u) + (id >= 100000u);
+    uint32_t pw = L == 1 ? 161051u : L == 2 ? 14641u : L == 3 ? 1331u : L == 4 ? 121u : L == 5 ? 11u : 1u;
+    uint32_t key = 0;
+    for (uint32_t q = 0; q < 6; ++q) {
+        if (q < L) {
+            uint32_t nx = id / 10u;
+            key += (id - nx * 10u + 1u) * pw;
+            pw *= 11u;
+            id = nx;
+        }
+    }
+    return key;
+}
+
+PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = wv::mulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = wv::mulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---------------------------------------------------------------------------------
+// one environment, one wavefront
+// ---------------------------------------------------------------------------------
+
+template <int NQ>
+struct Env {
+    static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
+
+    const KParams &P;
+    const int b;
+    const int ln;
+
+    uint16_t *map;   // LDS
+    double *val;     // LDS
+    uint64_t *scr;   // LDS
+    uint32_t *lut;   // LDS
+
+    // per-lane row fields
+    uint32_t xy[T];
+    int32_t id[T];
+    uint32_t key[T];
+    double e[T];
+    double cum[T];
+    int32_t act[T];
+    uint32_t ev[T];
+    uint32_t keep[T];  // row flags that survive a truncation call (ATE)
+
+    // wave-uniform state
+    uint64_t rows[T], alive[T], owns[T];
+    int n_rows[2], next_id[2], n_alive[2];
+    int step, fb_count, calls;
+    uint32_t envflags, status, episode;
+    uint64_t seed;
+    bool cooc[2];  // some cell may hold two live agents of this type
+
+    PPG_MEMBER Env(const KParams &p, int b_, unsigned char *lds)
+        : P(p), b(b_), ln(wv::lane()),
+          map((uint16_t *)(lds + p.off_map)), val((double *)(lds + p.off_val)),
+          scr((uint64_t *)(lds + p.off_scr)), lut((uint32_t *)(lds + p.off_lut)) {}
+
+    // ---- index helpers -------------------------------------------------------------
+    static PPG_MEMBER int type_of(int r) { return r ? 1 : 0; }
+    static PPG_MEMBER int row_of(int r, int k) { return r ? (r - 1) * 64 + k : k; }  // row within its type
+    PPG_MEMBER int slot_of(int r, int k) const { return r ? P.cap_pred + (r - 1) * 64 + k : k; }  // row in [0,S)
+    PPG_MEMBER int validx(int r, int k) const { return 1 + slot_of(r, k); }
+    PPG_MEMBER int grass_validx(int p) const { return 1 + P.S + p; }
+    PPG_MEMBER int cell_of(uint32_t s_xy) const { return (int)(s_xy >> 8) * P.G + (int)(s_xy & 255u); }
+    PPG_MEMBER uint16_t *chmap(int ch) const { return map + ch * P.map_n; }
+
+    // alive rows of `type` standing on s_xy, per register
+    PPG_MEMBER void match(int type, uint32_t s_xy, uint64_t (&m)[T]) const {
+#pragma unroll
+        for (int r = 0; r < T; ++r) m[r] = (type_of(r) == type) ? (wv::ballot(xy[r] == s_xy) & alive[r]) : 0ull;
+    }
+    PPG_MEMBER bool any_agent_at(uint32_t s_xy) const {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < T; ++r) acc |= wv::ballot(xy[r] == s_xy) & alive[r];
+        return acc != 0;
+    }
+
+    // "grid[ch][cell] = 0" (BASE:268,272,293,297,335): whoever owned the cell no longer does.
+    PPG_MEMBER void grid_zero(int type, uint32_t s_xy, bool touch_lds) {
+#pragma unroll
+        for (int r = 0; r < T; ++r)
+            if (type_of(r) == type) owns[r] &= ~wv::ballot(xy[r] == s_xy);
+        if (touch_lds && ln == 0) chmap(1 + type)[cell_of(s_xy)] = 0;
+    }
+    // "grid[ch][cell] = energy of row (r,k)" (BASE:247,250,269,273,325,368,405,406)
+    PPG_MEMBER void grid_set(int r, int k, uint32_t s_xy, double s_e, bool touch_lds) {
+        const int type = type_of(r);
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+            if (type_of(q) == type) owns[q] &= ~wv::ballot(xy[q] == s_xy);
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+            if (q == r) owns[q] |= bit64(k);
+        if (touch_lds && ln == 0) {
+            chmap(1 + type)[cell_of(s_xy)] = (uint16_t)validx(r, k);
+            val[validx(r, k)] = s_e;
+        }
+    }
+
+    // ---- load ----------------------------------------------------------------------
+    PPG_MEMBER void load_env_words() {
+        const int32_t *es = P.env_state + (size_t)b * PPG_ENV_WORDS;
+        uint32_t w = ln < PPG_ENV_WORDS ? (uint32_t)es[ln] : 0u;
+        n_rows[0] = (int)wv::readlane(w, PPG_ENV_N_PRED_ROWS);
+        n_rows[1] = (int)wv::readlane(w, PPG_ENV_N_PREY_ROWS);
+        next_id[0] = (int)wv::readlane(w, PPG_ENV_NEXT_PRED_ID);
+        next_id[1] = (int)wv::readlane(w, PPG_ENV_NEXT_PREY_ID);
+        step = (int)wv::readlane(w, PPG_ENV_STEP);
+        envflags = wv::readlane(w, PPG_ENV_FLAGS);
+        status = wv::readlane(w, PPG_ENV_STATUS);
+        episode = wv::readlane(w, PPG_ENV_EPISODE);
+        fb_count = (int)wv::readlane(w, PPG_ENV_FALLBACK_SPAWNS);
+        calls = (int)wv::readlane(w, PPG_ENV_CALLS);
+        uint64_t sd = P.env_seed[b];
+        seed = ((uint64_t)wv::first((uint32_t)(sd >> 32)) << 32) | wv::first((uint32_t)sd);
+    }
+
+    PPG_MEMBER void load_rows() {
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int i = row_of(r, ln);
+            const bool valid = i < n_rows[type_of(r)];
+            const size_t s = (size_t)b * P.S + slot_of(r, ln);
+            uint32_t fl = 0;
+            xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; cum[r] = 0.0; act[r] = -1; ev[r] = 0;
+            if (valid) {
+                xy[r] = P.row_xy[s];
+                e[r] = P.row_e[s];
+                id[r] = P.row_id[s];
+                key[r] = P.row_key[s];
+                cum[r] = P.row_cum[s];
+                fl = P.row_flags[s];
+            }
+            keep[r] = fl & PPG_ROW_ATE;
+            rows[r] = wv::ballot(valid);
+            alive[r] = rows[r] & ~wv::ballot(valid && (fl & PPG_ROW_DIED));
+            owns[r] = wv::ballot(valid && (fl & PPG_ROW_OWNS)) & alive[r];
+        }
+        n_alive[0] = n_alive[1] = 0;
+#pragma unroll
+        for (int r = 0; r < T; ++r) n_alive[type_of(r)] += wv::popc(alive[r]);
+    }
+
+    // maps -> all zero, observation descriptors -> LDS
+    PPG_MEMBER void init_lds() {
+        uint32_t *m32 = (uint32_t *)map;
+        const int n32 = 4 * P.map_n / 2;
+        for (int i = ln; i < n32; i += 64) m32[i] = 0u;
+        for (int i = ln; i < 2 * LUT_WORDS_PER_TYPE; i += 64) lut[i] = P.obs_lut[i];
+        if (ln == 0) val[0] = 0.0;
+    }
+
+    // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
+    PPG_MEMBER void load_grass(bool regrow) {
+        const size_t gb = (size_t)b * P.cap_grass;
+        for (int p = ln; p < P.n_grass; p += 64) {
+            double g = P.grass_e[gb + p];
+            if (regrow) {
+                double v = g + P.gain_g;
+                g = (P.e0_g < v) ? P.e0_g : v;  // Python min(v, cap)
+            }
+            val[grass_validx(p)] = g;
+            chmap(3)[cell_of(P.grass_xy[gb + p])] = (uint16_t)grass_validx(p);
+        }
+    }
+
+    // ---- actions -------------------------------------------------------------------
+    PPG_MEMBER void load_actions(uint64_t (&acted)[T]) {
+        bool bad = false;
+        if (P.flags & PPG_STEP_RANDOM_ACTIONS) {
+            uint32_t w[4];
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                if ((r & 3) == 0)
+                    philox4x32_10((uint32_t)step, (uint32_t)ln + 64u * (uint32_t)(r >> 2), 0u, episode,
+                                  (uint32_t)seed, (uint32_t)(seed >> 32) ^ TAG_ACT, w);
+                act[r] = (int32_t)wv::mulhi(w[r & 3], 9u);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                int a = -1;
+                if ((alive[r] >> ln) & 1ull) a = P.actions[(size_t)b * P.S + slot_of(r, ln)];
+                if (a < -1 || a > 8) { bad = true; a = -1; }
+                act[r] = a;
+            }
+        }
+        if (wv::ballot(bad)) status |= PPG_STATUS_BAD_ACTION;
+#pragma unroll
+        for (int r = 0; r < T; ++r) acted[r] = alive[r] & wv::ballot(act[r] >= 0);
+    }
+
+    // ---- step 1: decay (BASE:244-250) ----------------------------------------------
+    PPG_MEMBER void decay(const uint64_t (&acted)[T]) {
+        // Same-type co-occupancy check on the (still all-zero) channel maps used as claim boards.
+        bool mism[T];
+#pragma unroll
+        for (int r = 0; r < T; ++r)
+            if ((alive[r] >> ln) & 1ull) chmap(1 + type_of(r))[cell_of(xy[r])] = (uint16_t)validx(r, ln);
+        wv::sync();
+#pragma unroll
+        for (int r = 0; r < T; ++r)
+            mism[r] = ((alive[r] >> ln) & 1ull) && chmap(1 + type_of(r))[cell_of(xy[r])] != (uint16_t)validx(r, ln);
+        uint64_t mm[2] = {0, 0};
+#pragma unroll
+        for (int r = 0; r < T; ++r) mm[type_of(r)] |= wv::ballot(mism[r]);
+#pragma unroll
+        for (int r = 0; r < T; ++r)
+            if ((alive[r] >> ln) & 1ull) chmap(1 + type_of(r))[cell_of(xy[r])] = 0;
+        cooc[0] = mm[0] != 0;
+        cooc[1] = mm[1] != 0;
+
+#pragma unroll
+        for (int r = 0; r < T; ++r)
+            if ((acted[r] >> ln) & 1ull) e[r] -= (r ? P.loss_q : P.loss_p);
+
+        // grid[type, pos] = energy, in action (= row) order
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            if (!cooc[type_of(r)]) {
+                owns[r] |= acted[r];  // one live agent per cell: every acting agent now owns its cell
+            } else {
+                uint64_t m = acted[r];
+                while (m) {
+                    const int k = wv::ctz(m);
+                    m &= m - 1;
+                    grid_set(r, k, wv::readlane(xy[r], k), 0.0, false);
+                }
+            }
+        }
+    }
+
+    // ---- step 2: movement in action order (BASE:259-276, _get_move BASE:495-509) ------
+    PPG_MEMBER void move(const uint64_t (&acted)[T]) {
+        uint64_t pos[T];  // grid value > 0 requires the owner's energy > 0 (BASE:506)
+#pragma unroll
+        for (int r = 0; r < T; ++r) pos[r] = wv::ballot(e[r] > 0.0) & alive[r];
+        const int G1 = P.G - 1;
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int type = type_of(r);
+            uint64_t m = acted[r];
+            while (m) {
+                const int k = wv::ctz(m);
+                m &= m - 1;
+                const uint32_t s_xy = wv::readlane(xy[r], k);
+                const int a = (int)wv::readlane((uint32_t)act[r], k);
+                const int ax = (a * 11) >> 5;  // a / 3 for 0..8
+                int tx = (int)(s_xy >> 8) + ax - 1, ty = (int)(s_xy & 255u) + (a - 3 * ax) - 1;
+                tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);  // np.clip, BASE:505
+                ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
+                const uint32_t t_xy = ((uint32_t)tx << 8) | (uint32_t)ty;
+                uint64_t mt[T], mo[T];
+                match(type, t_xy, mt);
+                uint64_t occ = 0;
+#pragma unroll
+                for (int q = 0; q < T; ++q) occ |= mt[q] & owns[q] & pos[q];
+                if (t_xy == s_xy) {
+#pragma unroll
+                    for (int q = 0; q < T; ++q) mo[q] = mt[q];
+                } else {
+                    match(type, s_xy, mo);
+                }
+                // grid[old] = 0 (BASE:268/272)
+#pragma unroll
+                for (int q = 0; q < T; ++q) owns[q] &= ~mo[q];
+                uint64_t others = 0;
+                if (occ) {  // stay (BASE:506-507): grid[old] = energy
+#pragma unroll
+                    for (int q = 0; q < T; ++q) others |= mo[q] & ~((q == r) ? bit64(k) : 0ull);
+                } else {    // move: grid[new] = energy (BASE:269/273)
+                    xy[r] = wv::writelane(xy[r], k, t_xy);
+#pragma unroll
+                    for (int q = 0; q < T; ++q) {
+                        owns[q] &= ~mt[q];
+                        others |= mt[q] & ~((q == r) ? bit64(k) : 0ull);
+                    }
+                }
+                owns[r] |= bit64(k);
+                if (others) cooc[type] = true;
+            }
+        }
+    }
+
+    // ---- drop last call's dead rows and bring the rows into self.agents order ----------
+    // (BASE:222-225 removal; BASE:468 sort).  Rows are [sorted prefix..., appended rows...];
+    // appended rows are inserted by counting smaller keys with ballots.
+    PPG_MEMBER void compact_and_sort(bool do_sort) {
+#pragma unroll
+        for (int type = 0; type < 2; ++type) {
+            // sorted-prefix length m over this type's rows
+            int m_sorted = n_rows[type];
+            bool has_dead = false;
+#pragma unroll
+            for (int r = 0; r < T; ++r)
+                if (type_of(r) == type) has_dead = has_dead || ((rows[r] & ~alive[r]) != 0);
+            if (do_sort) {
+#pragma unroll
+                for (int r = T - 1; r >= 0; --r) {
+                    if (type_of(r) != type) continue;
+                    uint32_t prev = wv::shfl_up1(key[r]);
+                    if (r >= 2) {
+                        uint32_t carry = wv::readlane(key[r - 1], 63);
+                        if (ln == 0) prev = carry;
+                    }
+                    const bool first_row = (row_of(r, ln) == 0);
+                    uint64_t brk = wv::ballot(!first_row && key[r] < prev) & rows[r];
+                    if (brk) m_sorted = row_of(r, wv::ctz(brk));
+                }
+            }
+            if (!has_dead && m_sorted >= n_rows[type]) continue;  // nothing to do
+
+            uint32_t rk[T];
+            uint64_t sorted_alive[T], unsorted_alive[T];
+            int before = 0;
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                rk[r] = 0; sorted_alive[r] = 0; unsorted_alive[r] = 0;
+                if (type_of(r) != type) continue;
+                const int lo = row_of(r, 0);
+                uint64_t in_prefix = lowmask(m_sorted - lo);
+                sorted_alive[r] = alive[r] & in_prefix;
+                unsorted_alive[r] = alive[r] & ~in_prefix;
+                rk[r] = (uint32_t)before + wv::prefix(sorted_alive[r]);
+                before += wv::popc(sorted_alive[r]);
+            }
+#pragma unroll
+            for (int ru = 0; ru < T; ++ru) {
+                if (type_of(ru) != type) continue;
+                uint64_t mu = unsorted_alive[ru];
+                while (mu) {
+                    const int ku = wv::ctz(mu);
+                    mu &= mu - 1;
+                    const uint32_t s_key = wv::readlane(key[ru], ku);
+                    int cnt = 0;
+#pragma unroll
+                    for (int r = 0; r < T; ++r) {
+                        if (type_of(r) != type) continue;
+                        cnt += wv::popc(wv::ballot(key[r] < s_key) & alive[r]);
+                        if (((sorted_alive[r] >> ln) & 1ull) && key[r] > s_key) rk[r] += 1;
+                    }
+#pragma unroll
+                    for (int r = 0; r < T; ++r)
+                        if (r == ru) rk[r] = wv::writelane(rk[r], ku, (uint32_t)cnt);
+                }
+            }
+            // scatter through LDS, one 8-byte field at a time
+            const int sbase = type ? 64 : 0;
+            int n_new = 0;
+#pragma unroll
+            for (int r = 0; r < T; ++r)
+                if (type_of(r) == type) n_new += wv::popc(alive[r]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    if ((alive[r] >> ln) & 1ull) {
+                        uint64_t v;
+                        if (f == 0) v = (uint64_t)__double_as_longlong(e[r]);
+                        else if (f == 1) v = (uint64_t)__double_as_longlong(cum[r]);
+                        else if (f == 2) v = ((uint64_t)key[r] << 32) | (uint32_t)id[r];
+                        else v = (uint64_t)xy[r] | ((uint64_t)((owns[r] >> ln) & 1ull) << 16) | ((uint64_t)keep[r] << 20);
+                        scr[sbase + rk[r]] = v;
+                    }
+                }
+                wv::sync();
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    const int i = row_of(r, ln);
+                    if (i < n_new) {
+                        uint64_t v = scr[sbase + i];
+                        if (f == 0) e[r] = __longlong_as_double((long long)v);
+                        else if (f == 1) cum[r] = __longlong_as_double((long long)v);
+                        else if (f == 2) { key[r] = (uint32_t)(v >> 32); id[r] = (int32_t)(uint32_t)v; }
+                        else { xy[r] = (uint32_t)(v & 0xFFFFu); ev[r] = (uint32_t)((v >> 16) & 1u); keep[r] = (uint32_t)(v >> 20) & 0xFFu; }
+                    } else if (f == 3) {
+                        xy[r] = 0xFFFFu; ev[r] = 0; keep[r] = 0;
+                    }
+                }
+                wv::sync();
+            }
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                if (type_of(r) != type) continue;
+                rows[r] = lowmask(n_new - row_of(r, 0));
+                alive[r] = rows[r];
+                owns[r] = wv::ballot(ev[r] & 1u) & rows[r];
+                ev[r] = 0;
+            }
+            n_rows[type] = n_new;
+        }
+    }
+
+    // ---- LDS acceleration structure for observations --------------------------------
+    PPG_MEMBER void build_maps() {
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            if ((alive[r] >> ln) & 1ull) {
+                val[validx(r, ln)] = e[r];
+                if ((owns[r] >> ln) & 1ull) chmap(1 + type_of(r))[cell_of(xy[r])] = (uint16_t)validx(r, ln);
+            }
+        }
+        wv::sync();
+    }
+
+    // _get_observation (BASE:511-526) + _obs_clip (BASE:528-539) for the agent of `type` in
+    // per-type row j standing on s_xy; coalesced 16-byte stores of the (4,R,R) block.
+    PPG_MEMBER void obs_row(int type, int j, uint32_t s_xy) {
+        wv::sync();  // LDS writes of the sequential phases -> visible
+        const int R = type ? P.Rq : P.Rp;
+        const int blk = 4 * R * R;
+        const int off = (R - 1) / 2;
+        const int x0 = (int)(s_xy >> 8) - off, y0 = (int)(s_xy & 255u) - off;
+        const uint32_t *L = lut + type * LUT_WORDS_PER_TYPE;
+        const size_t obase = ((size_t)b * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)blk;
+        const int nch = (blk + 127) >> 7;
+        for (int ch = 0; ch < nch; ++ch) {
+            const uint32_t d = L[ch * 64 + ln];
+            double v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // element descriptor: bit0 exists, bits1-2 channel, bits3-6 i, bits7-10 j, bit11 inside the
+                // (2*off+1)^2 window (always for odd R; for even R the last row/column is outside, BASE:532-539)
+                const uint32_t dd = (d >> (12 * h)) & 0xFFFu;
+                const int c = (int)((dd >> 1) & 3u), i = (int)((dd >> 3) & 15u), jj = (int)((dd >> 7) & 15u);
+                const int gx = x0 + i, gy = y0 + jj;
+                const bool inb = (dd & 0x800u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+                const int a = inb ? c * P.map_n + gx * P.G + gy : 0;
+                const uint32_t idx = map[a];  // map[0][0] is always 0
+                double t = val[inb ? idx : 0u];
+                if (!inb && c == 0) t = 1.0;  // channel 0: 1 outside the grid (BASE:522-523)
+                v[h] = t;
+            }
+            if (d & 1u) {
+                const size_t o = obase + (size_t)ch * 128 + 2 * (size_t)ln;
+                if (P.obs_f32) {
+                    float2 f; f.x = (float)v[0]; f.y = (float)v[1];
+                    *(float2 *)((float *)(type ? P.obs_prey : P.obs_pred) + o) = f;
+                } else {
+                    double2 g; g.x = v[0]; g.y = v[1];
+                    *(double2 *)((double *)(type ? P.obs_prey : P.obs_pred) + o) = g;
+                }
+            }
+        }
+        wv::sync();  // reads done before the caller touches the maps again
+    }
+
+    PPG_MEMBER void obs_all_alive() {
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            uint64_t m = alive[r];
+            while (m) {
+                const int k = wv::ctz(m);
+                m &= m - 1;
+                obs_row(type_of(r), row_of(r, k), wv::readlane(xy[r], k));
+            }
+        }
+    }
+
+    // ---- step 3: engagement in self.agents order (BASE:279-380) ----------------------
+    PPG_MEMBER void starve(int r, int k, uint32_t s_xy) {  // BASE:284-301
+        const int type = type_of(r);
+        obs_row(type, row_of(r, k), s_xy);
+        if (ln == k) ev[r] |= EV_STARVED;
+        n_alive[type] -= 1;
+        grid_zero(type, s_xy, true);
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+            if (q == r) alive[q] &= ~bit64(k);
+    }
+
+    PPG_MEMBER void engage_predators() {
+        uint64_t m = alive[0];
+        while (m) {
+            const int k = wv::ctz(m);
+            m &= m - 1;
+            const double s_e = readlane_f64(e[0], k);
+            const uint32_t s_xy = wv::readlane(xy[0], k);
+            if (s_e <= 0.0) { starve(0, k, s_xy); continue; }
+            uint64_t pm[T];
+            match(1, s_xy, pm);
+            int total = 0;
+#pragma unroll
+            for (int q = 1; q < T; ++q) total += wv::popc(pm[q]);
+            if (total == 0) continue;  // reward_predator_step, BASE:341
+            // first prey in agent_positions order == lowest id (ids are handed out in insertion order)
+            int cr = 0, ck = 0;
+            int best = 0x7FFFFFFF;
+#pragma unroll
+            for (int q = 1; q < T; ++q) {
+                uint64_t mq = pm[q];
+                while (mq) {
+                    const int kk = wv::ctz(mq);
+                    mq &= mq - 1;
+                    const int cid = (int)wv::readlane((uint32_t)id[q], kk);
+                    if (cid < best) { best = cid; cr = q; ck = kk; }
+                }
+            }
+            double pe = 0.0;
+#pragma unroll
+            for (int q = 1; q < T; ++q)
+                if (q == cr) pe = readlane_f64(e[q], ck);
+            const double ne = s_e + pe;                     // BASE:324 (E1: pe may be <= 0)
+            e[0] = writelane_f64(e[0], k, ne);
+            if (ln == k) ev[0] |= EV_ATE;                   // BASE:319
+            grid_set(0, k, s_xy, ne, true);                 // BASE:325
+            obs_row(1, row_of(cr, ck), s_xy);               // BASE:327 (before the prey is erased)
+            n_alive[1] -= 1;
+#pragma unroll
+            for (int q = 1; q < T; ++q)
+                if (q == cr) {
+                    alive[q] &= ~bit64(ck);
+                    if (ln == ck) ev[q] |= EV_CAUGHT;
+                }
+            grid_zero(1, s_xy, true);                       // BASE:335
+        }
+    }
+
+    PPG_MEMBER void engage_prey() {
+        uint32_t pidx[T];
+        uint64_t ong[T], stv[T];
+        uint64_t anystv = 0;
+#pragma unroll
+        for (int r = 1; r < T; ++r) {
+            pidx[r] = ((alive[r] >> ln) & 1ull) ? chmap(3)[cell_of(xy[r])] : 0u;
+            ong[r] = wv::ballot(pidx[r] != 0u) & alive[r];
+            stv[r] = wv::ballot(e[r] <= 0.0) & alive[r];
+            anystv |= stv[r];
+        }
+        if (!anystv && !cooc[1]) {
+            // no mid-step observation needed and one prey per cell: all eaters at once (BASE:359-372)
+#pragma unroll
+            for (int r = 1; r < T; ++r) {
+                if ((ong[r] >> ln) & 1ull) {
+                    e[r] += val[pidx[r]];
+                    val[pidx[r]] = 0.0;
+                    val[validx(r, ln)] = e[r];
+                    chmap(2)[cell_of(xy[r])] = (uint16_t)validx(r, ln);
+                    ev[r] |= EV_ATE;
+                }
+                owns[r] |= ong[r];
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 1; r < T; ++r) {
+            uint64_t m = ong[r] | stv[r];
+            while (m) {
+                const int k = wv::ctz(m);
+                m &= m - 1;
+                const double s_e = readlane_f64(e[r], k);
+                const uint32_t s_xy = wv::readlane(xy[r], k);
+                if (s_e <= 0.0) { starve(r, k, s_xy); continue; }
+                const uint32_t p = wv::readlane(pidx[r], k);
+                wv::sync();
+                const double g = first_f64(val[p]);
+                const double ne = s_e + g;                  // BASE:367
+                e[r] = writelane_f64(e[r], k, ne);
+                if (ln == k) ev[r] |= EV_ATE;               // BASE:362
+                grid_set(r, k, s_xy, ne, true);             // BASE:368
+                if (ln == 0) val[p] = 0.0;                  // BASE:371-372
+            }
+        }
+    }
+
+    // ---- step 5: reproduction (BASE:389-448, _find_available_spawn_position BASE:738-766) ----
+    PPG_MEMBER bool fallback_spawn(int type, int cid, uint32_t &child_xy) {
+        // BASE:759-764.  The reference draws from the unseeded global np.random; the build's
+        // contract (oracle/ppg_oracle.c:find_spawn) is the k-th free cell in x-major order.
+        uint16_t *occ = chmap(0);
+        wv::sync();
+#pragma unroll
+        for (int r = 0; r < T; ++r)
+            if ((alive[r] >> ln) & 1ull) occ[cell_of(xy[r])] = 1;
+        wv::sync();
+        const int n = P.G * P.G;
+        int nfree = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int c = base + ln;
+            nfree += wv::popc(wv::ballot(c < n && occ[c] == 0));
+        }
+        bool ok = false;
+        if (nfree > 0) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)step, (uint32_t)cid, (uint32_t)type, episode, (uint32_t)seed,
+                          (uint32_t)(seed >> 32) ^ TAG_SPW, w);
+            int kth = (int)wv::mulhi(wv::first(w[0]), (uint32_t)nfree);
+            for (int base = 0; base < n; base += 64) {
+                const int c = base + ln;
+                uint64_t fm = wv::ballot(c < n && occ[c] == 0);
+                const int cnt = wv::popc(fm);
+                if (kth < cnt) {
+                    for (int s = 0; s < kth; ++s) fm &= fm - 1;
+                    const int cellidx = base + wv::ctz(fm);
+                    const uint32_t cx = wv::mulhi((uint32_t)cellidx, P.g_magic);
+                    child_xy = (cx << 8) | ((uint32_t)cellidx - cx * (uint32_t)P.G);
+                    ok = true;
+                    break;
+                }
+                kth -= cnt;
+            }
+        }
+        wv::sync();
+#pragma unroll
+        for (int r = 0; r < T; ++r)
+            if ((alive[r] >> ln) & 1ull) occ[cell_of(xy[r])] = 0;
+        wv::sync();
+        return ok;
+    }
+
+    PPG_MEMBER void reproduce() {
+        uint64_t cand[T];
+#pragma unroll
+        for (int r = 0; r < T; ++r) cand[r] = alive[r] & wv::ballot(e[r] >= (r ? P.thr_q : P.thr_p));
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int type = type_of(r);
+            const int npos = type ? P.npos_prey : P.npos_pred;
+            const int cap = type ? P.cap_prey : P.cap_pred;
+            const double e0 = type ? P.e0_q : P.e0_p;
+            uint64_t m = cand[r];
+            while (m) {
+                const int k = wv::ctz(m);
+                m &= m - 1;
+                if (next_id[type] >= npos) continue;  // id pool exhausted: no child, no reward (E6)
+                if (n_rows[type] >= cap) {
+                    status |= type ? PPG_STATUS_PREY_OVERFLOW : PPG_STATUS_PRED_OVERFLOW;
+                    continue;
+                }
+                const uint32_t s_xy = wv::readlane(xy[r], k);
+                const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
+                uint32_t child_xy = 0;
+                bool found = false;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {  // (x-1,y),(x+1,y),(x,y-1),(x,y+1), BASE:749
+                    const int cx = x + (d == 0 ? -1 : d == 1 ? 1 : 0), cy = y + (d == 2 ? -1 : d == 3 ? 1 : 0);
+                    if (found || cx < 0 || cx >= P.G || cy < 0 || cy >= P.G) continue;
+                    const uint32_t c_xy = ((uint32_t)cx << 8) | (uint32_t)cy;
+                    if (!any_agent_at(c_xy)) { child_xy = c_xy; found = true; }
+                }
+                const int cid = next_id[type];
+                if (!found) {
+                    status |= PPG_STATUS_FALLBACK_SPAWN;
+                    fb_count += 1;
+                    if (!fallback_spawn(type, cid, child_xy)) { status |= PPG_STATUS_FAILED_SPAWN; continue; }
+                }
+                next_id[type] += 1;                        // BASE:397/426
+                const int j = n_rows[type]++;              // appended to self.agents, BASE:398/427
+                const int cr = type ? 1 + (j >> 6) : 0, ck = j & 63;
+                const uint32_t ckey = lexkey((uint32_t)cid);
+#pragma unroll
+                for (int q = 0; q < T; ++q) {
+                    if (q != cr) continue;
+                    xy[q] = wv::writelane(xy[q], ck, child_xy);
+                    id[q] = (int32_t)wv::writelane((uint32_t)id[q], ck, (uint32_t)cid);
+                    key[q] = wv::writelane(key[q], ck, ckey);
+                    e[q] = writelane_f64(e[q], ck, e0);          // BASE:403
+                    cum[q] = writelane_f64(cum[q], ck, 0.0);     // BASE:410
+                    if (ln == ck) ev[q] = EV_BORN;
+                    rows[q] |= bit64(ck);
+                    alive[q] |= bit64(ck);
+                }
+                n_alive[type] += 1;
+                grid_set(cr, ck, child_xy, e0, true);        // BASE:405
+                const double ne = readlane_f64(e[r], k) - e0;  // BASE:404
+                e[r] = writelane_f64(e[r], k, ne);
+                if (ln == k) ev[r] |= EV_PARENT;               // reward overwrite, BASE:409/438 (E4)
+                grid_set(r, k, s_xy, ne, true);                // BASE:406
+            }
+        }
+    }
+
+    // ---- rewards, cumulative rewards (BASE:288,322-323,328-329,341-344,365-366,375-378,408-411) ----
+    PPG_MEMBER void rewards_and_store(bool write_grass, bool transition = true) {
+        int n_new[2] = {0, 0};
+#pragma unroll
+        for (int r = 0; r < T; ++r) n_new[type_of(r)] += wv::popc(wv::ballot(ev[r] & EV_BORN) & rows[r]);
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int i = row_of(r, ln);
+            if (i >= n_rows[type_of(r)]) continue;
+            const uint32_t v = ev[r];
+            double rew = 0.0, c = cum[r];
+            if (!transition) {
+                rew = 0.0;  // reset returns observations only; cumulative_rewards = 0 (BASE:150)
+            } else if (v & EV_BORN) {
+                c = 0.0;
+            } else if (v & EV_TRUNC) {
+                rew = 0.0;
+            } else if (v & EV_STARVED) {
+                rew = 0.0;
+            } else if (v & EV_CAUGHT) {
+                rew = P.r_caught; c += rew;
+            } else {
+                if (v & EV_ATE) { rew = r ? P.r_eat : P.r_catch; c += rew; c += rew; }
+                else { rew = r ? P.r_qstep : P.r_pstep; c += rew; }
+                if (v & EV_PARENT) { rew = r ? P.r_repro_q : P.r_repro_p; c += rew; }
+            }
+            uint32_t fl = 0;
+            if (v & (EV_STARVED | EV_CAUGHT)) fl |= PPG_ROW_DIED;
+            if ((owns[r] >> ln) & 1ull) fl |= PPG_ROW_OWNS;
+            if (v & EV_BORN) fl |= PPG_ROW_NEWBORN;
+            if (v & EV_ATE) fl |= PPG_ROW_ATE;
+            if (v & EV_TRUNC) fl |= PPG_ROW_TRUNC | keep[r];
+            const size_t s = (size_t)b * P.S + slot_of(r, ln);
+            P.row_xy[s] = (uint16_t)xy[r];
+            P.row_e[s] = e[r];
+            P.row_id[s] = id[r];
+            P.row_key[s] = key[r];
+            P.row_cum[s] = c;
+            P.row_flags[s] = (uint8_t)fl;
+            P.row_reward[s] = rew;
+        }
+        if (write_grass) {
+            const size_t gb = (size_t)b * P.cap_grass;
+            for (int p = ln; p < P.n_grass; p += 64) P.grass_e[gb + p] = val[grass_validx(p)];
+        }
+        int32_t *es = P.env_state + (size_t)b * PPG_ENV_WORDS;
+        if (ln < PPG_ENV_WORDS) {
+            int32_t w = 0;
+            switch (ln) {
+                case PPG_ENV_N_PRED_ROWS: w = n_rows[0]; break;
+                case PPG_ENV_N_PREY_ROWS: w = n_rows[1]; break;
+                case PPG_ENV_N_PRED_NEW: w = n_new[0]; break;
+                case PPG_ENV_N_PREY_NEW: w = n_new[1]; break;
+                case PPG_ENV_NEXT_PRED_ID: w = next_id[0]; break;
+                case PPG_ENV_NEXT_PREY_ID: w = next_id[1]; break;
+                case PPG_ENV_STEP: w = step; break;
+                case PPG_ENV_N_PRED_ALIVE: w = n_alive[0]; break;
+                case PPG_ENV_N_PREY_ALIVE: w = n_alive[1]; break;
+                case PPG_ENV_FLAGS: w = (int32_t)envflags; break;
+                case PPG_ENV_STATUS: w = (int32_t)status; break;
+                case PPG_ENV_EPISODE: w = (int32_t)episode; break;
+                case PPG_ENV_FALLBACK_SPAWNS: w = fb_count; break;
+                case PPG_ENV_CALLS: w = calls; break;
+                default: w = 0; break;
+            }
+            es[ln] = w;
+        }
+    }
+
+    // ---- reset (BASE:129-217) with Philox Fisher-Yates placement ---------------------
+    PPG_MEMBER void do_reset(uint32_t new_episode) {
+        episode = new_episode;
+        const int n = P.G * P.G;
+        const int K = P.n_init_pred + P.n_init_prey + P.n_grass;
+        uint16_t *perm = chmap(1), *ent = chmap(2);
+        uint32_t *rnd = (uint32_t *)scr;  // 256 words per round
+        wv::sync();
+        for (int i = ln; i < n; i += 64) perm[i] = (uint16_t)i;
+        for (int base = 0; base < K; base += 256) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)(base >> 2) + (uint32_t)ln, 0u, 0u, episode, (uint32_t)seed,
+                          (uint32_t)(seed >> 32) ^ TAG_RST, w);
+            wv::sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rnd[4 * ln + q] = w[q];
+            wv::sync();
+            const int hi = (K - base) < 256 ? (K - base) : 256;
+            for (int kk = 0; kk < hi; ++kk) {
+                const int k = base + kk;
+                const uint32_t rr = wv::first(rnd[kk]);
+                const int j = k + (int)wv::mulhi(rr, (uint32_t)(n - k));
+                const uint32_t a = wv::first(perm[k]);
+                const uint32_t bb = wv::first(perm[j]);
+                if (ln == 0) { perm[j] = (uint16_t)a; perm[k] = (uint16_t)bb; ent[k] = (uint16_t)bb; }
+            }
+        }
+        wv::sync();
+        const int P0 = P.n_init_pred, Q0 = P.n_init_prey;
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int i = row_of(r, ln);
+            const int cnt = r ? Q0 : P0;
+            const bool valid = i < cnt;
+            xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; cum[r] = 0.0; act[r] = -1; ev[r] = 0; keep[r] = 0;
+            if (valid) {
+                const uint32_t c = ent[(r ? P0 : 0) + i];
+                const uint32_t cx = wv::mulhi(c, P.g_magic);
+                xy[r] = (cx << 8) | (c - cx * (uint32_t)P.G);
+                id[r] = i;
+                key[r] = lexkey((uint32_t)i);
+                e[r] = r ? P.e0_q : P.e0_p;
+            }
+            rows[r] = wv::ballot(valid);
+            alive[r] = rows[r];
+            owns[r] = rows[r];
+        }
+        const size_t gb = (size_t)b * P.cap_grass;
+        for (int p = ln; p < P.n_grass; p += 64) {
+            const uint32_t c = ent[P0 + Q0 + p];
+            const uint32_t cx = wv::mulhi(c, P.g_magic);
+            P.grass_xy[gb + p] = (uint16_t)((cx << 8) | (c - cx * (uint32_t)P.G));
+            P.grass_e[gb + p] = P.e0_g;
+        }
+        wv::sync();
+        for (int i = ln; i < n; i += 64) { perm[i] = 0; ent[i] = 0; }
+        wv::sync();
+        for (int p = ln; p < P.n_grass; p += 64) {
+            // re-read what this lane just wrote (same lane, same address)
+            val[grass_validx(p)] = P.e0_g;
+            chmap(3)[cell_of(P.grass_xy[gb + p])] = (uint16_t)grass_validx(p);
+        }
+        n_rows[0] = P0; n_rows[1] = Q0;
+        next_id[0] = P0; next_id[1] = Q0;            // BASE:153-154
+        n_alive[0] = P0; n_alive[1] = Q0;            // BASE:210-211
+        step = 0;                                    // BASE:134
+        fb_count = 0;
+        envflags = PPG_ENVF_WAS_RESET | PPG_ENVF_LIST_IS_ROW_ORDER;
+        build_maps();
+        obs_all_alive();                             // BASE:215
+        rewards_and_store(false, false);
+    }
+
+    // ---- the transition ----------------------------------------------------------------
+    PPG_MEMBER void run_step() {
+        load_env_words();
+        calls += 1;
+        init_lds();
+        if ((P.flags & PPG_STEP_AUTO_RESET) && (envflags & PPG_ENVF_DONE)) {
+            wv::sync();
+            do_reset(episode + 1u);
+            return;
+        }
+        load_rows();
+        const bool list_is_row_order = (envflags & PPG_ENVF_LIST_IS_ROW_ORDER) != 0;
+
+        if (step >= P.max_steps) {  // truncation, BASE:228-238: no state change
+            wv::sync();
+            load_grass(false);
+            compact_and_sort(!list_is_row_order);
+            build_maps();
+            obs_all_alive();
+#pragma unroll
+            for (int r = 0; r < T; ++r) ev[r] = ((alive[r] >> ln) & 1ull) ? EV_TRUNC : 0u;
+            envflags = (envflags & PPG_ENVF_LIST_IS_ROW_ORDER) | PPG_ENVF_TRUNC_ALL | PPG_ENVF_DONE;
+            rewards_and_store(false);
+            return;
+        }
+
+        uint64_t acted[T];
+        load_actions(acted);
+#pragma unroll
+        for (int r = 0; r < T; ++r) keep[r] = 0;  // agents_just_ate.clear(), BASE:241
+        wv::sync();                                // init_lds() zeros visible
+        decay(acted);                              // BASE:244-250
+        load_grass(true);                          // BASE:252-256
+        move(acted);                               // BASE:259-276
+        compact_and_sort(!list_is_row_order);      // BASE:222-225 + the sort of BASE:468
+        build_maps();
+        engage_predators();                        // BASE:302-346 (+ starvation BASE:284-301)
+        wv::sync();
+        engage_prey();                             // BASE:347-380
+        wv::sync();
+        reproduce();                               // BASE:389-448
+        obs_all_alive();                           // BASE:451-453
+        step += 1;                                 // BASE:471
+        envflags = 0;
+        if (n_alive[0] <= 0 || n_alive[1] <= 0) envflags |= PPG_ENVF_TERM_ALL | PPG_ENVF_DONE;  // BASE:466
+        rewards_and_store(true);
+    }
+
+    PPG_MEMBER void run_reset() {
+        load_env_words();
+        init_lds();
+        if (P.seeds) {
+            uint64_t sd = P.seeds[b];
+            seed = ((uint64_t)wv::first((uint32_t)(sd >> 32)) << 32) | wv::first((uint32_t)sd);
+            if (ln == 0) P.env_seed[b] = seed;
+        }
+        status = 0;
+        calls = 0;
+        wv::sync();
+        do_reset(P.reset_episode);
+    }
+
+    PPG_MEMBER void run_observe() {
+        load_env_words();
+        init_lds();
+        load_rows();
+        wv::sync();
+        load_grass(false);
+        build_maps();
+        obs_all_alive();
+    }
+
+    PPG_MEMBER void run_export_grid() {
+        load_env_words();
+        init_lds();
+        load_rows();
+        wv::sync();
+        load_grass(false);
+        build_maps();
+        const int n = P.G * P.G;
+        double *out = P.grid_out + (size_t)b * 4 * n;
+        for (int i = ln; i < 4 * n; i += 64) {
+            const int ch = i / n, c = i - ch * n;
+            out[i] = ch ? val[chmap(ch)[c]] : 0.0;
+        }
+    }
+};
+
+template <int NQ, int MODE>
+PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
+    const int b = PPG_BLOCK_INDEX();
+    if (b >= P.batch) return;
+    Env<NQ> env(P, b, lds);
+    if (MODE == MODE_STEP) env.run_step();
+    else if (MODE == MODE_RESET) env.run_reset();
+    else if (MODE == MODE_OBSERVE) env.run_observe();
+    else env.run_export_grid();
+}
+
+}  // namespace ppg

@@ -1,0 +1,52 @@
+// wave.h -- the CDNA4 wavefront primitives the PredPreyGrass kernels are written against.
+//
+// One environment is stepped by ONE 64-lane wavefront (workgroup = 1 wave), so every
+// cross-lane exchange is a wave intrinsic and `sync()` is only an LDS ordering point
+// (s_waitcnt lgkmcnt(0); the s_barrier of a single-wave workgroup is free).
+//
+// Rule the kernels follow: these functions are only called from wave-uniform control
+// flow (all 64 lanes reach the call).  Values read from LDS that steer control flow are
+// made scalar with first() so branches stay on the scalar unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PPG_DEVICE __device__ __forceinline__
+#define PPG_MEMBER __device__ __forceinline__
+#define PPG_KERNEL(name) extern "C" __global__ void __launch_bounds__(64) name
+#define PPG_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define PPG_BLOCK_INDEX() ((int)blockIdx.x)
+
+namespace wv {
+
+PPG_DEVICE int lane() { return (int)threadIdx.x; }
+
+// 64-bit mask of lanes whose predicate is true (s_* result: lives in SGPRs).
+PPG_DEVICE uint64_t ballot(bool p) { return __ballot(p); }
+
+// v_readlane_b32: value of lane k (k wave-uniform) as a scalar.
+PPG_DEVICE uint32_t readlane(uint32_t v, int k) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, k);
+}
+// v_readfirstlane_b32: makes a value known to be wave-uniform scalar.
+PPG_DEVICE uint32_t first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// v with lane k replaced by the scalar s (v_cmp + v_cndmask; this clang has no writelane builtin).
+PPG_DEVICE uint32_t writelane(uint32_t v, int k, uint32_t s) { return lane() == k ? s : v; }
+
+// number of set bits of `mask` below this lane (v_mbcnt_lo/hi): exclusive prefix count.
+PPG_DEVICE uint32_t prefix(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// value held by lane-1 (lane 0 gets its own).
+PPG_DEVICE uint32_t shfl_up1(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1, 64); }
+
+// LDS ordering point between lanes of the wave.
+PPG_DEVICE void sync() { __syncthreads(); }
+
+PPG_DEVICE uint32_t mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+PPG_DEVICE int popc(uint64_t m) { return __popcll(m); }
+PPG_DEVICE int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }  // m != 0
+
+}  // namespace wv

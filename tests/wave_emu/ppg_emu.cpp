@@ -1,0 +1,62 @@
+// ppg_emu.cpp -- TEST-ONLY build of the C ABI in include/ppg.h that runs the kernel source
+// predpreygrass_amd/csrc/ppg_kernel.h on the CPU under tests/wave_emu/wave_emu.h.
+// "Device" pointers are host pointers.  Never loaded by predpreygrass_amd.
+#include "wave_emu.h"
+
+#include "../../predpreygrass_amd/csrc/ppg_host.h"
+
+#if defined(__x86_64__)
+__asm__(
+    ".text\n"
+    ".globl ppg_emu_ctx_switch\n"
+    ".type ppg_emu_ctx_switch,@function\n"
+    "ppg_emu_ctx_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size ppg_emu_ctx_switch, .-ppg_emu_ctx_switch\n");
+#else
+#error "wave emulator context switch is written for x86-64"
+#endif
+
+struct EmuLaunch {
+    const ppg::KParams *P;
+    int nq, mode;
+};
+
+template <int NQ>
+static void run_mode(const ppg::KParams &P, int mode) {
+    PPG_DYNAMIC_LDS(lds);
+    switch (mode) {
+        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP>(P, lds); break;
+        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET>(P, lds); break;
+        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE>(P, lds); break;
+        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID>(P, lds); break;
+    }
+}
+
+static void lane_entry(void *arg) {
+    const EmuLaunch *L = (const EmuLaunch *)arg;
+    if (L->nq == 1) run_mode<1>(*L->P, L->mode);
+    else if (L->nq == 2) run_mode<2>(*L->P, L->mode);
+    else run_mode<4>(*L->P, L->mode);
+}
+
+static int backend_init(ppg_handle *h, int) {
+    h->lut_dev = (uint32_t *)malloc(h->lut_host.size() * sizeof(uint32_t));
+    memcpy(h->lut_dev, h->lut_host.data(), h->lut_host.size() * sizeof(uint32_t));
+    return PPG_OK;
+}
+static void backend_release(ppg_handle *h) {
+    free(h->lut_dev);
+    h->lut_dev = nullptr;
+}
+static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *) {
+    EmuLaunch L{&P, h->nq, mode};
+    for (int b = 0; b < h->batch; ++b) wv::run_block(lane_entry, &L, b, (size_t)P.lds_bytes);
+    return PPG_OK;
+}
+
+extern "C" uint64_t ppg_emu_collectives(void) { return wv::emu().n_collectives; }

@@ -1,0 +1,177 @@
+// wave_emu.h -- TEST-ONLY lockstep emulator of the wave primitives in
+// predpreygrass_amd/csrc/wave.h, so that the *same kernel source* can be compiled with
+// g++ and debugged on a machine without a GPU (asan/ubsan/gdb).  It is never part of the
+// product: predpreygrass_amd loads libppg_hip.so only and fails loudly without it.
+//
+// Model: the 64 lanes of a workgroup are 64 cooperative fibers.  A fiber runs until its
+// next wave primitive (a "collective"), publishes its operand and yields; when all 64
+// have arrived the scheduler resumes them -- in a RANDOM order each round, so code that
+// silently relies on lane execution order or on which lane wins a same-address LDS
+// write fails here.  The emulator is stricter than hardware about LDS visibility:
+// a value written to LDS by one lane is only guaranteed visible to the others after a
+// collective, which is exactly the discipline the kernels document.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PPG_WAVE_EMU 1
+#define PPG_DEVICE static inline
+#define PPG_MEMBER inline
+#define PPG_KERNEL(name) static void name
+#define PPG_DYNAMIC_LDS(name) unsigned char *name = wv::emu().lds
+#define PPG_BLOCK_INDEX() (wv::emu().block)
+#define __restrict__
+
+namespace wv {
+
+constexpr int W = 64;
+
+extern "C" void ppg_emu_ctx_switch(void **save_sp, void *load_sp);
+
+struct Emu {
+    void *main_sp = nullptr;
+    void *fiber_sp[W];
+    unsigned char *stacks = nullptr;
+    bool done[W];
+    uint64_t phase[W];
+    uint64_t slot[2][W];
+    int cur = 0;
+    int block = 0;
+    unsigned char *lds = nullptr;
+    size_t lds_bytes = 0;
+    void (*entry)(void *) = nullptr;
+    void *arg = nullptr;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    uint64_t n_collectives = 0;
+};
+
+inline Emu &emu() {
+    static Emu e;
+    return e;
+}
+
+static void fiber_main() {
+    Emu &e = emu();
+    e.entry(e.arg);
+    e.done[e.cur] = true;
+    ppg_emu_ctx_switch(&e.fiber_sp[e.cur], e.main_sp);
+    abort();  // never resumed
+}
+
+// Publish `mine`, wait for the whole wave, return the 64 published operands.
+inline const uint64_t *exchange(uint64_t mine) {
+    Emu &e = emu();
+    int me = e.cur;
+    uint64_t ph = e.phase[me]++;
+    e.slot[ph & 1][me] = mine;
+    ppg_emu_ctx_switch(&e.fiber_sp[me], e.main_sp);
+    e.cur = me;
+    return e.slot[ph & 1];
+}
+
+constexpr size_t STACK_BYTES = 512 * 1024;
+
+// Run one workgroup (64 lanes) of `entry(arg)` with `lds_bytes` of shared memory.
+inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_bytes) {
+    Emu &e = emu();
+    if (!e.stacks) e.stacks = (unsigned char *)aligned_alloc(64, STACK_BYTES * W);
+    if (e.lds_bytes < lds_bytes + 64) {
+        free(e.lds);
+        e.lds = (unsigned char *)aligned_alloc(64, (lds_bytes + 127) / 64 * 64);
+        e.lds_bytes = lds_bytes + 64;
+    }
+    // LDS content is undefined at launch on hardware: poison it.
+    memset(e.lds, 0xA5, lds_bytes);
+    e.entry = entry;
+    e.arg = arg;
+    e.block = block;
+    for (int l = 0; l < W; ++l) {
+        e.done[l] = false;
+        e.phase[l] = 0;
+        uint64_t *top = (uint64_t *)(e.stacks + STACK_BYTES * (l + 1));
+        top[-1] = 0;                       // fake return address of fiber_main
+        top[-2] = (uint64_t)&fiber_main;   // `ret` target of the first switch
+        for (int k = 3; k <= 8; ++k) top[-k] = 0;  // rbp rbx r12 r13 r14 r15
+        e.fiber_sp[l] = (void *)(top - 8);
+    }
+    int order[W];
+    for (;;) {
+        int n = 0;
+        for (int l = 0; l < W; ++l)
+            if (!e.done[l]) order[n++] = l;
+        if (n == 0) break;
+        for (int i = n - 1; i > 0; --i) {  // random resume order
+            e.rng ^= e.rng << 13; e.rng ^= e.rng >> 7; e.rng ^= e.rng << 17;
+            int j = (int)(e.rng % (uint64_t)(i + 1));
+            int t = order[i]; order[i] = order[j]; order[j] = t;
+        }
+        for (int i = 0; i < n; ++i) {
+            e.cur = order[i];
+            ppg_emu_ctx_switch(&e.main_sp, e.fiber_sp[order[i]]);
+        }
+        // all lanes must now sit at the same collective, or all be done
+        int nd = 0;
+        uint64_t ph = 0;
+        bool have = false, bad = false;
+        for (int l = 0; l < W; ++l) {
+            if (e.done[l]) { nd++; continue; }
+            if (!have) { ph = e.phase[l]; have = true; }
+            else if (e.phase[l] != ph) bad = true;
+        }
+        if (bad || (nd != 0 && nd != W)) {
+            fprintf(stderr, "wave_emu: divergent collective in block %d (done=%d)\n", block, nd);
+            abort();
+        }
+        e.n_collectives++;
+    }
+}
+
+// ---- the primitives of wave.h ----
+inline int lane() { return emu().cur; }
+
+inline uint64_t ballot(bool p) {
+    const uint64_t *s = exchange(p ? 1 : 0);
+    uint64_t m = 0;
+    for (int l = 0; l < W; ++l) m |= (s[l] & 1) << l;
+    return m;
+}
+inline uint32_t readlane(uint32_t v, int k) {
+    const uint64_t *s = exchange(((uint64_t)(uint32_t)k << 32) | v);
+    for (int l = 0; l < W; ++l)
+        if ((int)(s[l] >> 32) != k) { fprintf(stderr, "wave_emu: readlane index not uniform\n"); abort(); }
+    if (k < 0 || k >= W) { fprintf(stderr, "wave_emu: readlane index %d\n", k); abort(); }
+    return (uint32_t)s[k];
+}
+inline uint32_t first(uint32_t v) {
+    const uint64_t *s = exchange(v);
+    // callers use first() on values they claim are uniform: verify the claim
+    for (int l = 1; l < W; ++l)
+        if ((uint32_t)s[l] != (uint32_t)s[0]) { fprintf(stderr, "wave_emu: first() on non-uniform value\n"); abort(); }
+    return (uint32_t)s[0];
+}
+inline uint32_t writelane(uint32_t v, int k, uint32_t sval) {
+    if (k < 0 || k >= W) { fprintf(stderr, "wave_emu: writelane index %d\n", k); abort(); }
+    return lane() == k ? sval : v;
+}
+inline uint32_t prefix(uint64_t mask) {
+    int l = lane();
+    return (uint32_t)__builtin_popcountll(l ? (mask & (~0ull >> (64 - l))) : 0ull);
+}
+inline uint32_t shfl_up1(uint32_t v) {
+    const uint64_t *s = exchange(v);
+    int l = lane();
+    return (uint32_t)s[l ? l - 1 : 0];
+}
+inline void sync() { (void)exchange(0); }
+inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+inline int popc(uint64_t m) { return __builtin_popcountll(m); }
+inline int ctz(uint64_t m) { return __builtin_ctzll(m); }
+
+}  // namespace wv
+
+struct double2 { double x, y; };
+struct float2 { float x, y; };
+static inline long long __double_as_longlong(double d) { long long r; memcpy(&r, &d, 8); return r; }
+static inline double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }
