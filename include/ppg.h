@@ -69,6 +69,8 @@ extern "C" {
 #define PPG_ENV_EPISODE 11
 #define PPG_ENV_FALLBACK_SPAWNS 12 /* count of BASE:759-764 events this episode */
 #define PPG_ENV_CALLS 13        /* step calls served (diagnostic) */
+#define PPG_ENV_OBS_PRED 14     /* predator observations written so far (wraps; for bandwidth accounting) */
+#define PPG_ENV_OBS_PREY 15     /* prey observations written so far */
 
 /* env_state[PPG_ENV_FLAGS] bits */
 #define PPG_ENVF_TERM_ALL 0x01   /* terminations["__all__"] of the last call (BASE:466) */

@@ -726,8 +726,9 @@ static void rollout_note_live(ppo_env *e, const ppo_step_out *o) {
     e->ro_done = o->terminated_all || o->truncated_all;
 }
 
-int64_t ppo_rollout_random(ppo_env *e, uint64_t seed, int64_t n_calls) {
+int64_t ppo_rollout_random(ppo_env *e, uint64_t seed, int64_t n_calls, ppo_step_out *last) {
     ppo_step_out o;
+    memset(&o, 0, sizeof o);
     int cap = e->rec_cap;
     int32_t *at = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
     int32_t *ai = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
@@ -750,5 +751,6 @@ int64_t ppo_rollout_random(ppo_env *e, uint64_t seed, int64_t n_calls) {
         rollout_note_live(e, &o);
     }
     free(at); free(ai); free(aa);
+    if (last) *last = o;
     return done_calls;
 }

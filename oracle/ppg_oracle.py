@@ -130,7 +130,7 @@ def lib():
         L.ppo_reset_philox.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(_StepOut)]
         L.ppo_random_action.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32]
         L.ppo_random_action.restype = C.c_int32
-        L.ppo_rollout_random.argtypes = [C.c_void_p, C.c_uint64, C.c_int64]
+        L.ppo_rollout_random.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(_StepOut)]
         L.ppo_rollout_random.restype = C.c_int64
         _lib = L
     return _lib
@@ -247,7 +247,7 @@ class OracleEnv:
         return obs, rew, term, trunc, {}
 
     def rollout_random(self, seed: int, n_calls: int) -> int:
-        return int(self._L.ppo_rollout_random(self._h, seed, n_calls))
+        return int(self._L.ppo_rollout_random(self._h, seed, n_calls, C.byref(self._out)))
 
     def last_records(self):
         """(type, id, reward, terminated, truncated) tuples + flags of the last call."""

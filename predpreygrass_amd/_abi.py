@@ -19,7 +19,7 @@ ROW_DIED, ROW_OWNS, ROW_NEWBORN, ROW_ATE, ROW_TRUNC = 0x01, 0x02, 0x04, 0x08, 0x
 ENV_WORDS = 16
 (ENV_N_PRED_ROWS, ENV_N_PREY_ROWS, ENV_N_PRED_NEW, ENV_N_PREY_NEW, ENV_NEXT_PRED_ID, ENV_NEXT_PREY_ID,
  ENV_STEP, ENV_N_PRED_ALIVE, ENV_N_PREY_ALIVE, ENV_FLAGS, ENV_STATUS, ENV_EPISODE, ENV_FALLBACK_SPAWNS,
- ENV_CALLS) = range(14)
+ ENV_CALLS, ENV_OBS_PRED, ENV_OBS_PREY) = range(16)
 ENVF_TERM_ALL, ENVF_TRUNC_ALL, ENVF_DONE, ENVF_WAS_RESET, ENVF_LIST_IS_ROW_ORDER = 0x01, 0x02, 0x04, 0x08, 0x10
 (STATUS_PRED_OVERFLOW, STATUS_PREY_OVERFLOW, STATUS_FALLBACK_SPAWN, STATUS_FAILED_SPAWN,
  STATUS_BAD_ACTION) = 0x01, 0x02, 0x04, 0x08, 0x10

@@ -169,6 +169,7 @@ struct Env {
     uint64_t rows[T], alive[T], owns[T];
     int n_rows[2], next_id[2], n_alive[2];
     int step, fb_count, calls;
+    int obs_count[2];
     uint32_t envflags, status, episode;
     uint64_t seed;
     bool cooc[2];  // some cell may hold two live agents of this type
@@ -235,6 +236,8 @@ struct Env {
         episode = wv::readlane(w, PPG_ENV_EPISODE);
         fb_count = (int)wv::readlane(w, PPG_ENV_FALLBACK_SPAWNS);
         calls = (int)wv::readlane(w, PPG_ENV_CALLS);
+        obs_count[0] = (int)wv::readlane(w, PPG_ENV_OBS_PRED);
+        obs_count[1] = (int)wv::readlane(w, PPG_ENV_OBS_PREY);
         uint64_t sd = P.env_seed[b];
         seed = ((uint64_t)wv::first((uint32_t)(sd >> 32)) << 32) | wv::first((uint32_t)sd);
     }
@@ -859,6 +862,8 @@ struct Env {
                 case PPG_ENV_EPISODE: w = (int32_t)episode; break;
                 case PPG_ENV_FALLBACK_SPAWNS: w = fb_count; break;
                 case PPG_ENV_CALLS: w = calls; break;
+                case PPG_ENV_OBS_PRED: w = obs_count[0] + n_rows[0]; break;  // every row in use got an observation
+                case PPG_ENV_OBS_PREY: w = obs_count[1] + n_rows[1]; break;
                 default: w = 0; break;
             }
             es[ln] = w;

@@ -116,3 +116,80 @@ def replay_golden_cases(make_env, names, defaults, check_grid=True, max_calls=No
                 assert call_digest(grid[b], obs, rew, te_d, tr_d) == c.digest(t), (c.name, t, "digest")
             recs[b] = r
     return env
+
+
+# ----------------------------------------------------------------------------------------
+# random rollouts: device-side Philox actions + auto-reset vs oracle ppo_rollout_random
+# ----------------------------------------------------------------------------------------
+
+def compare_env_with_oracle(env: BatchedPredPreyGrass, b, orc, tables, check_obs=True, tag=""):
+    """Env b's last call must equal the oracle's last call: dict order, rewards, flags, state, obs."""
+    recs = env.records(b, tables)
+    orecs, ota, otra = orc.last_records()
+    names = [r[0] for r in recs]
+    onames = [("predator_%d" if t == 0 else "prey_%d") % i for (t, i, _, _, _) in orecs]
+    assert names == onames, (tag, b, "dict order", names, onames)
+    for (name, ty, row, rw, te, tr), (_, _, orw, ote, otr) in zip(recs, orecs):
+        assert np.float64(rw).tobytes() == np.float64(orw).tobytes(), (tag, b, name, "reward", rw, orw)
+        assert te == bool(ote) and tr == bool(otr), (tag, b, name, "flags")
+    es = tables["env_state"][b]
+    fl = int(es[_abi.ENV_FLAGS])
+    assert (bool(fl & _abi.ENVF_TERM_ALL), bool(fl & _abi.ENVF_TRUNC_ALL)) == (ota, otra), (tag, b, "__all__")
+    assert int(es[_abi.ENV_STEP]) == orc.current_step, (tag, b, "current_step")
+    assert (int(es[_abi.ENV_NEXT_PRED_ID]), int(es[_abi.ENV_NEXT_PREY_ID])) == orc.next_ids, (tag, b, "next ids")
+    assert int(es[_abi.ENV_N_PRED_ALIVE]) == orc.current_num_predators, (tag, b)
+    assert int(es[_abi.ENV_N_PREY_ALIVE]) == orc.current_num_prey, (tag, b)
+    for (name, ty, row, _, te, _) in recs:
+        if te:
+            continue
+        s = row if ty == PREDATOR else env.pred_capacity + row
+        st = orc.agent_state(name)
+        xy = int(tables["row_xy"][b][s])
+        assert (xy >> 8, xy & 255) == st["pos"], (tag, b, name, "pos")
+        assert np.float64(tables["row_energy"][b][s]).tobytes() == np.float64(st["energy"]).tobytes(), (tag, b, name, "energy")
+        assert np.float64(tables["row_cumrew"][b][s]).tobytes() == np.float64(st["cumulative_reward"]).tobytes(), (tag, b, name, "cum")
+    gxy, ge = orc.grass_state()
+    assert tables["grass_energy"][b][: env.n_grass].tobytes() == ge.tobytes(), (tag, b, "grass energy")
+    gx = tables["grass_xy"][b][: env.n_grass].astype(np.int64)
+    assert ((gx >> 8) == gxy[:, 0]).all() and ((gx & 255) == gxy[:, 1]).all(), (tag, b, "grass xy")
+    if check_obs:
+        o = orc._out
+        op = env.obs_pred[b].cpu().numpy()
+        oq = env.obs_prey[b].cpu().numpy()
+        for k, (name, ty, row, _, _, _) in enumerate(recs):
+            r = o.records[k]
+            want = np.ctypeslib.as_array(o.obs, shape=(r.obs_offset + r.obs_len,))[r.obs_offset:]
+            got = (op if ty == PREDATOR else oq)[row].reshape(-1)
+            if got.dtype == np.float64:
+                assert got.tobytes() == want.tobytes(), (tag, b, name, "obs")
+            else:
+                assert (got == want.astype(np.float32)).all(), (tag, b, name, "obs f32")
+
+
+def rollout_vs_oracle(env: BatchedPredPreyGrass, make_oracle, seed0, n_calls, check_every=1, envs=None, check_grid=False):
+    """Step `env` n_calls times with device-side random actions + auto-reset and check it against
+    one oracle per env (same Philox contract).  The first call is the reset."""
+    B = env.batch_size
+    envs = list(range(B)) if envs is None else envs
+    oracles = {b: make_oracle() for b in envs}
+    env.set_seeds(seed0)
+    # mark every env done so that the first auto-reset call performs the reset (episode 0)
+    env.env_state.zero_()
+    env.env_state[:, _abi.ENV_FLAGS] = _abi.ENVF_DONE
+    env.env_state[:, _abi.ENV_EPISODE] = -1
+    n_resets = 0
+    for t in range(n_calls):
+        env.step(random_actions=True, auto_reset=True)
+        for b in envs:
+            assert oracles[b].rollout_random((seed0 + b) & (2 ** 64 - 1), 1) == 1
+        if t % check_every == 0 or t == n_calls - 1:
+            tables = env.host_tables()
+            grid = env.export_grid().cpu().numpy() if check_grid else None
+            for b in envs:
+                st = int(tables["env_state"][b][_abi.ENV_STATUS])
+                assert st & ~_abi.STATUS_FALLBACK_SPAWN == 0, (t, b, "status", st)
+                compare_env_with_oracle(env, b, oracles[b], tables, tag=f"call {t}")
+                if check_grid:
+                    assert grid[b].tobytes() == oracles[b].grid_world_state.tobytes(), (t, b, "grid")
+                n_resets += bool(int(tables["env_state"][b][_abi.ENV_FLAGS]) & _abi.ENVF_WAS_RESET)
+    return n_resets

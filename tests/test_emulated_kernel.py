@@ -1,0 +1,82 @@
+"""The kernel SOURCE (predpreygrass_amd/csrc/ppg_kernel.h) compiled for the CPU wave emulator
+(tests/wave_emu) must reproduce the reference bit-for-bit.  This is a CPU-side check of the device
+code and of the host wrappers; the GPU parity tests proper are in test_hip_parity.py (-m gpu)."""
+import numpy as np
+import pytest
+
+from oracle.ppg_oracle import OracleEnv
+from predpreygrass_amd.batched import BatchedPredPreyGrass, lexkey
+from predpreygrass_amd.config import config_env
+from tests.emu_backend import library
+from tests.parity_utils import replay_golden_cases, rollout_vs_oracle
+
+
+def make_env(cfg, B, **kw):
+    return BatchedPredPreyGrass(cfg, batch_size=B, _library=library(), **kw)
+
+
+@pytest.mark.parametrize("names,max_calls", [
+    (["c1_seed0"], None),
+    (["default_seed0", "default_seed1"], 260),
+    (["c4_seed0"], None),
+    (["dense_seed0", "dense_seed3"], None),
+    (["rewards_seed3"], None),
+    (["pool_seed3"], None),
+    (["even_obs_seed0"], None),
+])
+def test_golden_cases_through_emulated_kernel(names, max_calls):
+    replay_golden_cases(make_env, names, config_env, max_calls=max_calls)
+
+
+def test_truncation_call_after_max_steps():
+    """E8: max_steps real steps, then one all-truncated call that does not advance current_step."""
+    replay_golden_cases(make_env, ["even_obs_seed0"], config_env)  # 200 steps + truncation call
+
+
+@pytest.mark.parametrize("over,B,calls,cap", [
+    ({}, 3, 120, 128),
+    ({"n_initial_active_predator": 4, "n_initial_active_prey": 8, "initial_num_grass": 30}, 3, 150, 64),
+    ({"grid_size": 9, "n_initial_active_predator": 12, "n_initial_active_prey": 20, "initial_num_grass": 25,
+      "predator_obs_range": 5, "prey_obs_range": 7, "max_steps": 150}, 4, 200, 128),
+    ({"grid_size": 5, "n_initial_active_predator": 5, "n_initial_active_prey": 9, "initial_num_grass": 8,
+      "predator_obs_range": 3, "prey_obs_range": 5, "max_steps": 60, "energy_gain_per_step_grass": 0.5}, 4, 200, 256),
+])
+def test_random_rollout_matches_oracle(over, B, calls, cap):
+    """Device-side Philox reset + random actions + auto-reset vs oracle ppo_rollout_random."""
+    cfg = {**config_env, **over}
+    env = make_env(cfg, B, prey_capacity=cap)
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=99, n_calls=calls, check_grid=True)
+
+
+def test_float32_observations_are_rounded_float64():
+    cfg = dict(config_env)
+    env = make_env(cfg, 2, obs_dtype=__import__("torch").float32)
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=5, n_calls=40)
+
+
+def test_lexkey_orders_like_python_string_sort():
+    ids = list(range(0, 1300)) + [1999, 2000, 9999, 10000, 54321, 99999, 100000, 999999]
+    keys = lexkey(ids)
+    by_key = [i for _, i in sorted(zip(keys.tolist(), ids))]
+    assert by_key == sorted(ids, key=lambda i: str(i))
+    lib = library()
+    assert [int(lib.ppg_lexkey(i)) for i in ids] == keys.tolist()
+
+
+def test_prey_row_overflow_is_flagged_not_silent():
+    from predpreygrass_amd import _abi
+    cfg = {**config_env, "energy_gain_per_step_grass": 0.3, "initial_num_grass": 200, "max_steps": 300}
+    env = make_env(cfg, 1, prey_capacity=64)
+    env.reset(seed=3)
+    for _ in range(120):
+        env.step(random_actions=True)
+    st = int(env.env_state[0, _abi.ENV_STATUS])
+    assert st & _abi.STATUS_PREY_OVERFLOW
+    assert int(env.env_state[0, _abi.ENV_N_PREY_ROWS]) <= 64
+
+
+def test_invalid_configs_are_rejected():
+    with pytest.raises(ValueError, match="Cannot place more unique positions"):
+        make_env({**config_env, "grid_size": 5, "initial_num_grass": 30}, 1)
+    with pytest.raises(ValueError):
+        make_env({**config_env, "grid_size": 200}, 1)
