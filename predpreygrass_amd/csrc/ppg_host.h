@@ -10,6 +10,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -27,6 +28,7 @@ struct ppg_handle {
     std::vector<uint32_t> lut_host;
     uint32_t *lut_dev;
     void *backend;
+    unsigned long long *prof_dev;  // diagnostic build only
     char err[256];
 };
 
@@ -50,24 +52,23 @@ static uint32_t ppg_host_lexkey(uint32_t id) {
     return key;
 }
 
-// Observation element descriptors (see Env::obs_row): for type t, chunk ch, lane l the word
-// describes elements e = ch*128 + 2l and e+1 of the (4,R,R) block in C order.
-static void ppg_build_lut(int R, uint32_t *out) {
-    const int blk = 4 * R * R;
-    const int W = 2 * ((R - 1) / 2) + 1;  // BASE:532-539: window is x-off..x+off
-    for (int w = 0; w < ppg::LUT_WORDS_PER_TYPE; ++w) {
-        uint32_t word = 0;
-        for (int h = 0; h < 2; ++h) {
-            const int e = 2 * w + h;
-            uint32_t d = 0;
-            if (e < blk) {
-                const int c = e / (R * R), rem = e % (R * R), i = rem / R, j = rem % R;
-                d = 1u | ((uint32_t)c << 1) | ((uint32_t)i << 3) | ((uint32_t)j << 7) |
-                    ((i < W && j < W) ? 0x800u : 0u);
-            }
-            word |= d << (12 * h);
+// Observation element descriptors (see Env::obs_row): for chunk ch, lane l the two words describe
+// elements e = ch*128 + 2l and e+1 of the (4,R,R) block in C order.
+static int ppg_obs_chunks(int R) { return (4 * R * R + 127) / 128; }
+
+static void ppg_build_lut(int R, int G, int map_n, uint32_t *out) {
+    const int blk = 4 * R * R, off = (R - 1) / 2;
+    const int W = 2 * off + 1;  // BASE:532-539: the window is x-off..x+off
+    const int nwords = ppg_obs_chunks(R) * 128;
+    for (int e = 0; e < nwords; ++e) {
+        uint32_t d = 0;
+        if (e < blk) {
+            const int c = e / (R * R), rem = e % (R * R), i = rem / R, j = rem % R;
+            const int moff = c * map_n + (i - off) * G + (j - off);
+            d = ((uint32_t)moff & 0xFFFFu) | ((uint32_t)(i - off + 8) << 16) | ((uint32_t)(j - off + 8) << 20) |
+                ((uint32_t)c << 24) | 0x4000000u | ((i < W && j < W) ? 0x8000000u : 0u);
         }
-        out[w] = word;
+        out[e] = d;
     }
 }
 
@@ -124,8 +125,10 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.off_val = off; off += (1 + P.S + P.cap_grass) * 8;
     off = (off + 15) / 16 * 16;
     P.off_scr = off; off += (P.S * 8 > 1024 ? P.S * 8 : 1024);
-    P.off_lut = off; off += 2 * ppg::LUT_WORDS_PER_TYPE * 4;
+    P.nch_p = ppg_obs_chunks(P.Rp); P.nch_q = ppg_obs_chunks(P.Rq);
+    P.off_lut = off; off += (P.nch_p + P.nch_q) * 128 * 4;
     P.lds_bytes = off;
+    if (const char *pad = getenv("PPG_DEBUG_LDS_BYTES")) { int v = atoi(pad); if (v > P.lds_bytes) P.lds_bytes = v; }  // occupancy experiments
     if (P.lds_bytes > 64 * 1024) return ppg_fail(h, PPG_EINVAL, "configuration needs %d bytes of LDS per wave (> 64 KiB)", P.lds_bytes);
 
     P.row_xy = b.row_xy; P.row_e = b.row_energy; P.row_id = b.row_id; P.row_key = b.row_key;
@@ -134,9 +137,10 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.obs_pred = b.obs_pred; P.obs_prey = b.obs_prey;
     P.batch = h->batch;
 
-    h->lut_host.assign(2 * ppg::LUT_WORDS_PER_TYPE, 0u);
-    ppg_build_lut(P.Rp, h->lut_host.data());
-    ppg_build_lut(P.Rq, h->lut_host.data() + ppg::LUT_WORDS_PER_TYPE);
+    if (3 * P.map_n + 8 * c.grid_size + 8 > 32767) return ppg_fail(h, PPG_EINVAL, "grid too large for 16-bit map offsets");
+    h->lut_host.assign((size_t)(P.nch_p + P.nch_q) * 128, 0u);
+    ppg_build_lut(P.Rp, P.G, P.map_n, h->lut_host.data());
+    ppg_build_lut(P.Rq, P.G, P.map_n, h->lut_host.data() + (size_t)P.nch_p * 128);
     return PPG_OK;
 }
 
@@ -155,7 +159,7 @@ int ppg_create(const ppg_config *cfg, int32_t batch, int32_t device, const ppg_b
     ppg_handle *h = new (std::nothrow) ppg_handle();
     if (!h) return ppg_fail(nullptr, PPG_ENOMEM, "out of host memory");
     h->cfg = *cfg; h->bufs = *bufs; h->batch = batch; h->device = device;
-    h->lut_dev = nullptr; h->backend = nullptr; h->err[0] = 0;
+    h->lut_dev = nullptr; h->backend = nullptr; h->prof_dev = nullptr; h->err[0] = 0;
     int rc = ppg_validate_and_layout(h);
     if (rc == PPG_OK) rc = backend_init(h, device);
     if (rc != PPG_OK) {
@@ -195,7 +199,7 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
     ppg::KParams P = h->base;
-    P.mode = ppg::MODE_STEP; P.actions = actions; P.flags = flags;
+    P.mode = ppg::MODE_STEP; P.actions = actions; P.flags = flags; P.prof = h->prof_dev;
     return backend_launch(h, ppg::MODE_STEP, P, stream);
 }
 
@@ -208,6 +212,11 @@ int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream) {
 }
 
 int32_t ppg_lds_bytes(const ppg_handle *h) { return h ? h->base.lds_bytes : 0; }
+
+#ifdef PPG_PROFILE_PHASES
+// diagnostic build only: device buffer [B,16] of shader-clock stamps (see PPG_STAMP)
+int ppg_debug_set_profile_buffer(ppg_handle *h, unsigned long long *dev) { h->prof_dev = dev; return PPG_OK; }
+#endif
 
 const char *ppg_last_error(const ppg_handle *h) { return h ? h->err : g_ppg_create_error; }
 

@@ -29,6 +29,15 @@
 #include "wave.h"
 #endif
 
+// Diagnostic build only (-DPPG_PROFILE_PHASES, tools/phase_profile.py): per-env shader-clock stamps
+// at phase boundaries, written to a buffer that nothing else reads.  Never defined in the product.
+#ifdef PPG_PROFILE_PHASES
+#define PPG_STAMP(i) do { if (P.prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); if (ln == 0) P.prof[(size_t)b * 16 + (i)] = t_; } } while (0)
+#else
+#define PPG_STAMP(i) do { } while (0)
+#endif
+
 namespace ppg {
 
 enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3 };
@@ -40,7 +49,6 @@ constexpr uint32_t TAG_ACT = 0x41435431u;  // Philox key domains (see oracle/ppg
 constexpr uint32_t TAG_RST = 0x52535431u;
 constexpr uint32_t TAG_SPW = 0x53505731u;
 
-constexpr int LUT_WORDS_PER_TYPE = 8 * 64;  // up to 8 chunks of 128 elements (R <= 15)
 
 struct KParams {
     // config
@@ -56,7 +64,8 @@ struct KParams {
     int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
     int32_t off_val;  // float64 value table: [0]=0, 1+row predators, 1+cap_pred+row prey, then grass
     int32_t off_scr;  // 8-byte scratch per row (permutation / reset random words)
-    int32_t off_lut;  // observation element descriptors, 2 types x LUT_WORDS_PER_TYPE u32
+    int32_t off_lut;  // observation element descriptors (see Env::obs_row), predators then prey
+    int32_t nch_p, nch_q;  // 128-element chunks per (4,R,R) block: ceil(4*R*R/128)
     int32_t lds_bytes;
     // buffers (caller-owned)
     uint16_t *row_xy;
@@ -72,11 +81,12 @@ struct KParams {
     double *grass_e;
     void *obs_pred;
     void *obs_prey;
-    const uint32_t *obs_lut;  // library-owned, [2][LUT_WORDS_PER_TYPE]
+    const uint32_t *obs_lut;  // library-owned, (nch_p + nch_q) * 128 words
     // per-launch
     const int8_t *actions;
     const uint64_t *seeds;
     double *grid_out;
+    unsigned long long *prof;  // diagnostic build only
     uint32_t flags;
     uint32_t reset_episode;
     int32_t mode;
@@ -214,8 +224,7 @@ struct Env {
         for (int q = 0; q < T; ++q)
             if (type_of(q) == type) owns[q] &= ~wv::ballot(xy[q] == s_xy);
 #pragma unroll
-        for (int q = 0; q < T; ++q)
-            if (q == r) owns[q] |= bit64(k);
+        for (int q = 0; q < T; ++q) owns[q] |= (q == r) ? bit64(k) : 0ull;
         if (touch_lds && ln == 0) {
             chmap(1 + type)[cell_of(s_xy)] = (uint16_t)validx(r, k);
             val[validx(r, k)] = s_e;
@@ -273,7 +282,7 @@ struct Env {
         uint32_t *m32 = (uint32_t *)map;
         const int n32 = 4 * P.map_n / 2;
         for (int i = ln; i < n32; i += 64) m32[i] = 0u;
-        for (int i = ln; i < 2 * LUT_WORDS_PER_TYPE; i += 64) lut[i] = P.obs_lut[i];
+        for (int i = ln; i < (P.nch_p + P.nch_q) * 128; i += 64) lut[i] = P.obs_lut[i];
         if (ln == 0) val[0] = 0.0;
     }
 
@@ -534,33 +543,48 @@ struct Env {
 
     // _get_observation (BASE:511-526) + _obs_clip (BASE:528-539) for the agent of `type` in
     // per-type row j standing on s_xy; coalesced 16-byte stores of the (4,R,R) block.
+    //
+    // Lane l of chunk ch produces elements e = 128*ch + 2l and e+1 of the block (C order: channel,
+    // i, j).  Everything that depends only on (R, G, e) is precomputed on the host into one LDS word
+    // per element:  bits 0-15  moff = c*map_n + (i-off)*G + (j-off)   (signed; map index relative to
+    //               the observer's cell),  bits 16-19 (i-off)+8,  bits 20-23 (j-off)+8,  bits 24-25 c,
+    //               bit 26 element exists (e < 4*R*R),  bit 27 inside the (2*off+1)^2 window.
+    // A row whose window lies inside the grid takes the branch-uniform fast path: value =
+    // val[map[moff + cell]], no bounds checks (channel 0 reads the all-zero map 0).
     PPG_MEMBER void obs_row(int type, int j, uint32_t s_xy) {
         wv::sync();  // LDS writes of the sequential phases -> visible
         const int R = type ? P.Rq : P.Rp;
         const int blk = 4 * R * R;
         const int off = (R - 1) / 2;
-        const int x0 = (int)(s_xy >> 8) - off, y0 = (int)(s_xy & 255u) - off;
-        const uint32_t *L = lut + type * LUT_WORDS_PER_TYPE;
+        const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
+        const int s_cell = x * P.G + y;
+        const bool interior = (R & 1) && x >= off && y >= off && x + off < P.G && y + off < P.G;
+        const uint2 *L = (const uint2 *)(lut + (type ? P.nch_p * 128 : 0));
+        const int nch = type ? P.nch_q : P.nch_p;
         const size_t obase = ((size_t)b * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)blk;
-        const int nch = (blk + 127) >> 7;
         for (int ch = 0; ch < nch; ++ch) {
-            const uint32_t d = L[ch * 64 + ln];
+            const uint2 d = L[ch * 64 + ln];
             double v[2];
+            if (interior) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // element descriptor: bit0 exists, bits1-2 channel, bits3-6 i, bits7-10 j, bit11 inside the
-                // (2*off+1)^2 window (always for odd R; for even R the last row/column is outside, BASE:532-539)
-                const uint32_t dd = (d >> (12 * h)) & 0xFFFu;
-                const int c = (int)((dd >> 1) & 3u), i = (int)((dd >> 3) & 15u), jj = (int)((dd >> 7) & 15u);
-                const int gx = x0 + i, gy = y0 + jj;
-                const bool inb = (dd & 0x800u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
-                const int a = inb ? c * P.map_n + gx * P.G + gy : 0;
-                const uint32_t idx = map[a];  // map[0][0] is always 0
-                double t = val[inb ? idx : 0u];
-                if (!inb && c == 0) t = 1.0;  // channel 0: 1 outside the grid (BASE:522-523)
-                v[h] = t;
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t w = h ? d.y : d.x;
+                    const int a = (int)(int16_t)(w & 0xFFFFu) + s_cell;
+                    v[h] = val[map[a]];  // a non-existent element has moff 0: reads the observer's own cell, unused
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t w = h ? d.y : d.x;
+                    const int gx = x + (int)((w >> 16) & 15u) - 8, gy = y + (int)((w >> 20) & 15u) - 8;
+                    const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+                    const int a = (int)(int16_t)(w & 0xFFFFu) + s_cell;
+                    double t = val[map[inb ? a : 0]];        // map[0] (channel 0, cell 0) is always 0 -> val[0] = 0.0
+                    if (!inb && (w & 0x3000000u) == 0u) t = 1.0;  // channel 0: 1 outside the grid (BASE:522-523)
+                    v[h] = t;
+                }
             }
-            if (d & 1u) {
+            if (d.x & 0x4000000u) {
                 const size_t o = obase + (size_t)ch * 128 + 2 * (size_t)ln;
                 if (P.obs_f32) {
                     float2 f; f.x = (float)v[0]; f.y = (float)v[1];
@@ -594,8 +618,7 @@ struct Env {
         n_alive[type] -= 1;
         grid_zero(type, s_xy, true);
 #pragma unroll
-        for (int q = 0; q < T; ++q)
-            if (q == r) alive[q] &= ~bit64(k);
+        for (int q = 0; q < T; ++q) alive[q] &= ~((q == r) ? bit64(k) : 0ull);
     }
 
     PPG_MEMBER void engage_predators() {
@@ -636,11 +659,10 @@ struct Env {
             obs_row(1, row_of(cr, ck), s_xy);               // BASE:327 (before the prey is erased)
             n_alive[1] -= 1;
 #pragma unroll
-            for (int q = 1; q < T; ++q)
-                if (q == cr) {
-                    alive[q] &= ~bit64(ck);
-                    if (ln == ck) ev[q] |= EV_CAUGHT;
-                }
+            for (int q = 1; q < T; ++q) {
+                alive[q] &= ~((q == cr) ? bit64(ck) : 0ull);
+                ev[q] |= (q == cr && ln == ck) ? (uint32_t)EV_CAUGHT : 0u;
+            }
             grid_zero(1, s_xy, true);                       // BASE:335
         }
     }
@@ -786,8 +808,11 @@ struct Env {
                     e[q] = writelane_f64(e[q], ck, e0);          // BASE:403
                     cum[q] = writelane_f64(cum[q], ck, 0.0);     // BASE:410
                     if (ln == ck) ev[q] = EV_BORN;
-                    rows[q] |= bit64(ck);
-                    alive[q] |= bit64(ck);
+                }
+#pragma unroll
+                for (int q = 0; q < T; ++q) {
+                    rows[q] |= (q == cr) ? bit64(ck) : 0ull;
+                    alive[q] |= (q == cr) ? bit64(ck) : 0ull;
                 }
                 n_alive[type] += 1;
                 grid_set(cr, ck, child_xy, e0, true);        // BASE:405
@@ -945,6 +970,7 @@ struct Env {
 
     // ---- the transition ----------------------------------------------------------------
     PPG_MEMBER void run_step() {
+        PPG_STAMP(0);
         load_env_words();
         calls += 1;
         init_lds();
@@ -969,26 +995,38 @@ struct Env {
             return;
         }
 
+        PPG_STAMP(1);
         uint64_t acted[T];
         load_actions(acted);
 #pragma unroll
         for (int r = 0; r < T; ++r) keep[r] = 0;  // agents_just_ate.clear(), BASE:241
         wv::sync();                                // init_lds() zeros visible
+        PPG_STAMP(2);
         decay(acted);                              // BASE:244-250
+        PPG_STAMP(3);
         load_grass(true);                          // BASE:252-256
+        PPG_STAMP(4);
         move(acted);                               // BASE:259-276
+        PPG_STAMP(5);
         compact_and_sort(!list_is_row_order);      // BASE:222-225 + the sort of BASE:468
+        PPG_STAMP(6);
         build_maps();
+        PPG_STAMP(7);
         engage_predators();                        // BASE:302-346 (+ starvation BASE:284-301)
         wv::sync();
+        PPG_STAMP(8);
         engage_prey();                             // BASE:347-380
         wv::sync();
+        PPG_STAMP(9);
         reproduce();                               // BASE:389-448
+        PPG_STAMP(10);
         obs_all_alive();                           // BASE:451-453
+        PPG_STAMP(11);
         step += 1;                                 // BASE:471
         envflags = 0;
         if (n_alive[0] <= 0 || n_alive[1] <= 0) envflags |= PPG_ENVF_TERM_ALL | PPG_ENVF_DONE;  // BASE:466
         rewards_and_store(true);
+        PPG_STAMP(12);
     }
 
     PPG_MEMBER void run_reset() {

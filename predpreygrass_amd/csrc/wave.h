@@ -42,8 +42,11 @@ PPG_DEVICE uint32_t prefix(uint64_t mask) {
 // value held by lane-1 (lane 0 gets its own).
 PPG_DEVICE uint32_t shfl_up1(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1, 64); }
 
-// LDS ordering point between lanes of the wave.
-PPG_DEVICE void sync() { __syncthreads(); }
+// LDS ordering point between lanes of the wave.  A workgroup is ONE wavefront and the LDS unit
+// executes a wave's DS instructions in issue order, so no s_barrier and no counter drain is
+// needed -- only the compiler must not move LDS accesses across this point.  (__syncthreads()
+// would also drain vmcnt(0), i.e. wait for every outstanding observation store to reach HBM.)
+PPG_DEVICE void sync() { __asm__ volatile("" ::: "memory"); }
 
 PPG_DEVICE uint32_t mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 PPG_DEVICE int popc(uint64_t m) { return __popcll(m); }

@@ -172,6 +172,7 @@ inline int ctz(uint64_t m) { return __builtin_ctzll(m); }
 }  // namespace wv
 
 struct double2 { double x, y; };
+struct uint2 { uint32_t x, y; };
 struct float2 { float x, y; };
 static inline long long __double_as_longlong(double d) { long long r; memcpy(&r, &d, 8); return r; }
 static inline double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }

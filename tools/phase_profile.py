@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a wavefront spend its cycles?  Builds libppg_hip_prof.so
+(-DPPG_PROFILE_PHASES: s_memtime stamps at phase boundaries, written to a buffer nothing else
+reads) and prints per-phase cycle shares.  Never quote this build's run time; read the SHARES."""
+import ctypes, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from predpreygrass_amd import _abi
+from predpreygrass_amd.batched import BatchedPredPreyGrass
+from predpreygrass_amd.config import config_env
+
+CSRC = os.path.join(ROOT, "predpreygrass_amd", "csrc")
+LIB = os.path.join(ROOT, "gpurun_out", "libppg_hip_prof.so")
+os.makedirs(os.path.dirname(LIB), exist_ok=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
+                "-DPPG_PROFILE_PHASES", "-o", LIB, os.path.join(CSRC, "ppg_hip.hip")], check=True, cwd=CSRC)
+lib = _abi.bind(ctypes.CDLL(LIB))
+_abi._lib = lib  # this process only
+lib.ppg_debug_set_profile_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+env = BatchedPredPreyGrass(config_env, batch_size=B, device="cuda:0")
+env.reset()
+prof = torch.zeros((B, 16), dtype=torch.int64, device="cuda:0")
+for _ in range(warm):
+    env.step(random_actions=True, auto_reset=True)
+lib.ppg_debug_set_profile_buffer(env._handle, ctypes.c_void_p(prof.data_ptr()))
+names = ["load_env+rows", "actions", "decay", "grass", "move", "sort", "build_maps", "engage_pred", "engage_prey",
+         "reproduce", "obs", "store"]
+acc = np.zeros((12,)); accmax = np.zeros((12,)); tot = []; rows = []
+N = 20
+for it in range(N):
+    prof.zero_()
+    env.step(random_actions=True, auto_reset=True)
+    torch.cuda.synchronize()
+    p = prof.cpu().numpy().astype(np.float64)
+    es = env.env_state.cpu().numpy()
+    ok = (p[:, 12] > 0) & (p[:, 1] > 0)   # envs that took the normal path (not reset / truncation)
+    d = np.diff(p[ok][:, :13], axis=1)
+    acc += d.mean(axis=0)
+    whole = p[ok][:, 12] - p[ok][:, 0]
+    slow = np.argsort(whole)[-max(1, len(whole) // 100):]
+    accmax += d[slow].mean(axis=0)
+    tot.append((whole.mean(), whole.max(), np.percentile(whole, 99)))
+    n = (es[ok][:, 0] + es[ok][:, 1])
+    rows.append((n.mean(), n.max(), np.corrcoef(n, whole)[0, 1]))
+    span = p[ok][:, 12].max() - p[ok][:, 0].min()
+print("phase               mean cyc   share | slowest-1%% cyc  share")
+for k, n in enumerate(names):
+    print(f"{n:18s} {acc[k]/N:9.0f}  {acc[k]/acc.sum():6.1%} | {accmax[k]/N:9.0f}  {accmax[k]/accmax.sum():6.1%}")
+t = np.array(tot); r = np.array(rows)
+print(f"wave cycles: mean {t[:,0].mean():.0f}  p99 {t[:,2].mean():.0f}  max {t[:,1].mean():.0f};  first-start..last-end span {span:.0f}")
+print(f"rows/env: mean {r[:,0].mean():.1f} max {r[:,1].mean():.0f}; corr(rows, cycles) {r[:,2].mean():.3f}")
