@@ -12,8 +12,10 @@ and observation buffers are resident in HBM; nothing crosses PCIe inside the tim
 
 Workload (BASELINE.json configs[2], the headline): 4096 envs x 25x25 grid per GPU, default
 config (6 predators / 8 prey / 100 grass, obs 7x7 / 9x9).  N GPUs = N independent shards of 4096
-envs (weak scaling); with --gather (default for N>1) each step is followed by the RCCL all-gather
-of the compacted observation tensors that north_star specifies.
+envs (weak scaling, no data-path collective: envs never interact).  For N>1 an extra leg measures
+the step followed by the RCCL all-gather of the compacted observations that north_star specifies
+and reports it under "obs_gather" (it is bandwidth-bound on xGMI).  Within one GPU the
+4096 envs are stepped as --streams (default 3) independent sub-batches on separate HIP streams.
 
 Prints ONE JSON line (rank 0).
 """
@@ -73,8 +75,10 @@ def main():
     ap.add_argument("--obs-dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--gather", dest="gather", action="store_true", default=None)
-    ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step)")
+    ap.add_argument("--gather-steps", type=int, default=50,
+                    help="N>1 only: extra leg of this many steps with the RCCL observation all-gather after each step")
     args = ap.parse_args()
 
     import torch
@@ -92,55 +96,92 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank if distributed else 0)
+    torch.cuda.set_device(device)
     n_gpus = world if distributed else 1
-    gather = args.gather if args.gather is not None else distributed
 
     cfg = dict(config_env)
     B = args.envs
     obs_dtype = torch.float64 if args.obs_dtype == "f64" else torch.float32
-    env = BatchedPredPreyGrass(cfg, batch_size=B, device=device, obs_dtype=obs_dtype,
-                               seed=args.seed + rank * B)
-    env.reset()
-    gatherer = None
-    if gather and distributed:
-        from predpreygrass_amd.distributed import ObservationGatherer
-        gatherer = ObservationGatherer(env)
+    from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
+    n_sub = max(1, args.streams)
+    group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype,
+                                    seed=args.seed + rank * B)
+    group.reset()
+    group.synchronize()
+    env = group.subs[0]
 
     def one_step():
-        env.step(random_actions=True, auto_reset=True)
-        if gatherer is not None:
-            gatherer.gather()
+        group.step(random_actions=True, auto_reset=True)
 
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(device)
     # zero the observation counters (bandwidth accounting) -- outside the timed region
-    env.env_state[:, _abi.ENV_OBS_PRED:_abi.ENV_OBS_PREY + 1] = 0
-    calls0 = env.env_state[:, _abi.ENV_CALLS].clone()
+    calls0 = []
+    for e in group.subs:
+        e.env_state[:, _abi.ENV_OBS_PRED:_abi.ENV_OBS_PREY + 1] = 0
+        calls0.append(e.env_state[:, _abi.ENV_CALLS].clone())
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(device)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events on the streams the kernels are launched on
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in group.streams]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in group.streams]
     t0 = time.perf_counter()
-    ev0.record()
+    for s, e in zip(group.streams, ev0):
+        e.record(s)
     for _ in range(args.steps):
         one_step()
-    ev1.record()
+    for s, e in zip(group.streams, ev1):
+        e.record(s)
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    # mean launch-to-launch time of the step kernel on each stream (the n_sub streams run concurrently)
+    dev_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / len(ev0)
     if distributed:
         t = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    # counters of the timed region, snapshotted before anything else steps the envs
+    import numpy as np
+    es = np.concatenate([e.env_state.cpu().numpy() for e in group.subs]).astype("int64")
+    calls0 = np.concatenate([c.cpu().numpy() for c in calls0])
+    assert ((es[:, _abi.ENV_CALLS] - calls0) == args.steps).all()
+
+    # ---- optional leg: the RCCL observation all-gather north_star specifies (N > 1 only) ----
+    gather_info = None
+    if distributed and args.gather_steps > 0:
+        try:
+            from predpreygrass_amd.distributed import ObservationGatherer
+            gs = [ObservationGatherer(e) for e in group.subs]
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            tg = time.perf_counter()
+            nbytes = 0
+            for _ in range(args.gather_steps):
+                one_step()
+                group.synchronize()
+                for g in gs:
+                    g.gather()
+                    nbytes += g.last_bytes
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            tg = time.perf_counter() - tg
+            t = torch.tensor([tg], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gather_info = {"value": round(n_gpus * B * args.gather_steps / float(t.item()), 1), "unit": "env-steps/s",
+                           "steps": args.gather_steps, "ms_per_step": round(float(t.item()) / args.gather_steps * 1e3, 4),
+                           "gathered_bytes_per_step_per_rank": int(nbytes / args.gather_steps),
+                           "what": "step + synchronous all-gather (RCCL) of the compacted float64 observations, ids, rewards, flags"}
+        except Exception as ex:  # never lose the main measurement to the optional leg
+            gather_info = {"error": repr(ex)[:300]}
+
     # ---- accounting ------------------------------------------------------------------
-    es = env.env_state.cpu().numpy().astype("int64")
-    assert ((es[:, _abi.ENV_CALLS] - calls0.cpu().numpy()) == args.steps).all()
     status = int((es[:, _abi.ENV_STATUS]).max())
     n_obs_pred = int(es[:, _abi.ENV_OBS_PRED].sum())
     n_obs_prey = int(es[:, _abi.ENV_OBS_PREY].sum())
@@ -154,8 +195,8 @@ def main():
     # row tables r/w (27 B read, 35 B written per row) + grass table (8 B r/w, 2 B read) + env words
     min_bytes = n_obs_pred * 4 * Rp * Rp * osz + n_obs_prey * 4 * Rq * Rq * osz + \
         62 * (n_obs_pred + n_obs_prey) + env_steps_rank * (env.n_grass * 18 + 2 * 64 + 8)
-    kernel_s = dev_ms / 1e3 / args.steps
-    achieved = alg_bytes / args.steps / kernel_s / 1e9
+    kernel_s = dev_ms / 1e3 / args.steps          # per launch; n_sub launches are in flight concurrently
+    achieved = alg_bytes / args.steps / kernel_s / 1e9   # all n_sub concurrent launches together
     value = n_gpus * env_steps_rank / wall
 
     if rank == 0:
@@ -177,7 +218,8 @@ def main():
                             f"obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), device-side uniform random actions, "
                             "auto-reset, observations written every step (BASELINE.json configs[2])",
                 "envs_per_gpu": B,
-                "parallelism": f"batch-sharded x{n_gpus}" + (", RCCL all-gather of observations" if gatherer else ""),
+                "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
+                "sub_batches_per_gpu": n_sub,
                 "mean_agents_per_env": round((n_obs_pred + n_obs_prey) / env_steps_rank, 2),
                 "status_bits": status,
             },
@@ -190,13 +232,18 @@ def main():
                 "traffic": None,
                 "kernel": "ppg_step_q2",
                 "kernel_ms": round(kernel_s * 1e3, 5),
-                "algorithmic_bytes_per_launch": int(alg_bytes / args.steps),
-                "implementation_min_bytes_per_launch": int(min_bytes / args.steps),
-                "note": "achieved = SURVEY 8(d) algorithmic bytes / mean launch-to-launch time (HIP events on "
-                        "the launch stream). The dense grid term of that formula is never moved by this design; "
-                        "implementation_min_bytes_per_launch is what the kernel must actually touch.",
+                "concurrent_launches": n_sub,
+                "algorithmic_bytes_per_launch": int(alg_bytes / args.steps / n_sub),
+                "implementation_min_bytes_per_launch": int(min_bytes / args.steps / n_sub),
+                "note": "kernel_ms = mean launch-to-launch time of ppg_step_q2 on its stream (HIP events on that "
+                        "stream); concurrent_launches such kernels (one per sub-batch of envs_per_gpu/concurrent_"
+                        "launches envs) overlap in time, so achieved = concurrent_launches x algorithmic_bytes_per_"
+                        "launch / kernel_ms. Algorithmic bytes follow SURVEY 8(d); its dense-grid term is never moved "
+                        "by this design -- implementation_min_bytes_per_launch is what the kernel must actually touch.",
             },
         }
+        if gather_info is not None:
+            out["obs_gather"] = gather_info
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.seed, seconds=args.cpu_seconds)
         print(json.dumps(out), flush=True)

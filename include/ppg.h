@@ -171,6 +171,12 @@ int ppg_observe(ppg_handle *h, void *stream);
  * which is the order of the previous observation dict (RLlib's protocol). */
 int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream);
 
+/* Same, for an action dict whose iteration order differs from the previous observation dict
+ * (the order matters in the reference: movement and the decay writes are applied in dict order,
+ * BASE:244,259).  act_rank: device uint8 [B,S]; for every row with an action, its position among
+ * the acting agents OF ITS TYPE (0..n-1, a permutation).  NULL == row order (ppg_step). */
+int ppg_step_ordered(ppg_handle *h, const int8_t *actions, const uint8_t *act_rank, uint32_t flags, void *stream);
+
 /* grid_world_state (BASE:124): dense float64 [B,4,G,G] rebuilt from the rows. */
 int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream);
 

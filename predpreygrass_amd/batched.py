@@ -140,10 +140,13 @@ class BatchedPredPreyGrass:
         except Exception:
             pass
 
-    def _stream(self):
-        if self.device.type == "cuda":
+    def _stream(self, stream=None):
+        """hipStream_t for a launch: an explicit torch.cuda.Stream / raw handle, else torch's current stream."""
+        if self.device.type != "cuda":
+            return None
+        if stream is None:
             return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        return None
+        return C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
 
     def _check(self, rc, what):
         if rc != 0:
@@ -228,8 +231,12 @@ class BatchedPredPreyGrass:
         self._check(self._lib.ppg_observe(self._handle, self._stream()), "ppg_observe")
         return self
 
-    def step(self, actions=None, random_actions=False, auto_reset=False):
-        """One transition of every env (predpreygrass_rllib_env.py:219-473)."""
+    def step(self, actions=None, random_actions=False, auto_reset=False, act_rank=None, stream=None):
+        """One transition of every env (predpreygrass_rllib_env.py:219-473).
+
+        act_rank (optional uint8 [B,S]): position of each acting row within its type's action
+        sequence, for action dicts whose order differs from row order.
+        stream (optional): launch on this torch.cuda.Stream instead of torch's current stream."""
         flags = 0
         ptr = None
         if random_actions:
@@ -243,7 +250,16 @@ class BatchedPredPreyGrass:
             ptr = C.c_void_p(actions.data_ptr())
         if auto_reset:
             flags |= _abi.STEP_AUTO_RESET
-        self._check(self._lib.ppg_step(self._handle, ptr, flags, self._stream()), "ppg_step")
+        if act_rank is not None:
+            if random_actions:
+                raise ValueError("act_rank cannot be combined with random_actions")
+            if act_rank.dtype != torch.uint8 or tuple(act_rank.shape) != (self.batch_size, self.S) or \
+                    act_rank.device != self.device or not act_rank.is_contiguous():
+                raise ValueError("act_rank must be a contiguous uint8 tensor [B,S] on the env's device")
+            self._check(self._lib.ppg_step_ordered(self._handle, ptr, C.c_void_p(act_rank.data_ptr()), flags,
+                                                   self._stream(stream)), "ppg_step_ordered")
+        else:
+            self._check(self._lib.ppg_step(self._handle, ptr, flags, self._stream(stream)), "ppg_step")
         return self
 
     def export_grid(self):

@@ -7,11 +7,20 @@
 
 #include "ppg_host.h"
 
-#define PPG_DEFINE_KERNELS(NQ)                                                                         \
-    PPG_KERNEL(ppg_step_q##NQ)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP>(P, lds); }       \
-    PPG_KERNEL(ppg_reset_q##NQ)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_RESET>(P, lds); }     \
-    PPG_KERNEL(ppg_observe_q##NQ)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_OBSERVE>(P, lds); } \
-    PPG_KERNEL(ppg_grid_q##NQ)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_EXPORT_GRID>(P, lds); }
+// kernel name: ppg_<mode>_q<prey registers>[g]   (g = generic observation geometry, descriptors in LDS)
+#define PPG_K(name, NQ, MODE, FAST)                                                         \
+    PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, FAST>(P, lds); }
+#define PPG_DEFINE_KERNELS(NQ)                                        \
+    PPG_K(ppg_step_q##NQ, NQ, ppg::MODE_STEP, true)                   \
+    PPG_K(ppg_reset_q##NQ, NQ, ppg::MODE_RESET, true)                 \
+    PPG_K(ppg_observe_q##NQ, NQ, ppg::MODE_OBSERVE, true)             \
+    PPG_K(ppg_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID, true)            \
+    PPG_K(ppg_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED, true)       \
+    PPG_K(ppg_step_q##NQ##g, NQ, ppg::MODE_STEP, false)               \
+    PPG_K(ppg_reset_q##NQ##g, NQ, ppg::MODE_RESET, false)             \
+    PPG_K(ppg_observe_q##NQ##g, NQ, ppg::MODE_OBSERVE, false)         \
+    PPG_K(ppg_grid_q##NQ##g, NQ, ppg::MODE_EXPORT_GRID, false)        \
+    PPG_K(ppg_step_ord_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED, false)
 
 PPG_DEFINE_KERNELS(1)
 PPG_DEFINE_KERNELS(2)
@@ -19,13 +28,16 @@ PPG_DEFINE_KERNELS(4)
 
 typedef void (*ppg_kernel_fn)(const ppg::KParams);
 
-static ppg_kernel_fn pick_kernel(int nq, int mode) {
-    static const ppg_kernel_fn table[3][4] = {
-        {ppg_step_q1, ppg_reset_q1, ppg_observe_q1, ppg_grid_q1},
-        {ppg_step_q2, ppg_reset_q2, ppg_observe_q2, ppg_grid_q2},
-        {ppg_step_q4, ppg_reset_q4, ppg_observe_q4, ppg_grid_q4},
+static ppg_kernel_fn pick_kernel(int nq, int mode, bool fast) {
+    static const ppg_kernel_fn table[2][3][5] = {
+        {{ppg_step_q1g, ppg_reset_q1g, ppg_observe_q1g, ppg_grid_q1g, ppg_step_ord_q1g},
+         {ppg_step_q2g, ppg_reset_q2g, ppg_observe_q2g, ppg_grid_q2g, ppg_step_ord_q2g},
+         {ppg_step_q4g, ppg_reset_q4g, ppg_observe_q4g, ppg_grid_q4g, ppg_step_ord_q4g}},
+        {{ppg_step_q1, ppg_reset_q1, ppg_observe_q1, ppg_grid_q1, ppg_step_ord_q1},
+         {ppg_step_q2, ppg_reset_q2, ppg_observe_q2, ppg_grid_q2, ppg_step_ord_q2},
+         {ppg_step_q4, ppg_reset_q4, ppg_observe_q4, ppg_grid_q4, ppg_step_ord_q4}},
     };
-    return table[nq == 1 ? 0 : nq == 2 ? 1 : 2][mode];
+    return table[fast ? 1 : 0][nq == 1 ? 0 : nq == 2 ? 1 : 2][mode];
 }
 
 #define PPG_HIP_TRY(h, call)                                                                   \
@@ -55,7 +67,7 @@ static void backend_release(ppg_handle *h) {
 
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream) {
     // one workgroup = one wavefront = one environment
-    hipLaunchKernelGGL(pick_kernel(h->nq, mode), dim3((unsigned)h->batch), dim3(64), (size_t)P.lds_bytes,
+    hipLaunchKernelGGL(pick_kernel(h->nq, mode, P.nch_p <= 2 && P.nch_q <= 3), dim3((unsigned)h->batch), dim3(64), (size_t)P.lds_bytes,
                        (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());
     return PPG_OK;

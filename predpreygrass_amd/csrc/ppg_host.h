@@ -203,6 +203,16 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
     return backend_launch(h, ppg::MODE_STEP, P, stream);
 }
 
+int ppg_step_ordered(ppg_handle *h, const int8_t *actions, const uint8_t *act_rank, uint32_t flags, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!actions) return ppg_fail(h, PPG_EINVAL, "actions is NULL");
+    if (flags & ~PPG_STEP_AUTO_RESET) return ppg_fail(h, PPG_EINVAL, "ppg_step_ordered takes only PPG_STEP_AUTO_RESET");
+    ppg::KParams P = h->base;
+    const int mode = act_rank ? ppg::MODE_STEP_ORDERED : ppg::MODE_STEP;
+    P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev;
+    return backend_launch(h, mode, P, stream);
+}
+
 int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream) {
     if (!h) return PPG_EINVAL;
     if (!grid_out) return ppg_fail(h, PPG_EINVAL, "grid_out is NULL");

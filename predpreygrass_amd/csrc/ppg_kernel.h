@@ -40,7 +40,7 @@
 
 namespace ppg {
 
-enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3 };
+enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3, MODE_STEP_ORDERED = 4 };
 
 // event bits of a row during one call
 enum { EV_STARVED = 1, EV_CAUGHT = 2, EV_ATE = 4, EV_PARENT = 8, EV_BORN = 16, EV_TRUNC = 32 };
@@ -84,6 +84,7 @@ struct KParams {
     const uint32_t *obs_lut;  // library-owned, (nch_p + nch_q) * 128 words
     // per-launch
     const int8_t *actions;
+    const uint8_t *act_rank;  // optional [B,S]: position of each row in its type's action sequence
     const uint64_t *seeds;
     double *grid_out;
     unsigned long long *prof;  // diagnostic build only
@@ -152,7 +153,11 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // one environment, one wavefront
 // ---------------------------------------------------------------------------------
 
-template <int NQ>
+// ORDERED: compile the explicit-action-order path (ppg_step_ordered).  It indexes row registers with
+// run-time values, which costs registers and scratch, so it lives in its own kernel variant.
+// FASTOBS: observation descriptors of this lane live in registers (needs <= 2 predator and <= 3 prey
+// chunks, i.e. Rp <= 7 and Rq <= 9); otherwise they are read from an LDS copy.
+template <int NQ, bool ORDERED, bool FASTOBS>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
@@ -174,6 +179,8 @@ struct Env {
     int32_t act[T];
     uint32_t ev[T];
     uint32_t keep[T];  // row flags that survive a truncation call (ATE)
+    uint32_t rank[T];  // explicit action order (only when P.act_rank is given)
+    uint32_t lutr[10]; // FASTOBS: this lane's descriptors, predator chunks 0-1 then prey chunks 0-2, two words each
 
     // wave-uniform state
     uint64_t rows[T], alive[T], owns[T];
@@ -232,9 +239,57 @@ struct Env {
     }
 
     // ---- load ----------------------------------------------------------------------
-    PPG_MEMBER void load_env_words() {
+    // Every global load that does not depend on another load is issued first, back to back, so the
+    // wave pays ONE memory round trip: env words, seed, the first two row registers (speculatively:
+    // rows beyond n_rows are valid memory holding stale data and are masked out), the first 128 grass
+    // patches and the observation descriptor table.
+    struct Pre {
+        uint32_t w_env;
+        uint64_t sd;
+        uint32_t xy[T], key[T], fl[T];
+        int32_t id[T], a[T];
+        double e[T], cum[T];
+        uint32_t gxy[2];
+        double ge[2];
+        uint2 lutd[5];
+    };
+
+    PPG_MEMBER void prefetch(Pre &p, bool want_rows, bool want_actions) {
         const int32_t *es = P.env_state + (size_t)b * PPG_ENV_WORDS;
-        uint32_t w = ln < PPG_ENV_WORDS ? (uint32_t)es[ln] : 0u;
+        p.w_env = ln < PPG_ENV_WORDS ? (uint32_t)es[ln] : 0u;
+        p.sd = P.env_seed[b];
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            p.xy[r] = 0xFFFFu; p.key[r] = 0; p.fl[r] = 0; p.id[r] = 0; p.a[r] = -1; p.e[r] = 0.0; p.cum[r] = 0.0;
+            if (r < 2 && want_rows) {
+                const size_t s = (size_t)b * P.S + slot_of(r, ln);
+                p.xy[r] = P.row_xy[s];
+                p.e[r] = P.row_e[s];
+                p.id[r] = P.row_id[s];
+                p.key[r] = P.row_key[s];
+                p.cum[r] = P.row_cum[s];
+                p.fl[r] = P.row_flags[s];
+                if (want_actions) p.a[r] = P.actions[s];
+            }
+        }
+        const size_t gb = (size_t)b * P.cap_grass;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pp = ln + 64 * q;
+            p.gxy[q] = 0; p.ge[q] = 0.0;
+            if (want_rows && pp < P.n_grass) { p.gxy[q] = P.grass_xy[gb + pp]; p.ge[q] = P.grass_e[gb + pp]; }
+        }
+        if (FASTOBS) {  // this lane's observation descriptors (row-independent), kept in registers
+            const uint2 *L2 = (const uint2 *)P.obs_lut;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { p.lutd[c].x = 0; p.lutd[c].y = 0; if (c < P.nch_p) p.lutd[c] = L2[c * 64 + ln]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p.lutd[2 + c].x = 0; p.lutd[2 + c].y = 0; if (c < P.nch_q) p.lutd[2 + c] = L2[(P.nch_p + c) * 64 + ln]; }
+        }
+    }
+
+    PPG_MEMBER void load_env_words(const Pre &p) {
+        const uint32_t w = p.w_env;
         n_rows[0] = (int)wv::readlane(w, PPG_ENV_N_PRED_ROWS);
         n_rows[1] = (int)wv::readlane(w, PPG_ENV_N_PREY_ROWS);
         next_id[0] = (int)wv::readlane(w, PPG_ENV_NEXT_PRED_ID);
@@ -247,25 +302,30 @@ struct Env {
         calls = (int)wv::readlane(w, PPG_ENV_CALLS);
         obs_count[0] = (int)wv::readlane(w, PPG_ENV_OBS_PRED);
         obs_count[1] = (int)wv::readlane(w, PPG_ENV_OBS_PREY);
-        uint64_t sd = P.env_seed[b];
-        seed = ((uint64_t)wv::first((uint32_t)(sd >> 32)) << 32) | wv::first((uint32_t)sd);
+        seed = ((uint64_t)wv::first((uint32_t)(p.sd >> 32)) << 32) | wv::first((uint32_t)p.sd);
     }
 
-    PPG_MEMBER void load_rows() {
+    PPG_MEMBER void load_rows(const Pre &p) {
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);
             const bool valid = i < n_rows[type_of(r)];
-            const size_t s = (size_t)b * P.S + slot_of(r, ln);
             uint32_t fl = 0;
             xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; cum[r] = 0.0; act[r] = -1; ev[r] = 0;
             if (valid) {
-                xy[r] = P.row_xy[s];
-                e[r] = P.row_e[s];
-                id[r] = P.row_id[s];
-                key[r] = P.row_key[s];
-                cum[r] = P.row_cum[s];
-                fl = P.row_flags[s];
+                if (r < 2) {
+                    xy[r] = p.xy[r]; e[r] = p.e[r]; id[r] = p.id[r]; key[r] = p.key[r]; cum[r] = p.cum[r];
+                    fl = p.fl[r]; act[r] = p.a[r];
+                } else {  // rows 64.. of the prey table: rarely in use, loaded on demand
+                    const size_t s = (size_t)b * P.S + slot_of(r, ln);
+                    xy[r] = P.row_xy[s];
+                    e[r] = P.row_e[s];
+                    id[r] = P.row_id[s];
+                    key[r] = P.row_key[s];
+                    cum[r] = P.row_cum[s];
+                    fl = P.row_flags[s];
+                    if (P.actions) act[r] = P.actions[s];
+                }
             }
             keep[r] = fl & PPG_ROW_ATE;
             rows[r] = wv::ballot(valid);
@@ -278,25 +338,43 @@ struct Env {
     }
 
     // maps -> all zero, observation descriptors -> LDS
-    PPG_MEMBER void init_lds() {
+    PPG_MEMBER void init_lds(const Pre &p) {
         uint32_t *m32 = (uint32_t *)map;
         const int n32 = 4 * P.map_n / 2;
         for (int i = ln; i < n32; i += 64) m32[i] = 0u;
-        for (int i = ln; i < (P.nch_p + P.nch_q) * 128; i += 64) lut[i] = P.obs_lut[i];
+        if (FASTOBS) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { lutr[2 * c] = p.lutd[c].x; lutr[2 * c + 1] = p.lutd[c].y; }
+        } else {
+            for (int i = ln; i < (P.nch_p + P.nch_q) * 128; i += 64) lut[i] = P.obs_lut[i];
+        }
         if (ln == 0) val[0] = 0.0;
     }
 
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
-    PPG_MEMBER void load_grass(bool regrow) {
+    PPG_MEMBER void load_grass(bool regrow, const Pre &p) {
         const size_t gb = (size_t)b * P.cap_grass;
-        for (int p = ln; p < P.n_grass; p += 64) {
-            double g = P.grass_e[gb + p];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pp = ln + 64 * q;
+            if (pp < P.n_grass) {
+                double g = p.ge[q];
+                if (regrow) {
+                    double v = g + P.gain_g;
+                    g = (P.e0_g < v) ? P.e0_g : v;  // Python min(v, cap)
+                }
+                val[grass_validx(pp)] = g;
+                chmap(3)[cell_of(p.gxy[q])] = (uint16_t)grass_validx(pp);
+            }
+        }
+        for (int pp = 128 + ln; pp < P.n_grass; pp += 64) {
+            double g = P.grass_e[gb + pp];
             if (regrow) {
                 double v = g + P.gain_g;
-                g = (P.e0_g < v) ? P.e0_g : v;  // Python min(v, cap)
+                g = (P.e0_g < v) ? P.e0_g : v;
             }
-            val[grass_validx(p)] = g;
-            chmap(3)[cell_of(P.grass_xy[gb + p])] = (uint16_t)grass_validx(p);
+            val[grass_validx(pp)] = g;
+            chmap(3)[cell_of(P.grass_xy[gb + pp])] = (uint16_t)grass_validx(pp);
         }
     }
 
@@ -315,8 +393,7 @@ struct Env {
         } else {
 #pragma unroll
             for (int r = 0; r < T; ++r) {
-                int a = -1;
-                if ((alive[r] >> ln) & 1ull) a = P.actions[(size_t)b * P.S + slot_of(r, ln)];
+                int a = ((alive[r] >> ln) & 1ull) ? act[r] : -1;  // fetched with the rows
                 if (a < -1 || a > 8) { bad = true; a = -1; }
                 act[r] = a;
             }
@@ -324,6 +401,46 @@ struct Env {
         if (wv::ballot(bad)) status |= PPG_STATUS_BAD_ACTION;
 #pragma unroll
         for (int r = 0; r < T; ++r) acted[r] = alive[r] & wv::ballot(act[r] >= 0);
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            rank[r] = 0;
+            if (ORDERED && P.act_rank && ((acted[r] >> ln) & 1ull)) rank[r] = P.act_rank[(size_t)b * P.S + slot_of(r, ln)];
+        }
+    }
+
+    // Explicit action order (a dict whose order differs from the previous observation dict): rows of
+    // `type` that act, as (register, lane) pairs in action order, through the LDS scratch.
+    PPG_MEMBER int publish_order(int type, const uint64_t (&acted)[T]) {
+        uint16_t *ord = (uint16_t *)scr + (type ? 64 : 0);
+        int n = 0;
+        wv::sync();
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            if (type_of(r) != type) continue;
+            if ((acted[r] >> ln) & 1ull) ord[rank[r]] = (uint16_t)row_of(r, ln);
+            n += wv::popc(acted[r]);
+        }
+        wv::sync();
+        return n;
+    }
+    PPG_MEMBER void ordered_row(int type, int i, int &r, int &k) const {
+        const uint16_t *ord = (const uint16_t *)scr + (type ? 64 : 0);
+        const int row = (int)wv::first((uint32_t)ord[i]);
+        r = type ? 1 + (row >> 6) : 0;
+        k = row & 63;
+    }
+    // xy of row (r,k) where r may be a run-time (wave-uniform) register index
+    PPG_MEMBER uint32_t xy_at(int r, int k) const {
+        uint32_t v = xy[0];
+#pragma unroll
+        for (int q = 1; q < T; ++q) v = (q == r) ? xy[q] : v;
+        return wv::readlane(v, k);
+    }
+    PPG_MEMBER int act_at(int r, int k) const {
+        uint32_t v = (uint32_t)act[0];
+#pragma unroll
+        for (int q = 1; q < T; ++q) v = (q == r) ? (uint32_t)act[q] : v;
+        return (int)wv::readlane(v, k);
     }
 
     // ---- step 1: decay (BASE:244-250) ----------------------------------------------
@@ -350,70 +467,181 @@ struct Env {
         for (int r = 0; r < T; ++r)
             if ((acted[r] >> ln) & 1ull) e[r] -= (r ? P.loss_q : P.loss_p);
 
-        // grid[type, pos] = energy, in action (= row) order
+        // grid[type, pos] = energy, in action order
 #pragma unroll
-        for (int r = 0; r < T; ++r) {
-            if (!cooc[type_of(r)]) {
-                owns[r] |= acted[r];  // one live agent per cell: every acting agent now owns its cell
+        for (int type = 0; type < 2; ++type) {
+            if (!cooc[type]) {
+#pragma unroll
+                for (int r = 0; r < T; ++r)
+                    if (type_of(r) == type) owns[r] |= acted[r];  // one live agent per cell: each acting agent owns its cell
+            } else if (ORDERED && P.act_rank) {
+                const int n = publish_order(type, acted);
+                for (int i = 0; i < n; ++i) {
+                    int r, k;
+                    ordered_row(type, i, r, k);
+                    grid_set(r, k, xy_at(r, k), 0.0, false);
+                }
             } else {
-                uint64_t m = acted[r];
-                while (m) {
-                    const int k = wv::ctz(m);
-                    m &= m - 1;
-                    grid_set(r, k, wv::readlane(xy[r], k), 0.0, false);
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    uint64_t m = acted[r];
+                    while (m) {
+                        const int k = wv::ctz(m);
+                        m &= m - 1;
+                        grid_set(r, k, wv::readlane(xy[r], k), 0.0, false);
+                    }
                 }
             }
         }
     }
 
     // ---- step 2: movement in action order (BASE:259-276, _get_move BASE:495-509) ------
+    // One agent: row (r,k); r may be a run-time register index (explicit-order path) -- with a
+    // compile-time r every (q == r) below folds away.
+    PPG_MEMBER void move_agent(int r, int k, const uint64_t (&pos)[T]) {
+        const int type = type_of(r);
+        const int G1 = P.G - 1;
+        const uint32_t s_xy = xy_at(r, k);
+        const int a = act_at(r, k);
+        const int ax = (a * 11) >> 5;  // a / 3 for 0..8
+        int tx = (int)(s_xy >> 8) + ax - 1, ty = (int)(s_xy & 255u) + (a - 3 * ax) - 1;
+        tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);  // np.clip, BASE:505
+        ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
+        const uint32_t t_xy = ((uint32_t)tx << 8) | (uint32_t)ty;
+        uint64_t mt[T], mo[T];
+        match(type, t_xy, mt);
+        uint64_t occ = 0;  // grid[type, target] > 0 (BASE:506): an owner with positive energy sits there
+#pragma unroll
+        for (int q = 0; q < T; ++q) occ |= mt[q] & owns[q] & pos[q];
+        if (t_xy == s_xy) {
+#pragma unroll
+            for (int q = 0; q < T; ++q) mo[q] = mt[q];
+        } else {
+            match(type, s_xy, mo);
+        }
+        // grid[old] = 0 (BASE:268/272)
+#pragma unroll
+        for (int q = 0; q < T; ++q) owns[q] &= ~mo[q];
+        uint64_t others = 0;
+        if (occ) {  // stay (BASE:506-507): grid[old] = energy
+#pragma unroll
+            for (int q = 0; q < T; ++q) others |= mo[q] & ~((q == r) ? bit64(k) : 0ull);
+        } else {    // move: grid[new] = energy (BASE:269/273)
+#pragma unroll
+            for (int q = 0; q < T; ++q) {
+                xy[q] = (q == r) ? wv::writelane(xy[q], k, t_xy) : xy[q];
+                owns[q] &= ~mt[q];
+                others |= mt[q] & ~((q == r) ? bit64(k) : 0ull);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < T; ++q) owns[q] |= (q == r) ? bit64(k) : 0ull;
+        if (others) cooc[type] = true;
+    }
+
     PPG_MEMBER void move(const uint64_t (&acted)[T]) {
         uint64_t pos[T];  // grid value > 0 requires the owner's energy > 0 (BASE:506)
 #pragma unroll
         for (int r = 0; r < T; ++r) pos[r] = wv::ballot(e[r] > 0.0) & alive[r];
-        const int G1 = P.G - 1;
+        if (ORDERED && P.act_rank) {
 #pragma unroll
-        for (int r = 0; r < T; ++r) {
-            const int type = type_of(r);
-            uint64_t m = acted[r];
-            while (m) {
-                const int k = wv::ctz(m);
-                m &= m - 1;
-                const uint32_t s_xy = wv::readlane(xy[r], k);
-                const int a = (int)wv::readlane((uint32_t)act[r], k);
-                const int ax = (a * 11) >> 5;  // a / 3 for 0..8
-                int tx = (int)(s_xy >> 8) + ax - 1, ty = (int)(s_xy & 255u) + (a - 3 * ax) - 1;
-                tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);  // np.clip, BASE:505
-                ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
-                const uint32_t t_xy = ((uint32_t)tx << 8) | (uint32_t)ty;
-                uint64_t mt[T], mo[T];
-                match(type, t_xy, mt);
-                uint64_t occ = 0;
-#pragma unroll
-                for (int q = 0; q < T; ++q) occ |= mt[q] & owns[q] & pos[q];
-                if (t_xy == s_xy) {
-#pragma unroll
-                    for (int q = 0; q < T; ++q) mo[q] = mt[q];
-                } else {
-                    match(type, s_xy, mo);
+            for (int type = 0; type < 2; ++type) {
+                const int n = publish_order(type, acted);
+                for (int i = 0; i < n; ++i) {
+                    int r, k;
+                    ordered_row(type, i, r, k);
+                    move_agent(r, k, pos);
                 }
-                // grid[old] = 0 (BASE:268/272)
+            }
+            return;
+        }
+        // An agent whose old cell and target cell are touched by no other agent of its type commutes
+        // with all others: its move cannot be blocked (an empty target cell holds 0, see the header)
+        // and nobody reads or writes its cells.  Those agents move lane-parallel; only agents that
+        // share a cell with someone (contested target, target occupied, someone entering my cell)
+        // go through the ordered loop.  Cells are claimed on the (all-zero) channel maps.
 #pragma unroll
-                for (int q = 0; q < T; ++q) owns[q] &= ~mo[q];
-                uint64_t others = 0;
-                if (occ) {  // stay (BASE:506-507): grid[old] = energy
+        for (int type = 0; type < 2; ++type) {
+            uint64_t todo[T];
 #pragma unroll
-                    for (int q = 0; q < T; ++q) others |= mo[q] & ~((q == r) ? bit64(k) : 0ull);
-                } else {    // move: grid[new] = energy (BASE:269/273)
-                    xy[r] = wv::writelane(xy[r], k, t_xy);
+            for (int r = 0; r < T; ++r) todo[r] = (type_of(r) == type) ? acted[r] : 0ull;
+            if (!cooc[type]) {
+                uint16_t *A = chmap(1 + type), *F = chmap(0);
+                const int G1 = P.G - 1;
+                uint32_t t_xy[T], rd[T];
+                bool mover[T];
 #pragma unroll
-                    for (int q = 0; q < T; ++q) {
-                        owns[q] &= ~mt[q];
-                        others |= mt[q] & ~((q == r) ? bit64(k) : 0ull);
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    const int a = act[r] < 0 ? 4 : act[r];
+                    const int ax = (a * 11) >> 5;
+                    int tx = (int)(xy[r] >> 8) + ax - 1, ty = (int)(xy[r] & 255u) + (a - 3 * ax) - 1;
+                    tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);
+                    ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
+                    t_xy[r] = ((uint32_t)tx << 8) | (uint32_t)ty;
+                    mover[r] = ((acted[r] >> ln) & 1ull) && t_xy[r] != xy[r];
+                    rd[r] = 0;
+                    if ((alive[r] >> ln) & 1ull) A[cell_of(xy[r])] = (uint16_t)validx(r, ln);  // sitters
+                }
+                wv::sync();
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    if (mover[r]) {
+                        rd[r] = A[cell_of(t_xy[r])];
+                        if (rd[r] != 0u) F[cell_of(t_xy[r])] = 1;  // somebody sits on my target
                     }
                 }
-                owns[r] |= bit64(k);
-                if (others) cooc[type] = true;
+                wv::sync();
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    if (mover[r] && rd[r] == 0u) A[cell_of(t_xy[r])] = (uint16_t)validx(r, ln);  // claim
+                }
+                wv::sync();
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    if (mover[r] && rd[r] == 0u && A[cell_of(t_xy[r])] != (uint16_t)validx(r, ln))
+                        F[cell_of(t_xy[r])] = 1;  // contested target
+                }
+                wv::sync();
+                uint64_t cx[T];
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    cx[r] = 0;
+                    if (type_of(r) != type) continue;
+                    bool c = false;
+                    if ((alive[r] >> ln) & 1ull) c = F[cell_of(xy[r])] != 0 || (mover[r] && F[cell_of(t_xy[r])] != 0);
+                    cx[r] = wv::ballot(c) & acted[r];
+                }
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    if ((alive[r] >> ln) & 1ull) {
+                        A[cell_of(xy[r])] = 0; F[cell_of(xy[r])] = 0;
+                        if (mover[r]) { A[cell_of(t_xy[r])] = 0; F[cell_of(t_xy[r])] = 0; }
+                    }
+                }
+                wv::sync();
+#pragma unroll
+                for (int r = 0; r < T; ++r) {
+                    if (type_of(r) != type) continue;
+                    const uint64_t simple = acted[r] & ~cx[r];
+                    if ((simple >> ln) & 1ull) xy[r] = t_xy[r];   // BASE:263
+                    owns[r] |= simple;                            // grid[new] = energy, BASE:269/273
+                    todo[r] = cx[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                uint64_t m = todo[r];
+                while (m) {
+                    const int k = wv::ctz(m);
+                    m &= m - 1;
+                    move_agent(r, k, pos);
+                }
             }
         }
     }
@@ -551,7 +779,71 @@ struct Env {
     //               bit 26 element exists (e < 4*R*R),  bit 27 inside the (2*off+1)^2 window.
     // A row whose window lies inside the grid takes the branch-uniform fast path: value =
     // val[map[moff + cell]], no bounds checks (channel 0 reads the all-zero map 0).
+    // FASTOBS version: descriptors in registers, all map reads issued together, then all value reads,
+    // then the stores -- two LDS latencies per row.
+    template <int TYPE>
+    PPG_MEMBER void obs_row_fast(int j, uint32_t s_xy) {
+        constexpr int NCH = TYPE ? 3 : 2;
+        constexpr int BASE = TYPE ? 4 : 0;
+        wv::sync();
+        const int R = TYPE ? P.Rq : P.Rp;
+        const int blk = 4 * R * R;
+        const int off = (R - 1) / 2;
+        const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
+        const int s_cell = x * P.G + y;
+        const bool interior = (R & 1) && x >= off && y >= off && x + off < P.G && y + off < P.G;
+        const size_t obase = ((size_t)b * (TYPE ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)blk;
+        uint32_t idx[NCH][2];
+        bool one[NCH][2];
+        double v[NCH][2];
+        if (interior) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t w = lutr[BASE + 2 * c + h];
+                    idx[c][h] = map[(int)(int16_t)(w & 0xFFFFu) + s_cell];
+                    one[c][h] = false;
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t w = lutr[BASE + 2 * c + h];
+                    const int gx = x + (int)((w >> 16) & 15u) - 8, gy = y + (int)((w >> 20) & 15u) - 8;
+                    const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+                    idx[c][h] = map[inb ? (int)(int16_t)(w & 0xFFFFu) + s_cell : 0];
+                    one[c][h] = !inb && (w & 0x3000000u) == 0u;  // channel 0 outside the grid (BASE:522-523)
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[c][h] = val[idx[c][h]];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (lutr[BASE + 2 * c] & 0x4000000u) {
+                const double v0 = one[c][0] ? 1.0 : v[c][0], v1 = one[c][1] ? 1.0 : v[c][1];
+                const size_t o = obase + (size_t)c * 128 + 2 * (size_t)ln;
+                if (P.obs_f32) {
+                    float2 f; f.x = (float)v0; f.y = (float)v1;
+                    *(float2 *)((float *)(TYPE ? P.obs_prey : P.obs_pred) + o) = f;
+                } else {
+                    double2 g; g.x = v0; g.y = v1;
+                    *(double2 *)((double *)(TYPE ? P.obs_prey : P.obs_pred) + o) = g;
+                }
+            }
+        }
+        wv::sync();
+    }
+
     PPG_MEMBER void obs_row(int type, int j, uint32_t s_xy) {
+        if (FASTOBS) {
+            if (type) obs_row_fast<1>(j, s_xy);
+            else obs_row_fast<0>(j, s_xy);
+            return;
+        }
         wv::sync();  // LDS writes of the sequential phases -> visible
         const int R = type ? P.Rq : P.Rp;
         const int blk = 4 * R * R;
@@ -971,20 +1263,22 @@ struct Env {
     // ---- the transition ----------------------------------------------------------------
     PPG_MEMBER void run_step() {
         PPG_STAMP(0);
-        load_env_words();
+        Pre pre;
+        prefetch(pre, true, P.actions != nullptr && !(P.flags & PPG_STEP_RANDOM_ACTIONS));
+        load_env_words(pre);
         calls += 1;
-        init_lds();
+        init_lds(pre);
         if ((P.flags & PPG_STEP_AUTO_RESET) && (envflags & PPG_ENVF_DONE)) {
             wv::sync();
             do_reset(episode + 1u);
             return;
         }
-        load_rows();
+        load_rows(pre);
         const bool list_is_row_order = (envflags & PPG_ENVF_LIST_IS_ROW_ORDER) != 0;
 
         if (step >= P.max_steps) {  // truncation, BASE:228-238: no state change
             wv::sync();
-            load_grass(false);
+            load_grass(false, pre);
             compact_and_sort(!list_is_row_order);
             build_maps();
             obs_all_alive();
@@ -1004,7 +1298,7 @@ struct Env {
         PPG_STAMP(2);
         decay(acted);                              // BASE:244-250
         PPG_STAMP(3);
-        load_grass(true);                          // BASE:252-256
+        load_grass(true, pre);                     // BASE:252-256
         PPG_STAMP(4);
         move(acted);                               // BASE:259-276
         PPG_STAMP(5);
@@ -1030,8 +1324,10 @@ struct Env {
     }
 
     PPG_MEMBER void run_reset() {
-        load_env_words();
-        init_lds();
+        Pre pre;
+        prefetch(pre, false, false);
+        load_env_words(pre);
+        init_lds(pre);
         if (P.seeds) {
             uint64_t sd = P.seeds[b];
             seed = ((uint64_t)wv::first((uint32_t)(sd >> 32)) << 32) | wv::first((uint32_t)sd);
@@ -1044,21 +1340,25 @@ struct Env {
     }
 
     PPG_MEMBER void run_observe() {
-        load_env_words();
-        init_lds();
-        load_rows();
+        Pre pre;
+        prefetch(pre, true, false);
+        load_env_words(pre);
+        init_lds(pre);
+        load_rows(pre);
         wv::sync();
-        load_grass(false);
+        load_grass(false, pre);
         build_maps();
         obs_all_alive();
     }
 
     PPG_MEMBER void run_export_grid() {
-        load_env_words();
-        init_lds();
-        load_rows();
+        Pre pre;
+        prefetch(pre, true, false);
+        load_env_words(pre);
+        init_lds(pre);
+        load_rows(pre);
         wv::sync();
-        load_grass(false);
+        load_grass(false, pre);
         build_maps();
         const int n = P.G * P.G;
         double *out = P.grid_out + (size_t)b * 4 * n;
@@ -1069,12 +1369,12 @@ struct Env {
     }
 };
 
-template <int NQ, int MODE>
+template <int NQ, int MODE, bool FASTOBS>
 PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     const int b = PPG_BLOCK_INDEX();
     if (b >= P.batch) return;
-    Env<NQ> env(P, b, lds);
-    if (MODE == MODE_STEP) env.run_step();
+    Env<NQ, MODE == MODE_STEP_ORDERED, FASTOBS> env(P, b, lds);
+    if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();
     else if (MODE == MODE_OBSERVE) env.run_observe();
     else env.run_export_grid();

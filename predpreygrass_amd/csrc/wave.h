@@ -13,7 +13,9 @@
 
 #define PPG_DEVICE __device__ __forceinline__
 #define PPG_MEMBER __device__ __forceinline__
-#define PPG_KERNEL(name) extern "C" __global__ void __launch_bounds__(64) name
+// 64 threads = one wavefront per workgroup; W = waves per SIMD the register allocator must allow
+// (4 -> <= 128 VGPRs -> 16 waves per CU = 4096 co-resident envs per MI355X)
+#define PPG_KERNEL(name, W) extern "C" __global__ void __launch_bounds__(64, W) name
 #define PPG_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define PPG_BLOCK_INDEX() ((int)blockIdx.x)
 

@@ -1,0 +1,365 @@
+"""`PredPreyGrass(config)`: the reference's environment class on top of the HIP step kernel.
+
+Same constructor, methods, dict layouts, agent-id strings, dict ordering and error behaviour as
+predpreygrass/non_evolutionary/base_environment/predpreygrass_rllib_env.py in the reference
+(class PredPreyGrass, :17; reset :129; step :219; get_state_snapshot :768), so existing RLlib
+training / evaluation scripts (tune_ppo_base_environment.py:72-86, random_policy.py:14-47,
+evaluate_ppo_from_checkpoint_debug.py:99-302) can switch imports and run unchanged.
+
+This is the per-environment *view*: it owns a `BatchedPredPreyGrass` of batch 1 (or attaches to
+env index `index` of a shared batch) and converts the row tables into the reference's dicts.
+All transition logic runs on the GPU; there is no CPU implementation behind this class.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _abi
+from .batched import PREDATOR, PREY, BatchedPredPreyGrass, agent_name
+from .config import resolve_config
+
+try:  # the reference subclasses RLlib's MultiAgentEnv (predpreygrass_rllib_env.py:13,17)
+    from ray.rllib.env.multi_agent_env import MultiAgentEnv as _MultiAgentEnvBase  # type: ignore
+except Exception:  # ray is an optional dependency; same fallback idea as the reference's
+    # walls_occlusion/predpreygrass_rllib_env.py:20-38
+    class _MultiAgentEnvBase:  # minimal stand-in with the attributes RLlib reads
+        def __init__(self):
+            pass
+
+        def reset(self, *, seed=None, options=None):
+            return None
+
+        def close(self):
+            pass
+
+try:
+    import gymnasium as _gym  # type: ignore
+
+    def _box(shape):
+        return _gym.spaces.Box(low=0.0, high=100.0, shape=shape, dtype=np.float64)
+
+    def _discrete(n):
+        return _gym.spaces.Discrete(n)
+except Exception:
+    class _Box:  # predpreygrass_rllib_env.py:88-89
+        def __init__(self, low, high, shape, dtype):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.dtype(dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool((x >= self.low).all() and (x <= self.high).all())
+
+        def sample(self):
+            return np.random.uniform(self.low, self.high, self.shape).astype(self.dtype)
+
+    class _Discrete:  # predpreygrass_rllib_env.py:107
+        def __init__(self, n):
+            self.n = int(n)
+
+        def contains(self, x):
+            return 0 <= int(x) < self.n
+
+        def sample(self):
+            return int(np.random.randint(self.n))
+
+    def _box(shape):
+        return _Box(0.0, 100.0, shape, np.float64)
+
+    def _discrete(n):
+        return _Discrete(n)
+
+
+def _parse(name: str):
+    kind, idx = name.rsplit("_", 1)
+    if kind not in ("predator", "prey"):
+        raise KeyError(name)
+    return (PREDATOR if kind == "predator" else PREY), int(idx)
+
+
+class PredPreyGrass(_MultiAgentEnvBase):
+    def __init__(self, config=None, *, device=None, batched: BatchedPredPreyGrass | None = None, index: int = 0,
+                 _library=None):
+        super().__init__()
+        cfg = resolve_config(config)  # `config or config_env`, predpreygrass_rllib_env.py:20
+        self.config = cfg
+        for k, v in cfg.items():  # same attribute names as predpreygrass_rllib_env.py:22-61
+            setattr(self, k, v)
+        if batched is None:
+            need = max(128, (self.n_initial_active_prey + 63) // 64 * 64)
+            batched = BatchedPredPreyGrass(cfg, batch_size=1, device=device, prey_capacity=min(256, need),
+                                           _library=_library)
+            index = 0
+        self._b = batched
+        self._i = int(index)
+        self.possible_agents = [f"predator_{i}" for i in range(self.n_possible_predators)] + \
+                               [f"prey_{j}" for j in range(self.n_possible_prey)]
+        self.agents = [f"predator_{i}" for i in range(self.n_initial_active_predator)] + \
+                      [f"prey_{j}" for j in range(self.n_initial_active_prey)]
+        self.grass_agents = [f"grass_{k}" for k in range(self.initial_num_grass)]
+        pshape = (4, self.predator_obs_range, self.predator_obs_range)
+        qshape = (4, self.prey_obs_range, self.prey_obs_range)
+        self._pspace, self._qspace, self._aspace = _box(pshape), _box(qshape), _discrete(9)
+        self.observation_spaces = _SpaceDict(self._pspace, self._qspace, self)
+        self.action_spaces = _SpaceDict(self._aspace, self._aspace, self)
+        self.action_to_move_tuple = {a: (a // 3 - 1, a % 3 - 1) for a in range(9)}  # :96-106
+        self.num_actions = 9
+        self.grid_world_state_shape = (4, self.grid_size, self.grid_size)
+        self.cumulative_rewards = {}
+        self.agents_just_ate = set()
+        self.current_step = 0
+        self._records = []
+        self._insertion_order = []
+        self._tables = None
+
+    # ------------------------------------------------------------------
+    # reference API
+    def reset(self, *, seed=None, options=None):
+        """predpreygrass_rllib_env.py:129-217.  Placement is drawn on the device with Philox keyed by
+        `seed` (unique cells, predators / prey / grass disjoint, like the reference); pass
+        ``options={"placement": (pred_xy, prey_xy, grass_xy)}`` to start from given positions."""
+        placement = (options or {}).get("placement") if isinstance(options, dict) else None
+        b = self._b
+        if b.batch_size != 1:
+            raise RuntimeError("reset() of a view into a shared batch: reset the BatchedPredPreyGrass instead")
+        if placement is not None:
+            p, q, g = placement
+            b.set_placement(np.asarray(p)[None], np.asarray(q)[None], np.asarray(g)[None])
+        else:
+            b.reset(seed=0 if seed is None else int(seed))
+        self.cumulative_rewards = {}
+        self._insertion_order = []
+        obs = self._collect(after_reset=True)[0]
+        return obs, {}
+
+    def step(self, action_dict):
+        """predpreygrass_rllib_env.py:219-473."""
+        b, i = self._b, self._i
+        where = {name: (ty, row) for name, ty, row, _, te, _ in self._records if not te}
+        a = torch.full((b.S,), _abi.ACTION_NONE, dtype=torch.int8)
+        rk = torch.zeros((b.S,), dtype=torch.uint8)
+        last = {PREDATOR: -1, PREY: -1}
+        count = {PREDATOR: 0, PREY: 0}
+        in_row_order = True
+        truncated_call = self.current_step >= self.max_steps
+        for name, act in action_dict.items():
+            if name not in where:
+                if truncated_call:
+                    continue  # the reference returns before touching action_dict (:228-238)
+                raise KeyError(name)  # dead / unknown agent: predpreygrass_rllib_env.py:246/249
+            act = int(act)
+            if not 0 <= act <= 8:
+                raise KeyError(act)  # action_to_move_tuple[action], predpreygrass_rllib_env.py:502
+            ty, row = where[name]
+            s = row if ty == PREDATOR else b.pred_capacity + row
+            a[s] = act
+            rk[s] = count[ty]
+            count[ty] += 1
+            if row < last[ty]:
+                in_row_order = False
+            last[ty] = row
+        b.actions[i].copy_(a)
+        if in_row_order:
+            if b.batch_size == 1:
+                b.step()
+            else:
+                raise RuntimeError("step() of a view into a shared batch: step the BatchedPredPreyGrass instead")
+        else:
+            ranks = torch.zeros((b.batch_size, b.S), dtype=torch.uint8)
+            ranks[i] = rk
+            b.step(act_rank=ranks.to(b.device))
+        return self._collect(after_reset=False)
+
+    def close(self):
+        pass
+
+    # ------------------------------------------------------------------
+    def _collect(self, after_reset):
+        b, i = self._b, self._i
+        t = b.host_tables(i)
+        self._tables = t
+        es = t["env_state"][0]
+        status = int(es[_abi.ENV_STATUS])
+        if status & (_abi.STATUS_PRED_OVERFLOW | _abi.STATUS_PREY_OVERFLOW):
+            raise RuntimeError("agent row capacity exceeded: construct the env with a larger prey_capacity")
+        if status & _abi.STATUS_FAILED_SPAWN:
+            raise TypeError("no free cell for a newborn (the reference fails at predpreygrass_rllib_env.py:401-405)")
+        recs = b.records(0, t)
+        op = b.obs_pred[i].cpu().numpy()
+        oq = b.obs_prey[i].cpu().numpy()
+        obs, rew, term, trunc = {}, {}, {}, {}
+        for name, ty, row, r, te, tr in recs:
+            obs[name] = (op if ty == PREDATOR else oq)[row].astype(np.float64)
+            rew[name], term[name], trunc[name] = r, te, tr
+        fl = int(es[_abi.ENV_FLAGS])
+        was_trunc_call = bool(fl & _abi.ENVF_TRUNC_ALL)
+        self._records = recs
+        self.current_step = int(es[_abi.ENV_STEP])
+        self.current_num_predators = int(es[_abi.ENV_N_PRED_ALIVE])
+        self.current_num_prey = int(es[_abi.ENV_N_PREY_ALIVE])
+        self._next_predator_idx = int(es[_abi.ENV_NEXT_PRED_ID])
+        self._next_prey_idx = int(es[_abi.ENV_NEXT_PREY_ID])
+        cp = b.pred_capacity
+        for name, ty, row, *_ in recs:
+            s = row if ty == PREDATOR else cp + row
+            self.cumulative_rewards[name] = float(t["row_cumrew"][0][s])
+            if name not in self._insertion_order:
+                self._insertion_order.append(name)
+        self.agents_just_ate = {name for name, ty, row, *_ in recs
+                                if t["row_flags"][0][row if ty == PREDATOR else cp + row] & _abi.ROW_ATE}
+        names = [r[0] for r in recs]
+        # self.agents: reset leaves it in creation order (:143); every full step ends with .sort() (:468);
+        # the truncation call returns before the sort but the list is already sorted by then.
+        self.agents = names if (after_reset or (fl & _abi.ENVF_LIST_IS_ROW_ORDER)) else sorted(names)
+        self._pending_removal = [r[0] for r in recs if r[4]]
+        if after_reset:
+            return obs, {}
+        term["__all__"] = bool(fl & _abi.ENVF_TERM_ALL)
+        trunc["__all__"] = was_trunc_call
+        return obs, rew, term, trunc, {}
+
+    def _live(self):
+        b, t = self._b, self._tables
+        cp = b.pred_capacity
+        out = {}
+        for name, ty, row, _, te, _ in self._records:
+            if not te:
+                out[name] = row if ty == PREDATOR else cp + row
+        return out
+
+    # viewer-facing attributes (random_policy.py:32-39, evaluate_ppo_from_checkpoint_debug.py:190-197)
+    @property
+    def agent_positions(self):
+        live, t = self._live(), self._tables
+        order = [n for n in self._insertion_order if n in live]  # dict insertion order of the reference
+        return {n: (int(t["row_xy"][0][live[n]]) >> 8, int(t["row_xy"][0][live[n]]) & 255) for n in order}
+
+    @property
+    def agent_energies(self):
+        live, t = self._live(), self._tables
+        return {n: float(t["row_energy"][0][live[n]]) for n in self._insertion_order if n in live}
+
+    @property
+    def predator_positions(self):
+        return {k: v for k, v in self.agent_positions.items() if k.startswith("predator")}
+
+    @property
+    def prey_positions(self):
+        return {k: v for k, v in self.agent_positions.items() if k.startswith("prey")}
+
+    @property
+    def grass_positions(self):
+        t = self._tables
+        return {f"grass_{k}": (int(t["grass_xy"][0][k]) >> 8, int(t["grass_xy"][0][k]) & 255)
+                for k in range(self.initial_num_grass)}
+
+    @property
+    def grass_energies(self):
+        t = self._tables
+        return {f"grass_{k}": float(t["grass_energy"][0][k]) for k in range(self.initial_num_grass)}
+
+    @property
+    def grid_world_state(self):
+        return self._b.export_grid()[self._i].cpu().numpy()
+
+    def _get_observation(self, agent):
+        """predpreygrass_rllib_env.py:511-526 (called externally at evaluate_ppo_from_checkpoint_debug.py:182)."""
+        ty, _ = _parse(agent)
+        live = self._live()
+        if agent not in live:
+            raise KeyError(agent)
+        row = live[agent] if ty == PREDATOR else live[agent] - self._b.pred_capacity
+        self._b.observe()
+        t = self._b.obs_pred if ty == PREDATOR else self._b.obs_prey
+        return t[self._i, row].cpu().numpy().astype(np.float64)
+
+    # snapshot / restore (predpreygrass_rllib_env.py:768-804)
+    _STATE_TENSORS = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward",
+                      "env_state", "env_seed", "grass_xy", "grass_energy"]
+
+    def get_state_snapshot(self):
+        b, i = self._b, self._i
+        snap = {
+            "current_step": self.current_step,
+            "agent_positions": self.agent_positions,
+            "agent_energies": self.agent_energies,
+            "predator_positions": self.predator_positions,
+            "prey_positions": self.prey_positions,
+            "grass_positions": self.grass_positions,
+            "grass_energies": self.grass_energies,
+            "grid_world_state": self.grid_world_state,
+            "agents": list(self.agents),
+            "cumulative_rewards": dict(self.cumulative_rewards),
+            "current_num_predators": self.current_num_predators,
+            "current_num_prey": self.current_num_prey,
+            "agents_just_ate": set(self.agents_just_ate),
+            "pending_removal": list(self._pending_removal),
+            "next_predator_idx": self._next_predator_idx,
+            "next_prey_idx": self._next_prey_idx,
+            # device state of this implementation
+            "_device_state": {n: getattr(b, n)[i].cpu().clone() for n in self._STATE_TENSORS},
+            "_records": list(self._records),
+            "_insertion_order": list(self._insertion_order),
+        }
+        return snap
+
+    def restore_state_snapshot(self, snapshot):
+        b, i = self._b, self._i
+        for n, v in snapshot["_device_state"].items():
+            getattr(b, n)[i].copy_(v)
+        self.cumulative_rewards = dict(snapshot["cumulative_rewards"])
+        self._insertion_order = list(snapshot["_insertion_order"])
+        b.observe()
+        saved_agents = list(snapshot["agents"])
+        self._collect(after_reset=False)
+        self.agents = saved_agents
+        self.cumulative_rewards = dict(snapshot["cumulative_rewards"])
+
+
+class _SpaceDict(dict):
+    """observation_spaces / action_spaces keyed by every possible agent id
+    (predpreygrass_rllib_env.py:92-94,108) without materialising 4000 entries eagerly."""
+
+    def __init__(self, pred_space, prey_space, env):
+        super().__init__()
+        self._p, self._q, self._env = pred_space, prey_space, env
+
+    def __missing__(self, key):
+        ty, idx = _parse(key)
+        n = self._env.n_possible_predators if ty == PREDATOR else self._env.n_possible_prey
+        if not 0 <= idx < n:
+            raise KeyError(key)
+        return self._p if ty == PREDATOR else self._q
+
+    def __contains__(self, key):
+        try:
+            self.__missing__(key)
+            return True
+        except (KeyError, ValueError):
+            return False
+
+    def keys(self):
+        return list(self._env.possible_agents)
+
+    def __iter__(self):
+        return iter(self._env.possible_agents)
+
+    def __len__(self):
+        return len(self._env.possible_agents)
+
+    def items(self):
+        return [(k, self[k]) for k in self._env.possible_agents]
+
+    def values(self):
+        return [self[k] for k in self._env.possible_agents]
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+
+def env_creator(config):
+    """tune_ppo_base_environment.py:72-73 / random_policy.py:6-7 of the reference."""
+    return PredPreyGrass(config)

@@ -1,0 +1,144 @@
+"""PettingZoo-style façades over `PredPreyGrass`.
+
+The reference declares pettingzoo as a dependency but never imports it (its README points to a
+different repository for the PettingZoo version), so there is NO reference behaviour to pin these
+against: API shape only, parity unpinned.  They follow the PettingZoo 1.24
+conventions: `agents` lists the agents that are still acting, the per-agent dicts carry no
+"__all__" key, dead agents leave `agents` after the step that reports their termination.
+"""
+from __future__ import annotations
+
+from .env import PredPreyGrass
+
+try:
+    from pettingzoo import ParallelEnv as _ParallelBase  # type: ignore
+    from pettingzoo import AECEnv as _AECBase  # type: ignore
+except Exception:
+    class _ParallelBase:
+        pass
+
+    class _AECBase:
+        pass
+
+
+class PredPreyGrassParallelEnv(_ParallelBase):
+    metadata = {"name": "predpreygrass_amd_v0", "render_modes": []}
+
+    def __init__(self, config=None, **kw):
+        self._env = PredPreyGrass(config, **kw)
+        self.possible_agents = list(self._env.possible_agents)
+        self.agents = []
+
+    def observation_space(self, agent):
+        return self._env.observation_spaces[agent]
+
+    def action_space(self, agent):
+        return self._env.action_spaces[agent]
+
+    def reset(self, seed=None, options=None):
+        obs, _ = self._env.reset(seed=seed, options=options)
+        self.agents = list(obs)
+        return obs, {a: {} for a in obs}
+
+    def step(self, actions):
+        obs, rew, term, trunc, _ = self._env.step({a: actions[a] for a in self.agents if a in actions})
+        term = {k: v for k, v in term.items() if k != "__all__"}
+        trunc = {k: v for k, v in trunc.items() if k != "__all__"}
+        self.agents = [a for a in obs if not term[a] and not trunc[a]]
+        return obs, rew, term, trunc, {a: {} for a in obs}
+
+    def state(self):
+        return self._env.grid_world_state
+
+    def close(self):
+        self._env.close()
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+class PredPreyGrassAECEnv(_AECBase):
+    """Agent-environment-cycle view: actions are buffered per agent; the underlying parallel step
+    runs when the last live agent of the cycle has acted (PettingZoo's parallel_to_aec scheme)."""
+    metadata = {"name": "predpreygrass_amd_aec_v0", "render_modes": [], "is_parallelizable": True}
+
+    def __init__(self, config=None, **kw):
+        self._par = PredPreyGrassParallelEnv(config, **kw)
+        self.possible_agents = self._par.possible_agents
+        self.agents = []
+
+    def observation_space(self, agent):
+        return self._par.observation_space(agent)
+
+    def action_space(self, agent):
+        return self._par.action_space(agent)
+
+    def reset(self, seed=None, options=None):
+        obs, infos = self._par.reset(seed=seed, options=options)
+        self.agents = list(self._par.agents)
+        self._obs = dict(obs)
+        self.rewards = {a: 0.0 for a in self.agents}
+        self._cumulative_rewards = {a: 0.0 for a in self.agents}
+        self.terminations = {a: False for a in self.agents}
+        self.truncations = {a: False for a in self.agents}
+        self.infos = {a: {} for a in self.agents}
+        self._pending = {}
+        self._order = list(self.agents)
+        self._cursor = 0
+        self.agent_selection = self._order[0] if self._order else None
+
+    def observe(self, agent):
+        return self._obs[agent]
+
+    def last(self, observe=True):
+        a = self.agent_selection
+        return (self._obs[a] if observe else None, self._cumulative_rewards[a], self.terminations[a],
+                self.truncations[a], self.infos[a])
+
+    def agent_iter(self, max_iter=2 ** 63):
+        n = 0
+        while self.agents and n < max_iter:
+            yield self.agent_selection
+            n += 1
+
+    def step(self, action):
+        a = self.agent_selection
+        if self.terminations[a] or self.truncations[a]:
+            # dead-step: the agent is removed (PettingZoo's _was_dead_step); action must be None
+            self.agents.remove(a)
+            self._order = [x for x in self._order if x != a]
+            if self._cursor >= len(self._order):
+                self._cursor = 0
+            self.agent_selection = self._order[self._cursor] if self._order else None
+            return
+        self._cumulative_rewards[a] = 0.0
+        self._pending[a] = action
+        self._cursor += 1
+        live = [x for x in self._order if not (self.terminations[x] or self.truncations[x])]
+        if all(x in self._pending for x in live):
+            obs, rew, term, trunc, infos = self._par.step(self._pending)
+            self._pending = {}
+            for k in obs:
+                if k not in self.agents:
+                    self.agents.append(k)
+                self._obs[k] = obs[k]
+                self.rewards[k] = rew[k]
+                self._cumulative_rewards[k] = self._cumulative_rewards.get(k, 0.0) + rew[k]
+                self.terminations[k], self.truncations[k], self.infos[k] = term[k], trunc[k], infos[k]
+            self._order = list(obs)
+            self._cursor = 0
+        if self._cursor >= len(self._order):
+            self._cursor = 0
+        self.agent_selection = self._order[self._cursor] if self._order else None
+
+    def close(self):
+        self._par.close()
+
+
+def parallel_env(config=None, **kw):
+    return PredPreyGrassParallelEnv(config, **kw)
+
+
+def env(config=None, **kw):
+    return PredPreyGrassAECEnv(config, **kw)

@@ -26,22 +26,31 @@ struct EmuLaunch {
     int nq, mode;
 };
 
-template <int NQ>
+template <int NQ, bool FAST>
 static void run_mode(const ppg::KParams &P, int mode) {
     PPG_DYNAMIC_LDS(lds);
     switch (mode) {
-        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP>(P, lds); break;
-        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET>(P, lds); break;
-        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE>(P, lds); break;
-        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID>(P, lds); break;
+        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP, FAST>(P, lds); break;
+        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET, FAST>(P, lds); break;
+        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, FAST>(P, lds); break;
+        case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, FAST>(P, lds); break;
+        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, FAST>(P, lds); break;
     }
+}
+
+template <bool FAST>
+static void run_nq(const EmuLaunch *L) {
+    if (L->nq == 1) run_mode<1, FAST>(*L->P, L->mode);
+    else if (L->nq == 2) run_mode<2, FAST>(*L->P, L->mode);
+    else run_mode<4, FAST>(*L->P, L->mode);
 }
 
 static void lane_entry(void *arg) {
     const EmuLaunch *L = (const EmuLaunch *)arg;
-    if (L->nq == 1) run_mode<1>(*L->P, L->mode);
-    else if (L->nq == 2) run_mode<2>(*L->P, L->mode);
-    else run_mode<4>(*L->P, L->mode);
+    // same selection rule as the HIP backend; PPG_EMU_FORCE_GENERIC_OBS=1 exercises the LDS-descriptor path
+    static const bool force_generic = getenv("PPG_EMU_FORCE_GENERIC_OBS") != nullptr;
+    if (L->P->nch_p <= 2 && L->P->nch_q <= 3 && !force_generic) run_nq<true>(L);
+    else run_nq<false>(L);
 }
 
 static int backend_init(ppg_handle *h, int) {
