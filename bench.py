@@ -195,6 +195,15 @@ def main():
     # row tables r/w (27 B read, 35 B written per row) + grass table (8 B r/w, 2 B read) + env words
     min_bytes = n_obs_pred * 4 * Rp * Rp * osz + n_obs_prey * 4 * Rq * Rq * osz + \
         62 * (n_obs_pred + n_obs_prey) + env_steps_rank * (env.n_grass * 18 + 2 * 64 + 8)
+    # HBM bytes per launch from rocprofv3 PMC passes of this very command (FETCH_SIZE x2 + WRITE_SIZE,
+    # MI355X_MICROARCH.md HBM section); only quoted when the settings match the profiled run.
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "b_bench_default_summary.json")))
+        if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64:
+            traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
+    except Exception:
+        traffic = None
     kernel_s = dev_ms / 1e3 / args.steps          # per launch; n_sub launches are in flight concurrently
     achieved = alg_bytes / args.steps / kernel_s / 1e9   # all n_sub concurrent launches together
     value = n_gpus * env_steps_rank / wall
@@ -229,7 +238,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01/b_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                  "bytes per launch)" if traffic else None,
                 "kernel": "ppg_step_q2",
                 "kernel_ms": round(kernel_s * 1e3, 5),
                 "concurrent_launches": n_sub,

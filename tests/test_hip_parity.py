@@ -104,3 +104,54 @@ def test_full_size_4096_envs_properties_and_sampled_oracle():
             s = row if ty == 0 else env.pred_capacity + row
             if flags[b, s] & _abi.ROW_OWNS:
                 assert o[1 + ty, c, c] == en[b, s]
+
+
+def test_dict_api_on_gpu_including_shuffled_action_order():
+    """The reference-shaped class on the real device; dense_shuffled_seed17 drives the explicit-order
+    kernel variant (ppg_step_ordered)."""
+    from predpreygrass_amd.env import PredPreyGrass
+    from tests.test_env_api import replay_through_dict_api
+    mk = lambda cfg: PredPreyGrass(cfg, device="cuda:0")
+    replay_through_dict_api("c1_seed0", mk)
+    replay_through_dict_api("dense_shuffled_seed17", mk)
+    replay_through_dict_api("default_seed0", mk, max_calls=120)
+
+
+def test_sub_batches_on_streams_equal_one_batch():
+    """4096 envs as 3 sub-batches on 3 streams == one batch of 4096 (same seeds), state and observations."""
+    from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
+    cfg = dict(config_env)
+    B = 4096
+    one = make_env(cfg, B, seed=11)
+    one.reset()
+    grp = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=3, device="cuda:0", seed=11)
+    grp.reset()
+    for _ in range(150):
+        one.step(random_actions=True, auto_reset=True)
+        grp.step(random_actions=True, auto_reset=True)
+    grp.synchronize()
+    torch.cuda.synchronize()
+    for name in ("env_state", "row_xy", "row_energy", "row_flags", "grass_energy"):
+        cat = torch.cat([getattr(e, name) for e in grp.subs])
+        ref = getattr(one, name)
+        if name == "env_state":
+            assert torch.equal(cat[:, :13], ref[:, :13])
+        elif name.startswith("row"):
+            n = one.env_state[:, _abi.ENV_N_PRED_ROWS]
+            mask = torch.arange(one.S, device="cuda:0")[None, :] < n[:, None]   # predator rows in use
+            assert torch.equal(cat[mask], ref[mask]), name
+        else:
+            assert torch.equal(cat, ref), name
+    nq = one.env_state[:, _abi.ENV_N_PREY_ROWS]
+    mq = torch.arange(one.prey_capacity, device="cuda:0")[None, :] < nq[:, None]
+    assert torch.equal(torch.cat([e.obs_prey for e in grp.subs])[mq], one.obs_prey[mq])
+
+
+def test_full_size_64x64_config4_sampled_oracle():
+    """BASELINE config 4: 4096 envs x 64x64, 16 predators / 32 prey, obs 7x7 (LDS-tile stress)."""
+    cfg = {**config_env, **C4}
+    env = make_env(cfg, 4096)
+    assert env.lds_bytes < 64 * 1024
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=4242, n_calls=90, check_every=30, envs=list(range(0, 4096, 512)))
+    es = env.env_state.cpu().numpy()
+    assert (es[:, _abi.ENV_STATUS] & ~_abi.STATUS_FALLBACK_SPAWN == 0).all()
