@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=3,
                     help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="TEST ONLY: run the control flow on CPU (gloo, wave-emulator build of the kernel); numbers are meaningless")
     ap.add_argument("--gather-steps", type=int, default=50,
                     help="N>1 only: extra leg of this many steps with the RCCL observation all-gather after each step")
     args = ap.parse_args()
@@ -92,11 +94,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if distributed:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank if distributed else 0)
-    torch.cuda.set_device(device)
+    dry = args.dry_run_cpu
+    if dry:
+        from tests.emu_backend import library as _emu_library
+        if distributed:
+            dist.init_process_group("gloo")
+        device = torch.device("cpu")
+
+        class _NoEvent:
+            def __init__(self, **kw):
+                self.t = 0.0
+
+            def record(self, stream=None):
+                self.t = time.perf_counter()
+
+            def elapsed_time(self, other):
+                return (other.t - self.t) * 1e3
+
+        torch.cuda.synchronize = lambda *a, **k: None   # nothing asynchronous on the CPU path
+        torch.cuda.Event = _NoEvent
+    else:
+        if distributed:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        device = torch.device("cuda", local_rank if distributed else 0)
+        torch.cuda.set_device(device)
     n_gpus = world if distributed else 1
 
     cfg = dict(config_env)
@@ -105,7 +127,7 @@ def main():
     from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
     n_sub = max(1, args.streams)
     group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype,
-                                    seed=args.seed + rank * B)
+                                    seed=args.seed + rank * B, **({"_library": _emu_library()} if dry else {}))
     group.reset()
     group.synchronize()
     env = group.subs[0]
@@ -200,7 +222,7 @@ def main():
     traffic = None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "b_bench_default_summary.json")))
-        if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64:
+        if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry:
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
     except Exception:
         traffic = None
@@ -221,7 +243,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not dry else "DRY RUN ON CPU (emulated kernel) -- not a measurement",
             "config": {
                 "workload": f"{B} envs x {G}x{G} grid per GPU, default config (6 predators / 8 prey / 100 grass, "
                             f"obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), device-side uniform random actions, "
@@ -255,7 +277,7 @@ def main():
         }
         if gather_info is not None:
             out["obs_gather"] = gather_info
-        if not args.no_cpu_baseline and n_gpus == 1:
+        if not args.no_cpu_baseline and n_gpus == 1 and not dry:
             out["cpu_baseline"] = cpu_baseline(cfg, args.seed, seconds=args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if distributed:

@@ -177,6 +177,11 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
  * the acting agents OF ITS TYPE (0..n-1, a permutation).  NULL == row order (ppg_step). */
 int ppg_step_ordered(ppg_handle *h, const int8_t *actions, const uint8_t *act_rank, uint32_t flags, void *stream);
 
+/* ppg_step for n handles (sub-batches of one GPU's envs), handle k on streams[k], in one host call.
+ * actions may be NULL (with PPG_STEP_RANDOM_ACTIONS) or an array of n device pointers. */
+int ppg_step_many(ppg_handle *const *handles, int32_t n, const int8_t *const *actions, uint32_t flags,
+                  void *const *streams);
+
 /* grid_world_state (BASE:124): dense float64 [B,4,G,G] rebuilt from the rows. */
 int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream);
 

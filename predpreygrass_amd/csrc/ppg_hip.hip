@@ -67,6 +67,8 @@ static void backend_release(ppg_handle *h) {
 
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream) {
     // one workgroup = one wavefront = one environment
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(pick_kernel(h->nq, mode, P.nch_p <= 2 && P.nch_q <= 3), dim3((unsigned)h->batch), dim3(64), (size_t)P.lds_bytes,
                        (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());

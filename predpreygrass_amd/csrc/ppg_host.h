@@ -203,6 +203,16 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
     return backend_launch(h, ppg::MODE_STEP, P, stream);
 }
 
+int ppg_step_many(ppg_handle *const *handles, int32_t n, const int8_t *const *actions, uint32_t flags,
+                  void *const *streams) {
+    if (!handles || !streams || n < 1) return PPG_EINVAL;
+    for (int32_t k = 0; k < n; ++k) {
+        int rc = ppg_step(handles[k], actions ? actions[k] : nullptr, flags, streams[k]);
+        if (rc != PPG_OK) return rc;
+    }
+    return PPG_OK;
+}
+
 int ppg_step_ordered(ppg_handle *h, const int8_t *actions, const uint8_t *act_rank, uint32_t flags, void *stream) {
     if (!h) return PPG_EINVAL;
     if (!actions) return ppg_fail(h, PPG_EINVAL, "actions is NULL");

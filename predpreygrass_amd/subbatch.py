@@ -14,8 +14,11 @@ reading tensors from another stream.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
+from . import _abi
 from .batched import BatchedPredPreyGrass
 from .distributed import shard_range
 
@@ -27,25 +30,54 @@ class SubBatchedPredPreyGrass:
         self.offsets = [shard_range(self.batch_size, k, n_sub) for k in range(n_sub)]
         self.subs = [BatchedPredPreyGrass(config, batch_size=hi - lo, device=device, seed=seed + lo, **kw)
                      for lo, hi in self.offsets]
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.subs]
+        cuda = self.device.type == "cuda"   # (the CPU case exists only for the emulated-kernel tests)
+        self.streams = [torch.cuda.Stream(device=self.device) if cuda else None for _ in self.subs]
 
     def reset(self, seed=None):
         for k, (e, s) in enumerate(zip(self.subs, self.streams)):
+            sd = None if seed is None else seed + self.offsets[k][0]
+            if s is None:
+                e.reset(seed=sd)
+                continue
             s.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(s):
-                e.reset(seed=None if seed is None else seed + self.offsets[k][0])
+                e.reset(seed=sd)
         return self
 
     def step(self, actions=None, random_actions=False, auto_reset=False):
-        """One transition of every env; `actions` is a list of per-sub-batch int8 tensors (or None)."""
-        for k, (e, s) in enumerate(zip(self.subs, self.streams)):
-            e.step(None if actions is None else actions[k], random_actions=random_actions,
-                   auto_reset=auto_reset, stream=s)
+        """One transition of every env; `actions` is a list of per-sub-batch int8 tensors (or None ->
+        each sub-batch's own `.actions` tensor).  All sub-batches are launched by ONE C call
+        (ppg_step_many), sub-batch k on stream k."""
+        n = len(self.subs)
+        if self.streams[0] is None:   # CPU (emulated kernel, tests)
+            for k, e in enumerate(self.subs):
+                e.step(None if actions is None else actions[k], random_actions=random_actions, auto_reset=auto_reset)
+            return self
+        if not hasattr(self, "_c_handles"):
+            self._c_handles = (C.c_void_p * n)(*[e._handle for e in self.subs])
+            self._c_streams = (C.c_void_p * n)(*[s.cuda_stream for s in self.streams])
+            self._c_own_actions = (C.c_void_p * n)(*[e.actions.data_ptr() for e in self.subs])
+        flags = (_abi.STEP_RANDOM_ACTIONS if random_actions else 0) | (_abi.STEP_AUTO_RESET if auto_reset else 0)
+        if random_actions:
+            acts = None
+        elif actions is None:
+            acts = self._c_own_actions
+        else:
+            for k, a in enumerate(actions):
+                if a.dtype != torch.int8 or tuple(a.shape) != (self.subs[k].batch_size, self.subs[k].S) or \
+                        not a.is_contiguous() or a.device != self.subs[k].device:
+                    raise ValueError("actions[k] must be a contiguous int8 tensor [B_k, S] on the env's device")
+            acts = (C.c_void_p * n)(*[a.data_ptr() for a in actions])
+        lib = self.subs[0]._lib
+        rc = lib.ppg_step_many(self._c_handles, n, acts, flags, self._c_streams)
+        if rc != 0:
+            raise RuntimeError(f"ppg_step_many failed ({rc})")
         return self
 
     def synchronize(self):
         for s in self.streams:
-            s.synchronize()
+            if s is not None:
+                s.synchronize()
 
     def locate(self, b):
         for k, (lo, hi) in enumerate(self.offsets):

@@ -30,9 +30,11 @@ def build(sanitize=False):
     return out
 
 
-def library():
+def library(sanitize=False):
     global _lib
+    from predpreygrass_amd import _abi
+    if sanitize:  # UBSan build: traps (aborts the process) on signed overflow, bad shifts, misaligned access ...
+        return _abi.bind(ctypes.CDLL(build(sanitize=True)))
     if _lib is None:
-        from predpreygrass_amd import _abi
         _lib = _abi.bind(ctypes.CDLL(build()))
     return _lib

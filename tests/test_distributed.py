@@ -67,3 +67,41 @@ def test_shard_range_partitions_exactly():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _run_bench(args, nproc):
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200),
+               os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_process_dry_run():
+    """bench.py's control flow and JSON contract on CPU (emulated kernel; numbers meaningless)."""
+    d = _run_bench(["--dry-run-cpu", "--gpus", "1", "--steps", "6", "--warmup", "2", "--envs", "6", "--streams", "2"], 1)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_two_ranks_dry_run_with_gather_leg():
+    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver launches it (gloo on CPU):
+    barrier + max-over-ranks timing, rank-0 JSON, the obs_gather leg."""
+    d = _run_bench(["--dry-run-cpu", "--gpus", "2", "--steps", "5", "--warmup", "2", "--envs", "5", "--streams", "2",
+                    "--gather-steps", "3"], 2)
+    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 5
+    assert "obs_gather" in d and "error" not in d["obs_gather"], d.get("obs_gather")
+    assert d["obs_gather"]["steps"] == 3 and d["obs_gather"]["gathered_bytes_per_step_per_rank"] > 0

@@ -155,3 +155,11 @@ def test_full_size_64x64_config4_sampled_oracle():
     rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=4242, n_calls=90, check_every=30, envs=list(range(0, 4096, 512)))
     es = env.env_state.cpu().numpy()
     assert (es[:, _abi.ENV_STATUS] & ~_abi.STATUS_FALLBACK_SPAWN == 0).all()
+
+
+@pytest.mark.parametrize("seed", range(1000, 1030))
+def test_random_config_matches_oracle_on_gpu(seed):
+    """Random configurations x partial, shuffled action dicts (see tests/test_random_configs.py), on the device."""
+    from predpreygrass_amd.env import PredPreyGrass
+    from tests.test_random_configs import run_differential
+    run_differential(lambda cfg: PredPreyGrass(cfg, device="cuda:0"), seed)
