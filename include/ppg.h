@@ -124,6 +124,11 @@ typedef struct ppg_config {
     double initial_energy_prey;         /* BASE:50 */
     double initial_energy_grass;        /* BASE:60 (also the regrowth cap, BASE:254) */
     double energy_gain_per_step_grass;  /* BASE:61 */
+    /* seasonal grass regrowth (base_environment_seasonal/predpreygrass_rllib_env.py:63-66,224-234,268-271):
+     * gain x high for season_length_steps steps, x low for the next, repeating; <= 0 disables (base env) */
+    int32_t season_length_steps;
+    double season_high_multiplier;
+    double season_low_multiplier;
 } ppg_config;
 
 /* Caller-owned device buffers.  B = batch, S = pred_capacity + prey_capacity,

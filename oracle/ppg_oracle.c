@@ -517,9 +517,15 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
             *cell(e, 2, e->ent_x[k], e->ent_y[k]) = e->energy[t][id];
         }
     }
-    /* BASE:252-256 */
+    /* BASE:252-256; seasonal variant: base_environment_seasonal/predpreygrass_rllib_env.py:224-234,268-271
+     * (square wave on current_step; the product is rounded once, like the Python expression) */
+    double gain = c->energy_gain_per_step_grass;
+    if (c->season_length_steps > 0) {
+        int phase = (e->current_step / c->season_length_steps) % 2;
+        gain = c->energy_gain_per_step_grass * (phase == 0 ? c->season_high_multiplier : c->season_low_multiplier);
+    }
     for (int g = 0; g < e->n_grass; ++g) {
-        double v = e->grass_e[g] + c->energy_gain_per_step_grass;
+        double v = e->grass_e[g] + gain;
         /* Python min(a, b): b if b < a else a */
         e->grass_e[g] = (c->initial_energy_grass < v) ? c->initial_energy_grass : v;
         *cell(e, 3, e->grass_x[g], e->grass_y[g]) = e->grass_e[g];

@@ -69,7 +69,8 @@ _DBL_FIELDS = [
 
 
 class _Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS]
+    _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS] + [
+        ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double)]
 
 
 class _Record(C.Structure):
@@ -170,6 +171,10 @@ class OracleEnv:
             setattr(c, n, int(cfg[n]))
         for n in _DBL_FIELDS:
             setattr(c, n, float(cfg[n]))
+        # seasonal variant: only when the config carries its keys (the base env has none)
+        c.season_length_steps = int((config or {}).get("season_length_steps", 0))
+        c.season_high_multiplier = float((config or {}).get("season_high_multiplier", 1.0))
+        c.season_low_multiplier = float((config or {}).get("season_low_multiplier", 1.0))
         self._L = lib()
         self._h = self._L.ppo_create(C.byref(c))
         if not self._h:

@@ -26,6 +26,13 @@ import numpy as np
 
 REFERENCE_ROOT = os.environ.get("PPG_REFERENCE_ROOT", "/root/reference")
 BASE_ENV_RELPATH = "predpreygrass/non_evolutionary/base_environment/predpreygrass_rllib_env.py"
+# base-family variants whose step() is the base step() plus a small delta
+VARIANTS = {
+    "base": "predpreygrass/non_evolutionary/base_environment",
+    "seasonal": "predpreygrass/non_evolutionary/base_environment_seasonal",
+    "sparse_rewards": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards",
+    "sparse_rewards_plus_eating": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards_plus_eating",
+}
 
 
 def reference_available() -> bool:
@@ -118,44 +125,41 @@ def _rewrite_star_subscripts(text: str) -> tuple[str, int]:
     return "".join(out), count
 
 
-_cached_module = None
+_cached_modules = {}
 
 
-def load_reference_module():
-    """Return a module object holding the reference `PredPreyGrass` class."""
-    global _cached_module
-    if _cached_module is not None:
-        return _cached_module
+def load_reference_module(variant: str = "base"):
+    """Return a module object holding the reference `PredPreyGrass` class of a base-family variant."""
+    if variant in _cached_modules:
+        return _cached_modules[variant]
     if not reference_available():
         raise FileNotFoundError(f"reference not found under {REFERENCE_ROOT}")
     sys.dont_write_bytecode = True
     _install_stub_modules()
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
-    path = os.path.join(REFERENCE_ROOT, BASE_ENV_RELPATH)
+    path = os.path.join(REFERENCE_ROOT, VARIANTS[variant], "predpreygrass_rllib_env.py")
     with open(path, "r") as fh:
         text = fh.read()
     text, n = _rewrite_star_subscripts(text)
     if n == 0:
         raise RuntimeError("star-subscript rewrite found nothing; reference layout changed?")
-    mod = types.ModuleType("_ppg_reference_base_env")
+    mod = types.ModuleType("_ppg_reference_env_" + variant)
     mod.__file__ = path
     exec(compile(text, path, "exec"), mod.__dict__)
-    _cached_module = mod
+    _cached_modules[variant] = mod
     return mod
 
 
-def reference_default_config() -> dict:
-    load_reference_module()
-    from predpreygrass.non_evolutionary.base_environment.config_env import config_env
-
-    return dict(config_env)
+def reference_default_config(variant: str = "base") -> dict:
+    mod = load_reference_module(variant)
+    return dict(mod.config_env)  # each variant file imports its own config_env (line 5)
 
 
-def make_reference_env(overrides: dict | None = None):
-    """`PredPreyGrass(config)` of the reference with `config_env` defaults + overrides."""
-    mod = load_reference_module()
-    cfg = reference_default_config()
+def make_reference_env(overrides: dict | None = None, variant: str = "base"):
+    """`PredPreyGrass(config)` of the reference with the variant's `config_env` defaults + overrides."""
+    mod = load_reference_module(variant)
+    cfg = reference_default_config(variant)
     if overrides:
         cfg.update(overrides)
     return mod.PredPreyGrass(cfg)

@@ -113,6 +113,10 @@ class BatchedPredPreyGrass:
             ("initial_energy_prey",) * 2, ("initial_energy_grass",) * 2, ("energy_gain_per_step_grass",) * 2,
         ]:
             setattr(c, k_abi, float(cfg[k_cfg]))
+        # seasonal variant keys (base_environment_seasonal/config_env.py:35-40); absent -> base environment
+        c.season_length_steps = int(cfg.get("season_length_steps", 0) or 0)
+        c.season_high_multiplier = float(cfg.get("season_high_multiplier", 1.0))
+        c.season_low_multiplier = float(cfg.get("season_low_multiplier", 1.0))
         bufs = _abi.PpgBuffers()
         for name in _abi._BUF_FIELDS:
             setattr(bufs, name, getattr(self, name).data_ptr())

@@ -59,6 +59,9 @@ struct KParams {
     uint32_t g_magic;  // ceil(2^32 / G): cell / G == mulhi(cell, g_magic) for cell < G*G
     double r_catch, r_eat, r_pstep, r_qstep, r_caught, r_repro_p, r_repro_q;
     double loss_p, loss_q, thr_p, thr_q, e0_p, e0_q, e0_g, gain_g;
+    double season_hi, season_lo;  // seasonal regrowth multipliers
+    int32_t season_len;           // <= 0: no seasonal cycle
+    int32_t pad0_;
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
     int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
@@ -354,13 +357,16 @@ struct Env {
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
     PPG_MEMBER void load_grass(bool regrow, const Pre &p) {
         const size_t gb = (size_t)b * P.cap_grass;
+        // seasonal variant: square wave on current_step (base_environment_seasonal/...:224-234,268)
+        double gain = P.gain_g;
+        if (P.season_len > 0) gain = P.gain_g * (((step / P.season_len) & 1) ? P.season_lo : P.season_hi);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int pp = ln + 64 * q;
             if (pp < P.n_grass) {
                 double g = p.ge[q];
                 if (regrow) {
-                    double v = g + P.gain_g;
+                    double v = g + gain;
                     g = (P.e0_g < v) ? P.e0_g : v;  // Python min(v, cap)
                 }
                 val[grass_validx(pp)] = g;
@@ -370,7 +376,7 @@ struct Env {
         for (int pp = 128 + ln; pp < P.n_grass; pp += 64) {
             double g = P.grass_e[gb + pp];
             if (regrow) {
-                double v = g + P.gain_g;
+                double v = g + gain;
                 g = (P.e0_g < v) ? P.e0_g : v;
             }
             val[grass_validx(pp)] = g;

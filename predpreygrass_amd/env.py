@@ -262,6 +262,22 @@ class PredPreyGrass(_MultiAgentEnvBase):
     def grid_world_state(self):
         return self._b.export_grid()[self._i].cpu().numpy()
 
+    # seasonal variant (base_environment_seasonal/predpreygrass_rllib_env.py:224-234); 1.0 for the base env
+    def _current_season_multiplier(self) -> float:
+        length = int(self.config.get("season_length_steps", 0) or 0)
+        if length <= 0:
+            return 1.0
+        phase = (self.current_step // length) % 2
+        return float(self.config.get("season_high_multiplier", 1.0) if phase == 0
+                     else self.config.get("season_low_multiplier", 1.0))
+
+    def set_grass_energy(self, grass, energy):
+        """White-box state surgery used by tests in the reference's style
+        (base_environment_seasonal/tests/test_seasonal_grass_regrowth.py:66 assigns grass_energies[...])."""
+        k = int(str(grass).rsplit("_", 1)[1])
+        self._b.grass_energy[self._i, k] = float(energy)
+        self._tables = self._b.host_tables(self._i)
+
     def _get_observation(self, agent):
         """predpreygrass_rllib_env.py:511-526 (called externally at evaluate_ppo_from_checkpoint_debug.py:182)."""
         ty, _ = _parse(agent)

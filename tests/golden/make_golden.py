@@ -42,7 +42,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle.ref_shim import make_reference_env  # noqa: E402
+from oracle.ref_shim import make_reference_env, reference_default_config  # noqa: E402
 
 PREDATOR, PREY = 0, 1
 
@@ -91,6 +91,11 @@ CASES = {
                     "max_steps": 300}, 3, 1003, False, 15),
     "even_obs_seed0": ({"predator_obs_range": 6, "prey_obs_range": 8, "grid_size": 12, "initial_num_grass": 40,
                         "max_steps": 200}, 0, 1000, False, 20),
+    # base-family variants, generated from THEIR OWN reference files (6th element = oracle/ref_shim.py VARIANTS key);
+    # for these the stored config is the variant's full config_env + overrides
+    "seasonal_short_seed0": ({"season_length_steps": 7, "max_steps": 120}, 0, 1000, False, 8, "seasonal"),
+    "seasonal_default_seed1": ({"max_steps": 200}, 1, 1001, False, 20, "seasonal"),
+    "plus_eating_seed2": ({"max_steps": 200}, 2, 1002, False, 20, "sparse_rewards_plus_eating"),
 }
 
 
@@ -102,8 +107,11 @@ def capture(env):
     return pred, prey, grass
 
 
-def make_case(name, overrides, seed, action_seed, shuffle, full_every, max_calls=1200):
-    env = make_reference_env(overrides)
+def make_case(name, overrides, seed, action_seed, shuffle, full_every, variant="base", max_calls=1200):
+    env = make_reference_env(overrides, variant)
+    if variant != "base":
+        overrides = {**{k: v for k, v in reference_default_config(variant).items() if not k.startswith("verbose")},
+                     **overrides}
     obs, _ = env.reset(seed=seed)
     pred_xy, prey_xy, grass_xy = capture(env)
     reset_obs = np.concatenate([v.reshape(-1) for v in obs.values()])
@@ -168,7 +176,7 @@ def make_case(name, overrides, seed, action_seed, shuffle, full_every, max_calls
         if ended:
             break
     out = dict(
-        config_json=np.array(json.dumps(overrides)),
+        config_json=np.array(json.dumps(overrides)), variant=np.array(variant),
         seed=np.int64(seed), action_seed=np.int64(action_seed), shuffled=np.int8(shuffle),
         pred_xy=pred_xy, prey_xy=prey_xy, grass_xy=grass_xy,
         reset_keys=np.array(json.dumps(reset_keys)), reset_obs_data=reset_obs,
@@ -198,7 +206,7 @@ def make_case(name, overrides, seed, action_seed, shuffle, full_every, max_calls
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for name, (over, seed, aseed, shuffle, full_every) in CASES.items():
+    for name, spec in CASES.items():
         if only and name not in only:
             continue
-        make_case(name, over, seed, aseed, shuffle, full_every)
+        make_case(name, *spec)

@@ -23,6 +23,9 @@ def make_env(cfg, B, **kw):
     (["rewards_seed3"], None),
     (["pool_seed3"], None),
     (["even_obs_seed0"], None),
+    (["seasonal_short_seed0"], None),      # generated from base_environment_seasonal's own file
+    (["seasonal_default_seed1"], None),
+    (["plus_eating_seed2"], None),         # ...sparse_rewards_plus_eating's own file
 ])
 def test_golden_cases_through_emulated_kernel(names, max_calls):
     replay_golden_cases(make_env, names, config_env, max_calls=max_calls)
