@@ -176,6 +176,13 @@ int ppg_observe(ppg_handle *h, void *stream);
  * which is the order of the previous observation dict (RLlib's protocol). */
 int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream);
 
+/* n_steps transitions in ONE launch -- exactly what n_steps calls of ppg_step would do, each step
+ * writing its observations / rewards / flags / tables to the same buffers -- for policies that live on
+ * the device: PPG_STEP_RANDOM_ACTIONS (uniform random policy), or an open-loop action tape
+ * `actions` = device int8 [n_steps,B,S].  The agent table stays in registers and the grass table in LDS
+ * between steps, and a wavefront's observation stores drain while it computes its next step. */
+int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t flags, void *stream);
+
 /* Same, for an action dict whose iteration order differs from the previous observation dict
  * (the order matters in the reference: movement and the decay writes are applied in dict order,
  * BASE:244,259).  act_rank: device uint8 [B,S]; for every row with an action, its position among

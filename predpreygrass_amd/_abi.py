@@ -55,7 +55,7 @@ class PpgBuffers(C.Structure):
 
 EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
-    "ppg_step_ordered",
+    "ppg_rollout", "ppg_step_ordered",
     "ppg_export_grid",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_last_error",
 ]
@@ -76,6 +76,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.ppg_step_many.restype = C.c_int
     lib.ppg_step_many.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ppg_rollout.restype = C.c_int
+    lib.ppg_rollout.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.ppg_step_ordered.restype = C.c_int
     lib.ppg_step_ordered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.ppg_export_grid.restype = C.c_int

@@ -266,6 +266,20 @@ class BatchedPredPreyGrass:
             self._check(self._lib.ppg_step(self._handle, ptr, flags, self._stream(stream)), "ppg_step")
         return self
 
+    def rollout(self, n_steps, actions=None, random_actions=False, auto_reset=False, stream=None):
+        """`n_steps` transitions in ONE kernel launch (state stays on chip between steps): the same result
+        as `n_steps` calls of step().  Actions come from the device-side uniform random policy
+        (`random_actions=True`) or from an action tape `actions` int8 [n_steps, B, S]."""
+        flags = (_abi.STEP_RANDOM_ACTIONS if random_actions else 0) | (_abi.STEP_AUTO_RESET if auto_reset else 0)
+        ptr = None
+        if not random_actions:
+            if actions is None or actions.dtype != torch.int8 or tuple(actions.shape) != (n_steps, self.batch_size, self.S) \
+                    or actions.device != self.device or not actions.is_contiguous():
+                raise ValueError(f"actions must be a contiguous int8 tensor [{n_steps},{self.batch_size},{self.S}] on {self.device}")
+            ptr = C.c_void_p(actions.data_ptr())
+        self._check(self._lib.ppg_rollout(self._handle, int(n_steps), ptr, flags, self._stream(stream)), "ppg_rollout")
+        return self
+
     def export_grid(self):
         """grid_world_state of every env: float64 [B,4,G,G] (predpreygrass_rllib_env.py:124)."""
         G = self.grid_size

@@ -200,8 +200,18 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
     ppg::KParams P = h->base;
-    P.mode = ppg::MODE_STEP; P.actions = actions; P.flags = flags; P.prof = h->prof_dev;
+    P.mode = ppg::MODE_STEP; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
     return backend_launch(h, ppg::MODE_STEP, P, stream);
+}
+
+int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t flags, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (n_steps < 1) return ppg_fail(h, PPG_EINVAL, "n_steps must be >= 1");
+    if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
+    if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
+    ppg::KParams P = h->base;
+    P.mode = ppg::MODE_ROLLOUT; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = n_steps;
+    return backend_launch(h, ppg::MODE_ROLLOUT, P, stream);
 }
 
 int ppg_step_many(ppg_handle *const *handles, int32_t n, const int8_t *const *actions, uint32_t flags,
@@ -220,7 +230,7 @@ int ppg_step_ordered(ppg_handle *h, const int8_t *actions, const uint8_t *act_ra
     if (flags & ~PPG_STEP_AUTO_RESET) return ppg_fail(h, PPG_EINVAL, "ppg_step_ordered takes only PPG_STEP_AUTO_RESET");
     ppg::KParams P = h->base;
     const int mode = act_rank ? ppg::MODE_STEP_ORDERED : ppg::MODE_STEP;
-    P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev;
+    P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
     return backend_launch(h, mode, P, stream);
 }
 

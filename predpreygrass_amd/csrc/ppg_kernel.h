@@ -40,7 +40,7 @@
 
 namespace ppg {
 
-enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3, MODE_STEP_ORDERED = 4 };
+enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3, MODE_STEP_ORDERED = 4, MODE_ROLLOUT = 5 };
 
 // event bits of a row during one call
 enum { EV_STARVED = 1, EV_CAUGHT = 2, EV_ATE = 4, EV_PARENT = 8, EV_BORN = 16, EV_TRUNC = 32 };
@@ -93,6 +93,8 @@ struct KParams {
     unsigned long long *prof;  // diagnostic build only
     uint32_t flags;
     uint32_t reset_episode;
+    int32_t n_steps;   // transitions per launch (ppg_step: 1; ppg_rollout: n)
+    int32_t pad1_;
     int32_t mode;
     int32_t batch;
 };
@@ -160,7 +162,8 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // run-time values, which costs registers and scratch, so it lives in its own kernel variant.
 // FASTOBS: observation descriptors of this lane live in registers (needs <= 2 predator and <= 3 prey
 // chunks, i.e. Rp <= 7 and Rq <= 9); otherwise they are read from an LDS copy.
-template <int NQ, bool ORDERED, bool FASTOBS>
+// FUSED: the multi-step rollout loop (ppg_rollout) is compiled in; ppg_step's kernel has a single step body.
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
@@ -183,6 +186,7 @@ struct Env {
     uint32_t ev[T];
     uint32_t keep[T];  // row flags that survive a truncation call (ATE)
     uint32_t rank[T];  // explicit action order (only when P.act_rank is given)
+    uint32_t gxyr[2];  // grass_xy of patches ln and ln+64 (static within an episode)
     uint32_t lutr[10]; // FASTOBS: this lane's descriptors, predator chunks 0-1 then prey chunks 0-2, two words each
 
     // wave-uniform state
@@ -352,10 +356,14 @@ struct Env {
             for (int i = ln; i < (P.nch_p + P.nch_q) * 128; i += 64) lut[i] = P.obs_lut[i];
         }
         if (ln == 0) val[0] = 0.0;
+        gxyr[0] = p.gxy[0];
+        gxyr[1] = p.gxy[1];
     }
 
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
-    PPG_MEMBER void load_grass(bool regrow, const Pre &p) {
+    template <bool FROM_LDS>
+    PPG_MEMBER void load_grass_t(bool regrow, const Pre &p) {
+        const bool from_lds = FROM_LDS;
         const size_t gb = (size_t)b * P.cap_grass;
         // seasonal variant: square wave on current_step (base_environment_seasonal/...:224-234,268)
         double gain = P.gain_g;
@@ -364,17 +372,18 @@ struct Env {
         for (int q = 0; q < 2; ++q) {
             const int pp = ln + 64 * q;
             if (pp < P.n_grass) {
-                double g = p.ge[q];
+                double g;  // fused steps: energies are already in LDS
+                if (FROM_LDS) g = val[grass_validx(pp)]; else g = p.ge[q];
                 if (regrow) {
                     double v = g + gain;
                     g = (P.e0_g < v) ? P.e0_g : v;  // Python min(v, cap)
                 }
                 val[grass_validx(pp)] = g;
-                chmap(3)[cell_of(p.gxy[q])] = (uint16_t)grass_validx(pp);
+                chmap(3)[cell_of(gxyr[q])] = (uint16_t)grass_validx(pp);
             }
         }
         for (int pp = 128 + ln; pp < P.n_grass; pp += 64) {
-            double g = P.grass_e[gb + pp];
+            double g = from_lds ? val[grass_validx(pp)] : P.grass_e[gb + pp];
             if (regrow) {
                 double v = g + gain;
                 g = (P.e0_g < v) ? P.e0_g : v;
@@ -383,6 +392,8 @@ struct Env {
             chmap(3)[cell_of(P.grass_xy[gb + pp])] = (uint16_t)grass_validx(pp);
         }
     }
+
+    PPG_MEMBER void load_grass(bool regrow, const Pre &p) { load_grass_t<false>(regrow, p); }
 
     // ---- actions -------------------------------------------------------------------
     PPG_MEMBER void load_actions(uint64_t (&acted)[T]) {
@@ -827,6 +838,13 @@ struct Env {
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int h = 0; h < 2; ++h) v[c][h] = val[idx[c][h]];
+#ifdef PPG_EXP_NO_OBS_READS  // ablation build only (tools/exp_variants.py): stores without LDS lookups
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { v[c][0] = 0.0; v[c][1] = 0.0; }
+#endif
+#ifdef PPG_EXP_NO_OBS_STORES  // ablation build only: no observation stores at all
+        if (P.batch > 0) { wv::sync(); return; }
+#endif
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (lutr[BASE + 2 * c] & 0x4000000u) {
@@ -1162,7 +1180,11 @@ struct Env {
             P.row_cum[s] = c;
             P.row_flags[s] = (uint8_t)fl;
             P.row_reward[s] = rew;
+            cum[r] = c;                  // carried into the next fused step (ppg_rollout)
+            keep[r] = fl & PPG_ROW_ATE;
         }
+        obs_count[0] += n_rows[0];       // every row in use got an observation
+        obs_count[1] += n_rows[1];
         if (write_grass) {
             const size_t gb = (size_t)b * P.cap_grass;
             for (int p = ln; p < P.n_grass; p += 64) P.grass_e[gb + p] = val[grass_validx(p)];
@@ -1185,8 +1207,8 @@ struct Env {
                 case PPG_ENV_EPISODE: w = (int32_t)episode; break;
                 case PPG_ENV_FALLBACK_SPAWNS: w = fb_count; break;
                 case PPG_ENV_CALLS: w = calls; break;
-                case PPG_ENV_OBS_PRED: w = obs_count[0] + n_rows[0]; break;  // every row in use got an observation
-                case PPG_ENV_OBS_PREY: w = obs_count[1] + n_rows[1]; break;
+                case PPG_ENV_OBS_PRED: w = obs_count[0]; break;
+                case PPG_ENV_OBS_PREY: w = obs_count[1]; break;
                 default: w = 0; break;
             }
             es[ln] = w;
@@ -1244,8 +1266,11 @@ struct Env {
         for (int p = ln; p < P.n_grass; p += 64) {
             const uint32_t c = ent[P0 + Q0 + p];
             const uint32_t cx = wv::mulhi(c, P.g_magic);
-            P.grass_xy[gb + p] = (uint16_t)((cx << 8) | (c - cx * (uint32_t)P.G));
+            const uint32_t gxy = (cx << 8) | (c - cx * (uint32_t)P.G);
+            P.grass_xy[gb + p] = (uint16_t)gxy;
             P.grass_e[gb + p] = P.e0_g;
+            if (p == ln) gxyr[0] = gxy;
+            if (p == ln + 64) gxyr[1] = gxy;
         }
         wv::sync();
         for (int i = ln; i < n; i += 64) { perm[i] = 0; ent[i] = 0; }
@@ -1267,31 +1292,45 @@ struct Env {
     }
 
     // ---- the transition ----------------------------------------------------------------
-    PPG_MEMBER void run_step() {
-        PPG_STAMP(0);
-        Pre pre;
-        prefetch(pre, true, P.actions != nullptr && !(P.flags & PPG_STEP_RANDOM_ACTIONS));
-        load_env_words(pre);
+    // One transition.  FIRST: the tables were prefetched from HBM into `pre`.  !FIRST (fused rollout,
+    // ppg_rollout): the agent table, masks and env words are still in registers from the previous step and
+    // the grass energies in LDS; every step still writes its observations, rewards, flags and tables to
+    // HBM (same buffers), and those stores drain while the wave already computes its next step.
+    template <bool FIRST>
+    PPG_MEMBER void step_body(const Pre &pre, int it) {
         calls += 1;
-        init_lds(pre);
         if ((P.flags & PPG_STEP_AUTO_RESET) && (envflags & PPG_ENVF_DONE)) {
             wv::sync();
             do_reset(episode + 1u);
             return;
         }
-        load_rows(pre);
+        if (FIRST) {
+            load_rows(pre);
+        } else {  // what load_rows() would read back from the tables the previous step wrote
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                ev[r] = 0;
+                act[r] = -1;
+            }
+            if (P.actions && !(P.flags & PPG_STEP_RANDOM_ACTIONS)) {
+#pragma unroll
+                for (int r = 0; r < T; ++r)
+                    if ((alive[r] >> ln) & 1ull)
+                        act[r] = P.actions[((size_t)it * P.batch + b) * P.S + slot_of(r, ln)];
+            }
+        }
         const bool list_is_row_order = (envflags & PPG_ENVF_LIST_IS_ROW_ORDER) != 0;
 
         if (step >= P.max_steps) {  // truncation, BASE:228-238: no state change
             wv::sync();
-            load_grass(false, pre);
+            load_grass_t<!FIRST>(false, pre);
             compact_and_sort(!list_is_row_order);
             build_maps();
             obs_all_alive();
 #pragma unroll
             for (int r = 0; r < T; ++r) ev[r] = ((alive[r] >> ln) & 1ull) ? EV_TRUNC : 0u;
             envflags = (envflags & PPG_ENVF_LIST_IS_ROW_ORDER) | PPG_ENVF_TRUNC_ALL | PPG_ENVF_DONE;
-            rewards_and_store(false);
+            rewards_and_store(false);  // (agents_just_ate is untouched by a truncation call: keep[] rides along in the flags)
             return;
         }
 
@@ -1300,11 +1339,11 @@ struct Env {
         load_actions(acted);
 #pragma unroll
         for (int r = 0; r < T; ++r) keep[r] = 0;  // agents_just_ate.clear(), BASE:241
-        wv::sync();                                // init_lds() zeros visible
+        wv::sync();                                // LDS zeros visible
         PPG_STAMP(2);
         decay(acted);                              // BASE:244-250
         PPG_STAMP(3);
-        load_grass(true, pre);                     // BASE:252-256
+        load_grass_t<!FIRST>(true, pre);           // BASE:252-256
         PPG_STAMP(4);
         move(acted);                               // BASE:259-276
         PPG_STAMP(5);
@@ -1327,6 +1366,26 @@ struct Env {
         if (n_alive[0] <= 0 || n_alive[1] <= 0) envflags |= PPG_ENVF_TERM_ALL | PPG_ENVF_DONE;  // BASE:466
         rewards_and_store(true);
         PPG_STAMP(12);
+    }
+
+    // ppg_step: one transition.  ppg_rollout (FUSED): P.n_steps transitions in one launch.
+    // STATUS (round 1): the fused kernel is bit-identical to n single steps but NOT yet faster -- hipcc hoists
+    // loop-invariant values out of the step loop and spills; bench.py does not use it.
+    PPG_MEMBER void run_step() {
+        PPG_STAMP(0);
+        Pre pre;
+        prefetch(pre, true, P.actions != nullptr && !(P.flags & PPG_STEP_RANDOM_ACTIONS));
+        load_env_words(pre);
+        init_lds(pre);
+        step_body<true>(pre, 0);
+        if (FUSED) {
+            for (int it = 1; it < P.n_steps; ++it) {
+                wv::sync();  // LDS maps back to all-zero (init_lds did it for the first step)
+                uint32_t *m32 = (uint32_t *)map;
+                for (int i = ln; i < 4 * P.map_n / 2; i += 64) m32[i] = 0u;
+                step_body<false>(pre, it);
+            }
+        }
     }
 
     PPG_MEMBER void run_reset() {
@@ -1379,8 +1438,8 @@ template <int NQ, int MODE, bool FASTOBS>
 PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     const int b = PPG_BLOCK_INDEX();
     if (b >= P.batch) return;
-    Env<NQ, MODE == MODE_STEP_ORDERED, FASTOBS> env(P, b, lds);
-    if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED) env.run_step();
+    Env<NQ, MODE == MODE_STEP_ORDERED, FASTOBS, MODE == MODE_ROLLOUT> env(P, b, lds);
+    if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_ROLLOUT) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();
     else if (MODE == MODE_OBSERVE) env.run_observe();
     else env.run_export_grid();

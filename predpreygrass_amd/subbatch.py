@@ -74,6 +74,12 @@ class SubBatchedPredPreyGrass:
             raise RuntimeError(f"ppg_step_many failed ({rc})")
         return self
 
+    def rollout(self, n_steps, random_actions=True, auto_reset=False):
+        """`n_steps` fused transitions per sub-batch (one launch each, on its own stream)."""
+        for e, s in zip(self.subs, self.streams):
+            e.rollout(n_steps, random_actions=random_actions, auto_reset=auto_reset, stream=s)
+        return self
+
     def synchronize(self):
         for s in self.streams:
             if s is not None:

@@ -108,3 +108,59 @@ def test_kernel_source_is_clean_under_ubsan():
         "print('UBSAN-CLEAN')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "UBSAN-CLEAN" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+def _state(env):
+    names = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "grass_xy",
+             "grass_energy", "obs_pred", "obs_prey"]
+    st = {n: getattr(env, n).clone() for n in names}
+    st["env_state"] = env.env_state.clone()
+    return st
+
+
+def _assert_same_state(a, b, env):
+    import torch
+    from predpreygrass_amd import _abi
+    assert torch.equal(a["env_state"], b["env_state"])
+    nP, nQ = a["env_state"][:, _abi.ENV_N_PRED_ROWS], a["env_state"][:, _abi.ENV_N_PREY_ROWS]
+    cp = env.pred_capacity
+    rows = torch.arange(env.S)[None, :]
+    used = (rows < nP[:, None]) | ((rows >= cp) & (rows < cp + nQ[:, None]))
+    for n in ("row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward"):
+        assert torch.equal(a[n][used], b[n][used]), n
+    assert torch.equal(a["grass_xy"], b["grass_xy"]) and torch.equal(a["grass_energy"], b["grass_energy"])
+    assert torch.equal(a["obs_pred"][used[:, :cp]], b["obs_pred"][used[:, :cp]])
+    assert torch.equal(a["obs_prey"][used[:, cp:]], b["obs_prey"][used[:, cp:]])
+
+
+@pytest.mark.parametrize("over,K", [
+    ({}, 60),
+    ({"grid_size": 9, "n_initial_active_predator": 12, "n_initial_active_prey": 20, "initial_num_grass": 25,
+      "predator_obs_range": 5, "prey_obs_range": 7, "max_steps": 40}, 130),   # resets + truncations inside the rollout
+])
+def test_fused_rollout_equals_single_steps_random_policy(over, K):
+    """ppg_rollout(K) == K x ppg_step, device-side random policy with auto-reset (state, tables, observations)."""
+    cfg = {**config_env, **over}
+    a, b = make_env(cfg, 3, seed=21), make_env(cfg, 3, seed=21)
+    a.reset()
+    b.reset()
+    for _ in range(K):
+        a.step(random_actions=True, auto_reset=True)
+    b.rollout(K // 2, random_actions=True, auto_reset=True)
+    b.rollout(K - K // 2, random_actions=True, auto_reset=True)
+    _assert_same_state(_state(a), _state(b), a)
+
+
+def test_fused_rollout_equals_single_steps_action_tape():
+    import torch
+    cfg = {**config_env, "max_steps": 25}
+    K, B = 40, 2
+    a, b = make_env(cfg, B, seed=5), make_env(cfg, B, seed=5)
+    a.reset()
+    b.reset()
+    g = torch.Generator().manual_seed(0)
+    tape = torch.randint(-1, 9, (K, B, a.S), generator=g, dtype=torch.int8)
+    for t in range(K):
+        a.step(tape[t].contiguous())
+    b.rollout(K, actions=tape)
+    _assert_same_state(_state(a), _state(b), a)

@@ -164,3 +164,20 @@ def test_random_config_matches_oracle_on_gpu(seed):
     from predpreygrass_amd.env import PredPreyGrass
     from tests.test_random_configs import run_differential
     run_differential(lambda cfg: PredPreyGrass(cfg, device="cuda:0"), seed)
+
+
+def test_fused_rollout_equals_single_steps_on_gpu():
+    """ppg_rollout(K) == K x ppg_step on the device, 512 envs, resets inside the rollout."""
+    from tests.test_emulated_kernel import _assert_same_state, _state
+    cfg = {**config_env, "max_steps": 60}
+    a, b = make_env(cfg, 512, seed=77), make_env(cfg, 512, seed=77)
+    a.reset()
+    b.reset()
+    for _ in range(150):
+        a.step(random_actions=True, auto_reset=True)
+    b.rollout(100, random_actions=True, auto_reset=True)
+    b.rollout(50, random_actions=True, auto_reset=True)
+    torch.cuda.synchronize()
+    sa = {k: v.cpu() for k, v in _state(a).items()}
+    sb = {k: v.cpu() for k, v in _state(b).items()}
+    _assert_same_state(sa, sb, a)
