@@ -129,6 +129,10 @@ typedef struct ppg_config {
     int32_t season_length_steps;
     double season_high_multiplier;
     double season_low_multiplier;
+    /* rewards: 0 = base env (BASE:288,322,328,341,365,375,409,438); 1 = net energy delta of the step
+     * (project_reward_shaping/base_environment_dense_rewards/predpreygrass_rllib_env.py:242-245,291-292,328-329,440-449);
+     * 2 = the same plus the reproduction reward for a parent (.../base_environment_dense_rewards_additive:470) */
+    int32_t reward_mode;
 } ppg_config;
 
 /* Caller-owned device buffers.  B = batch, S = pred_capacity + prey_capacity,

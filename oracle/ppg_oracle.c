@@ -45,6 +45,9 @@ struct ppo_env {
 
     double *energy[2];   /* self.agent_energies */
     double *cumrew[2];   /* self.cumulative_rewards */
+    double *e_before[2]; /* dense variants: energy_before (DENSE:242-245) */
+    char *has_before[2];
+    double *bonus[2];    /* dense_additive: reproduction_bonus */
     char *just_ate[2];   /* self.agents_just_ate */
 
     int n_grass;
@@ -119,6 +122,9 @@ ppo_env *ppo_create(const ppo_config *cfg) {
         e->ent_index[t] = (int *)malloc(n * sizeof(int));
         e->energy[t] = (double *)calloc(n, sizeof(double));
         e->cumrew[t] = (double *)calloc(n, sizeof(double));
+        e->e_before[t] = (double *)calloc(n, sizeof(double));
+        e->has_before[t] = (char *)calloc(n, 1);
+        e->bonus[t] = (double *)calloc(n, sizeof(double));
         e->just_ate[t] = (char *)calloc(n, 1);
         e->has_obs[t] = (char *)calloc(n, 1);
         e->has_rew[t] = (char *)calloc(n, 1);
@@ -152,6 +158,7 @@ void ppo_destroy(ppo_env *e) {
     free(e->pend_type); free(e->pend_id);
     for (int t = 0; t < 2; ++t) {
         free(e->ent_index[t]); free(e->energy[t]); free(e->cumrew[t]); free(e->just_ate[t]);
+        free(e->e_before[t]); free(e->has_before[t]); free(e->bonus[t]);
         free(e->has_obs[t]); free(e->has_rew[t]); free(e->has_term[t]); free(e->has_trunc[t]);
         free(e->obs_at[t]); free(e->rew[t]); free(e->term[t]); free(e->trunc[t]);
     }
@@ -504,6 +511,15 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
     }
 
     for (int t = 0; t < 2; ++t) memset(e->just_ate[t], 0, npos(e, t) + 1); /* BASE:241 */
+    const int dense = c->reward_mode != 0;
+    if (dense) { /* energy_before = dict(self.agent_energies), DENSE:242-245 */
+        for (int t = 0; t < 2; ++t) { memset(e->has_before[t], 0, npos(e, t) + 1); }
+        for (int i = 0; i < e->n_entries; ++i)
+            if (e->ent_present[i]) {
+                int t = e->ent_type[i], id = e->ent_id[i];
+                e->e_before[t][id] = e->energy[t][id]; e->has_before[t][id] = 1; e->bonus[t][id] = 0.0;
+            }
+    }
 
     /* Step 1, BASE:244-250 */
     for (int a = 0; a < n_act; ++a) {
@@ -556,6 +572,10 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
         if (e->energy[t][id] <= 0) {                                  /* BASE:284 */
             put_obs(e, t, id);                                        /* BASE:287 */
             e->rew[t][id] = 0; e->has_rew[t][id] = 1;                 /* BASE:288 */
+            if (dense) { /* DENSE:291-292 */
+                e->rew[t][id] = e->energy[t][id] - e->e_before[t][id];
+                e->cumrew[t][id] += e->rew[t][id];
+            }
             e->term[t][id] = 1; e->has_term[t][id] = 1;
             e->trunc[t][id] = 0; e->has_trunc[t][id] = 1;
             e->cur_num[t] -= 1;
@@ -572,23 +592,26 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
             if (caught >= 0) {
                 int cid = e->ent_id[caught];
                 e->just_ate[t][id] = 1;                               /* BASE:319 */
-                e->rew[t][id] = c->reward_predator_catch_prey; e->has_rew[t][id] = 1; /* BASE:322 */
-                e->cumrew[t][id] += e->rew[t][id];                    /* BASE:323 */
+                if (!dense) {
+                    e->rew[t][id] = c->reward_predator_catch_prey; e->has_rew[t][id] = 1; /* BASE:322 */
+                    e->cumrew[t][id] += e->rew[t][id];                /* BASE:323 */
+                }
                 e->energy[t][id] += e->energy[PPO_PREY][cid];         /* BASE:324 */
                 *cell(e, 1, px, py) = e->energy[t][id];               /* BASE:325 */
                 put_obs(e, PPO_PREY, cid);                            /* BASE:327 */
                 e->rew[PPO_PREY][cid] = c->penalty_prey_caught; e->has_rew[PPO_PREY][cid] = 1;
+                if (dense) e->rew[PPO_PREY][cid] = 0.0 - e->e_before[PPO_PREY][cid]; /* DENSE:328-329 */
                 e->cumrew[PPO_PREY][cid] += e->rew[PPO_PREY][cid];    /* BASE:329 */
                 e->term[PPO_PREY][cid] = 1; e->has_term[PPO_PREY][cid] = 1;   /* BASE:332 */
                 e->trunc[PPO_PREY][cid] = 0; e->has_trunc[PPO_PREY][cid] = 1;
                 e->cur_num[PPO_PREY] -= 1;
                 *cell(e, 2, e->ent_x[caught], e->ent_y[caught]) = 0;  /* BASE:335 */
                 positions_delete(e, PPO_PREY, cid);                   /* BASE:336-338 */
-            } else {
+            } else if (!dense) {
                 e->rew[t][id] = c->reward_predator_step; e->has_rew[t][id] = 1; /* BASE:341 */
             }
             put_obs(e, t, id);                                        /* BASE:343 */
-            e->cumrew[t][id] += e->rew[t][id];                        /* BASE:344 */
+            if (!dense) e->cumrew[t][id] += e->rew[t][id];            /* BASE:344 */
             e->term[t][id] = 0; e->has_term[t][id] = 1;
             e->trunc[t][id] = 0; e->has_trunc[t][id] = 1;
         } else {
@@ -599,17 +622,19 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
                     if (e->grass_x[j] == px && e->grass_y[j] == py) { g = j; break; }
                 if (g >= 0) {
                     e->just_ate[t][id] = 1;                           /* BASE:362 */
-                    e->rew[t][id] = c->reward_prey_eat_grass; e->has_rew[t][id] = 1; /* BASE:365 */
-                    e->cumrew[t][id] += e->rew[t][id];                /* BASE:366 */
+                    if (!dense) {
+                        e->rew[t][id] = c->reward_prey_eat_grass; e->has_rew[t][id] = 1; /* BASE:365 */
+                        e->cumrew[t][id] += e->rew[t][id];            /* BASE:366 */
+                    }
                     e->energy[t][id] += e->grass_e[g];                /* BASE:367 */
                     *cell(e, 2, px, py) = e->energy[t][id];           /* BASE:368 */
                     *cell(e, 3, e->grass_x[g], e->grass_y[g]) = 0;    /* BASE:371 */
                     e->grass_e[g] = 0;                                /* BASE:372 */
-                } else {
+                } else if (!dense) {
                     e->rew[t][id] = c->reward_prey_step; e->has_rew[t][id] = 1; /* BASE:375 */
                 }
                 put_obs(e, t, id);                                    /* BASE:377 */
-                e->cumrew[t][id] += e->rew[t][id];                    /* BASE:378 */
+                if (!dense) e->cumrew[t][id] += e->rew[t][id];        /* BASE:378 */
                 e->term[t][id] = 0; e->has_term[t][id] = 1;
                 e->trunc[t][id] = 0; e->has_trunc[t][id] = 1;
             }
@@ -651,15 +676,31 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
                 *cell(e, ch, e->ent_x[k], e->ent_y[k]) = e->energy[t][id]; /* BASE:406 */
                 e->cur_num[t] += 1;
                 e->rew[t][cid] = 0; e->has_rew[t][cid] = 1;           /* BASE:408 */
-                e->rew[t][id] = t == PPO_PREDATOR ? c->reproduction_reward_predator
-                                                  : c->reproduction_reward_prey; /* BASE:409/438 */
-                e->has_rew[t][id] = 1;
+                if (!dense) {
+                    e->rew[t][id] = t == PPO_PREDATOR ? c->reproduction_reward_predator
+                                                      : c->reproduction_reward_prey; /* BASE:409/438 */
+                    e->has_rew[t][id] = 1;
+                    e->cumrew[t][id] += e->rew[t][id];                /* BASE:411 */
+                } else if (c->reward_mode == 2) {  /* dense_additive: reproduction_bonus[agent] */
+                    e->bonus[t][id] = t == PPO_PREDATOR ? c->reproduction_reward_predator : c->reproduction_reward_prey;
+                }
                 e->cumrew[t][cid] = 0;                                /* BASE:410 */
-                e->cumrew[t][id] += e->rew[t][id];                    /* BASE:411 */
                 put_obs(e, t, cid);                                   /* BASE:412 */
                 e->term[t][cid] = 0; e->has_term[t][cid] = 1;
                 e->trunc[t][cid] = 0; e->has_trunc[t][cid] = 1;
             }
+        }
+    }
+
+    /* Step 5b of the dense variants (DENSE:440-449; additive :463-470) */
+    if (dense) {
+        for (int k = 0; k < e->n_entries; ++k) {
+            int t = e->ent_type[k], id = e->ent_id[k];
+            if (!e->ent_present[k] || !e->has_before[t][id]) continue;
+            double d = e->energy[t][id] - e->e_before[t][id];
+            if (c->reward_mode == 2) d = d + e->bonus[t][id];
+            e->rew[t][id] = d; e->has_rew[t][id] = 1;
+            e->cumrew[t][id] += e->rew[t][id];
         }
     }
 

@@ -70,7 +70,8 @@ _DBL_FIELDS = [
 
 class _Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS] + [
-        ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double)]
+        ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double),
+        ("reward_mode", C.c_int32)]
 
 
 class _Record(C.Structure):
@@ -175,6 +176,8 @@ class OracleEnv:
         c.season_length_steps = int((config or {}).get("season_length_steps", 0))
         c.season_high_multiplier = float((config or {}).get("season_high_multiplier", 1.0))
         c.season_low_multiplier = float((config or {}).get("season_low_multiplier", 1.0))
+        c.reward_mode = {"sparse": 0, "dense_energy_delta": 1, "dense_energy_delta_plus_reproduction": 2}[
+            (config or {}).get("reward_mode", "sparse")]
         self._L = lib()
         self._h = self._L.ppo_create(C.byref(c))
         if not self._h:

@@ -32,6 +32,8 @@ VARIANTS = {
     "seasonal": "predpreygrass/non_evolutionary/base_environment_seasonal",
     "sparse_rewards": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards",
     "sparse_rewards_plus_eating": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards_plus_eating",
+    "dense_rewards": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_dense_rewards",
+    "dense_rewards_additive": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_dense_rewards_additive",
 }
 
 

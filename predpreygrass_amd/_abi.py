@@ -46,7 +46,8 @@ _BUF_FIELDS = [
 
 class PpgConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS] + [
-        ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double)]
+        ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double),
+        ("reward_mode", C.c_int32)]
 
 
 class PpgBuffers(C.Structure):

@@ -117,6 +117,10 @@ class BatchedPredPreyGrass:
         c.season_length_steps = int(cfg.get("season_length_steps", 0) or 0)
         c.season_high_multiplier = float(cfg.get("season_high_multiplier", 1.0))
         c.season_low_multiplier = float(cfg.get("season_low_multiplier", 1.0))
+        modes = {"sparse": 0, "dense_energy_delta": 1, "dense_energy_delta_plus_reproduction": 2}
+        if cfg.get("reward_mode", "sparse") not in modes:
+            raise ValueError(f"reward_mode must be one of {sorted(modes)}")
+        c.reward_mode = modes[cfg.get("reward_mode", "sparse")]
         bufs = _abi.PpgBuffers()
         for name in _abi._BUF_FIELDS:
             setattr(bufs, name, getattr(self, name).data_ptr())

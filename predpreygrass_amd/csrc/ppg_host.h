@@ -114,6 +114,8 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.thr_p = c.predator_creation_energy_threshold; P.thr_q = c.prey_creation_energy_threshold;
     P.e0_p = c.initial_energy_predator; P.e0_q = c.initial_energy_prey; P.e0_g = c.initial_energy_grass;
     P.gain_g = c.energy_gain_per_step_grass;
+    if (c.reward_mode < 0 || c.reward_mode > 2) return ppg_fail(h, PPG_EINVAL, "reward_mode must be 0, 1 or 2");
+    P.reward_mode = c.reward_mode;
     P.season_len = c.season_length_steps; P.season_hi = c.season_high_multiplier; P.season_lo = c.season_low_multiplier;
     h->nq = c.prey_capacity / 64;
 

@@ -61,7 +61,7 @@ struct KParams {
     double loss_p, loss_q, thr_p, thr_q, e0_p, e0_q, e0_g, gain_g;
     double season_hi, season_lo;  // seasonal regrowth multipliers
     int32_t season_len;           // <= 0: no seasonal cycle
-    int32_t pad0_;
+    int32_t reward_mode;          // 0 base rewards, 1 dense energy delta, 2 dense + reproduction bonus
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
     int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
@@ -334,7 +334,7 @@ struct Env {
                     if (P.actions) act[r] = P.actions[s];
                 }
             }
-            keep[r] = fl & PPG_ROW_ATE;
+            keep[r] = (fl & PPG_ROW_ATE) | ((uint32_t)slot_of(r, ln) << 8);  // bits 8..: where this row's start-of-step energy lives
             rows[r] = wv::ballot(valid);
             alive[r] = rows[r] & ~wv::ballot(valid && (fl & PPG_ROW_DIED));
             owns[r] = wv::ballot(valid && (fl & PPG_ROW_OWNS)) & alive[r];
@@ -755,7 +755,7 @@ struct Env {
                         if (f == 0) e[r] = __longlong_as_double((long long)v);
                         else if (f == 1) cum[r] = __longlong_as_double((long long)v);
                         else if (f == 2) { key[r] = (uint32_t)(v >> 32); id[r] = (int32_t)(uint32_t)v; }
-                        else { xy[r] = (uint32_t)(v & 0xFFFFu); ev[r] = (uint32_t)((v >> 16) & 1u); keep[r] = (uint32_t)(v >> 20) & 0xFFu; }
+                        else { xy[r] = (uint32_t)(v & 0xFFFFu); ev[r] = (uint32_t)((v >> 16) & 1u); keep[r] = (uint32_t)(v >> 20) & 0x3FFFFu; }
                     } else if (f == 3) {
                         xy[r] = 0xFFFFu; ev[r] = 0; keep[r] = 0;
                     }
@@ -1145,43 +1145,62 @@ struct Env {
         int n_new[2] = {0, 0};
 #pragma unroll
         for (int r = 0; r < T; ++r) n_new[type_of(r)] += wv::popc(wv::ballot(ev[r] & EV_BORN) & rows[r]);
+        double rew_[T], cum_[T];
+        uint32_t fl_[T];
+        const bool dense = transition && P.reward_mode != 0;
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int i = row_of(r, ln);
+            const uint32_t v = ev[r];
+            double rew = 0.0, c = cum[r];
+            uint32_t fl = 0;
+            if (i < n_rows[type_of(r)]) {
+                if (!transition) {
+                    rew = 0.0;  // reset returns observations only; cumulative_rewards = 0 (BASE:150)
+                } else if (v & EV_BORN) {
+                    c = 0.0;
+                } else if (v & EV_TRUNC) {
+                    rew = 0.0;
+                } else if (dense) {
+                    // dense variants: reward = energy now - energy at the start of the step (still in HBM at the
+                    // row's old slot); a caught prey's account goes to zero (0.0 - before)
+                    const double before = P.row_e[(size_t)b * P.S + (keep[r] >> 8)];
+                    rew = (v & EV_CAUGHT) ? (0.0 - before) : (e[r] - before);
+                    if (P.reward_mode == 2 && !(v & (EV_STARVED | EV_CAUGHT)))
+                        rew = rew + ((v & EV_PARENT) ? (r ? P.r_repro_q : P.r_repro_p) : 0.0);
+                    c += rew;
+                } else if (v & EV_STARVED) {
+                    rew = 0.0;
+                } else if (v & EV_CAUGHT) {
+                    rew = P.r_caught; c += rew;
+                } else {
+                    if (v & EV_ATE) { rew = r ? P.r_eat : P.r_catch; c += rew; c += rew; }
+                    else { rew = r ? P.r_qstep : P.r_pstep; c += rew; }
+                    if (v & EV_PARENT) { rew = r ? P.r_repro_q : P.r_repro_p; c += rew; }
+                }
+                if (v & (EV_STARVED | EV_CAUGHT)) fl |= PPG_ROW_DIED;
+                if ((owns[r] >> ln) & 1ull) fl |= PPG_ROW_OWNS;
+                if (v & EV_BORN) fl |= PPG_ROW_NEWBORN;
+                if (v & EV_ATE) fl |= PPG_ROW_ATE;
+                if (v & EV_TRUNC) fl |= PPG_ROW_TRUNC | (keep[r] & PPG_ROW_ATE);
+            }
+            rew_[r] = rew; cum_[r] = c; fl_[r] = fl;
+        }
+        if (dense) wv::drain_loads();  // every lane has its start-of-step energy before any row_energy is overwritten
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);
             if (i >= n_rows[type_of(r)]) continue;
-            const uint32_t v = ev[r];
-            double rew = 0.0, c = cum[r];
-            if (!transition) {
-                rew = 0.0;  // reset returns observations only; cumulative_rewards = 0 (BASE:150)
-            } else if (v & EV_BORN) {
-                c = 0.0;
-            } else if (v & EV_TRUNC) {
-                rew = 0.0;
-            } else if (v & EV_STARVED) {
-                rew = 0.0;
-            } else if (v & EV_CAUGHT) {
-                rew = P.r_caught; c += rew;
-            } else {
-                if (v & EV_ATE) { rew = r ? P.r_eat : P.r_catch; c += rew; c += rew; }
-                else { rew = r ? P.r_qstep : P.r_pstep; c += rew; }
-                if (v & EV_PARENT) { rew = r ? P.r_repro_q : P.r_repro_p; c += rew; }
-            }
-            uint32_t fl = 0;
-            if (v & (EV_STARVED | EV_CAUGHT)) fl |= PPG_ROW_DIED;
-            if ((owns[r] >> ln) & 1ull) fl |= PPG_ROW_OWNS;
-            if (v & EV_BORN) fl |= PPG_ROW_NEWBORN;
-            if (v & EV_ATE) fl |= PPG_ROW_ATE;
-            if (v & EV_TRUNC) fl |= PPG_ROW_TRUNC | keep[r];
             const size_t s = (size_t)b * P.S + slot_of(r, ln);
             P.row_xy[s] = (uint16_t)xy[r];
             P.row_e[s] = e[r];
             P.row_id[s] = id[r];
             P.row_key[s] = key[r];
-            P.row_cum[s] = c;
-            P.row_flags[s] = (uint8_t)fl;
-            P.row_reward[s] = rew;
-            cum[r] = c;                  // carried into the next fused step (ppg_rollout)
-            keep[r] = fl & PPG_ROW_ATE;
+            P.row_cum[s] = cum_[r];
+            P.row_flags[s] = (uint8_t)fl_[r];
+            P.row_reward[s] = rew_[r];
+            cum[r] = cum_[r];            // carried into the next fused step (ppg_rollout)
+            keep[r] = (keep[r] & ~0xFFu) | (fl_[r] & PPG_ROW_ATE);
         }
         obs_count[0] += n_rows[0];       // every row in use got an observation
         obs_count[1] += n_rows[1];
@@ -1311,6 +1330,7 @@ struct Env {
             for (int r = 0; r < T; ++r) {
                 ev[r] = 0;
                 act[r] = -1;
+                keep[r] = (keep[r] & 0xFFu) | ((uint32_t)slot_of(r, ln) << 8);
             }
             if (P.actions && !(P.flags & PPG_STEP_RANDOM_ACTIONS)) {
 #pragma unroll
@@ -1338,7 +1358,7 @@ struct Env {
         uint64_t acted[T];
         load_actions(acted);
 #pragma unroll
-        for (int r = 0; r < T; ++r) keep[r] = 0;  // agents_just_ate.clear(), BASE:241
+        for (int r = 0; r < T; ++r) keep[r] &= ~0xFFu;  // agents_just_ate.clear(), BASE:241
         wv::sync();                                // LDS zeros visible
         PPG_STAMP(2);
         decay(acted);                              // BASE:244-250

@@ -50,6 +50,9 @@ PPG_DEVICE uint32_t shfl_up1(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1,
 // would also drain vmcnt(0), i.e. wait for every outstanding observation store to reach HBM.)
 PPG_DEVICE void sync() { __asm__ volatile("" ::: "memory"); }
 
+// all of this wave's outstanding global loads have returned (used before overwriting memory other lanes just read)
+PPG_DEVICE void drain_loads() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 PPG_DEVICE uint32_t mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 PPG_DEVICE int popc(uint64_t m) { return __popcll(m); }
 PPG_DEVICE int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }  // m != 0

@@ -96,6 +96,8 @@ CASES = {
     "seasonal_short_seed0": ({"season_length_steps": 7, "max_steps": 120}, 0, 1000, False, 8, "seasonal"),
     "seasonal_default_seed1": ({"max_steps": 200}, 1, 1001, False, 20, "seasonal"),
     "plus_eating_seed2": ({"max_steps": 200}, 2, 1002, False, 20, "sparse_rewards_plus_eating"),
+    "dense_rewards_seed0": ({"max_steps": 250}, 0, 1000, False, 20, "dense_rewards"),
+    "dense_additive_seed4": ({"max_steps": 250}, 4, 1004, False, 20, "dense_rewards_additive"),
 }
 
 

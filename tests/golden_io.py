@@ -35,12 +35,21 @@ def call_digest(grid, obs, rew, term, trunc) -> bytes:
     return h.digest()
 
 
+# config keys of THIS implementation that select a base-family variant (the reference has one class per variant)
+VARIANT_CONFIG = {
+    "dense_rewards": {"reward_mode": "dense_energy_delta"},
+    "dense_rewards_additive": {"reward_mode": "dense_energy_delta_plus_reproduction"},
+}
+
+
 class GoldenCase:
     def __init__(self, name):
         self.name = name
         z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
         self.z = {k: z[k] for k in z.files}
         self.overrides = json.loads(str(self.z["config_json"]))
+        self.variant = str(self.z["variant"]) if "variant" in self.z else "base"
+        self.overrides.update(VARIANT_CONFIG.get(self.variant, {}))
         self.n_calls = len(self.z["term_all"])
         self.agents_after = json.loads(str(self.z["agents_after"]))
         self.reset_keys = json.loads(str(self.z["reset_keys"]))

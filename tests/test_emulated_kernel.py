@@ -26,6 +26,8 @@ def make_env(cfg, B, **kw):
     (["seasonal_short_seed0"], None),      # generated from base_environment_seasonal's own file
     (["seasonal_default_seed1"], None),
     (["plus_eating_seed2"], None),         # ...sparse_rewards_plus_eating's own file
+    (["dense_rewards_seed0"], None),       # ...base_environment_dense_rewards' own file (reward = energy delta)
+    (["dense_additive_seed4"], None),      # ...base_environment_dense_rewards_additive's own file
 ])
 def test_golden_cases_through_emulated_kernel(names, max_calls):
     replay_golden_cases(make_env, names, config_env, max_calls=max_calls)

@@ -34,6 +34,9 @@ def random_config(rng):
         "reward_predator_step": float(rng.choice([0.0, -0.01])), "reward_prey_step": float(rng.choice([0.0, 0.02])),
         "penalty_prey_caught": float(rng.choice([0.0, -2.0])),
         "reproduction_reward_predator": float(rng.choice([10.0, 7.0])), "reproduction_reward_prey": float(rng.choice([10.0, 3.0])),
+        "reward_mode": str(rng.choice(["sparse", "sparse", "dense_energy_delta", "dense_energy_delta_plus_reproduction"])),
+        **({"season_length_steps": int(rng.integers(1, 9)), "season_high_multiplier": 1.5, "season_low_multiplier": 0.5}
+           if rng.random() < 0.3 else {}),
     }
 
 
@@ -67,8 +70,12 @@ def run_differential(make_env, seed, max_calls=45):
             rng.shuffle(names)
         actions = {a: int(rng.integers(0, 9)) for a in names}
         r2 = orc.step(actions)
-        if orc.last_fallback_spawns:  # the build's own deterministic contract (seed 0) is shared by both sides
-            pass
+        if orc.last_failed_spawns:
+            # no free cell for a newborn: the reference raises TypeError (predpreygrass_rllib_env.py:401-405,766);
+            # the oracle counts it, this implementation raises the same exception type
+            with pytest.raises(TypeError):
+                env.step(actions)
+            return cfg
         r1 = env.step(actions)
         for i, what in enumerate(("obs", "rew", "term", "trunc")):
             assert list(r1[i]) == list(r2[i]), (seed, t, what, list(r1[i]), list(r2[i]))

@@ -165,6 +165,7 @@ inline uint32_t shfl_up1(uint32_t v) {
     return (uint32_t)s[l ? l - 1 : 0];
 }
 inline void sync() { (void)exchange(0); }
+inline void drain_loads() { (void)exchange(0); }  // lanes run one after another here: a collective orders reads before writes
 inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline int popc(uint64_t m) { return __builtin_popcountll(m); }
 inline int ctz(uint64_t m) { return __builtin_ctzll(m); }
