@@ -181,7 +181,6 @@ struct Env {
     int32_t id[T];
     uint32_t key[T];
     double e[T];
-    double cum[T];
     int32_t act[T];
     uint32_t ev[T];
     uint32_t keep[T];  // row flags that survive a truncation call (ATE)
@@ -255,7 +254,7 @@ struct Env {
         uint64_t sd;
         uint32_t xy[T], key[T], fl[T];
         int32_t id[T], a[T];
-        double e[T], cum[T];
+        double e[T];
         uint32_t gxy[2];
         double ge[2];
         uint2 lutd[5];
@@ -267,14 +266,13 @@ struct Env {
         p.sd = P.env_seed[b];
 #pragma unroll
         for (int r = 0; r < T; ++r) {
-            p.xy[r] = 0xFFFFu; p.key[r] = 0; p.fl[r] = 0; p.id[r] = 0; p.a[r] = -1; p.e[r] = 0.0; p.cum[r] = 0.0;
+            p.xy[r] = 0xFFFFu; p.key[r] = 0; p.fl[r] = 0; p.id[r] = 0; p.a[r] = -1; p.e[r] = 0.0;
             if (r < 2 && want_rows) {
                 const size_t s = (size_t)b * P.S + slot_of(r, ln);
                 p.xy[r] = P.row_xy[s];
                 p.e[r] = P.row_e[s];
                 p.id[r] = P.row_id[s];
                 p.key[r] = P.row_key[s];
-                p.cum[r] = P.row_cum[s];
                 p.fl[r] = P.row_flags[s];
                 if (want_actions) p.a[r] = P.actions[s];
             }
@@ -318,10 +316,10 @@ struct Env {
             const int i = row_of(r, ln);
             const bool valid = i < n_rows[type_of(r)];
             uint32_t fl = 0;
-            xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; cum[r] = 0.0; act[r] = -1; ev[r] = 0;
+            xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; act[r] = -1; ev[r] = 0;
             if (valid) {
                 if (r < 2) {
-                    xy[r] = p.xy[r]; e[r] = p.e[r]; id[r] = p.id[r]; key[r] = p.key[r]; cum[r] = p.cum[r];
+                    xy[r] = p.xy[r]; e[r] = p.e[r]; id[r] = p.id[r]; key[r] = p.key[r];
                     fl = p.fl[r]; act[r] = p.a[r];
                 } else {  // rows 64.. of the prey table: rarely in use, loaded on demand
                     const size_t s = (size_t)b * P.S + slot_of(r, ln);
@@ -329,7 +327,6 @@ struct Env {
                     e[r] = P.row_e[s];
                     id[r] = P.row_id[s];
                     key[r] = P.row_key[s];
-                    cum[r] = P.row_cum[s];
                     fl = P.row_flags[s];
                     if (P.actions) act[r] = P.actions[s];
                 }
@@ -733,13 +730,13 @@ struct Env {
                 if (type_of(r) == type) n_new += wv::popc(alive[r]);
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
+                if (f == 1) continue;  // (slot 1 was the cumulative reward: no longer carried in registers)
 #pragma unroll
                 for (int r = 0; r < T; ++r) {
                     if (type_of(r) != type) continue;
                     if ((alive[r] >> ln) & 1ull) {
                         uint64_t v;
                         if (f == 0) v = (uint64_t)__double_as_longlong(e[r]);
-                        else if (f == 1) v = (uint64_t)__double_as_longlong(cum[r]);
                         else if (f == 2) v = ((uint64_t)key[r] << 32) | (uint32_t)id[r];
                         else v = (uint64_t)xy[r] | ((uint64_t)((owns[r] >> ln) & 1ull) << 16) | ((uint64_t)keep[r] << 20);
                         scr[sbase + rk[r]] = v;
@@ -753,7 +750,6 @@ struct Env {
                     if (i < n_new) {
                         uint64_t v = scr[sbase + i];
                         if (f == 0) e[r] = __longlong_as_double((long long)v);
-                        else if (f == 1) cum[r] = __longlong_as_double((long long)v);
                         else if (f == 2) { key[r] = (uint32_t)(v >> 32); id[r] = (int32_t)(uint32_t)v; }
                         else { xy[r] = (uint32_t)(v & 0xFFFFu); ev[r] = (uint32_t)((v >> 16) & 1u); keep[r] = (uint32_t)(v >> 20) & 0x3FFFFu; }
                     } else if (f == 3) {
@@ -1122,7 +1118,6 @@ struct Env {
                     id[q] = (int32_t)wv::writelane((uint32_t)id[q], ck, (uint32_t)cid);
                     key[q] = wv::writelane(key[q], ck, ckey);
                     e[q] = writelane_f64(e[q], ck, e0);          // BASE:403
-                    cum[q] = writelane_f64(cum[q], ck, 0.0);     // BASE:410
                     if (ln == ck) ev[q] = EV_BORN;
                 }
 #pragma unroll
@@ -1152,13 +1147,16 @@ struct Env {
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);
             const uint32_t v = ev[r];
-            double rew = 0.0, c = cum[r];
+            double rew = 0.0, c = 0.0;
             uint32_t fl = 0;
             if (i < n_rows[type_of(r)]) {
+                // cumulative_rewards of a surviving agent still sits in HBM at the row's start-of-step slot
+                // (keep[] bits 8..): read it here instead of carrying two registers per row through the step
+                if (transition && !(v & EV_BORN)) c = P.row_cum[(size_t)b * P.S + (keep[r] >> 8)];
                 if (!transition) {
                     rew = 0.0;  // reset returns observations only; cumulative_rewards = 0 (BASE:150)
                 } else if (v & EV_BORN) {
-                    c = 0.0;
+                    c = 0.0;    // BASE:410
                 } else if (v & EV_TRUNC) {
                     rew = 0.0;
                 } else if (dense) {
@@ -1186,7 +1184,7 @@ struct Env {
             }
             rew_[r] = rew; cum_[r] = c; fl_[r] = fl;
         }
-        if (dense) wv::drain_loads();  // every lane has its start-of-step energy before any row_energy is overwritten
+        if (transition) wv::drain_loads();  // every lane has its start-of-step values before any row is overwritten
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);
@@ -1199,7 +1197,6 @@ struct Env {
             P.row_cum[s] = cum_[r];
             P.row_flags[s] = (uint8_t)fl_[r];
             P.row_reward[s] = rew_[r];
-            cum[r] = cum_[r];            // carried into the next fused step (ppg_rollout)
             keep[r] = (keep[r] & ~0xFFu) | (fl_[r] & PPG_ROW_ATE);
         }
         obs_count[0] += n_rows[0];       // every row in use got an observation
@@ -1268,7 +1265,7 @@ struct Env {
             const int i = row_of(r, ln);
             const int cnt = r ? Q0 : P0;
             const bool valid = i < cnt;
-            xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; cum[r] = 0.0; act[r] = -1; ev[r] = 0; keep[r] = 0;
+            xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; act[r] = -1; ev[r] = 0; keep[r] = 0;
             if (valid) {
                 const uint32_t c = ent[(r ? P0 : 0) + i];
                 const uint32_t cx = wv::mulhi(c, P.g_magic);
