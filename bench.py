@@ -221,7 +221,7 @@ def main():
     # MI355X_MICROARCH.md HBM section); only quoted when the settings match the profiled run.
     traffic = None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "b_bench_default_summary.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "c_bench_default_summary.json")))
         if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry:
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
     except Exception:
@@ -261,7 +261,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_source": "profiles/r01/b_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "traffic_source": "profiles/r01/c_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                   "bytes per launch)" if traffic else None,
                 "kernel": "ppg_step_q2",
                 "kernel_ms": round(kernel_s * 1e3, 5),
