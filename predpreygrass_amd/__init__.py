@@ -11,7 +11,7 @@ def __getattr__(name):  # lazy: importing the package must not require torch / a
     if name == "BatchedPredPreyGrass":
         from .batched import BatchedPredPreyGrass
         return BatchedPredPreyGrass
-    if name in ("PredPreyGrass", "env_creator"):
+    if name in ("PredPreyGrass", "env_creator", "VectorPredPreyGrass"):
         from . import env
         return getattr(env, name)
     if name in ("PredPreyGrassParallelEnv", "PredPreyGrassAECEnv", "parallel_env"):

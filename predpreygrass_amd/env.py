@@ -132,8 +132,9 @@ class PredPreyGrass(_MultiAgentEnvBase):
         obs = self._collect(after_reset=True)[0]
         return obs, {}
 
-    def step(self, action_dict):
-        """predpreygrass_rllib_env.py:219-473."""
+    def _stage(self, action_dict):
+        """Validate an action dict like the reference would and write it into this env's row of the
+        batch's action tensor.  Returns (ranks uint8 [S], dict order == row order)."""
         b, i = self._b, self._i
         where = {name: (ty, row) for name, ty, row, _, te, _ in self._records if not te}
         a = torch.full((b.S,), _abi.ACTION_NONE, dtype=torch.int8)
@@ -159,24 +160,27 @@ class PredPreyGrass(_MultiAgentEnvBase):
                 in_row_order = False
             last[ty] = row
         b.actions[i].copy_(a)
+        return rk, in_row_order
+
+    def step(self, action_dict):
+        """predpreygrass_rllib_env.py:219-473."""
+        b, i = self._b, self._i
+        if b.batch_size != 1:
+            raise RuntimeError("step() of a view into a shared batch: use VectorPredPreyGrass.step")
+        rk, in_row_order = self._stage(action_dict)
         if in_row_order:
-            if b.batch_size == 1:
-                b.step()
-            else:
-                raise RuntimeError("step() of a view into a shared batch: step the BatchedPredPreyGrass instead")
+            b.step()
         else:
-            ranks = torch.zeros((b.batch_size, b.S), dtype=torch.uint8)
-            ranks[i] = rk
-            b.step(act_rank=ranks.to(b.device))
+            b.step(act_rank=rk[None].to(b.device))
         return self._collect(after_reset=False)
 
     def close(self):
         pass
 
     # ------------------------------------------------------------------
-    def _collect(self, after_reset):
+    def _collect(self, after_reset, tables=None, obs=None):
         b, i = self._b, self._i
-        t = b.host_tables(i)
+        t = b.host_tables(i) if tables is None else {k: v[i:i + 1] for k, v in tables.items()}
         self._tables = t
         es = t["env_state"][0]
         status = int(es[_abi.ENV_STATUS])
@@ -185,8 +189,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
         if status & _abi.STATUS_FAILED_SPAWN:
             raise TypeError("no free cell for a newborn (the reference fails at predpreygrass_rllib_env.py:401-405)")
         recs = b.records(0, t)
-        op = b.obs_pred[i].cpu().numpy()
-        oq = b.obs_prey[i].cpu().numpy()
+        op = b.obs_pred[i].cpu().numpy() if obs is None else obs[0][i]
+        oq = b.obs_prey[i].cpu().numpy() if obs is None else obs[1][i]
         obs, rew, term, trunc = {}, {}, {}, {}
         for name, ty, row, r, te, tr in recs:
             obs[name] = (op if ty == PREDATOR else oq)[row].astype(np.float64)
@@ -374,6 +378,71 @@ class _SpaceDict(dict):
             return self[key]
         except KeyError:
             return default
+
+
+class VectorPredPreyGrass:
+    """`num_envs` reference-shaped environments behind ONE kernel launch per step.
+
+    `envs[i]` is a `PredPreyGrass` view (attributes, snapshot, `_get_observation` ...) of env i of a shared
+    `BatchedPredPreyGrass`; `step()` takes one action dict per env and returns one reference-style 5-tuple per
+    env.  With `auto_reset=True` an env whose episode ended is reset by the next `step()` (its action dict
+    is ignored for that call and the returned observations are those of the new episode, rewards 0)."""
+
+    def __init__(self, config=None, num_envs=8, device=None, seed=0, auto_reset=False, prey_capacity=128,
+                 _library=None):
+        self.num_envs = int(num_envs)
+        self.auto_reset = bool(auto_reset)
+        self.batch = BatchedPredPreyGrass(config, batch_size=self.num_envs, device=device, seed=seed,
+                                          prey_capacity=prey_capacity, _library=_library)
+        self.envs = [PredPreyGrass(config, batched=self.batch, index=i) for i in range(self.num_envs)]
+
+    def _collect_all(self, after_reset):
+        b = self.batch
+        tables = b.host_tables()
+        nP = int(tables["env_state"][:, _abi.ENV_N_PRED_ROWS].max())
+        nQ = int(tables["env_state"][:, _abi.ENV_N_PREY_ROWS].max())
+        obs = (b.obs_pred[:, :max(nP, 1)].cpu().numpy(), b.obs_prey[:, :max(nQ, 1)].cpu().numpy())
+        out = []
+        for i, e in enumerate(self.envs):
+            was_reset = bool(int(tables["env_state"][i][_abi.ENV_FLAGS]) & _abi.ENVF_WAS_RESET)
+            if was_reset and not after_reset:
+                e.cumulative_rewards, e._insertion_order = {}, []
+                o, _ = e._collect(True, tables, obs)
+                out.append((o, {a: 0.0 for a in o}, {**{a: False for a in o}, "__all__": False},
+                            {**{a: False for a in o}, "__all__": False}, {"reset": True}))
+            else:
+                out.append(e._collect(after_reset, tables, obs))
+        return out
+
+    def reset(self, seed=None):
+        """Device-side placement for every env (env i uses Philox key seed + i); returns [(obs, {}), ...]."""
+        self.batch.reset(seed=seed)
+        for e in self.envs:
+            e.cumulative_rewards, e._insertion_order = {}, []
+        return self._collect_all(after_reset=True)
+
+    def step(self, action_dicts):
+        if len(action_dicts) != self.num_envs:
+            raise ValueError("one action dict per env")
+        b = self.batch
+        ranks = torch.zeros((self.num_envs, b.S), dtype=torch.uint8)
+        all_in_order = True
+        for i, (e, ad) in enumerate(zip(self.envs, action_dicts)):
+            done = bool(int(e._tables["env_state"][0][_abi.ENV_FLAGS]) & _abi.ENVF_DONE)
+            if self.auto_reset and done:
+                b.actions[i].fill_(_abi.ACTION_NONE)  # ignored: this call resets the env
+                continue
+            rk, in_order = e._stage(ad)
+            ranks[i] = rk
+            all_in_order = all_in_order and in_order
+        if all_in_order:
+            b.step(auto_reset=self.auto_reset)
+        else:
+            b.step(auto_reset=self.auto_reset, act_rank=ranks.to(b.device))
+        return self._collect_all(after_reset=False)
+
+    def close(self):
+        self.batch.close()
 
 
 def env_creator(config):

@@ -168,3 +168,50 @@ def test_pettingzoo_parallel_and_aec_shapes():
         aec.step(None if (te or tr) else aec.action_space(agent).sample())
         n += 1
     assert n > 20
+
+
+def test_vector_env_matches_individual_envs_and_golden():
+    """VectorPredPreyGrass: N dict envs, one launch per step.  Two golden cases with the same config run side
+    by side in one vector env (placements injected), every returned dict compared with the reference."""
+    from predpreygrass_amd.env import VectorPredPreyGrass
+    cases = [GoldenCase("dense_seed0"), GoldenCase("dense_seed3")]
+    cfg = cases[0].config(config_env)
+    vec = VectorPredPreyGrass(cfg, num_envs=2, _library=library())
+    vec.batch.set_placement(np.stack([c.placement[0] for c in cases]), np.stack([c.placement[1] for c in cases]),
+                            np.stack([c.placement[2] for c in cases]))
+    first = vec._collect_all(after_reset=True)
+    for (o, info), c in zip(first, cases):
+        assert list(o) == c.reset_keys and info == {}
+    n = min(c.n_calls for c in cases)
+    for t in range(n):
+        res = vec.step([c.actions(t) for c in cases])
+        for (o, r, te, tr, info), c, e in zip(res, cases, vec.envs):
+            recs = c.records(t)
+            assert list(o) == [x[0] for x in recs]
+            for k, rew, term, trunc in recs:
+                assert np.float64(r[k]).tobytes() == np.float64(rew).tobytes() and te[k] is term and tr[k] is trunc
+            assert (te["__all__"], tr["__all__"]) == c.flags(t)
+            assert e.agents == c.agents_after[t]
+            assert call_digest(e.grid_world_state, o, r, te, tr) == c.digest(t)
+
+
+def test_vector_env_auto_reset_and_shuffled_orders():
+    from predpreygrass_amd.env import VectorPredPreyGrass
+    cfg = {**config_env, "max_steps": 12, "n_initial_active_predator": 3, "n_initial_active_prey": 5, "initial_num_grass": 20}
+    vec = VectorPredPreyGrass(cfg, num_envs=3, seed=9, auto_reset=True, _library=library())
+    rng = np.random.default_rng(1)
+    live = [list(o) for o, _ in vec.reset()]
+    n_resets = 0
+    for t in range(40):
+        dicts = []
+        for names in live:
+            names = list(names)
+            rng.shuffle(names)  # arbitrary dict order -> explicit-order kernel
+            dicts.append({a: int(rng.integers(9)) for a in names})
+        res = vec.step(dicts)
+        for i, (o, r, te, tr, info) in enumerate(res):
+            if info.get("reset"):
+                n_resets += 1
+                assert vec.envs[i].current_step == 0 and all(v == 0.0 for v in r.values())
+            live[i] = [a for a in o if not te[a]] if not (te["__all__"] or tr["__all__"]) else []
+    assert n_resets >= 3
