@@ -163,11 +163,13 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // FASTOBS: observation descriptors of this lane live in registers (needs <= 2 predator and <= 3 prey
 // chunks, i.e. Rp <= 7 and Rq <= 9); otherwise they are read from an LDS copy.
 // FUSED: the multi-step rollout loop (ppg_rollout) is compiled in; ppg_step's kernel has a single step body.
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED>
+// KP: the type the parameters are read through: `const KParams` (by-value kernel argument) or the same struct in
+// the constant address space, read in place from the kernarg segment (fused rollout).
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, class KP>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
-    const KParams &P;
+    KP &P;
     const int b;
     const int ln;
 
@@ -197,8 +199,8 @@ struct Env {
     uint64_t seed;
     bool cooc[2];  // some cell may hold two live agents of this type
 
-    PPG_MEMBER Env(const KParams &p, int b_, unsigned char *lds)
-        : P(p), b(b_), ln(wv::lane()),
+    PPG_MEMBER Env(KP &p, int b_, unsigned char *lds, int lane)
+        : P(p), b(b_), ln(lane),
           map((uint16_t *)(lds + p.off_map)), val((double *)(lds + p.off_val)),
           scr((uint64_t *)(lds + p.off_scr)), lut((uint32_t *)(lds + p.off_lut)) {}
 
@@ -358,9 +360,7 @@ struct Env {
     }
 
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
-    template <bool FROM_LDS>
-    PPG_MEMBER void load_grass_t(bool regrow, const Pre &p) {
-        const bool from_lds = FROM_LDS;
+    PPG_MEMBER void load_grass(bool regrow, const Pre &p) {
         const size_t gb = (size_t)b * P.cap_grass;
         // seasonal variant: square wave on current_step (base_environment_seasonal/...:224-234,268)
         double gain = P.gain_g;
@@ -369,8 +369,7 @@ struct Env {
         for (int q = 0; q < 2; ++q) {
             const int pp = ln + 64 * q;
             if (pp < P.n_grass) {
-                double g;  // fused steps: energies are already in LDS
-                if (FROM_LDS) g = val[grass_validx(pp)]; else g = p.ge[q];
+                double g = p.ge[q];
                 if (regrow) {
                     double v = g + gain;
                     g = (P.e0_g < v) ? P.e0_g : v;  // Python min(v, cap)
@@ -380,7 +379,7 @@ struct Env {
             }
         }
         for (int pp = 128 + ln; pp < P.n_grass; pp += 64) {
-            double g = from_lds ? val[grass_validx(pp)] : P.grass_e[gb + pp];
+            double g = P.grass_e[gb + pp];
             if (regrow) {
                 double v = g + gain;
                 g = (P.e0_g < v) ? P.e0_g : v;
@@ -389,8 +388,6 @@ struct Env {
             chmap(3)[cell_of(P.grass_xy[gb + pp])] = (uint16_t)grass_validx(pp);
         }
     }
-
-    PPG_MEMBER void load_grass(bool regrow, const Pre &p) { load_grass_t<false>(regrow, p); }
 
     // ---- actions -------------------------------------------------------------------
     PPG_MEMBER void load_actions(uint64_t (&acted)[T]) {
@@ -1308,11 +1305,7 @@ struct Env {
     }
 
     // ---- the transition ----------------------------------------------------------------
-    // One transition.  FIRST: the tables were prefetched from HBM into `pre`.  !FIRST (fused rollout,
-    // ppg_rollout): the agent table, masks and env words are still in registers from the previous step and
-    // the grass energies in LDS; every step still writes its observations, rewards, flags and tables to
-    // HBM (same buffers), and those stores drain while the wave already computes its next step.
-    template <bool FIRST>
+    // One transition: the tables were prefetched from HBM into `pre`.  `it` = index into the action tape.
     PPG_MEMBER void step_body(const Pre &pre, int it) {
         calls += 1;
         if ((P.flags & PPG_STEP_AUTO_RESET) && (envflags & PPG_ENVF_DONE)) {
@@ -1320,27 +1313,17 @@ struct Env {
             do_reset(episode + 1u);
             return;
         }
-        if (FIRST) {
-            load_rows(pre);
-        } else {  // what load_rows() would read back from the tables the previous step wrote
+        load_rows(pre);
+        if (FUSED && it > 0 && P.actions && !(P.flags & PPG_STEP_RANDOM_ACTIONS)) {  // action tape [n_steps,B,S]
 #pragma unroll
-            for (int r = 0; r < T; ++r) {
-                ev[r] = 0;
-                act[r] = -1;
-                keep[r] = (keep[r] & 0xFFu) | ((uint32_t)slot_of(r, ln) << 8);
-            }
-            if (P.actions && !(P.flags & PPG_STEP_RANDOM_ACTIONS)) {
-#pragma unroll
-                for (int r = 0; r < T; ++r)
-                    if ((alive[r] >> ln) & 1ull)
-                        act[r] = P.actions[((size_t)it * P.batch + b) * P.S + slot_of(r, ln)];
-            }
+            for (int r = 0; r < T; ++r)
+                if ((alive[r] >> ln) & 1ull) act[r] = P.actions[((size_t)it * P.batch + b) * P.S + slot_of(r, ln)];
         }
         const bool list_is_row_order = (envflags & PPG_ENVF_LIST_IS_ROW_ORDER) != 0;
 
         if (step >= P.max_steps) {  // truncation, BASE:228-238: no state change
             wv::sync();
-            load_grass_t<!FIRST>(false, pre);
+            load_grass(false, pre);
             compact_and_sort(!list_is_row_order);
             build_maps();
             obs_all_alive();
@@ -1360,7 +1343,7 @@ struct Env {
         PPG_STAMP(2);
         decay(acted);                              // BASE:244-250
         PPG_STAMP(3);
-        load_grass_t<!FIRST>(true, pre);           // BASE:252-256
+        load_grass(true, pre);                     // BASE:252-256
         PPG_STAMP(4);
         move(acted);                               // BASE:259-276
         PPG_STAMP(5);
@@ -1385,24 +1368,13 @@ struct Env {
         PPG_STAMP(12);
     }
 
-    // ppg_step: one transition.  ppg_rollout (FUSED): P.n_steps transitions in one launch.
-    // STATUS (round 1): the fused kernel is bit-identical to n single steps but NOT yet faster -- hipcc hoists
-    // loop-invariant values out of the step loop and spills; bench.py does not use it.
-    PPG_MEMBER void run_step() {
+    PPG_MEMBER void run_step(int it = 0) {
         PPG_STAMP(0);
         Pre pre;
         prefetch(pre, true, P.actions != nullptr && !(P.flags & PPG_STEP_RANDOM_ACTIONS));
         load_env_words(pre);
         init_lds(pre);
-        step_body<true>(pre, 0);
-        if (FUSED) {
-            for (int it = 1; it < P.n_steps; ++it) {
-                wv::sync();  // LDS maps back to all-zero (init_lds did it for the first step)
-                uint32_t *m32 = (uint32_t *)map;
-                for (int i = ln; i < 4 * P.map_n / 2; i += 64) m32[i] = 0u;
-                step_body<false>(pre, it);
-            }
-        }
+        step_body(pre, it);
     }
 
     PPG_MEMBER void run_reset() {
@@ -1455,8 +1427,32 @@ template <int NQ, int MODE, bool FASTOBS>
 PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     const int b = PPG_BLOCK_INDEX();
     if (b >= P.batch) return;
-    Env<NQ, MODE == MODE_STEP_ORDERED, FASTOBS, MODE == MODE_ROLLOUT> env(P, b, lds);
-    if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_ROLLOUT) env.run_step();
+    if (MODE == MODE_ROLLOUT) {
+        // ppg_rollout: n_steps transitions in one launch.  Every lane always loads and stores the same slots
+        // (its rows, its env words, its grass patches), so a fused step reads its state back through memory
+        // (L2-hot, same-lane read-after-write); nothing is carried in registers, there is no launch gap, and the
+        // observation stores of step t drain while step t+1 computes.  The whole per-env context is rebuilt
+        // every iteration from laundered roots so that hipcc cannot hoist loop-invariant values out of the
+        // step loop (that hoisting is what made earlier formulations spill hundreds of registers).
+        // STATUS (round 1): bit-identical to n single steps and spill-free, but each fused step is still slower
+        // than a ppg_step launch (parameters are scalar loads at their use sites here); bench.py does not use it.
+        const int n = P.n_steps;
+        for (int it = 0; it < n; ++it) {
+            const PPG_CONSTANT_AS KParams *Pc = PPG_KERNARG_PTR(KParams, P);
+            int bb = b, lane = wv::lane();
+            unsigned char *l = lds;
+            PPG_LAUNDER_S(Pc);
+            PPG_LAUNDER_S(bb);
+            PPG_LAUNDER_V(lane);
+            PPG_LAUNDER_V(l);
+            Env<NQ, false, FASTOBS, true, const PPG_CONSTANT_AS KParams> env(*Pc, bb, l, lane);
+            env.run_step(it);
+            wv::sync();
+        }
+        return;
+    }
+    Env<NQ, MODE == MODE_STEP_ORDERED, FASTOBS, false, const KParams> env(P, b, lds, wv::lane());
+    if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();
     else if (MODE == MODE_OBSERVE) env.run_observe();
     else env.run_export_grid();

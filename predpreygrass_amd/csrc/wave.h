@@ -18,6 +18,12 @@
 #define PPG_KERNEL(name, W) extern "C" __global__ void __launch_bounds__(64, W) name
 #define PPG_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define PPG_BLOCK_INDEX() ((int)blockIdx.x)
+// kernel parameters read in place from the kernarg segment (constant address space -> s_load)
+#define PPG_CONSTANT_AS __attribute__((address_space(4)))
+#define PPG_KERNARG_PTR(T, byval) ((const PPG_CONSTANT_AS T *)__builtin_amdgcn_kernarg_segment_ptr())
+// make a value opaque to the optimiser (no instruction is emitted)
+#define PPG_LAUNDER_S(x) __asm__ volatile("" : "+s"(x))
+#define PPG_LAUNDER_V(x) __asm__ volatile("" : "+v"(x))
 
 namespace wv {
 

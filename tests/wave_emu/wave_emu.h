@@ -22,6 +22,10 @@
 #define PPG_KERNEL(name, W) static void name
 #define PPG_DYNAMIC_LDS(name) unsigned char *name = wv::emu().lds
 #define PPG_BLOCK_INDEX() (wv::emu().block)
+#define PPG_CONSTANT_AS
+#define PPG_KERNARG_PTR(T, byval) (&(byval))
+#define PPG_LAUNDER_S(x) do { } while (0)
+#define PPG_LAUNDER_V(x) do { } while (0)
 #define __restrict__
 
 namespace wv {
