@@ -96,7 +96,7 @@ extern "C" {
  * plus the capacities of this implementation. */
 typedef struct ppg_config {
     int32_t abi_version;          /* PPG_ABI_VERSION */
-    int32_t grid_size;            /* BASE:53, 2..128 */
+    int32_t grid_size;            /* BASE:53, >= 2; bounded by 64 KiB of LDS per wavefront (about 80 with 7x7/9x9 windows) */
     int32_t predator_obs_range;   /* BASE:55, 1..15 */
     int32_t prey_obs_range;       /* BASE:56, 1..15 */
     int32_t max_steps;            /* BASE:26 */

@@ -79,7 +79,7 @@ def _parse(name: str):
 
 class PredPreyGrass(_MultiAgentEnvBase):
     def __init__(self, config=None, *, device=None, batched: BatchedPredPreyGrass | None = None, index: int = 0,
-                 _library=None):
+                 prey_capacity: int | None = None, _library=None):
         super().__init__()
         cfg = resolve_config(config)  # `config or config_env`, predpreygrass_rllib_env.py:20
         self.config = cfg
@@ -87,8 +87,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
             setattr(self, k, v)
         if batched is None:
             need = max(128, (self.n_initial_active_prey + 63) // 64 * 64)
-            batched = BatchedPredPreyGrass(cfg, batch_size=1, device=device, prey_capacity=min(256, need),
-                                           _library=_library)
+            batched = BatchedPredPreyGrass(cfg, batch_size=1, device=device,
+                                           prey_capacity=prey_capacity or min(256, need), _library=_library)
             index = 0
         self._b = batched
         self._i = int(index)

@@ -182,3 +182,11 @@ def test_fused_rollout_equals_single_steps_on_gpu():
     sa = {k: v.cpu() for k, v in _state(a).items()}
     sb = {k: v.cpu() for k, v in _state(b).items()}
     _assert_same_state(sa, sb, a)
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_maximum_size_configs_on_gpu(idx):
+    from predpreygrass_amd.env import PredPreyGrass
+    from tests.test_random_configs import BIG_CONFIGS, run_big
+    run_big(lambda cfg: PredPreyGrass(cfg, device="cuda:0", prey_capacity=256 if idx == 0 else None),
+            BIG_CONFIGS[idx], seed=idx)

@@ -102,3 +102,55 @@ def run_differential(make_env, seed, max_calls=45):
 def test_random_config_matches_oracle_emulated(seed):
     # the oracle's spawn fallback uses env seed 0 / episode 0; so does a placement-reset env here
     run_differential(lambda cfg: PredPreyGrass(cfg, _library=library()), seed)
+
+
+BIG_CONFIGS = [
+    # largest observation windows (15x15 > 8 chunks per agent -> generic LDS-descriptor path), 64x64 grid, 1000 grass
+    {"grid_size": 64, "predator_obs_range": 15, "prey_obs_range": 13, "initial_num_grass": 1000,
+     "n_initial_active_predator": 40, "n_initial_active_prey": 100, "max_steps": 30},
+    # row tables full at reset: 64 predators / 128 prey (every birth must be flagged as overflow, not corrupt state)
+    {"grid_size": 40, "predator_obs_range": 7, "prey_obs_range": 9, "initial_num_grass": 300,
+     "n_initial_active_predator": 64, "n_initial_active_prey": 128, "max_steps": 12,
+     "n_possible_predators": 64, "n_possible_prey": 128},
+    # the largest grid the LDS layout admits with 7x7 / 9x9 windows
+    {"grid_size": 80, "predator_obs_range": 7, "prey_obs_range": 9, "initial_num_grass": 500,
+     "n_initial_active_predator": 30, "n_initial_active_prey": 60, "max_steps": 20},
+]
+
+
+def run_big(make_env, cfg_over, seed=0, calls=25):
+    rng = np.random.default_rng(seed)
+    cfg = {**config_env, **cfg_over}
+    placement = random_placement(rng, cfg)
+    env = make_env(cfg)
+    orc = OracleEnv(cfg)
+    o1, _ = env.reset(options={"placement": placement})
+    o2, _ = orc.reset_from_placement(*placement)
+    assert list(o1) == list(o2) and all(o1[k].tobytes() == o2[k].tobytes() for k in o2)
+    live = list(o1)
+    for t in range(calls):
+        actions = {a: int(rng.integers(0, 9)) for a in live}
+        r2 = orc.step(actions)
+        r1 = env.step(actions)
+        assert list(r1[0]) == list(r2[0]), (t,)
+        for k in r2[0]:
+            assert r1[0][k].tobytes() == r2[0][k].tobytes(), (t, k)
+            assert np.float64(r1[1][k]).tobytes() == np.float64(r2[1][k]).tobytes() and r1[2][k] == r2[2][k]
+        assert env.grid_world_state.tobytes() == orc.grid_world_state.tobytes(), (t, "grid")
+        live = [a for a in r2[0] if not r2[2][a]]
+        if r2[2]["__all__"] or r2[3]["__all__"]:
+            break
+
+
+@pytest.mark.parametrize("idx", range(len(BIG_CONFIGS)))
+def test_maximum_size_configs_emulated(idx):
+    run_big(lambda cfg: PredPreyGrass(cfg, prey_capacity=256 if idx == 0 else None, _library=library()),
+            BIG_CONFIGS[idx], seed=idx)
+
+
+def test_configurations_beyond_the_limits_are_rejected_with_a_message():
+    with pytest.raises(ValueError, match="LDS|grid_size"):
+        PredPreyGrass({**config_env, "grid_size": 88, "predator_obs_range": 15, "prey_obs_range": 15,
+                       "initial_num_grass": 4000}, _library=library())
+    with pytest.raises(ValueError, match="capacities|capacity"):
+        PredPreyGrass({**config_env, "n_initial_active_predator": 65}, _library=library())
