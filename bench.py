@@ -263,6 +263,9 @@ def main():
                 "traffic": traffic,
                 "traffic_source": "profiles/r01/c_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                   "bytes per launch)" if traffic else None,
+                "achieved_from_pmc_traffic": round(traffic * n_sub / kernel_s / 1e9, 1) if traffic else None,
+                "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
+                                         "launch = 4.85 TB/s (profiles/r01/c_store_pattern_ceiling.txt); linear fill 6.5 TB/s",
                 "kernel": "ppg_step_q2",
                 "kernel_ms": round(kernel_s * 1e3, 5),
                 "concurrent_launches": n_sub,
