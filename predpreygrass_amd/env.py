@@ -189,8 +189,13 @@ class PredPreyGrass(_MultiAgentEnvBase):
         if status & _abi.STATUS_FAILED_SPAWN:
             raise TypeError("no free cell for a newborn (the reference fails at predpreygrass_rllib_env.py:401-405)")
         recs = b.records(0, t)
-        op = b.obs_pred[i].cpu().numpy() if obs is None else obs[0][i]
-        oq = b.obs_prey[i].cpu().numpy() if obs is None else obs[1][i]
+        if obs is None:  # copy only the rows in use (a (4,R,R) float64 block is 1.5-2.6 KB; the tables hold 64 + 128)
+            nP = max(int(es[_abi.ENV_N_PRED_ROWS]), 1)
+            nQ = max(int(es[_abi.ENV_N_PREY_ROWS]), 1)
+            op = b.obs_pred[i, :nP].cpu().numpy()
+            oq = b.obs_prey[i, :nQ].cpu().numpy()
+        else:
+            op, oq = obs[0][i], obs[1][i]
         obs, rew, term, trunc = {}, {}, {}, {}
         for name, ty, row, r, te, tr in recs:
             obs[name] = (op if ty == PREDATOR else oq)[row].astype(np.float64)
