@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PPG_ABI_VERSION 1
+#define PPG_ABI_VERSION 2
 
 /* error codes */
 #define PPG_OK 0
@@ -85,6 +85,7 @@ extern "C" {
 #define PPG_STATUS_FALLBACK_SPAWN 0x04 /* BASE:759-764 reached (reference is non-deterministic there) */
 #define PPG_STATUS_FAILED_SPAWN 0x08   /* BASE:766 reached (reference raises TypeError) */
 #define PPG_STATUS_BAD_ACTION 0x10     /* action outside -1..8 (reference: KeyError at BASE:502) */
+#define PPG_STATUS_KICK_OVERFLOW 0x20  /* more than 15 kickback rewards for one agent in one step (not representable) */
 
 /* ppg_step flags */
 #define PPG_STEP_RANDOM_ACTIONS 0x1u /* ignore `actions`; draw uniform actions with Philox4x32-10 on device */
@@ -133,6 +134,11 @@ typedef struct ppg_config {
      * (project_reward_shaping/base_environment_dense_rewards/predpreygrass_rllib_env.py:242-245,291-292,328-329,440-449);
      * 2 = the same plus the reproduction reward for a parent (.../base_environment_dense_rewards_additive:470) */
     int32_t reward_mode;
+    /* kickback variant (project_reward_shaping/base_environment_sparse_rewards_plus_kickback/predpreygrass_rllib_env.py
+     * :48-52,86-91,325,364,434,439-449): a grandparent that is still alive is rewarded every time its child reproduces */
+    int32_t kickback;                   /* 0 = base env */
+    double kickback_reward_predator;
+    double kickback_reward_prey;
 } ppg_config;
 
 /* Caller-owned device buffers.  B = batch, S = pred_capacity + prey_capacity,
@@ -151,6 +157,7 @@ typedef struct ppg_buffers {
     double *grass_energy;  /* [B,NG] grass_energies (BASE:117) */
     void *obs_pred;        /* [B,pred_capacity,4,Rp,Rp] float64|float32: observations (BASE:511-526) */
     void *obs_prey;        /* [B,prey_capacity,4,Rq,Rq] */
+    int32_t *row_parent;   /* [B,S]  id of the agent's (same-type) parent, -1 = none: agent_parent of the kickback variant */
 } ppg_buffers;
 
 typedef struct ppg_handle ppg_handle;

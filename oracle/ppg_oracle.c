@@ -48,6 +48,7 @@ struct ppo_env {
     double *e_before[2]; /* dense variants: energy_before (DENSE:242-245) */
     char *has_before[2];
     double *bonus[2];    /* dense_additive: reproduction_bonus */
+    int *parent[2];      /* kickback variant: self.agent_parent (id of the same-type parent, -1 = none) */
     char *just_ate[2];   /* self.agents_just_ate */
 
     int n_grass;
@@ -125,6 +126,8 @@ ppo_env *ppo_create(const ppo_config *cfg) {
         e->e_before[t] = (double *)calloc(n, sizeof(double));
         e->has_before[t] = (char *)calloc(n, 1);
         e->bonus[t] = (double *)calloc(n, sizeof(double));
+        e->parent[t] = (int *)malloc(n * sizeof(int));
+        for (int i = 0; i < n; ++i) e->parent[t][i] = -1;
         e->just_ate[t] = (char *)calloc(n, 1);
         e->has_obs[t] = (char *)calloc(n, 1);
         e->has_rew[t] = (char *)calloc(n, 1);
@@ -158,7 +161,7 @@ void ppo_destroy(ppo_env *e) {
     free(e->pend_type); free(e->pend_id);
     for (int t = 0; t < 2; ++t) {
         free(e->ent_index[t]); free(e->energy[t]); free(e->cumrew[t]); free(e->just_ate[t]);
-        free(e->e_before[t]); free(e->has_before[t]); free(e->bonus[t]);
+        free(e->e_before[t]); free(e->has_before[t]); free(e->bonus[t]); free(e->parent[t]);
         free(e->has_obs[t]); free(e->has_rew[t]); free(e->has_term[t]); free(e->has_trunc[t]);
         free(e->obs_at[t]); free(e->rew[t]); free(e->term[t]); free(e->trunc[t]);
     }
@@ -327,7 +330,7 @@ int ppo_reset_from_placement(ppo_env *e, const int32_t *pred_xy, const int32_t *
     e->n_entries = 0;
     for (int t = 0; t < 2; ++t) {
         int n = npos(e, t) + 1;
-        for (int i = 0; i < n; ++i) e->ent_index[t][i] = -1;
+        for (int i = 0; i < n; ++i) { e->ent_index[t][i] = -1; e->parent[t][i] = -1; }  /* KICK:178 */
         memset(e->just_ate[t], 0, n);
     }
     for (int i = 0; i < e->n_agents; ++i) e->cumrew[e->ag_type[i]][e->ag_id[i]] = 0; /* BASE:150 */
@@ -581,6 +584,7 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
             e->cur_num[t] -= 1;
             *cell(e, t == PPO_PREDATOR ? 1 : 2, e->ent_x[k], e->ent_y[k]) = 0; /* BASE:293/297 */
             positions_delete(e, t, id);                               /* BASE:299-300 */
+            e->parent[t][id] = -1;                                    /* KICK:325 */
             continue;
         } else if (t == PPO_PREDATOR) {
             int px = e->ent_x[k], py = e->ent_y[k];
@@ -607,6 +611,7 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
                 e->cur_num[PPO_PREY] -= 1;
                 *cell(e, 2, e->ent_x[caught], e->ent_y[caught]) = 0;  /* BASE:335 */
                 positions_delete(e, PPO_PREY, cid);                   /* BASE:336-338 */
+                e->parent[PPO_PREY][cid] = -1;                        /* KICK:364 */
             } else if (!dense) {
                 e->rew[t][id] = c->reward_predator_step; e->has_rew[t][id] = 1; /* BASE:341 */
             }
@@ -685,6 +690,16 @@ int ppo_step(ppo_env *e, int32_t n_act, const int32_t *act_type, const int32_t *
                     e->bonus[t][id] = t == PPO_PREDATOR ? c->reproduction_reward_predator : c->reproduction_reward_prey;
                 }
                 e->cumrew[t][cid] = 0;                                /* BASE:410 */
+                if (c->kickback) {
+                    e->parent[t][cid] = id;                           /* KICK:434/475 */
+                    int gp = e->parent[t][id];                        /* KICK:443 */
+                    if (gp >= 0 && entry_of(e, t, gp) >= 0) {
+                        double kb = t == PPO_PREDATOR ? c->kickback_reward_predator : c->kickback_reward_prey;
+                        e->rew[t][gp] = (e->has_rew[t][gp] ? e->rew[t][gp] : 0.0) + kb;   /* KICK:446 */
+                        e->has_rew[t][gp] = 1;
+                        e->cumrew[t][gp] = e->cumrew[t][gp] + kb;     /* KICK:447 */
+                    }
+                }
                 put_obs(e, t, cid);                                   /* BASE:412 */
                 e->term[t][cid] = 0; e->has_term[t][cid] = 1;
                 e->trunc[t][cid] = 0; e->has_trunc[t][cid] = 1;

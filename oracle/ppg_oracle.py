@@ -71,7 +71,8 @@ _DBL_FIELDS = [
 class _Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS] + [
         ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double),
-        ("reward_mode", C.c_int32)]
+        ("reward_mode", C.c_int32), ("kickback", C.c_int32), ("kickback_reward_predator", C.c_double),
+        ("kickback_reward_prey", C.c_double)]
 
 
 class _Record(C.Structure):
@@ -178,6 +179,10 @@ class OracleEnv:
         c.season_low_multiplier = float((config or {}).get("season_low_multiplier", 1.0))
         c.reward_mode = {"sparse": 0, "dense_energy_delta": 1, "dense_energy_delta_plus_reproduction": 2}[
             (config or {}).get("reward_mode", "sparse")]
+        kb = config or {}
+        c.kickback = int("kickback_reward_predator" in kb or "kickback_reward_prey" in kb)
+        c.kickback_reward_predator = float(kb.get("kickback_reward_predator", 10.0))
+        c.kickback_reward_prey = float(kb.get("kickback_reward_prey", 10.0))
         self._L = lib()
         self._h = self._L.ppo_create(C.byref(c))
         if not self._h:

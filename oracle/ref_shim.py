@@ -34,6 +34,7 @@ VARIANTS = {
     "sparse_rewards_plus_eating": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards_plus_eating",
     "dense_rewards": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_dense_rewards",
     "dense_rewards_additive": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_dense_rewards_additive",
+    "sparse_rewards_plus_kickback": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards_plus_kickback",
 }
 
 

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libppg_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # row_flags bits
 ROW_DIED, ROW_OWNS, ROW_NEWBORN, ROW_ATE, ROW_TRUNC = 0x01, 0x02, 0x04, 0x08, 0x10
@@ -22,7 +22,7 @@ ENV_WORDS = 16
  ENV_CALLS, ENV_OBS_PRED, ENV_OBS_PREY) = range(16)
 ENVF_TERM_ALL, ENVF_TRUNC_ALL, ENVF_DONE, ENVF_WAS_RESET, ENVF_LIST_IS_ROW_ORDER = 0x01, 0x02, 0x04, 0x08, 0x10
 (STATUS_PRED_OVERFLOW, STATUS_PREY_OVERFLOW, STATUS_FALLBACK_SPAWN, STATUS_FAILED_SPAWN,
- STATUS_BAD_ACTION) = 0x01, 0x02, 0x04, 0x08, 0x10
+ STATUS_BAD_ACTION, STATUS_KICK_OVERFLOW) = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
 STEP_RANDOM_ACTIONS, STEP_AUTO_RESET = 0x1, 0x2
 ACTION_NONE = -1
 
@@ -40,14 +40,15 @@ _DBL_FIELDS = [
 ]
 _BUF_FIELDS = [
     "row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "env_state", "env_seed",
-    "grass_xy", "grass_energy", "obs_pred", "obs_prey",
+    "grass_xy", "grass_energy", "obs_pred", "obs_prey", "row_parent",
 ]
 
 
 class PpgConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS] + [
         ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double),
-        ("reward_mode", C.c_int32)]
+        ("reward_mode", C.c_int32), ("kickback", C.c_int32), ("kickback_reward_predator", C.c_double),
+        ("kickback_reward_prey", C.c_double)]
 
 
 class PpgBuffers(C.Structure):
@@ -101,6 +102,10 @@ def load_hip_library() -> C.CDLL:
     """Load libppg_hip.so (HIP, gfx950).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        override = os.environ.get("PPG_HIP_LIB")  # A/B experiments with another build of the SAME HIP library
+        if override:
+            _lib = bind(C.CDLL(override))
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "

@@ -88,6 +88,7 @@ class BatchedPredPreyGrass:
         self.row_cumrew = z((B, S), torch.float64)
         self.row_flags = z((B, S), torch.uint8)
         self.row_reward = z((B, S), torch.float64)
+        self.row_parent = torch.full((B, S), -1, dtype=torch.int32, device=dev)
         self.env_state = z((B, _abi.ENV_WORDS), torch.int32)
         self.env_seed = z((B,), torch.int64)
         self.grass_xy = z((B, NG), torch.int16)
@@ -121,6 +122,12 @@ class BatchedPredPreyGrass:
         if cfg.get("reward_mode", "sparse") not in modes:
             raise ValueError(f"reward_mode must be one of {sorted(modes)}")
         c.reward_mode = modes[cfg.get("reward_mode", "sparse")]
+        # kickback variant keys (project_reward_shaping/base_environment_sparse_rewards_plus_kickback/config_env.py:24-25)
+        c.kickback = int("kickback_reward_predator" in cfg or "kickback_reward_prey" in cfg)
+        c.kickback_reward_predator = float(cfg.get("kickback_reward_predator", 10.0))
+        c.kickback_reward_prey = float(cfg.get("kickback_reward_prey", 10.0))
+        if c.kickback and c.reward_mode != 0:
+            raise ValueError("the kickback rewards are defined on top of the sparse reward mode only")
         bufs = _abi.PpgBuffers()
         for name in _abi._BUF_FIELDS:
             setattr(bufs, name, getattr(self, name).data_ptr())
@@ -231,6 +238,7 @@ class BatchedPredPreyGrass:
             t.copy_(torch.from_numpy(a))
         self.row_cumrew.zero_()
         self.row_reward.zero_()
+        self.row_parent.fill_(-1)
         self.observe()
         return self
 
@@ -296,7 +304,7 @@ class BatchedPredPreyGrass:
     def host_tables(self, b=None):
         """Small per-env tables copied to the host as numpy arrays."""
         sl = slice(None) if b is None else slice(b, b + 1)
-        names = ["row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state",
+        names = ["row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "row_parent", "env_state",
                  "grass_xy", "grass_energy"]
         return {n: getattr(self, n)[sl].cpu().numpy() for n in names}
 

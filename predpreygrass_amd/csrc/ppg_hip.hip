@@ -17,12 +17,16 @@
     PPG_K(ppg_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID, true)            \
     PPG_K(ppg_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED, true)       \
     PPG_K(ppg_rollout_q##NQ, NQ, ppg::MODE_ROLLOUT, true)             \
+    PPG_K(ppg_step_kick_q##NQ, NQ, ppg::MODE_STEP_KICK, true)         \
+    PPG_K(ppg_step_ord_kick_q##NQ, NQ, ppg::MODE_STEP_ORDERED_KICK, true) \
     PPG_K(ppg_step_q##NQ##g, NQ, ppg::MODE_STEP, false)               \
     PPG_K(ppg_reset_q##NQ##g, NQ, ppg::MODE_RESET, false)             \
     PPG_K(ppg_observe_q##NQ##g, NQ, ppg::MODE_OBSERVE, false)         \
     PPG_K(ppg_grid_q##NQ##g, NQ, ppg::MODE_EXPORT_GRID, false)        \
     PPG_K(ppg_step_ord_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED, false)   \
-    PPG_K(ppg_rollout_q##NQ##g, NQ, ppg::MODE_ROLLOUT, false)
+    PPG_K(ppg_rollout_q##NQ##g, NQ, ppg::MODE_ROLLOUT, false)         \
+    PPG_K(ppg_step_kick_q##NQ##g, NQ, ppg::MODE_STEP_KICK, false)     \
+    PPG_K(ppg_step_ord_kick_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED_KICK, false)
 
 PPG_DEFINE_KERNELS(1)
 PPG_DEFINE_KERNELS(2)
@@ -31,13 +35,13 @@ PPG_DEFINE_KERNELS(4)
 typedef void (*ppg_kernel_fn)(const ppg::KParams);
 
 static ppg_kernel_fn pick_kernel(int nq, int mode, bool fast) {
-    static const ppg_kernel_fn table[2][3][6] = {
-        {{ppg_step_q1g, ppg_reset_q1g, ppg_observe_q1g, ppg_grid_q1g, ppg_step_ord_q1g, ppg_rollout_q1g},
-         {ppg_step_q2g, ppg_reset_q2g, ppg_observe_q2g, ppg_grid_q2g, ppg_step_ord_q2g, ppg_rollout_q2g},
-         {ppg_step_q4g, ppg_reset_q4g, ppg_observe_q4g, ppg_grid_q4g, ppg_step_ord_q4g, ppg_rollout_q4g}},
-        {{ppg_step_q1, ppg_reset_q1, ppg_observe_q1, ppg_grid_q1, ppg_step_ord_q1, ppg_rollout_q1},
-         {ppg_step_q2, ppg_reset_q2, ppg_observe_q2, ppg_grid_q2, ppg_step_ord_q2, ppg_rollout_q2},
-         {ppg_step_q4, ppg_reset_q4, ppg_observe_q4, ppg_grid_q4, ppg_step_ord_q4, ppg_rollout_q4}},
+    static const ppg_kernel_fn table[2][3][ppg::N_MODES] = {
+        {{ppg_step_q1g, ppg_reset_q1g, ppg_observe_q1g, ppg_grid_q1g, ppg_step_ord_q1g, ppg_rollout_q1g, ppg_step_kick_q1g, ppg_step_ord_kick_q1g},
+         {ppg_step_q2g, ppg_reset_q2g, ppg_observe_q2g, ppg_grid_q2g, ppg_step_ord_q2g, ppg_rollout_q2g, ppg_step_kick_q2g, ppg_step_ord_kick_q2g},
+         {ppg_step_q4g, ppg_reset_q4g, ppg_observe_q4g, ppg_grid_q4g, ppg_step_ord_q4g, ppg_rollout_q4g, ppg_step_kick_q4g, ppg_step_ord_kick_q4g}},
+        {{ppg_step_q1, ppg_reset_q1, ppg_observe_q1, ppg_grid_q1, ppg_step_ord_q1, ppg_rollout_q1, ppg_step_kick_q1, ppg_step_ord_kick_q1},
+         {ppg_step_q2, ppg_reset_q2, ppg_observe_q2, ppg_grid_q2, ppg_step_ord_q2, ppg_rollout_q2, ppg_step_kick_q2, ppg_step_ord_kick_q2},
+         {ppg_step_q4, ppg_reset_q4, ppg_observe_q4, ppg_grid_q4, ppg_step_ord_q4, ppg_rollout_q4, ppg_step_kick_q4, ppg_step_ord_kick_q4}},
     };
     return table[fast ? 1 : 0][nq == 1 ? 0 : nq == 2 ? 1 : 2][mode];
 }

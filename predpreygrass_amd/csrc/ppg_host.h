@@ -95,7 +95,7 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     if (c.max_steps < 0) return ppg_fail(h, PPG_EINVAL, "max_steps < 0");
     const ppg_buffers &b = h->bufs;
     if (!b.row_xy || !b.row_energy || !b.row_id || !b.row_key || !b.row_cumrew || !b.row_flags || !b.row_reward ||
-        !b.env_state || !b.env_seed || !b.grass_xy || !b.grass_energy || !b.obs_pred || !b.obs_prey)
+        !b.env_state || !b.env_seed || !b.grass_xy || !b.grass_energy || !b.obs_pred || !b.obs_prey || !b.row_parent)
         return ppg_fail(h, PPG_EINVAL, "a buffer pointer is NULL");
 
     ppg::KParams &P = h->base;
@@ -116,6 +116,8 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.gain_g = c.energy_gain_per_step_grass;
     if (c.reward_mode < 0 || c.reward_mode > 2) return ppg_fail(h, PPG_EINVAL, "reward_mode must be 0, 1 or 2");
     P.reward_mode = c.reward_mode;
+    if (c.kickback && c.reward_mode != 0) return ppg_fail(h, PPG_EINVAL, "kickback requires reward_mode 0");
+    P.kickback = c.kickback ? 1 : 0; P.kick_p = c.kickback_reward_predator; P.kick_q = c.kickback_reward_prey;
     P.season_len = c.season_length_steps; P.season_hi = c.season_high_multiplier; P.season_lo = c.season_low_multiplier;
     h->nq = c.prey_capacity / 64;
 
@@ -137,7 +139,7 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.row_xy = b.row_xy; P.row_e = b.row_energy; P.row_id = b.row_id; P.row_key = b.row_key;
     P.row_cum = b.row_cumrew; P.row_flags = b.row_flags; P.row_reward = b.row_reward;
     P.env_state = b.env_state; P.env_seed = b.env_seed; P.grass_xy = b.grass_xy; P.grass_e = b.grass_energy;
-    P.obs_pred = b.obs_pred; P.obs_prey = b.obs_prey;
+    P.obs_pred = b.obs_pred; P.obs_prey = b.obs_prey; P.row_parent = b.row_parent;
     P.batch = h->batch;
 
     if (3 * P.map_n + 8 * c.grid_size + 8 > 32767) return ppg_fail(h, PPG_EINVAL, "grid too large for 16-bit map offsets");
@@ -202,13 +204,15 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
     ppg::KParams P = h->base;
-    P.mode = ppg::MODE_STEP; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
-    return backend_launch(h, ppg::MODE_STEP, P, stream);
+    const int mode = h->cfg.kickback ? ppg::MODE_STEP_KICK : ppg::MODE_STEP;
+    P.mode = mode; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
+    return backend_launch(h, mode, P, stream);
 }
 
 int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t flags, void *stream) {
     if (!h) return PPG_EINVAL;
     if (n_steps < 1) return ppg_fail(h, PPG_EINVAL, "n_steps must be >= 1");
+    if (h->cfg.kickback) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support the kickback variant");
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
     ppg::KParams P = h->base;
@@ -231,7 +235,8 @@ int ppg_step_ordered(ppg_handle *h, const int8_t *actions, const uint8_t *act_ra
     if (!actions) return ppg_fail(h, PPG_EINVAL, "actions is NULL");
     if (flags & ~PPG_STEP_AUTO_RESET) return ppg_fail(h, PPG_EINVAL, "ppg_step_ordered takes only PPG_STEP_AUTO_RESET");
     ppg::KParams P = h->base;
-    const int mode = act_rank ? ppg::MODE_STEP_ORDERED : ppg::MODE_STEP;
+    const int mode = act_rank ? (h->cfg.kickback ? ppg::MODE_STEP_ORDERED_KICK : ppg::MODE_STEP_ORDERED)
+                              : (h->cfg.kickback ? ppg::MODE_STEP_KICK : ppg::MODE_STEP);
     P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
     return backend_launch(h, mode, P, stream);
 }

@@ -40,7 +40,8 @@
 
 namespace ppg {
 
-enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3, MODE_STEP_ORDERED = 4, MODE_ROLLOUT = 5 };
+enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3, MODE_STEP_ORDERED = 4, MODE_ROLLOUT = 5,
+       MODE_STEP_KICK = 6, MODE_STEP_ORDERED_KICK = 7, N_MODES = 8 };
 
 // event bits of a row during one call
 enum { EV_STARVED = 1, EV_CAUGHT = 2, EV_ATE = 4, EV_PARENT = 8, EV_BORN = 16, EV_TRUNC = 32 };
@@ -62,6 +63,9 @@ struct KParams {
     double season_hi, season_lo;  // seasonal regrowth multipliers
     int32_t season_len;           // <= 0: no seasonal cycle
     int32_t reward_mode;          // 0 base rewards, 1 dense energy delta, 2 dense + reproduction bonus
+    double kick_p, kick_q;        // kickback rewards (grandparent bonus)
+    int32_t kickback;             // 0 = base env
+    int32_t pad2_;
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
     int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
@@ -84,6 +88,7 @@ struct KParams {
     double *grass_e;
     void *obs_pred;
     void *obs_prey;
+    int32_t *row_parent;
     const uint32_t *obs_lut;  // library-owned, (nch_p + nch_q) * 128 words
     // per-launch
     const int8_t *actions;
@@ -165,7 +170,9 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // FUSED: the multi-step rollout loop (ppg_rollout) is compiled in; ppg_step's kernel has a single step body.
 // KP: the type the parameters are read through: `const KParams` (by-value kernel argument) or the same struct in
 // the constant address space, read in place from the kernarg segment (fused rollout).
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, class KP>
+// KICK: the kickback-reward variant (grandparent bonus) is compiled in.  Measured: merely carrying that code costs the
+// base path 11 % (register / SGPR pressure), so it has its own kernel variants.
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, class KP>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
@@ -1128,6 +1135,30 @@ struct Env {
                 e[r] = writelane_f64(e[r], k, ne);
                 if (ln == k) ev[r] |= EV_PARENT;               // reward overwrite, BASE:409/438 (E4)
                 grid_set(r, k, s_xy, ne, true);                // BASE:406
+                if (KICK) {
+                    // kickback variant: agent_parent[child] = parent (KICK:434); the parent's own parent, if still
+                    // alive, gets a bonus (KICK:443-447).  Whether that bonus lands before or after the grandparent's
+                    // own reproduction in this loop decides if its reward survives (BASE:409 overwrites), so the two
+                    // cases are counted separately (ev bits 8-11 / 12-15) and replayed in rewards_and_store.
+                    const int my_id = (int)wv::readlane((uint32_t)id[r], k);
+                    if (ln == 0) ((int32_t *)scr)[slot_of(cr, ck)] = my_id;
+                    const uint32_t k_keep = wv::readlane(keep[r], k);
+                    const int gp = (int)wv::first((uint32_t)P.row_parent[(size_t)b * P.S + (k_keep >> 8)]);
+                    if (gp >= 0) {
+#pragma unroll
+                        for (int q = 0; q < T; ++q) {
+                            if (type_of(q) != type) continue;
+                            const uint64_t gm = wv::ballot(id[q] == gp) & alive[q] & ~wv::ballot(ev[q] & EV_BORN);
+                            if (gm) {
+                                const int gk = wv::ctz(gm);
+                                const uint32_t gev = wv::readlane(ev[q], gk);
+                                const int sh = (gev & EV_PARENT) ? 12 : 8;
+                                if (((gev >> sh) & 15u) == 15u) status |= PPG_STATUS_KICK_OVERFLOW;
+                                else if (ln == gk) ev[q] += 1u << sh;
+                            }
+                        }
+                    }
+                }
             }
         }
     }
@@ -1139,6 +1170,7 @@ struct Env {
         for (int r = 0; r < T; ++r) n_new[type_of(r)] += wv::popc(wv::ballot(ev[r] & EV_BORN) & rows[r]);
         double rew_[T], cum_[T];
         uint32_t fl_[T];
+        int32_t par_[T];
         const bool dense = transition && P.reward_mode != 0;
 #pragma unroll
         for (int r = 0; r < T; ++r) {
@@ -1171,7 +1203,15 @@ struct Env {
                 } else {
                     if (v & EV_ATE) { rew = r ? P.r_eat : P.r_catch; c += rew; c += rew; }
                     else { rew = r ? P.r_qstep : P.r_pstep; c += rew; }
-                    if (v & EV_PARENT) { rew = r ? P.r_repro_q : P.r_repro_p; c += rew; }
+                    if (KICK) {
+                        const double kb = r ? P.kick_q : P.kick_p;
+                        const uint32_t n_before = (v >> 8) & 15u, n_after = (v >> 12) & 15u;
+                        for (uint32_t i = 0; i < n_before; ++i) { rew = rew + kb; c = c + kb; }   // KICK:446-447
+                        if (v & EV_PARENT) { rew = r ? P.r_repro_q : P.r_repro_p; c += rew; }       // BASE:409 overwrites
+                        for (uint32_t i = 0; i < n_after; ++i) { rew = rew + kb; c = c + kb; }
+                    } else if (v & EV_PARENT) {
+                        rew = r ? P.r_repro_q : P.r_repro_p; c += rew;
+                    }
                 }
                 if (v & (EV_STARVED | EV_CAUGHT)) fl |= PPG_ROW_DIED;
                 if ((owns[r] >> ln) & 1ull) fl |= PPG_ROW_OWNS;
@@ -1180,6 +1220,12 @@ struct Env {
                 if (v & EV_TRUNC) fl |= PPG_ROW_TRUNC | (keep[r] & PPG_ROW_ATE);
             }
             rew_[r] = rew; cum_[r] = c; fl_[r] = fl;
+            par_[r] = -1;
+            if (KICK && transition && i < n_rows[type_of(r)] && !(v & (EV_STARVED | EV_CAUGHT))) {
+                // agent_parent rides along with its row: newborns got it in reproduce() (LDS), survivors keep theirs
+                if (v & EV_BORN) par_[r] = ((const int32_t *)scr)[slot_of(r, ln)];
+                else par_[r] = P.row_parent[(size_t)b * P.S + (keep[r] >> 8)];
+            }
         }
         if (transition) wv::drain_loads();  // every lane has its start-of-step values before any row is overwritten
 #pragma unroll
@@ -1194,6 +1240,7 @@ struct Env {
             P.row_cum[s] = cum_[r];
             P.row_flags[s] = (uint8_t)fl_[r];
             P.row_reward[s] = rew_[r];
+            if (KICK) P.row_parent[s] = par_[r];
             keep[r] = (keep[r] & ~0xFFu) | (fl_[r] & PPG_ROW_ATE);
         }
         obs_count[0] += n_rows[0];       // every row in use got an observation
@@ -1445,14 +1492,15 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
             PPG_LAUNDER_S(bb);
             PPG_LAUNDER_V(lane);
             PPG_LAUNDER_V(l);
-            Env<NQ, false, FASTOBS, true, const PPG_CONSTANT_AS KParams> env(*Pc, bb, l, lane);
+            Env<NQ, false, FASTOBS, true, false, const PPG_CONSTANT_AS KParams> env(*Pc, bb, l, lane);
             env.run_step(it);
             wv::sync();
         }
         return;
     }
-    Env<NQ, MODE == MODE_STEP_ORDERED, FASTOBS, false, const KParams> env(P, b, lds, wv::lane());
-    if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED) env.run_step();
+    Env<NQ, MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_ORDERED_KICK, FASTOBS, false,
+        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, const KParams> env(P, b, lds, wv::lane());
+    if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();
     else if (MODE == MODE_OBSERVE) env.run_observe();
     else env.run_export_grid();

@@ -249,6 +249,16 @@ class PredPreyGrass(_MultiAgentEnvBase):
         return {n: float(t["row_energy"][0][live[n]]) for n in self._insertion_order if n in live}
 
     @property
+    def agent_parent(self):
+        """child id -> parent id of the kickback variant (…plus_kickback/predpreygrass_rllib_env.py:86-91)."""
+        live, t = self._live(), self._tables
+        out = {}
+        for n in self._insertion_order:
+            if n in live and int(t["row_parent"][0][live[n]]) >= 0:
+                out[n] = n.rsplit("_", 1)[0] + "_%d" % int(t["row_parent"][0][live[n]])
+        return out
+
+    @property
     def predator_positions(self):
         return {k: v for k, v in self.agent_positions.items() if k.startswith("predator")}
 
@@ -299,7 +309,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
         return t[self._i, row].cpu().numpy().astype(np.float64)
 
     # snapshot / restore (predpreygrass_rllib_env.py:768-804)
-    _STATE_TENSORS = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward",
+    _STATE_TENSORS = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_parent",
                       "env_state", "env_seed", "grass_xy", "grass_energy"]
 
     def get_state_snapshot(self):
@@ -321,6 +331,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
             "pending_removal": list(self._pending_removal),
             "next_predator_idx": self._next_predator_idx,
             "next_prey_idx": self._next_prey_idx,
+            "agent_parent": self.agent_parent,
             # device state of this implementation
             "_device_state": {n: getattr(b, n)[i].cpu().clone() for n in self._STATE_TENSORS},
             "_records": list(self._records),

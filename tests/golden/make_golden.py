@@ -98,6 +98,11 @@ CASES = {
     "plus_eating_seed2": ({"max_steps": 200}, 2, 1002, False, 20, "sparse_rewards_plus_eating"),
     "dense_rewards_seed0": ({"max_steps": 250}, 0, 1000, False, 20, "dense_rewards"),
     "dense_additive_seed4": ({"max_steps": 250}, 4, 1004, False, 20, "dense_rewards_additive"),
+    "kickback_seed0": ({"max_steps": 400}, 0, 1000, False, 25, "sparse_rewards_plus_kickback"),
+    # fast reproduction + distinctive kickback values: many grandparent rewards (1.25 / 3.0 on top of 0 or 10)
+    "kickback_fast_seed5": ({"max_steps": 110, "prey_creation_energy_threshold": 4.5, "predator_creation_energy_threshold": 7.0,
+                             "energy_gain_per_step_grass": 0.12, "kickback_reward_predator": 3.0, "kickback_reward_prey": 1.25,
+                             "initial_num_grass": 110}, 5, 1005, False, 10, "sparse_rewards_plus_kickback"),
 }
 
 
@@ -109,7 +114,20 @@ def capture(env):
     return pred, prey, grass
 
 
+class _FallbackReached(Exception):
+    pass
+
+
+def _forbid_unseeded_fallback():
+    """The reference's spawn fallback draws from the UNSEEDED global np.random (predpreygrass_rllib_env.py:764):
+    an episode that reaches it is not reproducible and must not become a golden vector."""
+    def boom(*a, **k):
+        raise _FallbackReached("episode reaches the unseeded spawn fallback; pick another seed/config")
+    np.random.randint = boom
+
+
 def make_case(name, overrides, seed, action_seed, shuffle, full_every, variant="base", max_calls=1200):
+    _forbid_unseeded_fallback()
     env = make_reference_env(overrides, variant)
     if variant != "base":
         overrides = {**{k: v for k, v in reference_default_config(variant).items() if not k.startswith("verbose")},

@@ -28,6 +28,8 @@ def make_env(cfg, B, **kw):
     (["plus_eating_seed2"], None),         # ...sparse_rewards_plus_eating's own file
     (["dense_rewards_seed0"], None),       # ...base_environment_dense_rewards' own file (reward = energy delta)
     (["dense_additive_seed4"], None),      # ...base_environment_dense_rewards_additive's own file
+    (["kickback_seed0"], None),            # ...base_environment_sparse_rewards_plus_kickback's own file
+    (["kickback_fast_seed5"], None),       # 194 grandparent rewards incl. double kicks and kick-after-own-reproduction
 ])
 def test_golden_cases_through_emulated_kernel(names, max_calls):
     replay_golden_cases(make_env, names, config_env, max_calls=max_calls)

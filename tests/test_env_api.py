@@ -63,6 +63,17 @@ def test_dict_api_honours_shuffled_action_dict_order():
     replay_through_dict_api("dense_shuffled_seed17", make)
 
 
+def test_dict_api_kickback_variant_and_agent_parent():
+    """…sparse_rewards_plus_kickback: rewards to grandparents; agent_parent mirrors the reference attribute."""
+    env = replay_through_dict_api("kickback_fast_seed5", make)
+    parents = env.agent_parent
+    assert len(parents) > 20
+    for child, parent in parents.items():
+        assert child.rsplit("_", 1)[0] == parent.rsplit("_", 1)[0]           # same species
+        assert int(child.rsplit("_", 1)[1]) > int(parent.rsplit("_", 1)[1])  # ids are handed out in birth order
+    assert "agent_parent" in env.get_state_snapshot()
+
+
 def test_dict_api_default_config_first_calls():
     replay_through_dict_api("default_seed0", make, max_calls=60)
 

@@ -22,7 +22,7 @@ def make_env(cfg, B, **kw):
     ["c1_seed0"], ["default_seed0", "default_seed1"], ["c4_seed0"], ["dense_seed0", "dense_seed3"],
     ["rewards_seed3"], ["pool_seed3"], ["even_obs_seed0"],
     ["seasonal_short_seed0"], ["seasonal_default_seed1"], ["plus_eating_seed2"],
-    ["dense_rewards_seed0"], ["dense_additive_seed4"],
+    ["dense_rewards_seed0"], ["dense_additive_seed4"], ["kickback_seed0"], ["kickback_fast_seed5"],
 ])
 def test_golden_cases_on_gpu(names):
     replay_golden_cases(make_env, names, config_env)

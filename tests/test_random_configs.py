@@ -18,8 +18,11 @@ def random_config(rng):
     P0 = int(rng.integers(0, min(12, cells // 3) + 1))
     Q0 = int(rng.integers(0, min(20, cells // 3) + 1))
     NG = int(rng.integers(0, min(60, cells - P0 - Q0) + 1))
+    mode = str(rng.choice(["sparse", "sparse", "dense_energy_delta", "dense_energy_delta_plus_reproduction"]))
+    kick = {"kickback_reward_predator": float(rng.choice([10.0, 3.0])), "kickback_reward_prey": float(rng.choice([10.0, 1.25]))} \
+        if (mode == "sparse" and rng.random() < 0.4) else {}
     return {
-        **config_env,
+        **config_env, **kick,
         "grid_size": G, "max_steps": int(rng.integers(0, 40)),
         "predator_obs_range": int(rng.integers(1, 16)), "prey_obs_range": int(rng.integers(1, 16)),
         "n_initial_active_predator": P0, "n_initial_active_prey": Q0, "initial_num_grass": NG,
@@ -34,7 +37,7 @@ def random_config(rng):
         "reward_predator_step": float(rng.choice([0.0, -0.01])), "reward_prey_step": float(rng.choice([0.0, 0.02])),
         "penalty_prey_caught": float(rng.choice([0.0, -2.0])),
         "reproduction_reward_predator": float(rng.choice([10.0, 7.0])), "reproduction_reward_prey": float(rng.choice([10.0, 3.0])),
-        "reward_mode": str(rng.choice(["sparse", "sparse", "dense_energy_delta", "dense_energy_delta_plus_reproduction"])),
+        "reward_mode": mode,
         **({"season_length_steps": int(rng.integers(1, 9)), "season_high_multiplier": 1.5, "season_low_multiplier": 0.5}
            if rng.random() < 0.3 else {}),
     }

@@ -35,6 +35,8 @@ static void run_mode(const ppg::KParams &P, int mode) {
         case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, FAST>(P, lds); break;
         case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, FAST>(P, lds); break;
         case ppg::MODE_ROLLOUT: ppg::env_main<NQ, ppg::MODE_ROLLOUT, FAST>(P, lds); break;
+        case ppg::MODE_STEP_KICK: ppg::env_main<NQ, ppg::MODE_STEP_KICK, FAST>(P, lds); break;
+        case ppg::MODE_STEP_ORDERED_KICK: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED_KICK, FAST>(P, lds); break;
         default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, FAST>(P, lds); break;
     }
 }
