@@ -190,3 +190,18 @@ def test_maximum_size_configs_on_gpu(idx):
     from tests.test_random_configs import BIG_CONFIGS, run_big
     run_big(lambda cfg: PredPreyGrass(cfg, device="cuda:0", prey_capacity=256 if idx == 0 else None),
             BIG_CONFIGS[idx], seed=idx)
+
+
+def test_32768_envs_on_one_gpu_sampled_oracle():
+    """BASELINE config 5's 32768 envs on ONE device (8x the per-GPU shard): strides and indices beyond 32 bits
+    of bytes (obs_prey alone is 10.9 GB), sampled envs vs oracle, status clean everywhere."""
+    cfg = dict(config_env)
+    B = 32768
+    env = make_env(cfg, B)
+    sample = [0, 1, 4095, 4096, 16383, 16384, 32766, 32767]
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=2 ** 40 + 7, n_calls=120, check_every=40, envs=sample)
+    es = env.env_state.cpu().numpy()
+    assert (es[:, _abi.ENV_STATUS] & ~_abi.STATUS_FALLBACK_SPAWN == 0).all()
+    assert (es[:, _abi.ENV_CALLS] == 120).all()
+    del env
+    torch.cuda.empty_cache()
