@@ -32,8 +32,8 @@
 // Diagnostic build only (-DPPG_PROFILE_PHASES, tools/phase_profile.py): per-env shader-clock stamps
 // at phase boundaries, written to a buffer that nothing else reads.  Never defined in the product.
 #ifdef PPG_PROFILE_PHASES
-#define PPG_STAMP(i) do { if (P.prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-        __builtin_amdgcn_s_waitcnt(0xC07F); if (ln == 0) P.prof[(size_t)b * 16 + (i)] = t_; } } while (0)
+#define PPG_STAMP(i) do { if (C.prof) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); if (ln == 0) C.prof[(size_t)b * 16 + (i)] = t_; } } while (0)
 #else
 #define PPG_STAMP(i) do { } while (0)
 #endif
@@ -172,11 +172,13 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // the constant address space, read in place from the kernarg segment (fused rollout).
 // KICK: the kickback-reward variant (grandparent bonus) is compiled in.  Measured: merely carrying that code costs the
 // base path 11 % (register / SGPR pressure), so it has its own kernel variants.
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, class KP>
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, class KP, class KC>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
-    KP &P;
+    KP &P;   // hot parameters: by-value kernel argument, resident in SGPRs
+    KC &C;   // cold parameters (rewards, thresholds, table pointers ...): the same struct read in place from the
+             // kernarg segment at their single use sites, so they do not occupy SGPRs for the whole kernel
     const int b;
     const int ln;
 
@@ -193,7 +195,7 @@ struct Env {
     int32_t act[T];
     uint32_t ev[T];
     uint32_t keep[T];  // row flags that survive a truncation call (ATE)
-    uint32_t rank[T];  // explicit action order (only when P.act_rank is given)
+    uint32_t rank[T];  // explicit action order (only when C.act_rank is given)
     uint32_t gxyr[2];  // grass_xy of patches ln and ln+64 (static within an episode)
     uint32_t lutr[10]; // FASTOBS: this lane's descriptors, predator chunks 0-1 then prey chunks 0-2, two words each
 
@@ -206,8 +208,8 @@ struct Env {
     uint64_t seed;
     bool cooc[2];  // some cell may hold two live agents of this type
 
-    PPG_MEMBER Env(KP &p, int b_, unsigned char *lds, int lane)
-        : P(p), b(b_), ln(lane),
+    PPG_MEMBER Env(KP &p, KC &c, int b_, unsigned char *lds, int lane)
+        : P(p), C(c), b(b_), ln(lane),
           map((uint16_t *)(lds + p.off_map)), val((double *)(lds + p.off_val)),
           scr((uint64_t *)(lds + p.off_scr)), lut((uint32_t *)(lds + p.off_lut)) {}
 
@@ -270,31 +272,31 @@ struct Env {
     };
 
     PPG_MEMBER void prefetch(Pre &p, bool want_rows, bool want_actions) {
-        const int32_t *es = P.env_state + (size_t)b * PPG_ENV_WORDS;
+        const int32_t *es = C.env_state + (size_t)b * PPG_ENV_WORDS;
         p.w_env = ln < PPG_ENV_WORDS ? (uint32_t)es[ln] : 0u;
-        p.sd = P.env_seed[b];
+        p.sd = C.env_seed[b];
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             p.xy[r] = 0xFFFFu; p.key[r] = 0; p.fl[r] = 0; p.id[r] = 0; p.a[r] = -1; p.e[r] = 0.0;
             if (r < 2 && want_rows) {
                 const size_t s = (size_t)b * P.S + slot_of(r, ln);
-                p.xy[r] = P.row_xy[s];
-                p.e[r] = P.row_e[s];
-                p.id[r] = P.row_id[s];
-                p.key[r] = P.row_key[s];
-                p.fl[r] = P.row_flags[s];
-                if (want_actions) p.a[r] = P.actions[s];
+                p.xy[r] = C.row_xy[s];
+                p.e[r] = C.row_e[s];
+                p.id[r] = C.row_id[s];
+                p.key[r] = C.row_key[s];
+                p.fl[r] = C.row_flags[s];
+                if (want_actions) p.a[r] = C.actions[s];
             }
         }
-        const size_t gb = (size_t)b * P.cap_grass;
+        const size_t gb = (size_t)b * C.cap_grass;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int pp = ln + 64 * q;
             p.gxy[q] = 0; p.ge[q] = 0.0;
-            if (want_rows && pp < P.n_grass) { p.gxy[q] = P.grass_xy[gb + pp]; p.ge[q] = P.grass_e[gb + pp]; }
+            if (want_rows && pp < C.n_grass) { p.gxy[q] = C.grass_xy[gb + pp]; p.ge[q] = C.grass_e[gb + pp]; }
         }
         if (FASTOBS) {  // this lane's observation descriptors (row-independent), kept in registers
-            const uint2 *L2 = (const uint2 *)P.obs_lut;
+            const uint2 *L2 = (const uint2 *)C.obs_lut;
 #pragma unroll
             for (int c = 0; c < 2; ++c) { p.lutd[c].x = 0; p.lutd[c].y = 0; if (c < P.nch_p) p.lutd[c] = L2[c * 64 + ln]; }
 #pragma unroll
@@ -332,12 +334,12 @@ struct Env {
                     fl = p.fl[r]; act[r] = p.a[r];
                 } else {  // rows 64.. of the prey table: rarely in use, loaded on demand
                     const size_t s = (size_t)b * P.S + slot_of(r, ln);
-                    xy[r] = P.row_xy[s];
-                    e[r] = P.row_e[s];
-                    id[r] = P.row_id[s];
-                    key[r] = P.row_key[s];
-                    fl = P.row_flags[s];
-                    if (P.actions) act[r] = P.actions[s];
+                    xy[r] = C.row_xy[s];
+                    e[r] = C.row_e[s];
+                    id[r] = C.row_id[s];
+                    key[r] = C.row_key[s];
+                    fl = C.row_flags[s];
+                    if (C.actions) act[r] = C.actions[s];
                 }
             }
             keep[r] = (fl & PPG_ROW_ATE) | ((uint32_t)slot_of(r, ln) << 8);  // bits 8..: where this row's start-of-step energy lives
@@ -359,7 +361,7 @@ struct Env {
 #pragma unroll
             for (int c = 0; c < 5; ++c) { lutr[2 * c] = p.lutd[c].x; lutr[2 * c + 1] = p.lutd[c].y; }
         } else {
-            for (int i = ln; i < (P.nch_p + P.nch_q) * 128; i += 64) lut[i] = P.obs_lut[i];
+            for (int i = ln; i < (P.nch_p + P.nch_q) * 128; i += 64) lut[i] = C.obs_lut[i];
         }
         if (ln == 0) val[0] = 0.0;
         gxyr[0] = p.gxy[0];
@@ -368,38 +370,38 @@ struct Env {
 
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
     PPG_MEMBER void load_grass(bool regrow, const Pre &p) {
-        const size_t gb = (size_t)b * P.cap_grass;
+        const size_t gb = (size_t)b * C.cap_grass;
         // seasonal variant: square wave on current_step (base_environment_seasonal/...:224-234,268)
-        double gain = P.gain_g;
-        if (P.season_len > 0) gain = P.gain_g * (((step / P.season_len) & 1) ? P.season_lo : P.season_hi);
+        double gain = C.gain_g;
+        if (C.season_len > 0) gain = C.gain_g * (((step / C.season_len) & 1) ? C.season_lo : C.season_hi);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int pp = ln + 64 * q;
-            if (pp < P.n_grass) {
+            if (pp < C.n_grass) {
                 double g = p.ge[q];
                 if (regrow) {
                     double v = g + gain;
-                    g = (P.e0_g < v) ? P.e0_g : v;  // Python min(v, cap)
+                    g = (C.e0_g < v) ? C.e0_g : v;  // Python min(v, cap)
                 }
                 val[grass_validx(pp)] = g;
                 chmap(3)[cell_of(gxyr[q])] = (uint16_t)grass_validx(pp);
             }
         }
-        for (int pp = 128 + ln; pp < P.n_grass; pp += 64) {
-            double g = P.grass_e[gb + pp];
+        for (int pp = 128 + ln; pp < C.n_grass; pp += 64) {
+            double g = C.grass_e[gb + pp];
             if (regrow) {
                 double v = g + gain;
-                g = (P.e0_g < v) ? P.e0_g : v;
+                g = (C.e0_g < v) ? C.e0_g : v;
             }
             val[grass_validx(pp)] = g;
-            chmap(3)[cell_of(P.grass_xy[gb + pp])] = (uint16_t)grass_validx(pp);
+            chmap(3)[cell_of(C.grass_xy[gb + pp])] = (uint16_t)grass_validx(pp);
         }
     }
 
     // ---- actions -------------------------------------------------------------------
     PPG_MEMBER void load_actions(uint64_t (&acted)[T]) {
         bool bad = false;
-        if (P.flags & PPG_STEP_RANDOM_ACTIONS) {
+        if (C.flags & PPG_STEP_RANDOM_ACTIONS) {
             uint32_t w[4];
 #pragma unroll
             for (int r = 0; r < T; ++r) {
@@ -422,7 +424,7 @@ struct Env {
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             rank[r] = 0;
-            if (ORDERED && P.act_rank && ((acted[r] >> ln) & 1ull)) rank[r] = P.act_rank[(size_t)b * P.S + slot_of(r, ln)];
+            if (ORDERED && C.act_rank && ((acted[r] >> ln) & 1ull)) rank[r] = C.act_rank[(size_t)b * P.S + slot_of(r, ln)];
         }
     }
 
@@ -483,7 +485,7 @@ struct Env {
 
 #pragma unroll
         for (int r = 0; r < T; ++r)
-            if ((acted[r] >> ln) & 1ull) e[r] -= (r ? P.loss_q : P.loss_p);
+            if ((acted[r] >> ln) & 1ull) e[r] -= (r ? C.loss_q : C.loss_p);
 
         // grid[type, pos] = energy, in action order
 #pragma unroll
@@ -492,7 +494,7 @@ struct Env {
 #pragma unroll
                 for (int r = 0; r < T; ++r)
                     if (type_of(r) == type) owns[r] |= acted[r];  // one live agent per cell: each acting agent owns its cell
-            } else if (ORDERED && P.act_rank) {
+            } else if (ORDERED && C.act_rank) {
                 const int n = publish_order(type, acted);
                 for (int i = 0; i < n; ++i) {
                     int r, k;
@@ -562,7 +564,7 @@ struct Env {
         uint64_t pos[T];  // grid value > 0 requires the owner's energy > 0 (BASE:506)
 #pragma unroll
         for (int r = 0; r < T; ++r) pos[r] = wv::ballot(e[r] > 0.0) & alive[r];
-        if (ORDERED && P.act_rank) {
+        if (ORDERED && C.act_rank) {
 #pragma unroll
             for (int type = 0; type < 2; ++type) {
                 const int n = publish_order(type, acted);
@@ -1059,7 +1061,7 @@ struct Env {
                 if (kth < cnt) {
                     for (int s = 0; s < kth; ++s) fm &= fm - 1;
                     const int cellidx = base + wv::ctz(fm);
-                    const uint32_t cx = wv::mulhi((uint32_t)cellidx, P.g_magic);
+                    const uint32_t cx = wv::mulhi((uint32_t)cellidx, C.g_magic);
                     child_xy = (cx << 8) | ((uint32_t)cellidx - cx * (uint32_t)P.G);
                     ok = true;
                     break;
@@ -1078,13 +1080,13 @@ struct Env {
     PPG_MEMBER void reproduce() {
         uint64_t cand[T];
 #pragma unroll
-        for (int r = 0; r < T; ++r) cand[r] = alive[r] & wv::ballot(e[r] >= (r ? P.thr_q : P.thr_p));
+        for (int r = 0; r < T; ++r) cand[r] = alive[r] & wv::ballot(e[r] >= (r ? C.thr_q : C.thr_p));
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int type = type_of(r);
-            const int npos = type ? P.npos_prey : P.npos_pred;
+            const int npos = type ? C.npos_prey : C.npos_pred;
             const int cap = type ? P.cap_prey : P.cap_pred;
-            const double e0 = type ? P.e0_q : P.e0_p;
+            const double e0 = type ? C.e0_q : C.e0_p;
             uint64_t m = cand[r];
             while (m) {
                 const int k = wv::ctz(m);
@@ -1143,7 +1145,7 @@ struct Env {
                     const int my_id = (int)wv::readlane((uint32_t)id[r], k);
                     if (ln == 0) ((int32_t *)scr)[slot_of(cr, ck)] = my_id;
                     const uint32_t k_keep = wv::readlane(keep[r], k);
-                    const int gp = (int)wv::first((uint32_t)P.row_parent[(size_t)b * P.S + (k_keep >> 8)]);
+                    const int gp = (int)wv::first((uint32_t)C.row_parent[(size_t)b * P.S + (k_keep >> 8)]);
                     if (gp >= 0) {
 #pragma unroll
                         for (int q = 0; q < T; ++q) {
@@ -1171,7 +1173,7 @@ struct Env {
         double rew_[T], cum_[T];
         uint32_t fl_[T];
         int32_t par_[T];
-        const bool dense = transition && P.reward_mode != 0;
+        const bool dense = transition && C.reward_mode != 0;
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);
@@ -1181,7 +1183,7 @@ struct Env {
             if (i < n_rows[type_of(r)]) {
                 // cumulative_rewards of a surviving agent still sits in HBM at the row's start-of-step slot
                 // (keep[] bits 8..): read it here instead of carrying two registers per row through the step
-                if (transition && !(v & EV_BORN)) c = P.row_cum[(size_t)b * P.S + (keep[r] >> 8)];
+                if (transition && !(v & EV_BORN)) c = C.row_cum[(size_t)b * P.S + (keep[r] >> 8)];
                 if (!transition) {
                     rew = 0.0;  // reset returns observations only; cumulative_rewards = 0 (BASE:150)
                 } else if (v & EV_BORN) {
@@ -1191,26 +1193,26 @@ struct Env {
                 } else if (dense) {
                     // dense variants: reward = energy now - energy at the start of the step (still in HBM at the
                     // row's old slot); a caught prey's account goes to zero (0.0 - before)
-                    const double before = P.row_e[(size_t)b * P.S + (keep[r] >> 8)];
+                    const double before = C.row_e[(size_t)b * P.S + (keep[r] >> 8)];
                     rew = (v & EV_CAUGHT) ? (0.0 - before) : (e[r] - before);
-                    if (P.reward_mode == 2 && !(v & (EV_STARVED | EV_CAUGHT)))
-                        rew = rew + ((v & EV_PARENT) ? (r ? P.r_repro_q : P.r_repro_p) : 0.0);
+                    if (C.reward_mode == 2 && !(v & (EV_STARVED | EV_CAUGHT)))
+                        rew = rew + ((v & EV_PARENT) ? (r ? C.r_repro_q : C.r_repro_p) : 0.0);
                     c += rew;
                 } else if (v & EV_STARVED) {
                     rew = 0.0;
                 } else if (v & EV_CAUGHT) {
-                    rew = P.r_caught; c += rew;
+                    rew = C.r_caught; c += rew;
                 } else {
-                    if (v & EV_ATE) { rew = r ? P.r_eat : P.r_catch; c += rew; c += rew; }
-                    else { rew = r ? P.r_qstep : P.r_pstep; c += rew; }
+                    if (v & EV_ATE) { rew = r ? C.r_eat : C.r_catch; c += rew; c += rew; }
+                    else { rew = r ? C.r_qstep : C.r_pstep; c += rew; }
                     if (KICK) {
-                        const double kb = r ? P.kick_q : P.kick_p;
+                        const double kb = r ? C.kick_q : C.kick_p;
                         const uint32_t n_before = (v >> 8) & 15u, n_after = (v >> 12) & 15u;
                         for (uint32_t i = 0; i < n_before; ++i) { rew = rew + kb; c = c + kb; }   // KICK:446-447
-                        if (v & EV_PARENT) { rew = r ? P.r_repro_q : P.r_repro_p; c += rew; }       // BASE:409 overwrites
+                        if (v & EV_PARENT) { rew = r ? C.r_repro_q : C.r_repro_p; c += rew; }       // BASE:409 overwrites
                         for (uint32_t i = 0; i < n_after; ++i) { rew = rew + kb; c = c + kb; }
                     } else if (v & EV_PARENT) {
-                        rew = r ? P.r_repro_q : P.r_repro_p; c += rew;
+                        rew = r ? C.r_repro_q : C.r_repro_p; c += rew;
                     }
                 }
                 if (v & (EV_STARVED | EV_CAUGHT)) fl |= PPG_ROW_DIED;
@@ -1224,7 +1226,7 @@ struct Env {
             if (KICK && transition && i < n_rows[type_of(r)] && !(v & (EV_STARVED | EV_CAUGHT))) {
                 // agent_parent rides along with its row: newborns got it in reproduce() (LDS), survivors keep theirs
                 if (v & EV_BORN) par_[r] = ((const int32_t *)scr)[slot_of(r, ln)];
-                else par_[r] = P.row_parent[(size_t)b * P.S + (keep[r] >> 8)];
+                else par_[r] = C.row_parent[(size_t)b * P.S + (keep[r] >> 8)];
             }
         }
         if (transition) wv::drain_loads();  // every lane has its start-of-step values before any row is overwritten
@@ -1233,23 +1235,23 @@ struct Env {
             const int i = row_of(r, ln);
             if (i >= n_rows[type_of(r)]) continue;
             const size_t s = (size_t)b * P.S + slot_of(r, ln);
-            P.row_xy[s] = (uint16_t)xy[r];
-            P.row_e[s] = e[r];
-            P.row_id[s] = id[r];
-            P.row_key[s] = key[r];
-            P.row_cum[s] = cum_[r];
-            P.row_flags[s] = (uint8_t)fl_[r];
-            P.row_reward[s] = rew_[r];
-            if (KICK) P.row_parent[s] = par_[r];
+            C.row_xy[s] = (uint16_t)xy[r];
+            C.row_e[s] = e[r];
+            C.row_id[s] = id[r];
+            C.row_key[s] = key[r];
+            C.row_cum[s] = cum_[r];
+            C.row_flags[s] = (uint8_t)fl_[r];
+            C.row_reward[s] = rew_[r];
+            if (KICK) C.row_parent[s] = par_[r];
             keep[r] = (keep[r] & ~0xFFu) | (fl_[r] & PPG_ROW_ATE);
         }
         obs_count[0] += n_rows[0];       // every row in use got an observation
         obs_count[1] += n_rows[1];
         if (write_grass) {
-            const size_t gb = (size_t)b * P.cap_grass;
-            for (int p = ln; p < P.n_grass; p += 64) P.grass_e[gb + p] = val[grass_validx(p)];
+            const size_t gb = (size_t)b * C.cap_grass;
+            for (int p = ln; p < C.n_grass; p += 64) C.grass_e[gb + p] = val[grass_validx(p)];
         }
-        int32_t *es = P.env_state + (size_t)b * PPG_ENV_WORDS;
+        int32_t *es = C.env_state + (size_t)b * PPG_ENV_WORDS;
         if (ln < PPG_ENV_WORDS) {
             int32_t w = 0;
             switch (ln) {
@@ -1279,7 +1281,7 @@ struct Env {
     PPG_MEMBER void do_reset(uint32_t new_episode) {
         episode = new_episode;
         const int n = P.G * P.G;
-        const int K = P.n_init_pred + P.n_init_prey + P.n_grass;
+        const int K = C.n_init_pred + C.n_init_prey + C.n_grass;
         uint16_t *perm = chmap(1), *ent = chmap(2);
         uint32_t *rnd = (uint32_t *)scr;  // 256 words per round
         wv::sync();
@@ -1303,7 +1305,7 @@ struct Env {
             }
         }
         wv::sync();
-        const int P0 = P.n_init_pred, Q0 = P.n_init_prey;
+        const int P0 = C.n_init_pred, Q0 = C.n_init_prey;
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);
@@ -1312,33 +1314,33 @@ struct Env {
             xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; act[r] = -1; ev[r] = 0; keep[r] = 0;
             if (valid) {
                 const uint32_t c = ent[(r ? P0 : 0) + i];
-                const uint32_t cx = wv::mulhi(c, P.g_magic);
+                const uint32_t cx = wv::mulhi(c, C.g_magic);
                 xy[r] = (cx << 8) | (c - cx * (uint32_t)P.G);
                 id[r] = i;
                 key[r] = lexkey((uint32_t)i);
-                e[r] = r ? P.e0_q : P.e0_p;
+                e[r] = r ? C.e0_q : C.e0_p;
             }
             rows[r] = wv::ballot(valid);
             alive[r] = rows[r];
             owns[r] = rows[r];
         }
-        const size_t gb = (size_t)b * P.cap_grass;
-        for (int p = ln; p < P.n_grass; p += 64) {
+        const size_t gb = (size_t)b * C.cap_grass;
+        for (int p = ln; p < C.n_grass; p += 64) {
             const uint32_t c = ent[P0 + Q0 + p];
-            const uint32_t cx = wv::mulhi(c, P.g_magic);
+            const uint32_t cx = wv::mulhi(c, C.g_magic);
             const uint32_t gxy = (cx << 8) | (c - cx * (uint32_t)P.G);
-            P.grass_xy[gb + p] = (uint16_t)gxy;
-            P.grass_e[gb + p] = P.e0_g;
+            C.grass_xy[gb + p] = (uint16_t)gxy;
+            C.grass_e[gb + p] = C.e0_g;
             if (p == ln) gxyr[0] = gxy;
             if (p == ln + 64) gxyr[1] = gxy;
         }
         wv::sync();
         for (int i = ln; i < n; i += 64) { perm[i] = 0; ent[i] = 0; }
         wv::sync();
-        for (int p = ln; p < P.n_grass; p += 64) {
+        for (int p = ln; p < C.n_grass; p += 64) {
             // re-read what this lane just wrote (same lane, same address)
-            val[grass_validx(p)] = P.e0_g;
-            chmap(3)[cell_of(P.grass_xy[gb + p])] = (uint16_t)grass_validx(p);
+            val[grass_validx(p)] = C.e0_g;
+            chmap(3)[cell_of(C.grass_xy[gb + p])] = (uint16_t)grass_validx(p);
         }
         n_rows[0] = P0; n_rows[1] = Q0;
         next_id[0] = P0; next_id[1] = Q0;            // BASE:153-154
@@ -1355,20 +1357,20 @@ struct Env {
     // One transition: the tables were prefetched from HBM into `pre`.  `it` = index into the action tape.
     PPG_MEMBER void step_body(const Pre &pre, int it) {
         calls += 1;
-        if ((P.flags & PPG_STEP_AUTO_RESET) && (envflags & PPG_ENVF_DONE)) {
+        if ((C.flags & PPG_STEP_AUTO_RESET) && (envflags & PPG_ENVF_DONE)) {
             wv::sync();
             do_reset(episode + 1u);
             return;
         }
         load_rows(pre);
-        if (FUSED && it > 0 && P.actions && !(P.flags & PPG_STEP_RANDOM_ACTIONS)) {  // action tape [n_steps,B,S]
+        if (FUSED && it > 0 && C.actions && !(C.flags & PPG_STEP_RANDOM_ACTIONS)) {  // action tape [n_steps,B,S]
 #pragma unroll
             for (int r = 0; r < T; ++r)
-                if ((alive[r] >> ln) & 1ull) act[r] = P.actions[((size_t)it * P.batch + b) * P.S + slot_of(r, ln)];
+                if ((alive[r] >> ln) & 1ull) act[r] = C.actions[((size_t)it * P.batch + b) * P.S + slot_of(r, ln)];
         }
         const bool list_is_row_order = (envflags & PPG_ENVF_LIST_IS_ROW_ORDER) != 0;
 
-        if (step >= P.max_steps) {  // truncation, BASE:228-238: no state change
+        if (step >= C.max_steps) {  // truncation, BASE:228-238: no state change
             wv::sync();
             load_grass(false, pre);
             compact_and_sort(!list_is_row_order);
@@ -1418,7 +1420,7 @@ struct Env {
     PPG_MEMBER void run_step(int it = 0) {
         PPG_STAMP(0);
         Pre pre;
-        prefetch(pre, true, P.actions != nullptr && !(P.flags & PPG_STEP_RANDOM_ACTIONS));
+        prefetch(pre, true, C.actions != nullptr && !(C.flags & PPG_STEP_RANDOM_ACTIONS));
         load_env_words(pre);
         init_lds(pre);
         step_body(pre, it);
@@ -1429,15 +1431,15 @@ struct Env {
         prefetch(pre, false, false);
         load_env_words(pre);
         init_lds(pre);
-        if (P.seeds) {
-            uint64_t sd = P.seeds[b];
+        if (C.seeds) {
+            uint64_t sd = C.seeds[b];
             seed = ((uint64_t)wv::first((uint32_t)(sd >> 32)) << 32) | wv::first((uint32_t)sd);
-            if (ln == 0) P.env_seed[b] = seed;
+            if (ln == 0) C.env_seed[b] = seed;
         }
         status = 0;
         calls = 0;
         wv::sync();
-        do_reset(P.reset_episode);
+        do_reset(C.reset_episode);
     }
 
     PPG_MEMBER void run_observe() {
@@ -1462,7 +1464,7 @@ struct Env {
         load_grass(false, pre);
         build_maps();
         const int n = P.G * P.G;
-        double *out = P.grid_out + (size_t)b * 4 * n;
+        double *out = C.grid_out + (size_t)b * 4 * n;
         for (int i = ln; i < 4 * n; i += 64) {
             const int ch = i / n, c = i - ch * n;
             out[i] = ch ? val[chmap(ch)[c]] : 0.0;
@@ -1492,14 +1494,16 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
             PPG_LAUNDER_S(bb);
             PPG_LAUNDER_V(lane);
             PPG_LAUNDER_V(l);
-            Env<NQ, false, FASTOBS, true, false, const PPG_CONSTANT_AS KParams> env(*Pc, bb, l, lane);
+            Env<NQ, false, FASTOBS, true, false, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
             env.run_step(it);
             wv::sync();
         }
         return;
     }
+    const PPG_CONSTANT_AS KParams *Pcold = PPG_KERNARG_PTR(KParams, P);  // KParams is the kernel's only argument
     Env<NQ, MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_ORDERED_KICK, FASTOBS, false,
-        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, const KParams> env(P, b, lds, wv::lane());
+        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, const KParams, const PPG_CONSTANT_AS KParams>
+        env(P, *Pcold, b, lds, wv::lane());
     if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();
     else if (MODE == MODE_OBSERVE) env.run_observe();
