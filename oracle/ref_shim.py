@@ -35,6 +35,8 @@ VARIANTS = {
     "dense_rewards": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_dense_rewards",
     "dense_rewards_additive": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_dense_rewards_additive",
     "sparse_rewards_plus_kickback": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards_plus_kickback",
+    # second generation without walls / line of sight; its configs live in config/*.py
+    "red_queen": "predpreygrass/non_evolutionary/red_queen",
 }
 
 
@@ -155,8 +157,20 @@ def load_reference_module(variant: str = "base"):
 
 
 def reference_default_config(variant: str = "base") -> dict:
+    if variant == "red_queen":  # that env takes an explicit config (RQ:17-18); config/config_env_base.py is its base
+        return reference_config("predpreygrass.non_evolutionary.red_queen.config.config_env_base", "config_env_base")
     mod = load_reference_module(variant)
     return dict(mod.config_env)  # each variant file imports its own config_env (line 5)
+
+
+def reference_config(module: str, attr: str = "config_env") -> dict:
+    """A config dict defined by one of the reference's config modules (plain data, imported as is)."""
+    import importlib
+
+    sys.dont_write_bytecode = True
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    return dict(getattr(importlib.import_module(module), attr))
 
 
 def make_reference_env(overrides: dict | None = None, variant: str = "base"):
