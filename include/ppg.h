@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PPG_ABI_VERSION 2
+#define PPG_ABI_VERSION 3
 
 /* error codes */
 #define PPG_OK 0
@@ -52,9 +52,11 @@ extern "C" {
 #define PPG_ROW_NEWBORN 0x04u  /* created by the last call (BASE:396-414) */
 #define PPG_ROW_ATE 0x08u      /* agent in self.agents_just_ate (BASE:319,362) */
 #define PPG_ROW_TRUNC 0x10u    /* truncations[agent] == True in the last call (BASE:232) */
+#define PPG_ROW_GRID_E0 0x20u  /* second generation: grid[type, pos] still shows the full initial energy written at birth
+                                * (RQ:760) although the agent holds initial_energy * reproduction_energy_efficiency */
 
 /* env_state words (int32 per env) */
-#define PPG_ENV_WORDS 16
+#define PPG_ENV_WORDS 20
 #define PPG_ENV_N_PRED_ROWS 0   /* rows in use incl. agents that died in the last call */
 #define PPG_ENV_N_PREY_ROWS 1
 #define PPG_ENV_N_PRED_NEW 2    /* trailing rows that are newborns of the last call */
@@ -71,6 +73,9 @@ extern "C" {
 #define PPG_ENV_CALLS 13        /* step calls served (diagnostic) */
 #define PPG_ENV_OBS_PRED 14     /* predator observations written so far (wraps; for bandwidth accounting) */
 #define PPG_ENV_OBS_PREY 15     /* prey observations written so far */
+#define PPG_ENV_NEXT_PRED_ID_T2 16 /* second generation: _next_idx[("predator", 2)] (words 4/5 hold type 1) */
+#define PPG_ENV_NEXT_PREY_ID_T2 17 /* _next_idx[("prey", 2)] */
+#define PPG_ENV_DRAWS 18        /* second generation: uniforms the last call consumed (RQ:701,708) */
 
 /* env_state[PPG_ENV_FLAGS] bits */
 #define PPG_ENVF_TERM_ALL 0x01   /* terminations["__all__"] of the last call (BASE:466) */
@@ -86,6 +91,7 @@ extern "C" {
 #define PPG_STATUS_FAILED_SPAWN 0x08   /* BASE:766 reached (reference raises TypeError) */
 #define PPG_STATUS_BAD_ACTION 0x10     /* action outside -1..8 (reference: KeyError at BASE:502) */
 #define PPG_STATUS_KICK_OVERFLOW 0x20  /* more than 15 kickback rewards for one agent in one step (not representable) */
+#define PPG_STATUS_UNIFORMS_DRY 0x40   /* ppg_step_uniforms: an env needed more uniforms than were supplied */
 
 /* ppg_step flags */
 #define PPG_STEP_RANDOM_ACTIONS 0x1u /* ignore `actions`; draw uniform actions with Philox4x32-10 on device */
@@ -158,7 +164,62 @@ typedef struct ppg_buffers {
     void *obs_pred;        /* [B,pred_capacity,4,Rp,Rp] float64|float32: observations (BASE:511-526) */
     void *obs_prey;        /* [B,prey_capacity,4,Rq,Rq] */
     int32_t *row_parent;   /* [B,S]  id of the agent's (same-type) parent, -1 = none: agent_parent of the kickback variant */
+    int32_t *row_lastrep;  /* [B,S]  second generation: agent_last_reproduction (RQ:115,737,999); may be NULL for ppg_create */
 } ppg_buffers;
+
+/* ---- second generation ("RQ" = predpreygrass/non_evolutionary/red_queen/predpreygrass_rllib_env.py; the same step
+ * as walls_occlusion/predpreygrass_rllib_env.py without walls and line of sight) ------------------------------
+ * Two agent types per species ("type_<t>_<species>_<k>"), pools in the order reset() creates them:
+ * 0 type_1_predator, 1 type_2_predator, 2 type_1_prey, 3 type_2_prey.
+ * row_id  = creation_number << 17 | (type - 1) << 16 | k      (creation_number: 0,1,2,... over all agents of the
+ *           episode = insertion order of the reference's agent_positions dict, RQ:584-586)
+ * row_key = (type - 1) * 1771561 + ppg_lexkey(k)              (order of list.sort() on the id strings, RQ:270)
+ * Observations are what the reference returns (float32 grid, RQ:137-139,352-358): use obs_dtype 1. */
+typedef struct ppg_config_gen2 {
+    int32_t abi_version;
+    int32_t grid_size;            /* RQ:70 */
+    int32_t predator_obs_range;   /* RQ:72 */
+    int32_t prey_obs_range;       /* RQ:73 */
+    int32_t max_steps;            /* RQ:36 */
+    int32_t n_possible[4];        /* RQ:56-59, pool order; each <= 65535, sum <= 32767 */
+    int32_t n_initial[4];         /* RQ:61-64 */
+    int32_t n_grass;              /* RQ:76 */
+    int32_t pred_capacity;        /* 64 */
+    int32_t prey_capacity;        /* 64, 128 or 256 */
+    int32_t grass_capacity;
+    int32_t obs_dtype;            /* 0: float64, 1: float32 (the reference's dtype) */
+    int32_t type_1_action_range;  /* RQ:85: odd, 1..7 */
+    int32_t type_2_action_range;  /* RQ:86: odd, 1..7 (ignored when no type-2 agent can exist) */
+    int32_t reproduction_cooldown_steps; /* RQ:696 */
+    /* type-specific values, index = type - 1 (_get_type_specific, RQ:1099-1106) */
+    double reward_predator_catch_prey[2];
+    double reward_prey_eat_grass[2];
+    double reward_predator_step[2];
+    double reward_prey_step[2];
+    double penalty_prey_caught[2];
+    double reproduction_reward_predator[2];
+    double reproduction_reward_prey[2];
+    double energy_loss_per_step_predator;      /* RQ:50 */
+    double energy_loss_per_step_prey;          /* RQ:51 */
+    double predator_creation_energy_threshold; /* RQ:52 */
+    double prey_creation_energy_threshold;     /* RQ:53 */
+    double initial_energy_predator;            /* RQ:66 */
+    double initial_energy_prey;                /* RQ:67 */
+    double initial_energy_grass;               /* RQ:77 */
+    double energy_gain_per_step_grass;         /* RQ:78 */
+    double move_energy_cost_factor;            /* RQ:305: cost = distance * factor * energy */
+    double max_energy_gain_per_prey;           /* RQ:598 (INFINITY = no cap) */
+    double max_energy_gain_per_grass;          /* RQ:665 */
+    double max_energy_predator;                /* RQ:605 */
+    double max_energy_prey;                    /* RQ:672 */
+    double max_energy_grass;                   /* RQ:510 */
+    double energy_transfer_efficiency;         /* RQ:599,666 */
+    double reproduction_energy_efficiency;     /* RQ:754,840 */
+    double reproduction_chance_predator;       /* RQ:700-701 */
+    double reproduction_chance_prey;
+    double mutation_rate_predator;             /* RQ:81,708 */
+    double mutation_rate_prey;                 /* RQ:82,793 */
+} ppg_config_gen2;
 
 typedef struct ppg_handle ppg_handle;
 
@@ -167,6 +228,11 @@ int ppg_abi_version(void);
 /* Validates cfg and binds the buffers.  Replaces PredPreyGrass.__init__ (BASE:18-127). */
 int ppg_create(const ppg_config *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out);
 int ppg_destroy(ppg_handle *h);
+
+/* Second generation: replaces PredPreyGrass.__init__ of the red_queen env (RQ:15-86).  bufs->row_lastrep is required.
+ * The handle works with ppg_reset / ppg_observe / ppg_step / ppg_step_ordered / ppg_step_many / ppg_export_grid
+ * (reproduction uniforms from Philox, keyed like the random actions) and with ppg_step_uniforms; not with ppg_rollout. */
+int ppg_create_gen2(const ppg_config_gen2 *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out);
 
 /* reset() (BASE:129-217) for every env: unique random placement (Philox
  * Fisher-Yates keyed by env_seed -- distributionally, not bitwise, the
@@ -199,6 +265,14 @@ int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t 
  * BASE:244,259).  act_rank: device uint8 [B,S]; for every row with an action, its position among
  * the acting agents OF ITS TYPE (0..n-1, a permutation).  NULL == row order (ppg_step). */
 int ppg_step_ordered(ppg_handle *h, const int8_t *actions, const uint8_t *act_rank, uint32_t flags, void *stream);
+
+/* Second generation only: step(action_dict) (RQ:197-299) with the values `self.rng.random()` returns supplied by the
+ * caller.  uniforms: device double [B, uniforms_per_env]; env b consumes its row front to back, one value for every
+ * agent past its cooldown (chance gate, RQ:701) plus one more for each of those that passes the gate with enough energy
+ * (mutation, RQ:708), in self.agents order.  env_state[PPG_ENV_DRAWS] reports how many were used;
+ * PPG_STATUS_UNIFORMS_DRY is raised if the row was too short.  act_rank as in ppg_step_ordered (NULL = row order). */
+int ppg_step_uniforms(ppg_handle *h, const int8_t *actions, const uint8_t *act_rank, const double *uniforms,
+                      int32_t uniforms_per_env, uint32_t flags, void *stream);
 
 /* ppg_step for n handles (sub-batches of one GPU's envs), handle k on streams[k], in one host call.
  * actions may be NULL (with PPG_STEP_RANDOM_ACTIONS) or an array of n device pointers. */

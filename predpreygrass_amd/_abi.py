@@ -11,18 +11,19 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libppg_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # row_flags bits
-ROW_DIED, ROW_OWNS, ROW_NEWBORN, ROW_ATE, ROW_TRUNC = 0x01, 0x02, 0x04, 0x08, 0x10
+ROW_DIED, ROW_OWNS, ROW_NEWBORN, ROW_ATE, ROW_TRUNC, ROW_GRID_E0 = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
 # env_state words
-ENV_WORDS = 16
+ENV_WORDS = 20
 (ENV_N_PRED_ROWS, ENV_N_PREY_ROWS, ENV_N_PRED_NEW, ENV_N_PREY_NEW, ENV_NEXT_PRED_ID, ENV_NEXT_PREY_ID,
  ENV_STEP, ENV_N_PRED_ALIVE, ENV_N_PREY_ALIVE, ENV_FLAGS, ENV_STATUS, ENV_EPISODE, ENV_FALLBACK_SPAWNS,
- ENV_CALLS, ENV_OBS_PRED, ENV_OBS_PREY) = range(16)
+ ENV_CALLS, ENV_OBS_PRED, ENV_OBS_PREY, ENV_NEXT_PRED_ID_T2, ENV_NEXT_PREY_ID_T2, ENV_DRAWS) = range(19)
 ENVF_TERM_ALL, ENVF_TRUNC_ALL, ENVF_DONE, ENVF_WAS_RESET, ENVF_LIST_IS_ROW_ORDER = 0x01, 0x02, 0x04, 0x08, 0x10
 (STATUS_PRED_OVERFLOW, STATUS_PREY_OVERFLOW, STATUS_FALLBACK_SPAWN, STATUS_FAILED_SPAWN,
- STATUS_BAD_ACTION, STATUS_KICK_OVERFLOW) = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+ STATUS_BAD_ACTION, STATUS_KICK_OVERFLOW, STATUS_UNIFORMS_DRY) = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
+KEY_TYPE2 = 1771561  # row_key offset of second-generation type-2 agents
 STEP_RANDOM_ACTIONS, STEP_AUTO_RESET = 0x1, 0x2
 ACTION_NONE = -1
 
@@ -40,7 +41,7 @@ _DBL_FIELDS = [
 ]
 _BUF_FIELDS = [
     "row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "env_state", "env_seed",
-    "grass_xy", "grass_energy", "obs_pred", "obs_prey", "row_parent",
+    "grass_xy", "grass_energy", "obs_pred", "obs_prey", "row_parent", "row_lastrep",
 ]
 
 
@@ -51,13 +52,34 @@ class PpgConfig(C.Structure):
         ("kickback_reward_prey", C.c_double)]
 
 
+# include/ppg.h: struct ppg_config_gen2 (red_queen/predpreygrass_rllib_env.py:28-86 and the config.get calls in step())
+GEN2_TYPED = ["reward_predator_catch_prey", "reward_prey_eat_grass", "reward_predator_step", "reward_prey_step",
+              "penalty_prey_caught", "reproduction_reward_predator", "reproduction_reward_prey"]
+GEN2_SCALARS = [
+    "energy_loss_per_step_predator", "energy_loss_per_step_prey", "predator_creation_energy_threshold",
+    "prey_creation_energy_threshold", "initial_energy_predator", "initial_energy_prey", "initial_energy_grass",
+    "energy_gain_per_step_grass", "move_energy_cost_factor", "max_energy_gain_per_prey", "max_energy_gain_per_grass",
+    "max_energy_predator", "max_energy_prey", "max_energy_grass", "energy_transfer_efficiency",
+    "reproduction_energy_efficiency", "reproduction_chance_predator", "reproduction_chance_prey",
+    "mutation_rate_predator", "mutation_rate_prey",
+]
+
+
+class PpgConfigGen2(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "grid_size", "predator_obs_range", "prey_obs_range", "max_steps")] + [
+        ("n_possible", C.c_int32 * 4), ("n_initial", C.c_int32 * 4)] + [
+        (n, C.c_int32) for n in ("n_grass", "pred_capacity", "prey_capacity", "grass_capacity", "obs_dtype",
+                                 "type_1_action_range", "type_2_action_range", "reproduction_cooldown_steps")] + [
+        (n, C.c_double * 2) for n in GEN2_TYPED] + [(n, C.c_double) for n in GEN2_SCALARS]
+
+
 class PpgBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _BUF_FIELDS]
 
 
 EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
-    "ppg_rollout", "ppg_step_ordered",
+    "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms",
     "ppg_export_grid",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_last_error",
 ]
@@ -82,6 +104,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_rollout.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.ppg_step_ordered.restype = C.c_int
     lib.ppg_step_ordered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ppg_create_gen2.restype = C.c_int
+    lib.ppg_create_gen2.argtypes = [C.POINTER(PpgConfigGen2), C.c_int32, C.c_int32, C.POINTER(PpgBuffers), C.POINTER(C.c_void_p)]
+    lib.ppg_step_uniforms.restype = C.c_int
+    lib.ppg_step_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
     lib.ppg_export_grid.restype = C.c_int
     lib.ppg_export_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ppg_lexkey.restype = C.c_uint32

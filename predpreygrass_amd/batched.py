@@ -50,52 +50,13 @@ class BatchedPredPreyGrass:
         cfg = resolve_config(config)
         self.config = cfg
         self.batch_size = int(batch_size)
-        self._emulated = _library is not None
-        if _library is None:
-            # the product path: HIP on a real GPU, or an exception
-            self._lib = _abi.load_hip_library()
-            if not torch.cuda.is_available():
-                raise RuntimeError("predpreygrass_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False")
-            self.device = torch.device(device if device is not None else "cuda:0")
-            if self.device.type != "cuda":
-                raise RuntimeError(f"device must be a cuda (ROCm) device, got {self.device}")
-            if self.device.index is None:
-                self.device = torch.device("cuda", torch.cuda.current_device())
-        else:
-            # test hook (tests/wave_emu): the same kernel source compiled for the CPU wave emulator
-            self._lib = _library
-            self.device = torch.device("cpu")
-        if obs_dtype not in (torch.float64, torch.float32):
-            raise ValueError("obs_dtype must be torch.float64 or torch.float32")
-        self.obs_dtype = obs_dtype
+        self._init_device(device, obs_dtype, _library)
         self.grid_size = int(cfg["grid_size"])
         self.Rp, self.Rq = int(cfg["predator_obs_range"]), int(cfg["prey_obs_range"])
         self.P0, self.Q0 = int(cfg["n_initial_active_predator"]), int(cfg["n_initial_active_prey"])
         self.n_grass = int(cfg["initial_num_grass"])
-        self.pred_capacity = PRED_CAPACITY
-        self.prey_capacity = int(prey_capacity)
-        self.S = self.pred_capacity + self.prey_capacity
-        self.grass_capacity = max(64, (self.n_grass + 63) // 64 * 64)
-        B, S, NG, dev = self.batch_size, self.S, self.grass_capacity, self.device
-
-        def z(shape, dtype):
-            return torch.zeros(shape, dtype=dtype, device=dev)
-
-        self.row_xy = z((B, S), torch.int16)
-        self.row_energy = z((B, S), torch.float64)
-        self.row_id = z((B, S), torch.int32)
-        self.row_key = z((B, S), torch.int32)
-        self.row_cumrew = z((B, S), torch.float64)
-        self.row_flags = z((B, S), torch.uint8)
-        self.row_reward = z((B, S), torch.float64)
-        self.row_parent = torch.full((B, S), -1, dtype=torch.int32, device=dev)
-        self.env_state = z((B, _abi.ENV_WORDS), torch.int32)
-        self.env_seed = z((B,), torch.int64)
-        self.grass_xy = z((B, NG), torch.int16)
-        self.grass_energy = z((B, NG), torch.float64)
-        self.obs_pred = z((B, self.pred_capacity, 4, self.Rp, self.Rp), obs_dtype)
-        self.obs_prey = z((B, self.prey_capacity, 4, self.Rq, self.Rq), obs_dtype)
-        self.actions = torch.full((B, S), _abi.ACTION_NONE, dtype=torch.int8, device=dev)
+        self._alloc_buffers(prey_capacity)
+        NG = self.grass_capacity
 
         c = _abi.PpgConfig()
         c.abi_version = _abi.ABI_VERSION
@@ -128,12 +89,64 @@ class BatchedPredPreyGrass:
         c.kickback_reward_prey = float(cfg.get("kickback_reward_prey", 10.0))
         if c.kickback and c.reward_mode != 0:
             raise ValueError("the kickback rewards are defined on top of the sparse reward mode only")
+        self._create_handle(c, self._lib.ppg_create)
+        self.set_seeds(seed)
+
+    # ------------------------------------------------------------------
+    def _init_device(self, device, obs_dtype, _library):
+        self._emulated = _library is not None
+        if _library is None:
+            # the product path: HIP on a real GPU, or an exception
+            self._lib = _abi.load_hip_library()
+            if not torch.cuda.is_available():
+                raise RuntimeError("predpreygrass_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False")
+            self.device = torch.device(device if device is not None else "cuda:0")
+            if self.device.type != "cuda":
+                raise RuntimeError(f"device must be a cuda (ROCm) device, got {self.device}")
+            if self.device.index is None:
+                self.device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            # test hook (tests/wave_emu): the same kernel source compiled for the CPU wave emulator
+            self._lib = _library
+            self.device = torch.device("cpu")
+        if obs_dtype not in (torch.float64, torch.float32):
+            raise ValueError("obs_dtype must be torch.float64 or torch.float32")
+        self.obs_dtype = obs_dtype
+
+    def _alloc_buffers(self, prey_capacity):
+        self.pred_capacity = PRED_CAPACITY
+        self.prey_capacity = int(prey_capacity)
+        self.S = self.pred_capacity + self.prey_capacity
+        self.grass_capacity = max(64, (self.n_grass + 63) // 64 * 64)
+        B, S, NG, dev = self.batch_size, self.S, self.grass_capacity, self.device
+
+        def z(shape, dtype):
+            return torch.zeros(shape, dtype=dtype, device=dev)
+
+        self.row_xy = z((B, S), torch.int16)
+        self.row_energy = z((B, S), torch.float64)
+        self.row_id = z((B, S), torch.int32)
+        self.row_key = z((B, S), torch.int32)
+        self.row_cumrew = z((B, S), torch.float64)
+        self.row_flags = z((B, S), torch.uint8)
+        self.row_reward = z((B, S), torch.float64)
+        self.row_parent = torch.full((B, S), -1, dtype=torch.int32, device=dev)
+        self.row_lastrep = z((B, S), torch.int32)  # second generation only (agent_last_reproduction)
+        self.env_state = z((B, _abi.ENV_WORDS), torch.int32)
+        self.env_seed = z((B,), torch.int64)
+        self.grass_xy = z((B, NG), torch.int16)
+        self.grass_energy = z((B, NG), torch.float64)
+        self.obs_pred = z((B, self.pred_capacity, 4, self.Rp, self.Rp), self.obs_dtype)
+        self.obs_prey = z((B, self.prey_capacity, 4, self.Rq, self.Rq), self.obs_dtype)
+        self.actions = torch.full((B, S), _abi.ACTION_NONE, dtype=torch.int8, device=dev)
+
+    def _create_handle(self, c, create_fn):
         bufs = _abi.PpgBuffers()
         for name in _abi._BUF_FIELDS:
             setattr(bufs, name, getattr(self, name).data_ptr())
         self._handle = C.c_void_p()
         dev_index = self.device.index if self.device.type == "cuda" else 0
-        rc = self._lib.ppg_create(C.byref(c), B, dev_index, C.byref(bufs), C.byref(self._handle))
+        rc = create_fn(C.byref(c), self.batch_size, dev_index, C.byref(bufs), C.byref(self._handle))
         if rc != 0:
             msg = self._lib.ppg_last_error(None).decode()
             self._handle = None
@@ -141,7 +154,6 @@ class BatchedPredPreyGrass:
                 raise ValueError(msg)  # e.g. "Cannot place more unique positions than grid cells."
             raise RuntimeError(f"ppg_create failed ({rc}): {msg}")
         self.lds_bytes = int(self._lib.ppg_lds_bytes(self._handle))
-        self.set_seeds(seed)
 
     # ------------------------------------------------------------------
     def close(self):

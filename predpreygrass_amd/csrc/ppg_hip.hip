@@ -1,38 +1,41 @@
 // ppg_hip.hip -- libppg_hip.so: the gfx950 kernels and the HIP backend of include/ppg.h.
 //
-// Build (see __graft_entry__.build):
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -o libppg_hip.so ppg_hip.hip
+// Build (see __graft_entry__.build_hip): every unit with
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -c   (ppg_hip.hip, and ppg_kernels.hip once per
+//   -DPPG_TU_GEN=1|2 -DPPG_TU_NQ=1|2|4), then hipcc -shared -o libppg_hip.so *.o
 // -ffp-contract=off: energies are IEEE float64 sums that must round exactly like CPython's.
 #include <hip/hip_runtime.h>
 
 #include "ppg_host.h"
 
-// kernel name: ppg_<mode>_q<prey registers>[g]   (g = generic observation geometry, descriptors in LDS)
-#define PPG_K(name, NQ, MODE, FAST)                                                         \
-    PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, FAST>(P, lds); }
-#define PPG_DEFINE_KERNELS(NQ)                                        \
-    PPG_K(ppg_step_q##NQ, NQ, ppg::MODE_STEP, true)                   \
-    PPG_K(ppg_reset_q##NQ, NQ, ppg::MODE_RESET, true)                 \
-    PPG_K(ppg_observe_q##NQ, NQ, ppg::MODE_OBSERVE, true)             \
-    PPG_K(ppg_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID, true)            \
-    PPG_K(ppg_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED, true)       \
-    PPG_K(ppg_rollout_q##NQ, NQ, ppg::MODE_ROLLOUT, true)             \
-    PPG_K(ppg_step_kick_q##NQ, NQ, ppg::MODE_STEP_KICK, true)         \
-    PPG_K(ppg_step_ord_kick_q##NQ, NQ, ppg::MODE_STEP_ORDERED_KICK, true) \
-    PPG_K(ppg_step_q##NQ##g, NQ, ppg::MODE_STEP, false)               \
-    PPG_K(ppg_reset_q##NQ##g, NQ, ppg::MODE_RESET, false)             \
-    PPG_K(ppg_observe_q##NQ##g, NQ, ppg::MODE_OBSERVE, false)         \
-    PPG_K(ppg_grid_q##NQ##g, NQ, ppg::MODE_EXPORT_GRID, false)        \
-    PPG_K(ppg_step_ord_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED, false)   \
-    PPG_K(ppg_rollout_q##NQ##g, NQ, ppg::MODE_ROLLOUT, false)         \
-    PPG_K(ppg_step_kick_q##NQ##g, NQ, ppg::MODE_STEP_KICK, false)     \
-    PPG_K(ppg_step_ord_kick_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED_KICK, false)
+// The kernels are compiled in separate translation units (ppg_kernels.hip, one per generation and prey-register
+// count) so that the build runs in parallel; this unit holds the host side and only declares them.
+// kernel name: ppg_<mode>_q<prey registers>[g]   (g = generic observation geometry, descriptors in LDS);
+// ppg2_* = second generation (two agent types, stochastic reproduction)
+#define PPG_K(name, NQ, MODE, FAST) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
+#define PPG_K2(name, NQ, MODE, FAST) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
+#include "ppg_kernel_list.h"
 
 PPG_DEFINE_KERNELS(1)
 PPG_DEFINE_KERNELS(2)
 PPG_DEFINE_KERNELS(4)
+PPG_DEFINE_KERNELS2(1)
+PPG_DEFINE_KERNELS2(2)
+PPG_DEFINE_KERNELS2(4)
 
 typedef void (*ppg_kernel_fn)(const ppg::KParams);
+
+static ppg_kernel_fn pick_kernel_gen2(int nq, int mode, bool fast) {
+    static const ppg_kernel_fn table[2][3][5] = {
+        {{ppg2_step_q1g, ppg2_reset_q1g, ppg2_observe_q1g, ppg2_grid_q1g, ppg2_step_ord_q1g},
+         {ppg2_step_q2g, ppg2_reset_q2g, ppg2_observe_q2g, ppg2_grid_q2g, ppg2_step_ord_q2g},
+         {ppg2_step_q4g, ppg2_reset_q4g, ppg2_observe_q4g, ppg2_grid_q4g, ppg2_step_ord_q4g}},
+        {{ppg2_step_q1, ppg2_reset_q1, ppg2_observe_q1, ppg2_grid_q1, ppg2_step_ord_q1},
+         {ppg2_step_q2, ppg2_reset_q2, ppg2_observe_q2, ppg2_grid_q2, ppg2_step_ord_q2},
+         {ppg2_step_q4, ppg2_reset_q4, ppg2_observe_q4, ppg2_grid_q4, ppg2_step_ord_q4}},
+    };
+    return table[fast ? 1 : 0][nq == 1 ? 0 : nq == 2 ? 1 : 2][mode];
+}
 
 static ppg_kernel_fn pick_kernel(int nq, int mode, bool fast) {
     static const ppg_kernel_fn table[2][3][ppg::N_MODES] = {
@@ -75,8 +78,10 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     // one workgroup = one wavefront = one environment
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(pick_kernel(h->nq, mode, P.nch_p <= 2 && P.nch_q <= 3), dim3((unsigned)h->batch), dim3(64), (size_t)P.lds_bytes,
-                       (hipStream_t)stream, P);
+    const bool fast = P.nch_p <= 2 && P.nch_q <= 3;
+    if (h->gen2 && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for second-generation handles", mode);
+    hipLaunchKernelGGL(h->gen2 ? pick_kernel_gen2(h->nq, mode, fast) : pick_kernel(h->nq, mode, fast), dim3((unsigned)h->batch),
+                       dim3(64), (size_t)P.lds_bytes, (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());
     return PPG_OK;
 }

@@ -20,6 +20,8 @@
 
 struct ppg_handle {
     ppg_config cfg;
+    ppg_config_gen2 cfg2;
+    int32_t gen2;  // created by ppg_create_gen2
     ppg_buffers bufs;
     int32_t batch;
     int32_t device;
@@ -113,7 +115,7 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.loss_p = c.energy_loss_per_step_predator; P.loss_q = c.energy_loss_per_step_prey;
     P.thr_p = c.predator_creation_energy_threshold; P.thr_q = c.prey_creation_energy_threshold;
     P.e0_p = c.initial_energy_predator; P.e0_q = c.initial_energy_prey; P.e0_g = c.initial_energy_grass;
-    P.gain_g = c.energy_gain_per_step_grass;
+    P.gain_g = c.energy_gain_per_step_grass; P.cap_g = c.initial_energy_grass;
     if (c.reward_mode < 0 || c.reward_mode > 2) return ppg_fail(h, PPG_EINVAL, "reward_mode must be 0, 1 or 2");
     P.reward_mode = c.reward_mode;
     if (c.kickback && c.reward_mode != 0) return ppg_fail(h, PPG_EINVAL, "kickback requires reward_mode 0");
@@ -139,13 +141,67 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.row_xy = b.row_xy; P.row_e = b.row_energy; P.row_id = b.row_id; P.row_key = b.row_key;
     P.row_cum = b.row_cumrew; P.row_flags = b.row_flags; P.row_reward = b.row_reward;
     P.env_state = b.env_state; P.env_seed = b.env_seed; P.grass_xy = b.grass_xy; P.grass_e = b.grass_energy;
-    P.obs_pred = b.obs_pred; P.obs_prey = b.obs_prey; P.row_parent = b.row_parent;
+    P.obs_pred = b.obs_pred; P.obs_prey = b.obs_prey; P.row_parent = b.row_parent; P.row_lastrep = b.row_lastrep;
     P.batch = h->batch;
 
     if (3 * P.map_n + 8 * c.grid_size + 8 > 32767) return ppg_fail(h, PPG_EINVAL, "grid too large for 16-bit map offsets");
     h->lut_host.assign((size_t)(P.nch_p + P.nch_q) * 128, 0u);
     ppg_build_lut(P.Rp, P.G, P.map_n, h->lut_host.data());
     ppg_build_lut(P.Rq, P.G, P.map_n, h->lut_host.data() + (size_t)P.nch_p * 128);
+    return PPG_OK;
+}
+
+// Second generation: express the common part through the base layout code, then add the gen-2 parameters.
+static int ppg_validate_and_layout_gen2(ppg_handle *h) {
+    const ppg_config_gen2 &g = h->cfg2;
+    if (g.abi_version != PPG_ABI_VERSION) return ppg_fail(h, PPG_EINVAL, "abi_version %d != %d", g.abi_version, PPG_ABI_VERSION);
+    int total = 0;
+    for (int p = 0; p < 4; ++p) {
+        if (g.n_possible[p] < 0 || g.n_possible[p] > 65535) return ppg_fail(h, PPG_EINVAL, "n_possible[%d] outside 0..65535", p);
+        if (g.n_initial[p] < 0) return ppg_fail(h, PPG_EINVAL, "n_initial[%d] < 0", p);
+        total += g.n_possible[p] > g.n_initial[p] ? g.n_possible[p] : g.n_initial[p];
+    }
+    if (total > 32767) return ppg_fail(h, PPG_EINVAL, "more than 32767 agent ids per episode (creation numbers are 15 bits)");
+    const bool has_t2 = g.n_possible[1] > 0 || g.n_possible[3] > 0 || g.n_initial[1] > 0 || g.n_initial[3] > 0;
+    const int ar1 = g.type_1_action_range, ar2 = has_t2 ? g.type_2_action_range : 1;
+    if (ar1 < 1 || ar1 > 7 || !(ar1 & 1) || ar2 < 1 || ar2 > 7 || !(ar2 & 1))
+        return ppg_fail(h, PPG_EINVAL, "action ranges must be odd and in 1..7");
+    if (g.reproduction_cooldown_steps < 0 || g.reproduction_cooldown_steps > 1000000)
+        return ppg_fail(h, PPG_EINVAL, "reproduction_cooldown_steps outside 0..1000000");
+    if (!h->bufs.row_lastrep) return ppg_fail(h, PPG_EINVAL, "row_lastrep is NULL");
+    ppg_config &c = h->cfg;
+    memset(&c, 0, sizeof c);
+    c.abi_version = g.abi_version; c.grid_size = g.grid_size; c.predator_obs_range = g.predator_obs_range;
+    c.prey_obs_range = g.prey_obs_range; c.max_steps = g.max_steps;
+    c.n_possible_predators = g.n_possible[0] + g.n_possible[1]; c.n_possible_prey = g.n_possible[2] + g.n_possible[3];
+    c.n_initial_predators = g.n_initial[0] + g.n_initial[1]; c.n_initial_prey = g.n_initial[2] + g.n_initial[3];
+    c.n_grass = g.n_grass; c.pred_capacity = g.pred_capacity; c.prey_capacity = g.prey_capacity;
+    c.grass_capacity = g.grass_capacity; c.obs_dtype = g.obs_dtype;
+    c.energy_loss_per_step_predator = g.energy_loss_per_step_predator; c.energy_loss_per_step_prey = g.energy_loss_per_step_prey;
+    c.predator_creation_energy_threshold = g.predator_creation_energy_threshold;
+    c.prey_creation_energy_threshold = g.prey_creation_energy_threshold;
+    c.initial_energy_predator = g.initial_energy_predator; c.initial_energy_prey = g.initial_energy_prey;
+    c.initial_energy_grass = g.initial_energy_grass; c.energy_gain_per_step_grass = g.energy_gain_per_step_grass;
+    c.season_high_multiplier = c.season_low_multiplier = 1.0;
+    int rc = ppg_validate_and_layout(h);
+    if (rc != PPG_OK) return rc;
+    ppg::KParams &P = h->base;
+    P.gen2 = 1;
+    for (int p = 0; p < 4; ++p) { P.npos2[p] = g.n_possible[p]; P.ninit2[p] = g.n_initial[p]; }
+    P.ar[0] = ar1; P.ar[1] = ar2;
+    P.ar_inv[0] = (uint32_t)((65536 + ar1 - 1) / ar1); P.ar_inv[1] = (uint32_t)((65536 + ar2 - 1) / ar2);
+    P.cooldown = g.reproduction_cooldown_steps;
+    for (int t = 0; t < 2; ++t) {
+        P.r2_catch[t] = g.reward_predator_catch_prey[t]; P.r2_eat[t] = g.reward_prey_eat_grass[t];
+        P.r2_pstep[t] = g.reward_predator_step[t]; P.r2_qstep[t] = g.reward_prey_step[t];
+        P.r2_caught[t] = g.penalty_prey_caught[t]; P.r2_repro_p[t] = g.reproduction_reward_predator[t];
+        P.r2_repro_q[t] = g.reproduction_reward_prey[t];
+    }
+    P.move_factor = g.move_energy_cost_factor; P.cap_gain_prey = g.max_energy_gain_per_prey;
+    P.cap_gain_grass = g.max_energy_gain_per_grass; P.max_e_pred = g.max_energy_predator; P.max_e_prey = g.max_energy_prey;
+    P.cap_g = g.max_energy_grass; P.eff_transfer = g.energy_transfer_efficiency; P.eff_repro = g.reproduction_energy_efficiency;
+    P.chance_p = g.reproduction_chance_predator; P.chance_q = g.reproduction_chance_prey;
+    P.mut_p = g.mutation_rate_predator; P.mut_q = g.mutation_rate_prey;
     return PPG_OK;
 }
 
@@ -159,13 +215,16 @@ int ppg_abi_version(void) { return PPG_ABI_VERSION; }
 
 uint32_t ppg_lexkey(uint32_t id) { return ppg_host_lexkey(id); }
 
-int ppg_create(const ppg_config *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out) {
-    if (!cfg || !bufs || !out) return ppg_fail(nullptr, PPG_EINVAL, "null argument");
+static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2, int32_t batch, int32_t device,
+                             const ppg_buffers *bufs, ppg_handle **out) {
+    if ((!cfg && !cfg2) || !bufs || !out) return ppg_fail(nullptr, PPG_EINVAL, "null argument");
     ppg_handle *h = new (std::nothrow) ppg_handle();
     if (!h) return ppg_fail(nullptr, PPG_ENOMEM, "out of host memory");
-    h->cfg = *cfg; h->bufs = *bufs; h->batch = batch; h->device = device;
+    h->gen2 = cfg2 ? 1 : 0;
+    if (cfg) h->cfg = *cfg; else h->cfg2 = *cfg2;
+    h->bufs = *bufs; h->batch = batch; h->device = device;
     h->lut_dev = nullptr; h->backend = nullptr; h->prof_dev = nullptr; h->err[0] = 0;
-    int rc = ppg_validate_and_layout(h);
+    int rc = cfg2 ? ppg_validate_and_layout_gen2(h) : ppg_validate_and_layout(h);
     if (rc == PPG_OK) rc = backend_init(h, device);
     if (rc != PPG_OK) {
         memcpy(g_ppg_create_error, h->err, sizeof g_ppg_create_error);
@@ -176,6 +235,14 @@ int ppg_create(const ppg_config *cfg, int32_t batch, int32_t device, const ppg_b
     h->base.obs_lut = h->lut_dev;
     *out = h;
     return PPG_OK;
+}
+
+int ppg_create(const ppg_config *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out) {
+    return ppg_create_common(cfg, nullptr, batch, device, bufs, out);
+}
+
+int ppg_create_gen2(const ppg_config_gen2 *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out) {
+    return ppg_create_common(nullptr, cfg, batch, device, bufs, out);
 }
 
 int ppg_destroy(ppg_handle *h) {
@@ -213,6 +280,7 @@ int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t 
     if (!h) return PPG_EINVAL;
     if (n_steps < 1) return ppg_fail(h, PPG_EINVAL, "n_steps must be >= 1");
     if (h->cfg.kickback) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support the kickback variant");
+    if (h->gen2) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support second-generation handles");
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
     ppg::KParams P = h->base;
@@ -238,6 +306,21 @@ int ppg_step_ordered(ppg_handle *h, const int8_t *actions, const uint8_t *act_ra
     const int mode = act_rank ? (h->cfg.kickback ? ppg::MODE_STEP_ORDERED_KICK : ppg::MODE_STEP_ORDERED)
                               : (h->cfg.kickback ? ppg::MODE_STEP_KICK : ppg::MODE_STEP);
     P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
+    return backend_launch(h, mode, P, stream);
+}
+
+int ppg_step_uniforms(ppg_handle *h, const int8_t *actions, const uint8_t *act_rank, const double *uniforms,
+                      int32_t uniforms_per_env, uint32_t flags, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!h->gen2) return ppg_fail(h, PPG_EINVAL, "ppg_step_uniforms needs a handle from ppg_create_gen2");
+    if (!uniforms || uniforms_per_env < 1) return ppg_fail(h, PPG_EINVAL, "uniforms is NULL or empty");
+    if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
+    if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
+    if (act_rank && (flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "act_rank with PPG_STEP_RANDOM_ACTIONS");
+    ppg::KParams P = h->base;
+    const int mode = act_rank ? ppg::MODE_STEP_ORDERED : ppg::MODE_STEP;
+    P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
+    P.uniforms = uniforms; P.uniforms_per_env = uniforms_per_env;
     return backend_launch(h, mode, P, stream);
 }
 

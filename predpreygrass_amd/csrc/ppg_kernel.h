@@ -43,12 +43,16 @@ namespace ppg {
 enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3, MODE_STEP_ORDERED = 4, MODE_ROLLOUT = 5,
        MODE_STEP_KICK = 6, MODE_STEP_ORDERED_KICK = 7, N_MODES = 8 };
 
-// event bits of a row during one call
-enum { EV_STARVED = 1, EV_CAUGHT = 2, EV_ATE = 4, EV_PARENT = 8, EV_BORN = 16, EV_TRUNC = 32 };
+// event bits of a row during one call (bits 8-15: kickback counters).  Second generation: EV_REPRO = a child was
+// actually created (EV_PARENT alone = reward without a free id, RQ:715-725); EV_TURN = the prey had its own engagement
+// turn before a predator of a later class caught it (RQ:225-233 runs in self.agents order, types interleaved).
+enum { EV_STARVED = 1, EV_CAUGHT = 2, EV_ATE = 4, EV_PARENT = 8, EV_BORN = 16, EV_TRUNC = 32, EV_REPRO = 64, EV_TURN = 128 };
 
 constexpr uint32_t TAG_ACT = 0x41435431u;  // Philox key domains (see oracle/ppg_oracle.c)
 constexpr uint32_t TAG_RST = 0x52535431u;
 constexpr uint32_t TAG_SPW = 0x53505731u;
+constexpr uint32_t TAG_REP = 0x52455031u;  // second generation: reproduction uniforms
+constexpr uint32_t KEY_TYPE2 = 1771561u;   // 11^6: row_key offset of type-2 agents ("type_2_..." sorts after "type_1_...")
 
 
 struct KParams {
@@ -65,7 +69,16 @@ struct KParams {
     int32_t reward_mode;          // 0 base rewards, 1 dense energy delta, 2 dense + reproduction bonus
     double kick_p, kick_q;        // kickback rewards (grandparent bonus)
     int32_t kickback;             // 0 = base env
-    int32_t pad2_;
+    int32_t gen2;                 // 1 = second generation (ppg_config_gen2); everything below up to the LDS layout is its config
+    int32_t npos2[4], ninit2[4];  // pool order: type_1_predator, type_2_predator, type_1_prey, type_2_prey
+    int32_t ar[2];                // action range per type (RQ:85-86)
+    uint32_t ar_inv[2];           // ceil(65536 / range): a / range == (a * inv) >> 16 for a < 49
+    int32_t cooldown;             // RQ:696
+    int32_t uniforms_per_env;
+    double r2_catch[2], r2_eat[2], r2_pstep[2], r2_qstep[2], r2_caught[2], r2_repro_p[2], r2_repro_q[2];  // by type
+    double move_factor, cap_gain_prey, cap_gain_grass, max_e_pred, max_e_prey, eff_transfer, eff_repro;
+    double chance_p, chance_q, mut_p, mut_q;
+    double cap_g;                 // grass regrowth cap: initial_energy_grass (BASE:254) / max_energy_grass (RQ:510)
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
     int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
@@ -89,11 +102,13 @@ struct KParams {
     void *obs_pred;
     void *obs_prey;
     int32_t *row_parent;
+    int32_t *row_lastrep;     // second generation: agent_last_reproduction
     const uint32_t *obs_lut;  // library-owned, (nch_p + nch_q) * 128 words
     // per-launch
     const int8_t *actions;
     const uint8_t *act_rank;  // optional [B,S]: position of each row in its type's action sequence
     const uint64_t *seeds;
+    const double *uniforms;   // second generation, ppg_step_uniforms: [B, uniforms_per_env]
     double *grid_out;
     unsigned long long *prof;  // diagnostic build only
     uint32_t flags;
@@ -146,6 +161,13 @@ PPG_DEVICE uint32_t lexkey(uint32_t id) {
     return key;
 }
 
+// math.sqrt(dx*dx + dy*dy) for displacements of at most 3 cells per axis (RQ:310): correctly rounded constants
+PPG_DEVICE double move_distance(int d2) {
+    return d2 == 0 ? 0.0 : d2 == 1 ? 1.0 : d2 == 2 ? 1.4142135623730951 : d2 == 4 ? 2.0 : d2 == 5 ? 2.23606797749979
+         : d2 == 8 ? 2.8284271247461903 : d2 == 9 ? 3.0 : d2 == 10 ? 3.1622776601683795 : d2 == 13 ? 3.605551275463989
+         : 4.242640687119285;
+}
+
 PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                               uint32_t (&out)[4]) {
 #pragma unroll
@@ -172,7 +194,9 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // the constant address space, read in place from the kernarg segment (fused rollout).
 // KICK: the kickback-reward variant (grandparent bonus) is compiled in.  Measured: merely carrying that code costs the
 // base path 11 % (register / SGPR pressure), so it has its own kernel variants.
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, class KP, class KC>
+// GEN2: the second-generation step (two agent types per species, move cost, energy caps, stochastic reproduction:
+// red_queen/predpreygrass_rllib_env.py, "RQ").  Its own kernel variants; the base kernels compile none of it.
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, class KP, class KC>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
@@ -198,6 +222,7 @@ struct Env {
     uint32_t rank[T];  // explicit action order (only when C.act_rank is given)
     uint32_t gxyr[2];  // grass_xy of patches ln and ln+64 (static within an episode)
     uint32_t lutr[10]; // FASTOBS: this lane's descriptors, predator chunks 0-1 then prey chunks 0-2, two words each
+    int32_t lr[T];     // GEN2: agent_last_reproduction of the row
 
     // wave-uniform state
     uint64_t rows[T], alive[T], owns[T];
@@ -207,6 +232,9 @@ struct Env {
     uint32_t envflags, status, episode;
     uint64_t seed;
     bool cooc[2];  // some cell may hold two live agents of this type
+    uint64_t t2m[T];   // GEN2: rows holding a type-2 agent
+    int next_id2[2];   // GEN2: _next_idx of the type-2 pools (next_id: type 1)
+    int draws;         // GEN2: uniforms consumed by this call
 
     PPG_MEMBER Env(KP &p, KC &c, int b_, unsigned char *lds, int lane)
         : P(p), C(c), b(b_), ln(lane),
@@ -318,6 +346,12 @@ struct Env {
         calls = (int)wv::readlane(w, PPG_ENV_CALLS);
         obs_count[0] = (int)wv::readlane(w, PPG_ENV_OBS_PRED);
         obs_count[1] = (int)wv::readlane(w, PPG_ENV_OBS_PREY);
+        next_id2[0] = next_id2[1] = 0;
+        draws = 0;
+        if (GEN2) {
+            next_id2[0] = (int)wv::readlane(w, PPG_ENV_NEXT_PRED_ID_T2);
+            next_id2[1] = (int)wv::readlane(w, PPG_ENV_NEXT_PREY_ID_T2);
+        }
         seed = ((uint64_t)wv::first((uint32_t)(p.sd >> 32)) << 32) | wv::first((uint32_t)p.sd);
     }
 
@@ -342,7 +376,9 @@ struct Env {
                     if (C.actions) act[r] = C.actions[s];
                 }
             }
-            keep[r] = (fl & PPG_ROW_ATE) | ((uint32_t)slot_of(r, ln) << 8);  // bits 8..: where this row's start-of-step energy lives
+            keep[r] = (fl & (PPG_ROW_ATE | (GEN2 ? PPG_ROW_GRID_E0 : 0u))) | ((uint32_t)slot_of(r, ln) << 8);  // bits 8..: where this row's start-of-step energy lives
+            lr[r] = 0;
+            t2m[r] = GEN2 ? (wv::ballot(valid && ((id[r] >> 16) & 1)) ) : 0ull;
             rows[r] = wv::ballot(valid);
             alive[r] = rows[r] & ~wv::ballot(valid && (fl & PPG_ROW_DIED));
             owns[r] = wv::ballot(valid && (fl & PPG_ROW_OWNS)) & alive[r];
@@ -381,7 +417,7 @@ struct Env {
                 double g = p.ge[q];
                 if (regrow) {
                     double v = g + gain;
-                    g = (C.e0_g < v) ? C.e0_g : v;  // Python min(v, cap)
+                    g = (C.cap_g < v) ? C.cap_g : v;  // Python min(v, cap)
                 }
                 val[grass_validx(pp)] = g;
                 chmap(3)[cell_of(gxyr[q])] = (uint16_t)grass_validx(pp);
@@ -391,7 +427,7 @@ struct Env {
             double g = C.grass_e[gb + pp];
             if (regrow) {
                 double v = g + gain;
-                g = (C.e0_g < v) ? C.e0_g : v;
+                g = (C.cap_g < v) ? C.cap_g : v;
             }
             val[grass_validx(pp)] = g;
             chmap(3)[cell_of(C.grass_xy[gb + pp])] = (uint16_t)grass_validx(pp);
@@ -399,6 +435,34 @@ struct Env {
     }
 
     // ---- actions -------------------------------------------------------------------
+    // size of this lane's action space: 9 (BASE:108), or range^2 of the agent's type (RQ:974-985)
+    PPG_MEMBER int n_actions(int r) const {
+        if (!GEN2) return 9;
+        const int a = ((id[r] >> 16) & 1) ? C.ar[1] : C.ar[0];
+        return a * a;
+    }
+    // action -> (dx, dy): BASE:96-106 (a//3-1, a%3-1); RQ:141-146 with the range of the agent's type
+    PPG_MEMBER void move_vector(int a, bool type2, int &dx, int &dy) const {
+        if (!GEN2) {
+            const int ax = (a * 11) >> 5;  // a / 3 for 0..8
+            dx = ax - 1; dy = a - 3 * ax - 1;
+        } else {
+            const int side = type2 ? C.ar[1] : C.ar[0];
+            const uint32_t inv = type2 ? C.ar_inv[1] : C.ar_inv[0];
+            const int ax = (int)(((uint32_t)a * inv) >> 16), delta = (side - 1) >> 1;
+            dx = ax - delta; dy = a - ax * side - delta;
+        }
+    }
+    // the value grid[type, pos] shows for this lane's row: its energy, or the birth value (RQ:760)
+    PPG_MEMBER double shown(int r) const {
+        if (GEN2 && (keep[r] & PPG_ROW_GRID_E0)) return r ? C.e0_q : C.e0_p;
+        return e[r];
+    }
+    PPG_MEMBER bool shown_positive(int r) const {
+        if (GEN2) return (float)shown(r) > 0.0f;  // the reference's grid is float32 (RQ:138,339)
+        return e[r] > 0.0;
+    }
+
     PPG_MEMBER void load_actions(uint64_t (&acted)[T]) {
         bool bad = false;
         if (C.flags & PPG_STEP_RANDOM_ACTIONS) {
@@ -408,13 +472,13 @@ struct Env {
                 if ((r & 3) == 0)
                     philox4x32_10((uint32_t)step, (uint32_t)ln + 64u * (uint32_t)(r >> 2), 0u, episode,
                                   (uint32_t)seed, (uint32_t)(seed >> 32) ^ TAG_ACT, w);
-                act[r] = (int32_t)wv::mulhi(w[r & 3], 9u);
+                act[r] = (int32_t)wv::mulhi(w[r & 3], (uint32_t)n_actions(r));
             }
         } else {
 #pragma unroll
             for (int r = 0; r < T; ++r) {
                 int a = ((alive[r] >> ln) & 1ull) ? act[r] : -1;  // fetched with the rows
-                if (a < -1 || a > 8) { bad = true; a = -1; }
+                if (a < -1 || a >= n_actions(r)) { bad = true; a = -1; }
                 act[r] = a;
             }
         }
@@ -449,18 +513,33 @@ struct Env {
         r = type ? 1 + (row >> 6) : 0;
         k = row & 63;
     }
-    // xy of row (r,k) where r may be a run-time (wave-uniform) register index
+    // xy of row (r,k) where r may be a run-time (wave-uniform) register index.  The lane is read from every
+    // register first and the scalars are selected afterwards: selecting between the member arrays themselves makes
+    // the compiler select between their ADDRESSES, which pins the whole Env object (and the parameters) in scratch.
+    // With a compile-time r the unused reads fold away.
     PPG_MEMBER uint32_t xy_at(int r, int k) const {
-        uint32_t v = xy[0];
+        uint32_t v = wv::readlane(xy[0], k);
 #pragma unroll
-        for (int q = 1; q < T; ++q) v = (q == r) ? xy[q] : v;
-        return wv::readlane(v, k);
+        for (int q = 1; q < T; ++q) { const uint32_t vq = wv::readlane(xy[q], k); v = (q == r) ? vq : v; }
+        return v;
     }
     PPG_MEMBER int act_at(int r, int k) const {
-        uint32_t v = (uint32_t)act[0];
+        uint32_t v = wv::readlane((uint32_t)act[0], k);
 #pragma unroll
-        for (int q = 1; q < T; ++q) v = (q == r) ? (uint32_t)act[q] : v;
-        return (int)wv::readlane(v, k);
+        for (int q = 1; q < T; ++q) { const uint32_t vq = wv::readlane((uint32_t)act[q], k); v = (q == r) ? vq : v; }
+        return (int)v;
+    }
+    PPG_MEMBER uint32_t id_at(int r, int k) const {
+        uint32_t v = wv::readlane((uint32_t)id[0], k);
+#pragma unroll
+        for (int q = 1; q < T; ++q) { const uint32_t vq = wv::readlane((uint32_t)id[q], k); v = (q == r) ? vq : v; }
+        return v;
+    }
+    PPG_MEMBER double e_at(int r, int k) const {
+        double v = readlane_f64(e[0], k);
+#pragma unroll
+        for (int q = 1; q < T; ++q) { const double vq = readlane_f64(e[q], k); v = (q == r) ? vq : v; }
+        return v;
     }
 
     // ---- step 1: decay (BASE:244-250) ----------------------------------------------
@@ -485,7 +564,10 @@ struct Env {
 
 #pragma unroll
         for (int r = 0; r < T; ++r)
-            if ((acted[r] >> ln) & 1ull) e[r] -= (r ? C.loss_q : C.loss_p);
+            if ((acted[r] >> ln) & 1ull) {
+                e[r] -= (r ? C.loss_q : C.loss_p);
+                if (GEN2) keep[r] &= ~(uint32_t)PPG_ROW_GRID_E0;  // RQ:489: the grid now shows the real energy
+            }
 
         // grid[type, pos] = energy, in action order
 #pragma unroll
@@ -519,13 +601,14 @@ struct Env {
     // ---- step 2: movement in action order (BASE:259-276, _get_move BASE:495-509) ------
     // One agent: row (r,k); r may be a run-time register index (explicit-order path) -- with a
     // compile-time r every (q == r) below folds away.
-    PPG_MEMBER void move_agent(int r, int k, const uint64_t (&pos)[T]) {
+    PPG_MEMBER void move_agent(int r, int k, uint64_t (&pos)[T]) {
         const int type = type_of(r);
         const int G1 = P.G - 1;
         const uint32_t s_xy = xy_at(r, k);
         const int a = act_at(r, k);
-        const int ax = (a * 11) >> 5;  // a / 3 for 0..8
-        int tx = (int)(s_xy >> 8) + ax - 1, ty = (int)(s_xy & 255u) + (a - 3 * ax) - 1;
+        int dx, dy;
+        move_vector(a, GEN2 && ((id_at(r, k) >> 16) & 1u), dx, dy);
+        int tx = (int)(s_xy >> 8) + dx, ty = (int)(s_xy & 255u) + dy;
         tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);  // np.clip, BASE:505
         ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
         const uint32_t t_xy = ((uint32_t)tx << 8) | (uint32_t)ty;
@@ -554,6 +637,18 @@ struct Env {
                 owns[q] &= ~mt[q];
                 others |= mt[q] & ~((q == r) ? bit64(k) : 0ull);
             }
+            if (GEN2 && t_xy != s_xy && C.move_factor != 0.0) {
+                // _get_movement_energy_cost (RQ:301-313): distance * factor * energy, paid before the grid write (RQ:526,538)
+                const int ddx = tx - (int)(s_xy >> 8), ddy = ty - (int)(s_xy & 255u);
+                const double s_e = e_at(r, k);
+                const double ne = s_e - move_distance(ddx * ddx + ddy * ddy) * C.move_factor * s_e;
+                const bool still_pos = (float)ne > 0.0f;
+#pragma unroll
+                for (int q = 0; q < T; ++q) {
+                    e[q] = (q == r) ? writelane_f64(e[q], k, ne) : e[q];
+                    if (q == r) pos[q] = still_pos ? (pos[q] | bit64(k)) : (pos[q] & ~bit64(k));
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < T; ++q) owns[q] |= (q == r) ? bit64(k) : 0ull;
@@ -563,7 +658,7 @@ struct Env {
     PPG_MEMBER void move(const uint64_t (&acted)[T]) {
         uint64_t pos[T];  // grid value > 0 requires the owner's energy > 0 (BASE:506)
 #pragma unroll
-        for (int r = 0; r < T; ++r) pos[r] = wv::ballot(e[r] > 0.0) & alive[r];
+        for (int r = 0; r < T; ++r) pos[r] = wv::ballot(shown_positive(r)) & alive[r];
         if (ORDERED && C.act_rank) {
 #pragma unroll
             for (int type = 0; type < 2; ++type) {
@@ -594,9 +689,9 @@ struct Env {
 #pragma unroll
                 for (int r = 0; r < T; ++r) {
                     if (type_of(r) != type) continue;
-                    const int a = act[r] < 0 ? 4 : act[r];
-                    const int ax = (a * 11) >> 5;
-                    int tx = (int)(xy[r] >> 8) + ax - 1, ty = (int)(xy[r] & 255u) + (a - 3 * ax) - 1;
+                    int dx = 0, dy = 0;
+                    if (act[r] >= 0) move_vector(act[r], GEN2 && ((id[r] >> 16) & 1), dx, dy);
+                    int tx = (int)(xy[r] >> 8) + dx, ty = (int)(xy[r] & 255u) + dy;
                     tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);
                     ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
                     t_xy[r] = ((uint32_t)tx << 8) | (uint32_t)ty;
@@ -649,6 +744,10 @@ struct Env {
                 for (int r = 0; r < T; ++r) {
                     if (type_of(r) != type) continue;
                     const uint64_t simple = acted[r] & ~cx[r];
+                    if (GEN2 && ((simple >> ln) & 1ull) && t_xy[r] != xy[r] && C.move_factor != 0.0) {  // RQ:301-313,526
+                        const int ddx = (int)(t_xy[r] >> 8) - (int)(xy[r] >> 8), ddy = (int)(t_xy[r] & 255u) - (int)(xy[r] & 255u);
+                        e[r] = e[r] - move_distance(ddx * ddx + ddy * ddy) * C.move_factor * e[r];
+                    }
                     if ((simple >> ln) & 1ull) xy[r] = t_xy[r];   // BASE:263
                     owns[r] |= simple;                            // grid[new] = energy, BASE:269/273
                     todo[r] = cx[r];
@@ -776,12 +875,22 @@ struct Env {
         }
     }
 
+    // GEN2, after the rows have their final order: type masks, and agent_last_reproduction of every surviving row,
+    // read from HBM at the row's start-of-step slot like the cumulative rewards
+    PPG_MEMBER void after_compact() {
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            t2m[r] = wv::ballot((id[r] >> 16) & 1) & rows[r];
+            lr[r] = ((alive[r] >> ln) & 1ull) ? C.row_lastrep[(size_t)b * P.S + (keep[r] >> 8)] : 0;
+        }
+    }
+
     // ---- LDS acceleration structure for observations --------------------------------
     PPG_MEMBER void build_maps() {
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             if ((alive[r] >> ln) & 1ull) {
-                val[validx(r, ln)] = e[r];
+                val[validx(r, ln)] = shown(r);
                 if ((owns[r] >> ln) & 1ull) chmap(1 + type_of(r))[cell_of(xy[r])] = (uint16_t)validx(r, ln);
             }
         }
@@ -939,8 +1048,8 @@ struct Env {
         for (int q = 0; q < T; ++q) alive[q] &= ~((q == r) ? bit64(k) : 0ull);
     }
 
-    PPG_MEMBER void engage_predators() {
-        uint64_t m = alive[0];
+    PPG_MEMBER void engage_predators(uint64_t sel = ~0ull) {
+        uint64_t m = alive[0] & sel;
         while (m) {
             const int k = wv::ctz(m);
             m &= m - 1;
@@ -954,15 +1063,16 @@ struct Env {
             for (int q = 1; q < T; ++q) total += wv::popc(pm[q]);
             if (total == 0) continue;  // reward_predator_step, BASE:341
             // first prey in agent_positions order == lowest id (ids are handed out in insertion order)
+            // (GEN2: the creation number sits in the top bits of row_id, so the same comparison picks the first-inserted prey)
             int cr = 0, ck = 0;
-            int best = 0x7FFFFFFF;
+            uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
             for (int q = 1; q < T; ++q) {
                 uint64_t mq = pm[q];
                 while (mq) {
                     const int kk = wv::ctz(mq);
                     mq &= mq - 1;
-                    const int cid = (int)wv::readlane((uint32_t)id[q], kk);
+                    const uint32_t cid = wv::readlane((uint32_t)id[q], kk);
                     if (cid < best) { best = cid; cr = q; ck = kk; }
                 }
             }
@@ -970,7 +1080,13 @@ struct Env {
 #pragma unroll
             for (int q = 1; q < T; ++q)
                 if (q == cr) pe = readlane_f64(e[q], ck);
-            const double ne = s_e + pe;                     // BASE:324 (E1: pe may be <= 0)
+            double ne = s_e + pe;                           // BASE:324 (E1: pe may be <= 0)
+            if (GEN2) {  // RQ:598-606: capped gain times the transfer efficiency, then the predator's energy cap
+                const double raw = (C.cap_gain_prey < pe) ? C.cap_gain_prey : pe;
+                ne = s_e + raw * C.eff_transfer;
+                ne = (C.max_e_pred < ne) ? C.max_e_pred : ne;
+                if (ln == k) keep[0] &= ~(uint32_t)PPG_ROW_GRID_E0;
+            }
             e[0] = writelane_f64(e[0], k, ne);
             if (ln == k) ev[0] |= EV_ATE;                   // BASE:319
             grid_set(0, k, s_xy, ne, true);                 // BASE:325
@@ -985,23 +1101,35 @@ struct Env {
         }
     }
 
-    PPG_MEMBER void engage_prey() {
+    // GEN2: the gain of a prey eating grass energy g (RQ:665-673)
+    PPG_MEMBER double prey_after_eating(double s_e, double g) const {
+        if (!GEN2) return s_e + g;                          // BASE:367
+        const double raw = (C.cap_gain_grass < g) ? C.cap_gain_grass : g;
+        const double ne = s_e + raw * C.eff_transfer;
+        return (C.max_e_prey < ne) ? C.max_e_prey : ne;
+    }
+
+    // sel: 0 = every live prey; 1 / 2 = only type-1 / type-2 prey (GEN2 runs the engagement class by class)
+    PPG_MEMBER void engage_prey(int sel = 0) {
         uint32_t pidx[T];
         uint64_t ong[T], stv[T];
         uint64_t anystv = 0;
 #pragma unroll
         for (int r = 1; r < T; ++r) {
-            pidx[r] = ((alive[r] >> ln) & 1ull) ? chmap(3)[cell_of(xy[r])] : 0u;
-            ong[r] = wv::ballot(pidx[r] != 0u) & alive[r];
-            stv[r] = wv::ballot(e[r] <= 0.0) & alive[r];
+            const uint64_t mine = alive[r] & (sel == 0 ? ~0ull : (sel == 2 ? t2m[r] : ~t2m[r]));
+            pidx[r] = ((mine >> ln) & 1ull) ? chmap(3)[cell_of(xy[r])] : 0u;
+            ong[r] = wv::ballot(pidx[r] != 0u) & mine;
+            stv[r] = wv::ballot(e[r] <= 0.0) & mine;
             anystv |= stv[r];
+            if (GEN2 && ((mine >> ln) & 1ull)) ev[r] |= EV_TURN;
         }
         if (!anystv && !cooc[1]) {
             // no mid-step observation needed and one prey per cell: all eaters at once (BASE:359-372)
 #pragma unroll
             for (int r = 1; r < T; ++r) {
                 if ((ong[r] >> ln) & 1ull) {
-                    e[r] += val[pidx[r]];
+                    e[r] = prey_after_eating(e[r], val[pidx[r]]);
+                    if (GEN2) keep[r] &= ~(uint32_t)PPG_ROW_GRID_E0;
                     val[pidx[r]] = 0.0;
                     val[validx(r, ln)] = e[r];
                     chmap(2)[cell_of(xy[r])] = (uint16_t)validx(r, ln);
@@ -1023,9 +1151,9 @@ struct Env {
                 const uint32_t p = wv::readlane(pidx[r], k);
                 wv::sync();
                 const double g = first_f64(val[p]);
-                const double ne = s_e + g;                  // BASE:367
+                const double ne = prey_after_eating(s_e, g);  // BASE:367
                 e[r] = writelane_f64(e[r], k, ne);
-                if (ln == k) ev[r] |= EV_ATE;               // BASE:362
+                if (ln == k) { ev[r] |= EV_ATE; if (GEN2) keep[r] &= ~(uint32_t)PPG_ROW_GRID_E0; }  // BASE:362
                 grid_set(r, k, s_xy, ne, true);             // BASE:368
                 if (ln == 0) val[p] = 0.0;                  // BASE:371-372
             }
@@ -1165,6 +1293,126 @@ struct Env {
         }
     }
 
+    // ---- second generation: reproduction with cooldown, chance gate and mutation (RQ:695-866) ----------
+    // self.rng.random() number d of this call: the caller's stream (ppg_step_uniforms) or Philox keyed by (step, d)
+    PPG_MEMBER double uniform(int d) {
+        if (C.uniforms) {
+            if (d >= C.uniforms_per_env) { status |= PPG_STATUS_UNIFORMS_DRY; return 0.0; }
+            return first_f64(C.uniforms[(size_t)b * C.uniforms_per_env + d]);
+        }
+        uint32_t w[4];
+        philox4x32_10((uint32_t)step, (uint32_t)d, 0u, episode, (uint32_t)seed, (uint32_t)(seed >> 32) ^ TAG_REP, w);
+        return first_f64(((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) * (1.0 / 9007199254740992.0));
+    }
+
+    // The parent in row (r,k) of species SP passed the gates with enough energy (RQ:704-778 / 789-866).
+    template <int SP>
+    PPG_MEMBER void spawn2(int r, int k, bool mutated) {
+        const uint32_t pid = id_at(r, k);
+        const int pty = (int)((pid >> 16) & 1u), nty = mutated ? (pty ^ 1) : pty;   // RQ:705-712
+        const int cur = nty ? next_id2[SP] : next_id[SP];
+        if (cur >= C.npos2[SP * 2 + nty]) {  // RQ:715-725: no id left in that pool -- the reward is granted anyway
+#pragma unroll
+            for (int q = 0; q < T; ++q) ev[q] |= (q == r && ln == k) ? (uint32_t)EV_PARENT : 0u;
+            return;
+        }
+        const int cap = SP ? P.cap_prey : P.cap_pred;
+        if (n_rows[SP] >= cap) { status |= SP ? PPG_STATUS_PREY_OVERFLOW : PPG_STATUS_PRED_OVERFLOW; return; }
+        const uint32_t s_xy = xy_at(r, k);
+        const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
+        uint32_t child_xy = 0;
+        bool found = false;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {  // (x-1,y),(x+1,y),(x,y-1),(x,y+1), RQ:384-394
+            const int cx = x + (d == 0 ? -1 : d == 1 ? 1 : 0), cy = y + (d == 2 ? -1 : d == 3 ? 1 : 0);
+            if (found || cx < 0 || cx >= P.G || cy < 0 || cy >= P.G) continue;
+            const uint32_t c_xy = ((uint32_t)cx << 8) | (uint32_t)cy;
+            if (!any_agent_at(c_xy)) { child_xy = c_xy; found = true; }
+        }
+        if (!found) {
+            status |= PPG_STATUS_FALLBACK_SPAWN;
+            fb_count += 1;
+            if (!fallback_spawn(SP, cur, child_xy)) { status |= PPG_STATUS_FAILED_SPAWN; return; }
+        }
+        const int seq = next_id[0] + next_id2[0] + next_id[1] + next_id2[1];  // agents created so far this episode
+        if (nty) next_id2[SP] += 1; else next_id[SP] += 1;    // RQ:728
+        const int j = n_rows[SP]++;                           // appended to self.agents, RQ:729
+        const int cr = SP ? 1 + (j >> 6) : 0, ck = j & 63;
+        const uint32_t cidw = ((uint32_t)seq << 17) | ((uint32_t)nty << 16) | (uint32_t)cur;
+        const uint32_t ckey = (nty ? KEY_TYPE2 : 0u) + lexkey((uint32_t)cur);
+        const double e0 = SP ? C.e0_q : C.e0_p;
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            if (type_of(q) != SP || q != cr) continue;
+            xy[q] = wv::writelane(xy[q], ck, child_xy);
+            id[q] = (int32_t)wv::writelane((uint32_t)id[q], ck, cidw);
+            key[q] = wv::writelane(key[q], ck, ckey);
+            e[q] = writelane_f64(e[q], ck, e0 * C.eff_repro);   // RQ:754-756
+            if (ln == ck) { ev[q] = EV_BORN; keep[q] = PPG_ROW_GRID_E0; }
+        }
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            rows[q] |= (q == cr) ? bit64(ck) : 0ull;
+            alive[q] |= (q == cr) ? bit64(ck) : 0ull;
+            t2m[q] |= (q == cr && nty) ? bit64(ck) : 0ull;
+        }
+        n_alive[SP] += 1;                                     // RQ:763
+        grid_set(cr, ck, child_xy, e0, true);                 // RQ:760: the grid shows the full initial energy
+        const double ne = e_at(r, k) - e0;                    // RQ:757
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            if (type_of(q) != SP) continue;
+            e[q] = (q == r) ? writelane_f64(e[q], k, ne) : e[q];
+            if (q == r && ln == k) { ev[q] |= EV_PARENT | EV_REPRO; keep[q] &= ~(uint32_t)PPG_ROW_GRID_E0; }  // RQ:737,767
+        }
+        grid_set(r, k, s_xy, ne, true);                       // RQ:761
+    }
+
+    // row_order: self.agents is still in creation order (the call right after reset): predators then prey.  Otherwise
+    // it is sorted: type_1_predator*, type_1_prey*, type_2_predator*, type_2_prey* (RQ:270).
+    PPG_MEMBER void reproduce2(bool row_order) {
+        uint64_t elig[T], cand[T];
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            elig[r] = alive[r] & wv::ballot(step - lr[r] >= C.cooldown);                 // RQ:697
+            cand[r] = elig[r] & wv::ballot(e[r] >= (r ? C.thr_q : C.thr_p));             // RQ:704/789
+        }
+        // Every eligible agent draws once (chance gate); only those with enough energy matter afterwards.  Publish
+        // the candidates in self.agents order, each with the number of eligible agents in front of it.
+        uint32_t *lst = (uint32_t *)scr;
+        int n_cand = 0, base = 0;
+        wv::sync();
+#pragma unroll
+        for (int sgi = 0; sgi < 4; ++sgi) {
+            if (row_order && sgi >= 2) continue;
+            const int species = sgi & 1, ty = sgi >> 1;
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                if (type_of(r) != species) continue;
+                const uint64_t segm = row_order ? ~0ull : (ty ? t2m[r] : ~t2m[r]);
+                const uint64_t el = elig[r] & segm, cm = cand[r] & segm;
+                if ((cm >> ln) & 1ull)
+                    lst[n_cand + (int)wv::prefix(cm)] = ((uint32_t)(base + (int)wv::prefix(el)) << 16) |
+                                                        ((uint32_t)species << 15) | (uint32_t)row_of(r, ln);
+                n_cand += wv::popc(cm);
+                base += wv::popc(el);
+            }
+        }
+        wv::sync();
+        int n_second = 0;
+        for (int i = 0; i < n_cand; ++i) {
+            const uint32_t w = wv::first(lst[i]);
+            const int species = (int)((w >> 15) & 1u), row = (int)(w & 0x7FFFu);
+            const int d1 = (int)(w >> 16) + n_second;
+            if (uniform(d1) > (species ? C.chance_q : C.chance_p)) continue;             // RQ:701-702
+            const double u2 = uniform(d1 + 1);                                          // RQ:708/793
+            n_second += 1;
+            if (species) spawn2<1>(1 + (row >> 6), row & 63, u2 < C.mut_q);
+            else spawn2<0>(0, row & 63, u2 < C.mut_p);
+        }
+        draws = base + n_second;
+    }
+
     // ---- rewards, cumulative rewards (BASE:288,322-323,328-329,341-344,365-366,375-378,408-411) ----
     PPG_MEMBER void rewards_and_store(bool write_grass, bool transition = true) {
         int n_new[2] = {0, 0};
@@ -1173,7 +1421,7 @@ struct Env {
         double rew_[T], cum_[T];
         uint32_t fl_[T];
         int32_t par_[T];
-        const bool dense = transition && C.reward_mode != 0;
+        const bool dense = !GEN2 && transition && C.reward_mode != 0;
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);
@@ -1190,6 +1438,32 @@ struct Env {
                     c = 0.0;    // BASE:410
                 } else if (v & EV_TRUNC) {
                     rew = 0.0;
+                } else if (GEN2) {
+                    // type-specific rewards (_get_type_specific, RQ:1099-1106); cumulative_rewards is credited where the
+                    // reference credits it (RQ:596,618,643,663,691,721,769)
+                    const bool t2 = (id[r] >> 16) & 1;
+                    if (v & EV_STARVED) {
+                        rew = 0.0;                                                       // RQ:554
+                    } else if (v & EV_CAUGHT) {
+                        if (v & EV_TURN) {  // it had its own turn before a predator of a later class caught it
+                            const double x = (v & EV_ATE) ? (t2 ? C.r2_eat[1] : C.r2_eat[0]) : (t2 ? C.r2_qstep[1] : C.r2_qstep[0]);
+                            c += x;
+                            if (v & EV_ATE) c += x;
+                        }
+                        rew = t2 ? C.r2_caught[1] : C.r2_caught[0]; c += rew;           // RQ:616-618
+                    } else {
+                        if (v & EV_ATE) {
+                            rew = r ? (t2 ? C.r2_eat[1] : C.r2_eat[0]) : (t2 ? C.r2_catch[1] : C.r2_catch[0]);
+                            c += rew; c += rew;                                          // RQ:596+643 / 663+691
+                        } else {
+                            rew = r ? (t2 ? C.r2_qstep[1] : C.r2_qstep[0]) : (t2 ? C.r2_pstep[1] : C.r2_pstep[0]);
+                            c += rew;                                                    // RQ:643 / 691
+                        }
+                        if (v & EV_PARENT) {                                             // RQ:719-721 / 767-769 overwrite
+                            rew = r ? (t2 ? C.r2_repro_q[1] : C.r2_repro_q[0]) : (t2 ? C.r2_repro_p[1] : C.r2_repro_p[0]);
+                            c += rew;
+                        }
+                    }
                 } else if (dense) {
                     // dense variants: reward = energy now - energy at the start of the step (still in HBM at the
                     // row's old slot); a caught prey's account goes to zero (0.0 - before)
@@ -1219,7 +1493,14 @@ struct Env {
                 if ((owns[r] >> ln) & 1ull) fl |= PPG_ROW_OWNS;
                 if (v & EV_BORN) fl |= PPG_ROW_NEWBORN;
                 if (v & EV_ATE) fl |= PPG_ROW_ATE;
-                if (v & EV_TRUNC) fl |= PPG_ROW_TRUNC | (keep[r] & PPG_ROW_ATE);
+                if (v & EV_TRUNC) fl |= PPG_ROW_TRUNC | (GEN2 ? 0u : (keep[r] & PPG_ROW_ATE));  // RQ:200 clears agents_just_ate first
+                if (GEN2) {
+                    fl |= keep[r] & PPG_ROW_GRID_E0;
+                    // agent_last_reproduction: -cooldown at registration (RQ:999), current_step at a birth (RQ:737;
+                    // `step` has already been advanced when this runs)
+                    if (!transition || (v & EV_BORN)) lr[r] = -C.cooldown;
+                    else if (v & EV_REPRO) lr[r] = step - 1;
+                }
             }
             rew_[r] = rew; cum_[r] = c; fl_[r] = fl;
             par_[r] = -1;
@@ -1243,6 +1524,7 @@ struct Env {
             C.row_flags[s] = (uint8_t)fl_[r];
             C.row_reward[s] = rew_[r];
             if (KICK) C.row_parent[s] = par_[r];
+            if (GEN2) C.row_lastrep[s] = lr[r];
             keep[r] = (keep[r] & ~0xFFu) | (fl_[r] & PPG_ROW_ATE);
         }
         obs_count[0] += n_rows[0];       // every row in use got an observation
@@ -1271,6 +1553,9 @@ struct Env {
                 case PPG_ENV_CALLS: w = calls; break;
                 case PPG_ENV_OBS_PRED: w = obs_count[0]; break;
                 case PPG_ENV_OBS_PREY: w = obs_count[1]; break;
+                case PPG_ENV_NEXT_PRED_ID_T2: w = next_id2[0]; break;
+                case PPG_ENV_NEXT_PREY_ID_T2: w = next_id2[1]; break;
+                case PPG_ENV_DRAWS: w = draws; break;
                 default: w = 0; break;
             }
             es[ln] = w;
@@ -1318,6 +1603,12 @@ struct Env {
                 xy[r] = (cx << 8) | (c - cx * (uint32_t)P.G);
                 id[r] = i;
                 key[r] = lexkey((uint32_t)i);
+                if (GEN2) {  // RQ:125-133: type 1 first, then type 2; creation number = position in self.agents
+                    const int n1 = r ? C.ninit2[2] : C.ninit2[0];
+                    const int t2 = i >= n1, idx = t2 ? i - n1 : i, seq = r ? P0 + i : i;
+                    id[r] = (int32_t)(((uint32_t)seq << 17) | ((uint32_t)t2 << 16) | (uint32_t)idx);
+                    key[r] = (t2 ? KEY_TYPE2 : 0u) + lexkey((uint32_t)idx);
+                }
                 e[r] = r ? C.e0_q : C.e0_p;
             }
             rows[r] = wv::ballot(valid);
@@ -1344,6 +1635,12 @@ struct Env {
         }
         n_rows[0] = P0; n_rows[1] = Q0;
         next_id[0] = P0; next_id[1] = Q0;            // BASE:153-154
+        if (GEN2) {                                  // RQ:129
+            next_id[0] = C.ninit2[0]; next_id2[0] = C.ninit2[1];
+            next_id[1] = C.ninit2[2]; next_id2[1] = C.ninit2[3];
+#pragma unroll
+            for (int r = 0; r < T; ++r) t2m[r] = wv::ballot((id[r] >> 16) & 1) & rows[r];
+        }
         n_alive[0] = P0; n_alive[1] = Q0;            // BASE:210-211
         step = 0;                                    // BASE:134
         fb_count = 0;
@@ -1374,6 +1671,7 @@ struct Env {
             wv::sync();
             load_grass(false, pre);
             compact_and_sort(!list_is_row_order);
+            if (GEN2) after_compact();
             build_maps();
             obs_all_alive();
 #pragma unroll
@@ -1387,7 +1685,7 @@ struct Env {
         uint64_t acted[T];
         load_actions(acted);
 #pragma unroll
-        for (int r = 0; r < T; ++r) keep[r] &= ~0xFFu;  // agents_just_ate.clear(), BASE:241
+        for (int r = 0; r < T; ++r) keep[r] &= GEN2 ? ~(uint32_t)PPG_ROW_ATE : ~0xFFu;  // agents_just_ate.clear(), BASE:241
         wv::sync();                                // LDS zeros visible
         PPG_STAMP(2);
         decay(acted);                              // BASE:244-250
@@ -1398,15 +1696,29 @@ struct Env {
         PPG_STAMP(5);
         compact_and_sort(!list_is_row_order);      // BASE:222-225 + the sort of BASE:468
         PPG_STAMP(6);
+        if (GEN2) after_compact();
         build_maps();
         PPG_STAMP(7);
-        engage_predators();                        // BASE:302-346 (+ starvation BASE:284-301)
-        wv::sync();
-        PPG_STAMP(8);
-        engage_prey();                             // BASE:347-380
-        wv::sync();
+        if (!GEN2 || list_is_row_order) {
+            engage_predators();                    // BASE:302-346 (+ starvation BASE:284-301)
+            wv::sync();
+            PPG_STAMP(8);
+            engage_prey();                         // BASE:347-380
+            wv::sync();
+        } else {
+            // RQ:225-233 walks the sorted self.agents: type_1_predator*, type_1_prey*, type_2_predator*, type_2_prey*
+            engage_predators(~t2m[0]);
+            wv::sync();
+            engage_prey(1);
+            wv::sync();
+            engage_predators(t2m[0]);
+            wv::sync();
+            engage_prey(2);
+            wv::sync();
+        }
         PPG_STAMP(9);
-        reproduce();                               // BASE:389-448
+        if (GEN2) reproduce2(list_is_row_order);   // RQ:248-254
+        else reproduce();                          // BASE:389-448
         PPG_STAMP(10);
         obs_all_alive();                           // BASE:451-453
         PPG_STAMP(11);
@@ -1472,7 +1784,7 @@ struct Env {
     }
 };
 
-template <int NQ, int MODE, bool FASTOBS>
+template <int NQ, int MODE, bool FASTOBS, bool GEN2 = false>
 PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     const int b = PPG_BLOCK_INDEX();
     if (b >= P.batch) return;
@@ -1494,7 +1806,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
             PPG_LAUNDER_S(bb);
             PPG_LAUNDER_V(lane);
             PPG_LAUNDER_V(l);
-            Env<NQ, false, FASTOBS, true, false, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
+            Env<NQ, false, FASTOBS, true, false, false, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
             env.run_step(it);
             wv::sync();
         }
@@ -1502,7 +1814,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     }
     const PPG_CONSTANT_AS KParams *Pcold = PPG_KERNARG_PTR(KParams, P);  // KParams is the kernel's only argument
     Env<NQ, MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_ORDERED_KICK, FASTOBS, false,
-        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, const KParams, const PPG_CONSTANT_AS KParams>
+        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, GEN2, const KParams, const PPG_CONSTANT_AS KParams>
         env(P, *Pcold, b, lds, wv::lane());
     if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();

@@ -1,0 +1,33 @@
+// ppg_kernel_list.h -- the kernel instantiations of libppg_hip.so.  The including unit defines PPG_K / PPG_K2
+// (a definition in ppg_kernels.hip, a declaration in ppg_hip.hip).
+#pragma once
+
+#define PPG_DEFINE_KERNELS(NQ)                                        \
+    PPG_K(ppg_step_q##NQ, NQ, ppg::MODE_STEP, true)                   \
+    PPG_K(ppg_reset_q##NQ, NQ, ppg::MODE_RESET, true)                 \
+    PPG_K(ppg_observe_q##NQ, NQ, ppg::MODE_OBSERVE, true)             \
+    PPG_K(ppg_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID, true)            \
+    PPG_K(ppg_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED, true)       \
+    PPG_K(ppg_rollout_q##NQ, NQ, ppg::MODE_ROLLOUT, true)             \
+    PPG_K(ppg_step_kick_q##NQ, NQ, ppg::MODE_STEP_KICK, true)         \
+    PPG_K(ppg_step_ord_kick_q##NQ, NQ, ppg::MODE_STEP_ORDERED_KICK, true) \
+    PPG_K(ppg_step_q##NQ##g, NQ, ppg::MODE_STEP, false)               \
+    PPG_K(ppg_reset_q##NQ##g, NQ, ppg::MODE_RESET, false)             \
+    PPG_K(ppg_observe_q##NQ##g, NQ, ppg::MODE_OBSERVE, false)         \
+    PPG_K(ppg_grid_q##NQ##g, NQ, ppg::MODE_EXPORT_GRID, false)        \
+    PPG_K(ppg_step_ord_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED, false)   \
+    PPG_K(ppg_rollout_q##NQ##g, NQ, ppg::MODE_ROLLOUT, false)         \
+    PPG_K(ppg_step_kick_q##NQ##g, NQ, ppg::MODE_STEP_KICK, false)     \
+    PPG_K(ppg_step_ord_kick_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED_KICK, false)
+
+#define PPG_DEFINE_KERNELS2(NQ)                                       \
+    PPG_K2(ppg2_step_q##NQ, NQ, ppg::MODE_STEP, true)                 \
+    PPG_K2(ppg2_reset_q##NQ, NQ, ppg::MODE_RESET, true)               \
+    PPG_K2(ppg2_observe_q##NQ, NQ, ppg::MODE_OBSERVE, true)           \
+    PPG_K2(ppg2_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID, true)          \
+    PPG_K2(ppg2_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED, true)     \
+    PPG_K2(ppg2_step_q##NQ##g, NQ, ppg::MODE_STEP, false)             \
+    PPG_K2(ppg2_reset_q##NQ##g, NQ, ppg::MODE_RESET, false)           \
+    PPG_K2(ppg2_observe_q##NQ##g, NQ, ppg::MODE_OBSERVE, false)       \
+    PPG_K2(ppg2_grid_q##NQ##g, NQ, ppg::MODE_EXPORT_GRID, false)      \
+    PPG_K2(ppg2_step_ord_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED, false)

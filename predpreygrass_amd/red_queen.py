@@ -1,0 +1,292 @@
+"""Second-generation PredPreyGrass ("red queen"): two agent types per species, a 5x5 action range for type 2,
+distance-proportional move cost, energy caps and transfer efficiency, reproduction cooldown / chance gate /
+mutation.  Host plumbing for the gen-2 kernels of libppg_hip.so (include/ppg.h: ppg_create_gen2,
+ppg_step_uniforms); all environment logic runs in predpreygrass_amd/csrc/ppg_kernel.h.
+
+"RQ:n" = line n of predpreygrass/non_evolutionary/red_queen/predpreygrass_rllib_env.py in the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _abi
+from .batched import BatchedPredPreyGrass, lexkey
+
+POOLS = ("type_1_predator", "type_2_predator", "type_1_prey", "type_2_prey")  # creation order, RQ:125-133
+_POSSIBLE_KEYS = ("n_possible_type_1_predators", "n_possible_type_2_predators", "n_possible_type_1_prey",
+                  "n_possible_type_2_prey")  # RQ:56-59
+_INITIAL_KEYS = tuple(f"n_initial_active_{p}" for p in POOLS)  # RQ:61-64
+
+# red_queen/config/config_env_base.py:1-81 (values restated)
+config_env_base = {
+    "max_steps": 1000, "grid_size": 25, "num_obs_channels": 4, "predator_obs_range": 7, "prey_obs_range": 9,
+    "type_1_action_range": 3, "type_2_action_range": 5,
+    "reward_predator_catch_prey": {"type_1_predator": 0.0, "type_2_predator": 0.0},
+    "reward_prey_eat_grass": {"type_1_prey": 0.0, "type_2_prey": 0.0},
+    "reward_predator_step": {"type_1_predator": 0.0, "type_2_predator": 0.0},
+    "reward_prey_step": {"type_1_prey": 0.0, "type_2_prey": 0.0},
+    "penalty_prey_caught": {"type_1_prey": 0.0, "type_2_prey": 0.0},
+    "reproduction_reward_predator": {"type_1_predator": 10.0, "type_2_predator": 10.0},
+    "reproduction_reward_prey": {"type_1_prey": 10.0, "type_2_prey": 10.0},
+    "energy_loss_per_step_predator": 0.06, "energy_loss_per_step_prey": 0.02,
+    "predator_creation_energy_threshold": 12.0, "prey_creation_energy_threshold": 8.0,
+    "move_energy_cost_factor": 0.01, "initial_energy_predator": 6.0, "initial_energy_prey": 3.0,
+    "n_possible_type_1_predators": 2000, "n_possible_type_2_predators": 0,
+    "n_possible_type_1_prey": 1600, "n_possible_type_2_prey": 1600,
+    "n_initial_active_type_1_predator": 12, "n_initial_active_type_2_predator": 0,
+    "n_initial_active_type_1_prey": 10, "n_initial_active_type_2_prey": 10,
+    "mutation_rate_predator": 0.05, "mutation_rate_prey": 0.05,
+    "initial_num_grass": 100, "initial_energy_grass": 2.0, "energy_gain_per_step_grass": 0.1,
+    "verbose_engagement": False, "verbose_movement": False, "verbose_decay": False, "verbose_reproduction": False,
+    "debug_mode": False,
+    "max_energy_gain_per_grass": 1.5, "max_energy_gain_per_prey": 5.0, "max_energy_predator": 20.0,
+    "max_energy_prey": 14.0, "max_energy_grass": 2.0,
+    "reproduction_cooldown_steps": 5, "reproduction_chance_predator": 0.95, "reproduction_chance_prey": 0.95,
+    "energy_transfer_efficiency": 0.9, "reproduction_energy_efficiency": 0.9,
+}
+
+# `config.get(key, default)` fallbacks of the reference (RQ:30-86 and inside step(): RQ:305,510,598-605,665-672,696,
+# 700-701,754)
+_IN_CODE_DEFAULTS = {
+    "max_steps": 10000, "grid_size": 10, "num_obs_channels": 4, "predator_obs_range": 7, "prey_obs_range": 5,
+    "n_possible_type_1_predators": 25, "n_possible_type_2_predators": 25,
+    "n_possible_type_1_prey": 25, "n_possible_type_2_prey": 25,
+    "n_initial_active_type_1_predator": 6, "n_initial_active_type_2_predator": 0,
+    "n_initial_active_type_1_prey": 8, "n_initial_active_type_2_prey": 0,
+    "initial_num_grass": 25, "type_1_action_range": 3, "type_2_action_range": 5, "reproduction_cooldown_steps": 10,
+    "reward_predator_catch_prey": 0.0, "reward_prey_eat_grass": 0.0, "reward_predator_step": 0.0,
+    "reward_prey_step": 0.0, "penalty_prey_caught": 0.0,
+    "reproduction_reward_predator": 10.0, "reproduction_reward_prey": 10.0,
+    "energy_loss_per_step_predator": 0.15, "energy_loss_per_step_prey": 0.05,
+    "predator_creation_energy_threshold": 12.0, "prey_creation_energy_threshold": 8.0,
+    "initial_energy_predator": 5.0, "initial_energy_prey": 3.0, "initial_energy_grass": 2.0,
+    "energy_gain_per_step_grass": 0.2, "move_energy_cost_factor": 0.01,
+    "max_energy_gain_per_prey": math.inf, "max_energy_gain_per_grass": math.inf,
+    "max_energy_predator": math.inf, "max_energy_prey": math.inf, "max_energy_grass": math.inf,
+    "energy_transfer_efficiency": 1.0, "reproduction_energy_efficiency": 1.0,
+    "reproduction_chance_predator": 1.0, "reproduction_chance_prey": 1.0,
+    "mutation_rate_predator": 0.1, "mutation_rate_prey": 0.1,
+}
+
+
+def resolve_config(config: dict) -> dict:
+    """The red_queen env needs an explicit config (RQ:17-18); absent keys get the reference's in-code defaults."""
+    if config is None:
+        raise ValueError("Environment config must be provided explicitly.")  # RQ:17-18
+    out = dict(_IN_CODE_DEFAULTS)
+    out.update(config)
+    if int(out["num_obs_channels"]) != 4:
+        raise ValueError("num_obs_channels must be 4 (border, predator, prey, grass)")
+    return out
+
+
+def typed_value(raw, species: str, type_: int) -> float:
+    """_get_type_specific (RQ:1099-1106): a scalar, or a dict keyed by 'type_<t>_<species>' prefixes."""
+    if isinstance(raw, dict):
+        name = f"type_{type_}_{species}"
+        for k in raw:
+            if name.startswith(k):
+                return float(raw[k])
+        raise KeyError(f"Type-specific key '{name}' not found")
+    return float(raw)
+
+
+def agent_name(pool: int, idx: int) -> str:
+    return f"{POOLS[int(pool)]}_{int(idx)}"
+
+
+def parse_agent(name: str) -> tuple[int, int]:
+    kind, idx = name.rsplit("_", 1)
+    return POOLS.index(kind), int(idx)
+
+
+def make_row_id(seq, type2, idx):
+    """row_id of include/ppg.h: creation number << 17 | (type - 1) << 16 | k."""
+    return (np.asarray(seq, dtype=np.int64) << 17 | np.asarray(type2, dtype=np.int64) << 16 | np.asarray(idx, dtype=np.int64)).astype(np.int32)
+
+
+def split_row_id(row_id):
+    """-> (creation number, type - 1, k)."""
+    v = np.asarray(row_id).astype(np.int64) & 0xFFFFFFFF
+    return v >> 17, (v >> 16) & 1, v & 0xFFFF
+
+
+class BatchedRedQueen(BatchedPredPreyGrass):
+    """Tensor API of the second-generation env: same row layout as `BatchedPredPreyGrass` (predator rows, then prey
+    rows; survivors in self.agents order followed by newborns), with the agent's type and creation number packed into
+    ``row_id``.  Observations default to float32, the reference's dtype (RQ:352-355)."""
+
+    def __init__(self, config, batch_size=1, device=None, obs_dtype=torch.float32, prey_capacity=128, seed=0,
+                 _library=None):
+        cfg = resolve_config(config)
+        self.config = cfg
+        self.batch_size = int(batch_size)
+        self._init_device(device, obs_dtype, _library)
+        self.grid_size = int(cfg["grid_size"])
+        self.Rp, self.Rq = int(cfg["predator_obs_range"]), int(cfg["prey_obs_range"])
+        self.n_initial = [int(cfg[k]) for k in _INITIAL_KEYS]
+        self.n_possible = [int(cfg[k]) for k in _POSSIBLE_KEYS]
+        self.P0, self.Q0 = self.n_initial[0] + self.n_initial[1], self.n_initial[2] + self.n_initial[3]
+        self.n_grass = int(cfg["initial_num_grass"])
+        self.cooldown = int(cfg["reproduction_cooldown_steps"])
+        self.action_ranges = (int(cfg["type_1_action_range"]), int(cfg["type_2_action_range"]))
+        self._alloc_buffers(prey_capacity)
+
+        c = _abi.PpgConfigGen2()
+        c.abi_version = _abi.ABI_VERSION
+        c.grid_size, c.predator_obs_range, c.prey_obs_range = self.grid_size, self.Rp, self.Rq
+        c.max_steps = int(cfg["max_steps"])
+        for p in range(4):
+            c.n_possible[p], c.n_initial[p] = self.n_possible[p], self.n_initial[p]
+        c.n_grass = self.n_grass
+        c.pred_capacity, c.prey_capacity, c.grass_capacity = self.pred_capacity, self.prey_capacity, self.grass_capacity
+        c.obs_dtype = 0 if obs_dtype == torch.float64 else 1
+        c.type_1_action_range, c.type_2_action_range = self.action_ranges
+        c.reproduction_cooldown_steps = self.cooldown
+        for name in _abi.GEN2_TYPED:
+            species = "predator" if name in ("reward_predator_catch_prey", "reward_predator_step",
+                                             "reproduction_reward_predator") else "prey"
+            for t in (1, 2):
+                getattr(c, name)[t - 1] = typed_value(cfg[name], species, t)
+        for name in _abi.GEN2_SCALARS:
+            setattr(c, name, float(cfg[name]))
+        self._create_handle(c, self._lib.ppg_create_gen2)
+        self.set_seeds(seed)
+
+    # ------------------------------------------------------------------
+    def set_placement(self, pred_xy, prey_xy, grass_xy, episode=0):
+        """reset() with a given placement (RQ:151-195): predators / prey in creation order (type 1 then type 2),
+        grass in id order; arrays [B,P0,2], [B,Q0,2], [B,n_grass,2] of (x, y)."""
+        B, G = self.batch_size, self.grid_size
+        pred = np.asarray(pred_xy, dtype=np.int64).reshape(B, self.P0, 2)
+        prey = np.asarray(prey_xy, dtype=np.int64).reshape(B, self.Q0, 2)
+        grass = np.asarray(grass_xy, dtype=np.int64).reshape(B, self.n_grass, 2)
+        for a in (pred, prey, grass):
+            if a.size and (a.min() < 0 or a.max() >= G):
+                raise ValueError("position outside the grid")
+        gcell = grass[..., 0] * G + grass[..., 1]
+        for b in range(B):
+            if len(np.unique(gcell[b])) != self.n_grass:
+                raise ValueError("grass positions must be unique")
+        S, cp = self.S, self.pred_capacity
+        xy = np.zeros((B, S), dtype=np.int16)
+        en = np.zeros((B, S), dtype=np.float64)
+        ids = np.zeros((B, S), dtype=np.int32)
+        keys = np.zeros((B, S), dtype=np.int32)
+        fl = np.zeros((B, S), dtype=np.uint8)
+        lastrep = np.full((B, S), -self.cooldown, dtype=np.int32)           # RQ:999
+        xy[:, : self.P0] = (pred[..., 0] << 8 | pred[..., 1]).astype(np.int16)
+        xy[:, cp: cp + self.Q0] = (prey[..., 0] << 8 | prey[..., 1]).astype(np.int16)
+        en[:, : self.P0] = float(self.config["initial_energy_predator"])
+        en[:, cp: cp + self.Q0] = float(self.config["initial_energy_prey"])
+        for lo, n1, n, seq0 in ((0, self.n_initial[0], self.P0, 0), (cp, self.n_initial[2], self.Q0, self.P0)):
+            i = np.arange(n)
+            t2 = (i >= n1).astype(np.int64)
+            idx = np.where(t2 == 1, i - n1, i)
+            ids[:, lo: lo + n] = make_row_id(seq0 + i, t2, idx)
+            keys[:, lo: lo + n] = (t2 * _abi.KEY_TYPE2 + lexkey(idx)).astype(np.int32)
+        for b in range(B):  # grid[type, pos] = energy in creation order (RQ:168-180): the last writer owns the cell
+            for lo, arr in ((0, pred[b]), (cp, prey[b])):
+                owner = {}
+                for i, (x, y) in enumerate(arr):
+                    owner[(int(x), int(y))] = i
+                for i in owner.values():
+                    fl[b, lo + i] = _abi.ROW_OWNS
+        es = np.zeros((B, _abi.ENV_WORDS), dtype=np.int32)
+        es[:, _abi.ENV_N_PRED_ROWS] = self.P0
+        es[:, _abi.ENV_N_PREY_ROWS] = self.Q0
+        es[:, _abi.ENV_NEXT_PRED_ID] = self.n_initial[0]                    # RQ:129
+        es[:, _abi.ENV_NEXT_PRED_ID_T2] = self.n_initial[1]
+        es[:, _abi.ENV_NEXT_PREY_ID] = self.n_initial[2]
+        es[:, _abi.ENV_NEXT_PREY_ID_T2] = self.n_initial[3]
+        es[:, _abi.ENV_N_PRED_ALIVE] = self.P0
+        es[:, _abi.ENV_N_PREY_ALIVE] = self.Q0
+        es[:, _abi.ENV_FLAGS] = _abi.ENVF_WAS_RESET | _abi.ENVF_LIST_IS_ROW_ORDER
+        es[:, _abi.ENV_EPISODE] = int(episode)
+        gxy = np.zeros((B, self.grass_capacity), dtype=np.int16)
+        ge = np.zeros((B, self.grass_capacity), dtype=np.float64)
+        gxy[:, : self.n_grass] = (grass[..., 0] << 8 | grass[..., 1]).astype(np.int16)
+        ge[:, : self.n_grass] = float(self.config["initial_energy_grass"])
+        for t, a in ((self.row_xy, xy), (self.row_energy, en), (self.row_id, ids), (self.row_key, keys),
+                     (self.row_flags, fl), (self.row_lastrep, lastrep), (self.env_state, es), (self.grass_xy, gxy),
+                     (self.grass_energy, ge)):
+            t.copy_(torch.from_numpy(a))
+        self.row_cumrew.zero_()
+        self.row_reward.zero_()
+        self.observe()
+        return self
+
+    def step(self, actions=None, random_actions=False, auto_reset=False, act_rank=None, uniforms=None, stream=None):
+        """One transition of every env (RQ:197-299).
+
+        uniforms (optional float64 [B,U]): the values the reference's ``self.rng.random()`` would return for each env
+        in this call, in draw order (RQ:701,708); ``env_state[:, ENV_DRAWS]`` tells how many were used.  Without it
+        the draws come from Philox on the device."""
+        if uniforms is None:
+            return super().step(actions, random_actions=random_actions, auto_reset=auto_reset, act_rank=act_rank,
+                                stream=stream)
+        if uniforms.dtype != torch.float64 or uniforms.dim() != 2 or uniforms.shape[0] != self.batch_size or \
+                uniforms.device != self.device or not uniforms.is_contiguous():
+            raise ValueError("uniforms must be a contiguous float64 tensor [B,U] on the env's device")
+        flags = (_abi.STEP_RANDOM_ACTIONS if random_actions else 0) | (_abi.STEP_AUTO_RESET if auto_reset else 0)
+        ptr = None
+        if not random_actions:
+            if actions is None:
+                actions = self.actions
+            if actions.dtype != torch.int8 or tuple(actions.shape) != (self.batch_size, self.S) or \
+                    actions.device != self.device or not actions.is_contiguous():
+                raise ValueError(f"actions must be a contiguous int8 tensor [{self.batch_size},{self.S}] on {self.device}")
+            ptr = C.c_void_p(actions.data_ptr())
+        rank_ptr = None
+        if act_rank is not None:
+            if act_rank.dtype != torch.uint8 or tuple(act_rank.shape) != (self.batch_size, self.S) or \
+                    act_rank.device != self.device or not act_rank.is_contiguous():
+                raise ValueError("act_rank must be a contiguous uint8 tensor [B,S] on the env's device")
+            rank_ptr = C.c_void_p(act_rank.data_ptr())
+        self._check(self._lib.ppg_step_uniforms(self._handle, ptr, rank_ptr, C.c_void_p(uniforms.data_ptr()),
+                                                int(uniforms.shape[1]), flags, self._stream(stream)), "ppg_step_uniforms")
+        return self
+
+    def rollout(self, *a, **k):
+        raise NotImplementedError("ppg_rollout is not available for the second-generation env")
+
+    # ------------------------------------------------------------------
+    def host_tables(self, b=None):
+        sl = slice(None) if b is None else slice(b, b + 1)
+        names = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_lastrep",
+                 "env_state", "grass_xy", "grass_energy"]
+        return {n: getattr(self, n)[sl].cpu().numpy() for n in names}
+
+    def records(self, b, tables=None):
+        """The returned dicts of env b's last call as an ordered list of (name, species, row, reward, terminated,
+        truncated) in the reference's dict order: self.agents order (creation order right after reset, otherwise the
+        sorted id strings: type_1_predator*, type_1_prey*, type_2_predator*, type_2_prey*, RQ:270) followed by the
+        newborns of the call in birth order (RQ:729)."""
+        t = tables if tables is not None else self.host_tables(b)
+        i = 0 if tables is None else b
+        es = t["env_state"][i]
+        nP, nQ = int(es[_abi.ENV_N_PRED_ROWS]), int(es[_abi.ENV_N_PREY_ROWS])
+        newP, newQ = int(es[_abi.ENV_N_PRED_NEW]), int(es[_abi.ENV_N_PREY_NEW])
+        flags = int(es[_abi.ENV_FLAGS])
+        cp = self.pred_capacity
+        creation_order = bool(flags & (_abi.ENVF_WAS_RESET | _abi.ENVF_LIST_IS_ROW_ORDER)) or \
+            (int(es[_abi.ENV_STEP]) == 1 and not flags & _abi.ENVF_TRUNC_ALL)
+        rows = [(0, r, r) for r in range(nP)] + [(1, r, cp + r) for r in range(nQ)]
+        seq, t2, idx = split_row_id(t["row_id"][i])
+        surv = [x for x in rows if not (x[1] >= (nP - newP if x[0] == 0 else nQ - newQ))]
+        born = [x for x in rows if x[1] >= (nP - newP if x[0] == 0 else nQ - newQ)]
+        if creation_order:
+            surv.sort(key=lambda x: int(seq[x[2]]))
+        else:
+            surv.sort(key=lambda x: (int(t2[x[2]]), x[0], int(t["row_key"][i, x[2]])))
+        born.sort(key=lambda x: int(seq[x[2]]))
+        out = []
+        for sp, r, s in surv + born:
+            fl = int(t["row_flags"][i, s])
+            out.append((agent_name(sp * 2 + int(t2[s]), idx[s]), sp, r, float(t["row_reward"][i, s]),
+                        bool(fl & _abi.ROW_DIED), bool(fl & _abi.ROW_TRUNC)))
+        return out

@@ -17,7 +17,7 @@ def hip_lib_path():
 
 def test_hip_library_exports_every_declared_symbol(hip_lib_path):
     header = open(os.path.join(ROOT, "include", "ppg.h")).read()
-    declared = set(re.findall(r"\b(ppg_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(ppg_[a-z0-9_]+)\s*\(", header))
     from predpreygrass_amd import _abi
     assert declared == set(_abi.EXPORTED_SYMBOLS)
     lib = ctypes.CDLL(hip_lib_path)

@@ -23,7 +23,7 @@ __asm__(
 
 struct EmuLaunch {
     const ppg::KParams *P;
-    int nq, mode;
+    int nq, mode, gen2;
 };
 
 template <int NQ, bool FAST>
@@ -41,8 +41,26 @@ static void run_mode(const ppg::KParams &P, int mode) {
     }
 }
 
+template <int NQ, bool FAST>
+static void run_mode2(const ppg::KParams &P, int mode) {
+    PPG_DYNAMIC_LDS(lds);
+    switch (mode) {
+        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP, FAST, true>(P, lds); break;
+        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET, FAST, true>(P, lds); break;
+        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, FAST, true>(P, lds); break;
+        case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, FAST, true>(P, lds); break;
+        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, FAST, true>(P, lds); break;
+    }
+}
+
 template <bool FAST>
 static void run_nq(const EmuLaunch *L) {
+    if (L->gen2) {
+        if (L->nq == 1) run_mode2<1, FAST>(*L->P, L->mode);
+        else if (L->nq == 2) run_mode2<2, FAST>(*L->P, L->mode);
+        else run_mode2<4, FAST>(*L->P, L->mode);
+        return;
+    }
     if (L->nq == 1) run_mode<1, FAST>(*L->P, L->mode);
     else if (L->nq == 2) run_mode<2, FAST>(*L->P, L->mode);
     else run_mode<4, FAST>(*L->P, L->mode);
@@ -66,7 +84,7 @@ static void backend_release(ppg_handle *h) {
     h->lut_dev = nullptr;
 }
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *) {
-    EmuLaunch L{&P, h->nq, mode};
+    EmuLaunch L{&P, h->nq, mode, h->gen2};
     for (int b = 0; b < h->batch; ++b) wv::run_block(lane_entry, &L, b, (size_t)P.lds_bytes);
     return PPG_OK;
 }
