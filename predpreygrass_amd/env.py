@@ -18,6 +18,7 @@ import torch
 from . import _abi
 from .batched import PREDATOR, PREY, BatchedPredPreyGrass, agent_name
 from .config import resolve_config
+from .placement import reference_placement
 
 try:  # the reference subclasses RLlib's MultiAgentEnv (predpreygrass_rllib_env.py:13,17)
     from ray.rllib.env.multi_agent_env import MultiAgentEnv as _MultiAgentEnvBase  # type: ignore
@@ -115,18 +116,23 @@ class PredPreyGrass(_MultiAgentEnvBase):
     # ------------------------------------------------------------------
     # reference API
     def reset(self, *, seed=None, options=None):
-        """predpreygrass_rllib_env.py:129-217.  Placement is drawn on the device with Philox keyed by
-        `seed` (unique cells, predators / prey / grass disjoint, like the reference); pass
-        ``options={"placement": (pred_xy, prey_xy, grass_xy)}`` to start from given positions."""
+        """predpreygrass_rllib_env.py:129-217.  The initial cells are the ones the reference picks for `seed`
+        (placement.reference_placement: same generator, same set order; seed=None draws OS entropy like the
+        reference).  ``options={"placement": (pred_xy, prey_xy, grass_xy)}`` starts from given positions;
+        ``options={"placement": "device"}`` draws them on the GPU instead (Philox keyed by `seed`)."""
         placement = (options or {}).get("placement") if isinstance(options, dict) else None
         b = self._b
         if b.batch_size != 1:
             raise RuntimeError("reset() of a view into a shared batch: reset the BatchedPredPreyGrass instead")
-        if placement is not None:
-            p, q, g = placement
-            b.set_placement(np.asarray(p)[None], np.asarray(q)[None], np.asarray(g)[None])
-        else:
+        if isinstance(placement, str) and placement == "device":
             b.reset(seed=0 if seed is None else int(seed))
+        else:
+            if placement is None:
+                nP, nQ = self.n_initial_active_predator, self.n_initial_active_prey
+                cells = reference_placement(self.grid_size, nP + nQ + self.initial_num_grass, seed)
+                placement = (cells[:nP], cells[nP:nP + nQ], cells[nP + nQ:])   # :185-187
+            p, q, g = placement
+            b.set_placement(np.asarray(p).reshape(1, -1, 2), np.asarray(q).reshape(1, -1, 2), np.asarray(g).reshape(1, -1, 2))
         self.cumulative_rewards = {}
         self._insertion_order = []
         obs = self._collect(after_reset=True)[0]

@@ -290,3 +290,256 @@ class BatchedRedQueen(BatchedPredPreyGrass):
             out.append((agent_name(sp * 2 + int(t2[s]), idx[s]), sp, r, float(t["row_reward"][i, s]),
                         bool(fl & _abi.ROW_DIED), bool(fl & _abi.ROW_TRUNC)))
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's class on top of the kernels
+# ---------------------------------------------------------------------------------------------------------
+
+from .env import _MultiAgentEnvBase  # noqa: E402  (RLlib's MultiAgentEnv when ray is installed)
+from .placement import reference_placement  # noqa: E402
+
+try:
+    import gymnasium as _gym  # type: ignore
+
+    def _box(shape):
+        return _gym.spaces.Box(low=0, high=100.0, shape=shape, dtype=np.float32)  # RQ:963,967
+
+    def _discrete(n):
+        return _gym.spaces.Discrete(n)
+except Exception:
+    from .env import _Box, _Discrete  # noqa: E402
+
+    def _box(shape):
+        return _Box(0, 100.0, shape, np.float32)
+
+    def _discrete(n):
+        return _Discrete(n)
+
+
+class PredPreyGrass(_MultiAgentEnvBase):
+    """`PredPreyGrass(config)` of red_queen/predpreygrass_rllib_env.py (class :14, reset :151, step :197): same
+    constructor, dict layouts, id strings, dict ordering, float32 observations and viewer-facing attributes, with the
+    transition running on the GPU.  `reset(seed=s)` places the agents where the reference does and seeds the same
+    PCG64 stream for the reproduction uniforms, so an episode driven with the same actions is identical.
+
+    Not carried over: the per-agent analytics the reference accumulates on the side (unique_agent_stats,
+    per_step_agent_data, death statistics, offspring lists, agent_ages)."""
+
+    def __init__(self, config=None, *, device=None, prey_capacity: int | None = None, _library=None):
+        super().__init__()
+        cfg = resolve_config(config)
+        self.config = config
+        b = BatchedRedQueen(cfg, batch_size=1, device=device, prey_capacity=prey_capacity or 128, _library=_library)
+        self._b = b
+        self._cfg = cfg
+        for k in ("max_steps", "grid_size", "num_obs_channels", "predator_obs_range", "prey_obs_range",
+                  "initial_num_grass", "initial_energy_grass", "initial_energy_predator", "initial_energy_prey"):
+            setattr(self, k, cfg[k])                                               # RQ:36-78
+        self.type_1_act_range, self.type_2_act_range = b.action_ranges               # RQ:85-86
+        self.possible_agents = [f"{POOLS[p]}_{i}" for p in (0, 1, 2, 3) for i in range(b.n_possible[p])]  # RQ:941-955
+        self._pspace = _box((4, b.Rp, b.Rp))
+        self._qspace = _box((4, b.Rq, b.Rq))
+        self._aspace = {1: _discrete(self.type_1_act_range ** 2), 2: _discrete(self.type_2_act_range ** 2)}  # RQ:974-985
+        self.observation_spaces = {a: (self._pspace if "predator" in a else self._qspace) for a in self.possible_agents}
+        self.action_spaces = {a: self._aspace[int(a[5])] for a in self.possible_agents}
+        self.grass_agents = [f"grass_{k}" for k in range(b.n_grass)]
+        self.rng = np.random.default_rng(cfg.get("seed", 42))                       # RQ:37
+        self.agents = []
+        self.cumulative_rewards = {}
+        self.agents_just_ate = set()
+        self.current_step = 0
+        self._records = []
+        self._insertion_order = []
+        self._tables = None
+
+    # ------------------------------------------------------------------
+    def reset(self, *, seed=None, options=None):
+        """RQ:151-195.  ``options={"placement": (pred_xy, prey_xy, grass_xy)}`` overrides the cells."""
+        b = self._b
+        self.rng = np.random.default_rng(seed)                                       # RQ:91
+        placement = (options or {}).get("placement") if isinstance(options, dict) else None
+        if placement is None:
+            cells = reference_placement(b.grid_size, b.P0 + b.Q0 + b.n_grass, seed)   # RQ:158-166
+            placement = (cells[:b.P0], cells[b.P0:b.P0 + b.Q0], cells[b.P0 + b.Q0:])
+        p, q, g = placement
+        b.set_placement(np.asarray(p).reshape(1, -1, 2), np.asarray(q).reshape(1, -1, 2), np.asarray(g).reshape(1, -1, 2))
+        self.cumulative_rewards = {}
+        self._insertion_order = []
+        return self._collect(after_reset=True)[0], {}
+
+    def step(self, action_dict):
+        """RQ:197-299."""
+        b = self._b
+        where = {name: (sp, row) for name, sp, row, _, te, _ in self._records if not te}
+        a = torch.full((b.S,), _abi.ACTION_NONE, dtype=torch.int8)
+        rk = torch.zeros((b.S,), dtype=torch.uint8)
+        last, count, in_order = [-1, -1], [0, 0], True
+        truncated_call = self.current_step >= self.max_steps
+        for name, act in action_dict.items():
+            if name not in where:
+                continue                                    # agents that are gone are skipped (RQ:467,521)
+            act = int(act)
+            if not truncated_call and not 0 <= act < self._aspace[int(name[5])].n:
+                raise KeyError(act)                         # action_to_move_tuple_type_*_agents[action], RQ:323/325
+            sp, row = where[name]
+            s = b.pred_capacity * sp + row
+            a[s], rk[s] = act, count[sp]
+            count[sp] += 1
+            in_order = in_order and row >= last[sp]
+            last[sp] = row
+        if not truncated_call and count[0] + count[1] != len(where):
+            # the reference itself fails for a live agent without an action (KeyError in its per-step bookkeeping, RQ:279)
+            missing = [n for n in where if n not in action_dict]
+            raise KeyError(missing[0])
+        b.actions[0].copy_(a)
+        # the uniforms self.rng.random() would hand out (RQ:701,708): at most two per live agent; the stream is then
+        # advanced by exactly the number the step consumed
+        state = self.rng.bit_generator.state
+        u = torch.from_numpy(self.rng.random(2 * len(where) + 2)).reshape(1, -1).to(b.device)
+        b.step(uniforms=u, act_rank=None if in_order else rk[None].to(b.device))
+        out = self._collect(after_reset=False)
+        self.rng.bit_generator.state = state
+        self.rng.bit_generator.advance(int(self._tables["env_state"][0][_abi.ENV_DRAWS]))
+        return out
+
+    def close(self):
+        pass
+
+    # ------------------------------------------------------------------
+    def _collect(self, after_reset):
+        b = self._b
+        t = b.host_tables(0)
+        self._tables = t
+        es = t["env_state"][0]
+        status = int(es[_abi.ENV_STATUS])
+        if status & (_abi.STATUS_PRED_OVERFLOW | _abi.STATUS_PREY_OVERFLOW):
+            raise RuntimeError("agent row capacity exceeded: construct the env with a larger prey_capacity")
+        if status & _abi.STATUS_FAILED_SPAWN:
+            raise TypeError("no free cell for a newborn (the reference fails at RQ:751-760)")
+        recs = b.records(0, t)
+        nP, nQ = max(int(es[_abi.ENV_N_PRED_ROWS]), 1), max(int(es[_abi.ENV_N_PREY_ROWS]), 1)
+        op = b.obs_pred[0, :nP].cpu().numpy()
+        oq = b.obs_prey[0, :nQ].cpu().numpy()
+        obs, rew, term, trunc = {}, {}, {}, {}
+        for name, sp, row, r, te, tr in recs:
+            obs[name] = (oq if sp else op)[row].astype(np.float32)
+            rew[name], term[name], trunc[name] = r, te, tr
+        fl = int(es[_abi.ENV_FLAGS])
+        self._records = recs
+        self.current_step = int(es[_abi.ENV_STEP])
+        self.active_num_predators = int(es[_abi.ENV_N_PRED_ALIVE])
+        self.active_num_prey = int(es[_abi.ENV_N_PREY_ALIVE])
+        self._next_idx = {("predator", 1): int(es[_abi.ENV_NEXT_PRED_ID]), ("predator", 2): int(es[_abi.ENV_NEXT_PRED_ID_T2]),
+                          ("prey", 1): int(es[_abi.ENV_NEXT_PREY_ID]), ("prey", 2): int(es[_abi.ENV_NEXT_PREY_ID_T2])}
+        cp = b.pred_capacity
+        for name, sp, row, *_ in recs:
+            self.cumulative_rewards[name] = float(t["row_cumrew"][0][cp * sp + row])
+            if name not in self._insertion_order:
+                self._insertion_order.append(name)
+        self.agents_just_ate = {name for name, sp, row, *_ in recs if t["row_flags"][0][cp * sp + row] & _abi.ROW_ATE}
+        names = [r[0] for r in recs]
+        self.agents = names if (after_reset or (fl & _abi.ENVF_LIST_IS_ROW_ORDER)) else sorted(names)   # RQ:270
+        self._pending_removal = [r[0] for r in recs if r[4]]
+        if after_reset:
+            return obs, {}
+        term["__all__"] = bool(fl & _abi.ENVF_TERM_ALL)
+        trunc["__all__"] = bool(fl & _abi.ENVF_TRUNC_ALL)
+        return obs, rew, term, trunc, {}
+
+    def _live(self):
+        cp = self._b.pred_capacity
+        return {name: cp * sp + row for name, sp, row, _, te, _ in self._records if not te}
+
+    # viewer-facing attributes (RQ:93-98,108-109)
+    @property
+    def agent_positions(self):
+        live, t = self._live(), self._tables
+        return {n: (int(t["row_xy"][0][live[n]]) >> 8, int(t["row_xy"][0][live[n]]) & 255)
+                for n in self._insertion_order if n in live}
+
+    @property
+    def predator_positions(self):
+        return {k: v for k, v in self.agent_positions.items() if "predator" in k}
+
+    @property
+    def prey_positions(self):
+        return {k: v for k, v in self.agent_positions.items() if "prey" in k}
+
+    @property
+    def agent_energies(self):
+        live, t = self._live(), self._tables
+        return {n: float(t["row_energy"][0][live[n]]) for n in self._insertion_order if n in live}
+
+    @property
+    def agent_last_reproduction(self):
+        live, t = self._live(), self._tables
+        return {n: int(t["row_lastrep"][0][live[n]]) for n in self._insertion_order if n in live}
+
+    @property
+    def grass_positions(self):
+        t = self._tables
+        return {f"grass_{k}": (int(t["grass_xy"][0][k]) >> 8, int(t["grass_xy"][0][k]) & 255) for k in range(self._b.n_grass)}
+
+    @property
+    def grass_energies(self):
+        t = self._tables
+        return {f"grass_{k}": float(t["grass_energy"][0][k]) for k in range(self._b.n_grass)}
+
+    @property
+    def grid_world_state(self):
+        return self._b.export_grid()[0].cpu().numpy().astype(np.float32)            # RQ:137-139
+
+    def _get_observation(self, agent):
+        """RQ:345-360."""
+        live = self._live()
+        if agent not in live:
+            raise KeyError(agent)
+        sp = int("prey" in agent)
+        self._b.observe()
+        t = self._b.obs_prey if sp else self._b.obs_pred
+        return t[0, live[agent] - self._b.pred_capacity * sp].cpu().numpy().astype(np.float32)
+
+    def get_total_energy_by_type(self):
+        """RQ:1020-1053."""
+        out = {"predator": 0.0, "prey": 0.0, "grass": sum(self.grass_energies.values()),
+               "type_1_predator": 0.0, "type_2_predator": 0.0, "type_1_prey": 0.0, "type_2_prey": 0.0}
+        for a, e in self.agent_energies.items():
+            out["predator" if "predator" in a else "prey"] += e
+            out[a.rsplit("_", 1)[0]] += e
+        return out
+
+    # snapshot / restore (RQ:893-939)
+    _STATE_TENSORS = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_lastrep",
+                      "env_state", "env_seed", "grass_xy", "grass_energy"]
+
+    def get_state_snapshot(self):
+        b = self._b
+        return {
+            "current_step": self.current_step, "agent_positions": self.agent_positions,
+            "agent_energies": self.agent_energies, "predator_positions": self.predator_positions,
+            "prey_positions": self.prey_positions, "grass_positions": self.grass_positions,
+            "grass_energies": self.grass_energies, "grid_world_state": self.grid_world_state,
+            "agents": list(self.agents), "cumulative_rewards": dict(self.cumulative_rewards),
+            "active_num_predators": self.active_num_predators, "active_num_prey": self.active_num_prey,
+            "agents_just_ate": set(self.agents_just_ate), "agent_last_reproduction": self.agent_last_reproduction,
+            "pending_removal": list(self._pending_removal), "next_idx": dict(self._next_idx),
+            "_device_state": {n: getattr(b, n)[0].cpu().clone() for n in self._STATE_TENSORS},
+            "_insertion_order": list(self._insertion_order), "_rng_state": self.rng.bit_generator.state,
+        }
+
+    def restore_state_snapshot(self, snapshot):
+        b = self._b
+        for n, v in snapshot["_device_state"].items():
+            getattr(b, n)[0].copy_(v)
+        self._insertion_order = list(snapshot["_insertion_order"])
+        self.rng.bit_generator.state = snapshot["_rng_state"]
+        b.observe()
+        self._collect(after_reset=False)
+        self.agents = list(snapshot["agents"])
+        self.cumulative_rewards = dict(snapshot["cumulative_rewards"])
+
+
+def env_creator(config):
+    """red_queen/tune_ppo_red_queen.py registers the env through a creator like this one."""
+    return PredPreyGrass(config)
