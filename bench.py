@@ -34,11 +34,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 
 
-def cpu_baseline(cfg, seed0, seconds=12.0, threads=None):
+def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
     """The CPU oracle (C restatement of the reference step(), kind "port") timed on this host on a
     bounded sample of the same workload: one env per thread, random actions, auto-reset."""
     import concurrent.futures as cf
-    from oracle.ppg_oracle import OracleEnv
+    if workload == "red_queen":
+        from oracle.rq_oracle import RQOracleEnv as OracleEnv
+    else:
+        from oracle.ppg_oracle import OracleEnv
     threads = threads or os.cpu_count() or 1
     chunk = 2000
 
@@ -58,8 +61,9 @@ def cpu_baseline(cfg, seed0, seconds=12.0, threads=None):
     return {
         "value": round(tot / wall, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
         "single_thread_value": round(n1 / t1, 1),
-        "sample": f"{threads} threads x 1 env each, default config, Philox random actions + auto-reset, "
-                  f"{seconds:.0f} s per thread ({tot} env-steps); oracle/ppg_oracle.c (-O2 -ffp-contract=off)",
+        "sample": f"{threads} threads x 1 env each, {'red_queen config_env_base' if workload == 'red_queen' else 'default config'}, "
+                  f"Philox random actions + auto-reset, {seconds:.0f} s per thread ({tot} env-steps); "
+                  f"oracle/{'rq_oracle.c' if workload == 'red_queen' else 'ppg_oracle.c'} (-O2 -ffp-contract=off)",
         "reference_python_fixed": "reference Python step(): 45 env-steps/s on 1 core, ~400 on 8 cores "
                                   "(measured in the survey container, BASELINE.md section 2)",
     }
@@ -72,7 +76,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--obs-dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--obs-dtype", choices=["f64", "f32"], default=None,
+                    help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen)")
+    ap.add_argument("--workload", choices=["base", "red_queen"], default="base",
+                    help="base: BASELINE.json configs[2] (the headline); red_queen: the second-generation env "
+                         "(SURVEY 8(f) N2) with its reference config, same batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=3,
@@ -121,12 +129,19 @@ def main():
         torch.cuda.set_device(device)
     n_gpus = world if distributed else 1
 
-    cfg = dict(config_env)
+    rq = args.workload == "red_queen"
+    if args.obs_dtype is None:
+        args.obs_dtype = "f32" if rq else "f64"
+    if rq:
+        from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
+        cfg, env_class = dict(config_env_base), BatchedRedQueen
+    else:
+        cfg, env_class = dict(config_env), BatchedPredPreyGrass
     B = args.envs
     obs_dtype = torch.float64 if args.obs_dtype == "f64" else torch.float32
     from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
     n_sub = max(1, args.streams)
-    group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype,
+    group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype, env_class=env_class,
                                     seed=args.seed + rank * B, **({"_library": _emu_library()} if dry else {}))
     group.reset()
     group.synchronize()
@@ -222,7 +237,7 @@ def main():
     traffic = None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "c_bench_default_summary.json")))
-        if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry:
+        if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry and not rq:
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
     except Exception:
         traffic = None
@@ -245,9 +260,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if not dry else "DRY RUN ON CPU (emulated kernel) -- not a measurement",
             "config": {
-                "workload": f"{B} envs x {G}x{G} grid per GPU, default config (6 predators / 8 prey / 100 grass, "
-                            f"obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), device-side uniform random actions, "
-                            "auto-reset, observations written every step (BASELINE.json configs[2])",
+                "workload": (f"{B} envs x {G}x{G} grid per GPU, default config (6 predators / 8 prey / 100 grass, "
+                             f"obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), device-side uniform random actions, "
+                             "auto-reset, observations written every step (BASELINE.json configs[2])") if not rq else
+                            (f"SECOND-GENERATION env (red_queen config_env_base: 12 predators / 10+10 prey of two types / 100 "
+                             f"grass, obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), {B} envs x {G}x{G} grid per GPU, device-side "
+                             "random actions and reproduction uniforms, auto-reset; NOT the BASELINE.json headline config"),
                 "envs_per_gpu": B,
                 "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
                 "sub_batches_per_gpu": n_sub,
@@ -266,7 +284,7 @@ def main():
                 "achieved_from_pmc_traffic": round(traffic * n_sub / kernel_s / 1e9, 1) if traffic else None,
                 "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
                                          "launch = 4.85 TB/s (profiles/r01/c_store_pattern_ceiling.txt); linear fill 6.5 TB/s",
-                "kernel": "ppg_step_q2",
+                "kernel": "ppg2_step_q2" if rq else "ppg_step_q2",
                 "kernel_ms": round(kernel_s * 1e3, 5),
                 "concurrent_launches": n_sub,
                 "algorithmic_bytes_per_launch": int(alg_bytes / args.steps / n_sub),
@@ -281,7 +299,7 @@ def main():
         if gather_info is not None:
             out["obs_gather"] = gather_info
         if not args.no_cpu_baseline and n_gpus == 1 and not dry:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.seed, seconds=args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.seed, seconds=args.cpu_seconds, workload=args.workload)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -24,11 +24,12 @@ from .distributed import shard_range
 
 
 class SubBatchedPredPreyGrass:
-    def __init__(self, config=None, batch_size=4096, n_sub=2, device="cuda:0", seed=0, **kw):
+    def __init__(self, config=None, batch_size=4096, n_sub=2, device="cuda:0", seed=0, env_class=BatchedPredPreyGrass, **kw):
+        """env_class: BatchedPredPreyGrass (base family) or red_queen.BatchedRedQueen (second generation)."""
         self.device = torch.device(device)
         self.batch_size = int(batch_size)
         self.offsets = [shard_range(self.batch_size, k, n_sub) for k in range(n_sub)]
-        self.subs = [BatchedPredPreyGrass(config, batch_size=hi - lo, device=device, seed=seed + lo, **kw)
+        self.subs = [env_class(config, batch_size=hi - lo, device=device, seed=seed + lo, **kw)
                      for lo, hi in self.offsets]
         cuda = self.device.type == "cuda"   # (the CPU case exists only for the emulated-kernel tests)
         self.streams = [torch.cuda.Stream(device=self.device) if cuda else None for _ in self.subs]
