@@ -69,3 +69,10 @@ def test_full_size_4096_envs_sampled_oracle_and_determinism():
         if name == "env_state":
             a, b = a[:, : _abi.ENV_CALLS], b[:, : _abi.ENV_CALLS]
         assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("seed", range(100, 130))
+def test_random_gen2_config_matches_oracle_on_gpu(seed):
+    from predpreygrass_amd.red_queen import PredPreyGrass
+    from tests.test_rq_random_configs import run_differential
+    run_differential(lambda cfg: PredPreyGrass(cfg, device="cuda:0"), seed)

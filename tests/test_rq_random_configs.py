@@ -1,0 +1,128 @@
+"""Randomised differential test of the second-generation step: random configurations (grid 3-28, odd and even
+observation ranges 1-15, action ranges 1/3/5/7, one or two types per species, typed rewards, move cost, caps,
+efficiencies, cooldown, chance, mutation, small id pools) x shuffled full action dicts with stray actions for dead
+agents; the kernel source (wave emulator here, GPU in test_hip_parity_rq.py) against the oracle, call by call, bit for
+bit, both fed the same PCG64 uniform stream."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.rq_oracle import RQOracleEnv
+from predpreygrass_amd.red_queen import PredPreyGrass, config_env_base
+from tests.emu_backend import library
+
+
+def random_config(rng):
+    G = int(rng.integers(3, 29))
+    cells = G * G
+    n = [int(rng.integers(0, min(7, cells // 8) + 1)) for _ in range(4)]
+    if rng.random() < 0.3:
+        n[1] = n[3] = 0
+    NG = int(rng.integers(0, min(50, cells - sum(n)) + 1))
+    inf = math.inf
+    typed = lambda a, b, sp: {f"type_1_{sp}": a, f"type_2_{sp}": b} if rng.random() < 0.7 else a  # noqa: E731
+    return {
+        **config_env_base,
+        "grid_size": G, "max_steps": int(rng.integers(1, 45)),
+        "predator_obs_range": int(rng.integers(1, 16)), "prey_obs_range": int(rng.integers(1, 16)),
+        "type_1_action_range": int(rng.choice([1, 3, 3, 5])), "type_2_action_range": int(rng.choice([3, 5, 5, 7])),
+        "n_initial_active_type_1_predator": n[0], "n_initial_active_type_2_predator": n[1],
+        "n_initial_active_type_1_prey": n[2], "n_initial_active_type_2_prey": n[3],
+        "n_possible_type_1_predators": int(rng.integers(n[0], n[0] + 12)), "n_possible_type_2_predators": int(rng.integers(n[1], n[1] + 12)),
+        "n_possible_type_1_prey": int(rng.integers(n[2], n[2] + 20)), "n_possible_type_2_prey": int(rng.integers(n[3], n[3] + 20)),
+        "initial_num_grass": NG,
+        "energy_loss_per_step_predator": float(rng.choice([0.06, 0.5, 1.0, 0.0])),
+        "energy_loss_per_step_prey": float(rng.choice([0.02, 0.3, 1.0])),
+        "predator_creation_energy_threshold": float(rng.choice([12.0, 6.0, 5.5])),
+        "prey_creation_energy_threshold": float(rng.choice([8.0, 3.5, 3.0])),
+        "initial_energy_predator": float(rng.choice([6.0, 1.0])), "initial_energy_prey": float(rng.choice([3.0, 0.5])),
+        "initial_energy_grass": float(rng.choice([2.0, 0.7])), "energy_gain_per_step_grass": float(rng.choice([0.1, 0.5, 0.0])),
+        "max_energy_grass": float(rng.choice([2.0, 1.0, inf])),
+        "move_energy_cost_factor": float(rng.choice([0.0, 0.01, 0.05, 0.3])),
+        "max_energy_gain_per_grass": float(rng.choice([1.5, 0.4, inf])), "max_energy_gain_per_prey": float(rng.choice([5.0, 1.0, inf])),
+        "max_energy_predator": float(rng.choice([20.0, 7.0, inf])), "max_energy_prey": float(rng.choice([14.0, 4.0, inf])),
+        "energy_transfer_efficiency": float(rng.choice([1.0, 0.9, 0.5])),
+        "reproduction_energy_efficiency": float(rng.choice([1.0, 0.9, 0.25])),
+        "reproduction_cooldown_steps": int(rng.choice([0, 1, 3, 10])),
+        "reproduction_chance_predator": float(rng.choice([1.0, 0.95, 0.5])), "reproduction_chance_prey": float(rng.choice([1.0, 0.8, 0.3])),
+        "mutation_rate_predator": float(rng.choice([0.0, 0.05, 0.5, 1.0])), "mutation_rate_prey": float(rng.choice([0.0, 0.1, 0.6])),
+        "reward_predator_catch_prey": typed(float(rng.choice([0.0, 1.5])), 2.5, "predator"),
+        "reward_prey_eat_grass": typed(float(rng.choice([0.0, 0.25])), 0.75, "prey"),
+        "reward_predator_step": typed(float(rng.choice([0.0, -0.01])), 0.125, "predator"),
+        "reward_prey_step": typed(float(rng.choice([0.0, 0.02])), -0.5, "prey"),
+        "penalty_prey_caught": typed(float(rng.choice([0.0, -2.0])), -3.0, "prey"),
+        "reproduction_reward_predator": typed(float(rng.choice([10.0, 7.0])), 1.0, "predator"),
+        "reproduction_reward_prey": typed(float(rng.choice([10.0, 3.0])), 2.0, "prey"),
+    }
+
+
+def random_placement(rng, cfg):
+    G = cfg["grid_size"]
+    P = cfg["n_initial_active_type_1_predator"] + cfg["n_initial_active_type_2_predator"]
+    Q = cfg["n_initial_active_type_1_prey"] + cfg["n_initial_active_type_2_prey"]
+    cells = rng.choice(G * G, size=P + Q + cfg["initial_num_grass"], replace=False)
+    xy = np.stack([cells // G, cells % G], axis=1).astype(np.int32)
+    return xy[:P], xy[P:P + Q], xy[P + Q:]
+
+
+def run_differential(make_env, seed, max_calls=45):
+    rng = np.random.default_rng(1000 + seed)
+    cfg = random_config(rng)
+    placement = random_placement(rng, cfg)
+    env = make_env(cfg)
+    orc = RQOracleEnv(cfg)
+    orc.set_seed(0, 0)   # the spawn fallback contract of a placement-reset env: Philox key 0, episode 0
+    stream = np.random.default_rng(seed)   # the stream reset(seed) seeds inside the env (RQ:91)
+    o1, _ = env.reset(seed=seed, options={"placement": placement})
+    o2, _ = orc.reset_from_placement(*placement)
+    assert list(o1) == list(o2)
+    for k in o2:
+        assert o1[k].tobytes() == o2[k].tobytes(), ("reset", seed, k)
+    live, dead = list(o1), []
+    births = 0
+    for t in range(max_calls):
+        names = list(live)
+        rng.shuffle(names)
+        if dead and rng.random() < 0.3:
+            names.insert(int(rng.integers(len(names) + 1)), dead[int(rng.integers(len(dead)))])
+        actions = {a: int(rng.integers(env.action_spaces[a].n)) for a in names}
+        state = stream.bit_generator.state
+        u = stream.random(2 * len(live) + 2)
+        r2 = orc.step(actions, uniforms=u)
+        stream.bit_generator.state = state
+        stream.bit_generator.advance(orc.last_draws)
+        if orc.last_failed_spawns:
+            with pytest.raises(TypeError):
+                env.step(actions)
+            return cfg, births
+        r1 = env.step(actions)
+        for i, what in enumerate(("obs", "rew", "term", "trunc")):
+            assert list(r1[i]) == list(r2[i]), (seed, t, what, list(r1[i]), list(r2[i]))
+            for k in r2[i]:
+                a, b = r1[i][k], r2[i][k]
+                if what == "obs":
+                    assert a.dtype == np.float32 and a.tobytes() == b.tobytes(), (seed, t, what, k)
+                elif what == "rew":
+                    assert np.float64(a).tobytes() == np.float64(b).tobytes(), (seed, t, what, k, a, b)
+                else:
+                    assert bool(a) == bool(b), (seed, t, what, k)
+        assert env.grid_world_state.tobytes() == orc.grid_world_state.tobytes(), (seed, t, "grid")
+        assert env.agents == orc.agents, (seed, t, "agents")
+        assert env.current_step == orc.current_step
+        assert tuple(env._next_idx.values()) == orc.next_ids, (seed, t)
+        for a, e in env.agent_energies.items():
+            st = orc.agent_state(a)
+            assert e == st["energy"] and env.cumulative_rewards[a] == st["cumulative_reward"], (seed, t, a)
+            assert env.agent_last_reproduction[a] == st["last_reproduction"], (seed, t, a)
+        births += sum(1 for a in r2[0] if a not in live and not r2[2][a])
+        dead += [a for a in r2[0] if r2[2][a]]
+        live = [a for a in r2[0] if not r2[2][a]]
+        if r2[3]["__all__"]:
+            break
+    return cfg, births
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_gen2_config_matches_oracle_emulated(seed):
+    run_differential(lambda cfg: PredPreyGrass(cfg, _library=library()), seed)
