@@ -78,9 +78,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--obs-dtype", choices=["f64", "f32"], default=None,
                     help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen)")
-    ap.add_argument("--workload", choices=["base", "red_queen"], default="base",
-                    help="base: BASELINE.json configs[2] (the headline); red_queen: the second-generation env "
-                         "(SURVEY 8(f) N2) with its reference config, same batch size")
+    ap.add_argument("--workload", choices=["base", "c4", "red_queen"], default="base",
+                    help="base: BASELINE.json configs[2] (the headline); c4: configs[3] (64x64 grid, 16 predators / 32 prey, "
+                         "7x7 windows); red_queen: the second-generation env (SURVEY 8(f) N2) with its reference config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=3,
@@ -137,6 +137,9 @@ def main():
         cfg, env_class = dict(config_env_base), BatchedRedQueen
     else:
         cfg, env_class = dict(config_env), BatchedPredPreyGrass
+        if args.workload == "c4":   # BASELINE.json configs[3]
+            cfg.update({"grid_size": 64, "n_initial_active_predator": 16, "n_initial_active_prey": 32,
+                        "predator_obs_range": 7, "prey_obs_range": 7})
     B = args.envs
     obs_dtype = torch.float64 if args.obs_dtype == "f64" else torch.float32
     from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
@@ -237,7 +240,7 @@ def main():
     traffic = None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "c_bench_default_summary.json")))
-        if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry and not rq:
+        if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry and args.workload == "base":
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
     except Exception:
         traffic = None
@@ -260,9 +263,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if not dry else "DRY RUN ON CPU (emulated kernel) -- not a measurement",
             "config": {
-                "workload": (f"{B} envs x {G}x{G} grid per GPU, default config (6 predators / 8 prey / 100 grass, "
+                "workload": (f"{B} envs x {G}x{G} grid per GPU, default config ({cfg['n_initial_active_predator']} predators / "
+                             f"{cfg['n_initial_active_prey']} prey / 100 grass, "
                              f"obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), device-side uniform random actions, "
-                             "auto-reset, observations written every step (BASELINE.json configs[2])") if not rq else
+                             f"auto-reset, observations written every step (BASELINE.json configs[{3 if args.workload == 'c4' else 2}])") if not rq else
                             (f"SECOND-GENERATION env (red_queen config_env_base: 12 predators / 10+10 prey of two types / 100 "
                              f"grass, obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), {B} envs x {G}x{G} grid per GPU, device-side "
                              "random actions and reproduction uniforms, auto-reset; NOT the BASELINE.json headline config"),
