@@ -1711,6 +1711,7 @@ struct Env {
             wv::sync();
             engage_prey(1);
             wv::sync();
+            PPG_STAMP(8);
             engage_predators(t2m[0]);
             wv::sync();
             engage_prey(2);

@@ -12,16 +12,22 @@ from predpreygrass_amd.batched import BatchedPredPreyGrass
 from predpreygrass_amd.config import config_env
 
 CSRC = os.path.join(ROOT, "predpreygrass_amd", "csrc")
-LIB = os.path.join(ROOT, "gpurun_out", "libppg_hip_prof.so")
+LIB = os.path.join(ROOT, "tools", "_build", "libppg_hip_prof.so")  # diagnostic build, git-ignored
 os.makedirs(os.path.dirname(LIB), exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
-                "-DPPG_PROFILE_PHASES", "-o", LIB, os.path.join(CSRC, "ppg_hip.hip")], check=True, cwd=CSRC)
+import __graft_entry__ as graft
+graft.build_hip(force=not os.path.exists(LIB), extra_flags=["-DPPG_PROFILE_PHASES"], out=LIB)
 lib = _abi.bind(ctypes.CDLL(LIB))
 _abi._lib = lib  # this process only
 lib.ppg_debug_set_profile_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-warm = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-env = BatchedPredPreyGrass(config_env, batch_size=B, device="cuda:0")
+RQ = "--rq" in sys.argv   # second-generation env on its reference config ("engage_pred" = type-1 classes, "engage_prey" = type-2)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(args[0]) if len(args) > 0 else 4096
+warm = int(args[1]) if len(args) > 1 else 400
+if RQ:
+    from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
+    env = BatchedRedQueen(config_env_base, batch_size=B, device="cuda:0")
+else:
+    env = BatchedPredPreyGrass(config_env, batch_size=B, device="cuda:0")
 env.reset()
 prof = torch.zeros((B, 16), dtype=torch.int64, device="cuda:0")
 for _ in range(warm):
