@@ -165,7 +165,18 @@ typedef struct ppg_buffers {
     void *obs_prey;        /* [B,prey_capacity,4,Rq,Rq] */
     int32_t *row_parent;   /* [B,S]  id of the agent's (same-type) parent, -1 = none: agent_parent of the kickback variant */
     int32_t *row_lastrep;  /* [B,S]  second generation: agent_last_reproduction (RQ:115,737,999); may be NULL for ppg_create */
+    uint32_t *wall_bits;   /* [B,W]  walls variant: bit (x*G + y) of env b's W = ceil(G*G/32) words set = wall cell (WO:210-250);
+                            *        written by the caller, never by the library; NULL unless ppg_config_gen2.walls */
+    uint8_t *row_info;     /* [B,S]  walls variant: 0 = the agent did not go through the movement phase of the last call,
+                            *        else 1 + move_blocked_reason (PPG_MOVE_*); NULL unless ppg_config_gen2.walls */
 } ppg_buffers;
+
+/* move_blocked_reason of the walls variant (WO:466-488), as row_info - 1 */
+#define PPG_MOVE_FREE 0
+#define PPG_MOVE_WALL 1
+#define PPG_MOVE_OCCUPIED 2
+#define PPG_MOVE_CORNER_CUT 3
+#define PPG_MOVE_LOS 4
 
 /* ---- second generation ("RQ" = predpreygrass/non_evolutionary/red_queen/predpreygrass_rllib_env.py; the same step
  * as walls_occlusion/predpreygrass_rllib_env.py without walls and line of sight) ------------------------------
@@ -219,6 +230,14 @@ typedef struct ppg_config_gen2 {
     double reproduction_chance_prey;
     double mutation_rate_predator;             /* RQ:81,708 */
     double mutation_rate_prey;                 /* RQ:82,793 */
+    /* "WO" = walls_occlusion/predpreygrass_rllib_env.py: the same env plus static walls.  walls != 0 selects it:
+     * observation channel 0 shows the walls inside the window (WO:536-541) instead of the out-of-grid mask, a move into a
+     * wall cell is refused (WO:469-471), ppg_buffers.wall_bits / row_info are used, the observation tensors have
+     * 4 + include_visibility_channel channels. */
+    int32_t walls;
+    int32_t include_visibility_channel;        /* WO:104: last channel = line-of-sight mask (WO:577-598) */
+    int32_t respect_los_for_movement;          /* WO:106: no corner cutting, no moves through walls (WO:475-488) */
+    int32_t mask_observation_with_visibility;  /* WO:111: channels 1-3 multiplied by the mask (WO:591-594) */
 } ppg_config_gen2;
 
 typedef struct ppg_handle ppg_handle;

@@ -37,6 +37,8 @@ VARIANTS = {
     "sparse_rewards_plus_kickback": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards_plus_kickback",
     # second generation without walls / line of sight; its configs live in config/*.py
     "red_queen": "predpreygrass/non_evolutionary/red_queen",
+    # the same plus static walls, line-of-sight masking and per-agent infos
+    "walls_occlusion": "predpreygrass/non_evolutionary/walls_occlusion",
 }
 
 
@@ -157,8 +159,8 @@ def load_reference_module(variant: str = "base"):
 
 
 def reference_default_config(variant: str = "base") -> dict:
-    if variant == "red_queen":  # that env takes an explicit config (RQ:17-18); config/config_env_base.py is its base
-        return reference_config("predpreygrass.non_evolutionary.red_queen.config.config_env_base", "config_env_base")
+    if variant in ("red_queen", "walls_occlusion"):  # these envs take an explicit config; config/config_env_base.py is their base
+        return reference_config(f"predpreygrass.non_evolutionary.{variant}.config.config_env_base", "config_env_base")
     mod = load_reference_module(variant)
     return dict(mod.config_env)  # each variant file imports its own config_env (line 5)
 

@@ -7,6 +7,8 @@
  * on the "type_<t>_<species>_<id>" strings.  It shares no data structure with the HIP path.
  *
  * "RQ:n" = line n of /root/reference/predpreygrass/non_evolutionary/red_queen/predpreygrass_rllib_env.py
+ * "WO:n" = line n of /root/reference/predpreygrass/non_evolutionary/walls_occlusion/predpreygrass_rllib_env.py
+ * (the same env plus static walls, line-of-sight masking and per-agent infos; selected by config.walls)
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared -o librq_oracle.so rq_oracle.c -lm
  */
@@ -21,6 +23,8 @@ struct rqo_env {
     rqo_config c;
     int G;
     float *grid; /* grid_world_state float32 [ch][x][y], RQ:137-139 */
+    char *wall;  /* WO: wall_positions as a G*G bitmap */
+    int *block_reason; /* WO: _last_move_block_reason of this call, per flat agent index */
 
     int off[5];  /* flat index of (pool, id) = off[pool] + id */
     int tot;
@@ -93,6 +97,8 @@ rqo_env *rqo_create(const rqo_config *cfg) {
     for (int p = 0; p < 4; ++p) e->off[p + 1] = e->off[p] + pool_cap(e, p);
     int tot = e->tot = e->off[4];
     e->grid = (float *)calloc((size_t)4 * e->G * e->G, sizeof(float));
+    e->wall = (char *)calloc((size_t)e->G * e->G, 1);
+    e->block_reason = (int *)calloc(tot + 8, sizeof(int));
     e->ag_pool = (int *)calloc(tot + 8, sizeof(int));
     e->ag_id = (int *)calloc(tot + 8, sizeof(int));
     e->ent_pool = (int *)calloc(tot + 8, sizeof(int));
@@ -134,7 +140,7 @@ rqo_env *rqo_create(const rqo_config *cfg) {
 
 void rqo_destroy(rqo_env *e) {
     if (!e) return;
-    free(e->grid); free(e->ag_pool); free(e->ag_id);
+    free(e->grid); free(e->wall); free(e->block_reason); free(e->ag_pool); free(e->ag_id);
     free(e->ent_pool); free(e->ent_id); free(e->ent_x); free(e->ent_y); free(e->ent_present); free(e->ent_index);
     free(e->pend_pool); free(e->pend_id);
     free(e->energy); free(e->cumrew); free(e->age); free(e->last_repro); free(e->just_ate);
@@ -154,8 +160,72 @@ void rqo_set_seed(rqo_env *e, uint64_t seed, uint32_t episode) { e->seed = seed;
 
 static int clipi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* _line_of_sight_clear (WO:492-525) / the bresenham generator inside _get_observation (WO:550-575): no wall on the
+ * cells strictly between start and end.  The error term is the reference's float (dx / 2.0). */
+static int los_clear(const rqo_env *e, int x0, int y0, int x1, int y1) {
+    const int G = e->G;
+    int dx = abs(x1 - x0), dy = abs(y1 - y0);
+    int x = x0, y = y0;
+    int sx = x1 > x0 ? 1 : -1, sy = y1 > y0 ? 1 : -1;
+    if (dx >= dy) {
+        double err = dx / 2.0;
+        while (x != x1) {
+            if (!(x == x0 && y == y0) && !(x == x1 && y == y1) && e->wall[x * G + y]) return 0;
+            err -= dy;
+            if (err < 0) { y += sy; err += dx; }
+            x += sx;
+        }
+    } else {
+        double err = dy / 2.0;
+        while (y != y1) {
+            if (!(x == x0 && y == y0) && !(x == x1 && y == y1) && e->wall[x * G + y]) return 0;
+            err -= dx;
+            if (err < 0) { x += sx; err += dy; }
+            y += sy;
+        }
+    }
+    return 1;
+}
+
+static int n_channels(const rqo_env *e) { return 4 + (e->c.walls && e->c.include_visibility_channel ? 1 : 0); }
+
+/* _get_observation of the walls env, WO:527-601 */
+static void observe_at_walls(const rqo_env *e, int xp, int yp, int R, float *obs) {
+    const int G = e->G;
+    int off = (R - 1) / 2;
+    int xld = xp - off, xhd = xp + off, yld = yp - off, yhd = yp + off;
+    int xlo = clipi(xld, 0, G - 1), xhi = clipi(xhd, 0, G - 1);
+    int ylo = clipi(yld, 0, G - 1), yhi = clipi(yhd, 0, G - 1);
+    int xolo = abs(clipi(xld, -off, 0)), yolo = abs(clipi(yld, -off, 0));
+    int xohi = xolo + (xhi - xlo) + 1, yohi = yolo + (yhi - ylo) + 1;
+    const int C = n_channels(e);
+    for (int i = 0; i < C * R * R; ++i) obs[i] = 0.0f;                 /* WO:535 */
+    for (int i = xolo; i < xohi; ++i)
+        for (int j = yolo; j < yohi; ++j) {
+            int gx = xlo + (i - xolo), gy = ylo + (j - yolo);
+            if (e->wall[gx * G + gy]) obs[(0 * R + i) * R + j] = 1.0f; /* WO:537-541 */
+            for (int ch = 1; ch < 4; ++ch)                             /* WO:543 */
+                obs[((size_t)ch * R + i) * R + j] = e->grid[((size_t)ch * G + gx) * G + gy];
+        }
+    if (!(e->c.include_visibility_channel || e->c.mask_observation_with_visibility)) return;
+    float *vis = (float *)calloc((size_t)R * R, sizeof(float));        /* WO:548 */
+    for (int lx = 0; lx < R; ++lx)
+        for (int ly = 0; ly < R; ++ly) {                               /* WO:577-589 */
+            int gx = xlo + (lx - xolo), gy = ylo + (ly - yolo);
+            if (!(0 <= gx && gx < G && 0 <= gy && gy < G)) continue;
+            vis[lx * R + ly] = los_clear(e, xp, yp, gx, gy) ? 1.0f : 0.0f;
+        }
+    if (e->c.mask_observation_with_visibility)                         /* WO:591-594: float32 multiply */
+        for (int ch = 1; ch < 4; ++ch)
+            for (int i = 0; i < R * R; ++i) obs[(size_t)ch * R * R + i] *= vis[i];
+    if (e->c.include_visibility_channel)                               /* WO:596-598 */
+        for (int i = 0; i < R * R; ++i) obs[(size_t)4 * R * R + i] = vis[i];
+    free(vis);
+}
+
 static void observe_at(const rqo_env *e, int xp, int yp, int R, float *obs) {
     const int G = e->G;
+    if (e->c.walls) { observe_at_walls(e, xp, yp, R, obs); return; }
     int off = (R - 1) / 2;                                             /* RQ:366 */
     int xld = xp - off, xhd = xp + off, yld = yp - off, yhd = yp + off;
     int xlo = clipi(xld, 0, G - 1), xhi = clipi(xhd, 0, G - 1);
@@ -189,7 +259,7 @@ int rqo_observe(const rqo_env *e, int32_t pool, int32_t id, float *dst) {
 
 static void put_obs(rqo_env *e, int pool, int id) {
     int R = obs_range(e, pool);
-    size_t len = (size_t)4 * R * R;
+    size_t len = (size_t)n_channels(e) * R * R;
     if (e->arena_len + len > e->arena_cap) {
         while (e->arena_len + len > e->arena_cap) e->arena_cap *= 2;
         e->arena = (float *)realloc(e->arena, e->arena_cap * sizeof(float));
@@ -203,6 +273,7 @@ static void put_obs(rqo_env *e, int pool, int id) {
 }
 
 static void clear_call_dicts(rqo_env *e) {
+    for (int i = 0; i < e->tot; ++i) e->block_reason[i] = RQO_BLOCK_NO_INFO;   /* WO:308-309 */
     memset(e->has_obs, 0, e->tot); memset(e->has_rew, 0, e->tot);
     memset(e->has_term, 0, e->tot); memset(e->has_trunc, 0, e->tot);
     e->arena_len = 0;
@@ -249,7 +320,8 @@ static int emit_records(rqo_env *e, rqo_step_out *out) { /* RQ:262-265 */
         r->terminated = e->term[f];
         r->truncated = e->trunc[f];
         r->obs_offset = e->obs_at[f];
-        r->obs_len = 4 * R * R;
+        r->obs_len = n_channels(e) * R * R;
+        r->block_reason = e->c.walls ? e->block_reason[f] : RQO_BLOCK_NO_INFO;
     }
     out->n_records = n;
     out->records = e->rec;
@@ -268,6 +340,17 @@ static void register_new_agent(rqo_env *e, int pool, int id) {
 /* reset: RQ:88-195 with the placement supplied by the caller         */
 /* ------------------------------------------------------------------ */
 
+int rqo_set_walls(rqo_env *e, int32_t n, const int32_t *xy) {
+    const int G = e->G;
+    memset(e->wall, 0, (size_t)G * G);
+    for (int i = 0; i < n; ++i) {
+        int x = xy[2 * i], y = xy[2 * i + 1];
+        if (x < 0 || x >= G || y < 0 || y >= G) return -5;
+        e->wall[x * G + y] = 1;
+    }
+    return 0;
+}
+
 int rqo_reset_from_placement(rqo_env *e, const int32_t *pred_xy, const int32_t *prey_xy,
                              const int32_t *grass_xy, rqo_step_out *out) {
     const rqo_config *c = &e->c;
@@ -277,6 +360,9 @@ int rqo_reset_from_placement(rqo_env *e, const int32_t *pred_xy, const int32_t *
     if (total > G * G) return -4;                                      /* RQ:881-882 */
     e->current_step = 0;                                               /* RQ:90 */
     memset(e->grid, 0, (size_t)4 * G * G * sizeof(float));             /* RQ:138-139 */
+    if (e->c.walls)
+        for (int i = 0; i < G * G; ++i)
+            if (e->wall[i]) e->grid[i] = 1.0f;                         /* WO:271-273: walls painted into channel 0 */
     e->n_agents = 0; e->n_entries = 0; e->n_pending = 0;
     for (int i = 0; i < e->tot; ++i) e->ent_index[i] = -1;
     memset(e->just_ate, 0, e->tot);
@@ -376,15 +462,18 @@ int rqo_reset_philox(rqo_env *e, uint64_t seed, uint32_t episode, rqo_step_out *
     const int G = e->G, n = G * G;
     int P = c->n_initial[0] + c->n_initial[1], Q = c->n_initial[2] + c->n_initial[3];
     int K = P + Q + c->initial_num_grass;
-    if (K > n) return -4;
-    rqo_set_seed(e, seed, episode);
+    /* build contract: partial Fisher-Yates over the cells that are not walls, in cell-index order */
     int *perm = (int *)malloc((size_t)n * sizeof(int));
+    int nfree = 0;
+    for (int i = 0; i < n; ++i)
+        if (!(c->walls && e->wall[i])) perm[nfree++] = i;
+    if (K > nfree) { free(perm); return -4; }
+    rqo_set_seed(e, seed, episode);
     int32_t *xy = (int32_t *)malloc((size_t)2 * K * sizeof(int32_t) + 8);
-    for (int i = 0; i < n; ++i) perm[i] = i;
     for (int k = 0; k < K; ++k) {
         uint32_t w[4];
         philox_words(seed, RQO_TAG_RST, (uint32_t)k >> 2, 0u, 0u, episode, w);
-        int j = k + (int)(((uint64_t)w[k & 3] * (uint32_t)(n - k)) >> 32);
+        int j = k + (int)(((uint64_t)w[k & 3] * (uint32_t)(nfree - k)) >> 32);
         int a = perm[k], b = perm[j];
         perm[j] = a; perm[k] = b;
         xy[2 * k] = b / G; xy[2 * k + 1] = b % G;
@@ -565,7 +654,20 @@ int rqo_step(rqo_env *e, int32_t n_act, const int32_t *act_pool, const int32_t *
         int dx = act[a] / side - delta, dy = act[a] % side - delta;
         int nx = clipi(ox + dx, 0, G - 1), ny = clipi(oy + dy, 0, G - 1);   /* RQ:336 */
         int ch = RQO_IS_PREY(p) ? 2 : 1;                               /* RQ:338 */
-        if (*cell(e, ch, nx, ny) > 0) { nx = ox; ny = oy; }            /* RQ:339-341 */
+        if (!c->walls) {
+            if (*cell(e, ch, nx, ny) > 0) { nx = ox; ny = oy; }        /* RQ:339-341 */
+        } else {                                                       /* WO:466-488 */
+            int reason = RQO_BLOCK_NONE;
+            if (e->wall[nx * G + ny]) { nx = ox; ny = oy; reason = RQO_BLOCK_WALL; }
+            else if (*cell(e, ch, nx, ny) > 0) { nx = ox; ny = oy; reason = RQO_BLOCK_OCCUPIED; }
+            else if (c->respect_los_for_movement && !(nx == ox && ny == oy)) {
+                int ddx = nx - ox, ddy = ny - oy;
+                if (abs(ddx) == 1 && abs(ddy) == 1) {                  /* no corner cutting */
+                    if (e->wall[(ox + ddx) * G + oy] || e->wall[ox * G + (oy + ddy)]) { nx = ox; ny = oy; reason = RQO_BLOCK_CORNER_CUT; }
+                } else if (!los_clear(e, ox, oy, nx, ny)) { nx = ox; ny = oy; reason = RQO_BLOCK_LOS; }
+            }
+            e->block_reason[f] = reason;                               /* WO:766-778 */
+        }
         e->ent_x[k] = nx; e->ent_y[k] = ny;                            /* RQ:524 */
         /* _get_movement_energy_cost, RQ:301-313 */
         double distance = sqrt((double)((nx - ox) * (nx - ox) + (ny - oy) * (ny - oy)));

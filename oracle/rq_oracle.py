@@ -68,12 +68,18 @@ class _Config(C.Structure):
         ("n_possible", C.c_int32 * 4), ("n_initial", C.c_int32 * 4), ("initial_num_grass", C.c_int32),
         ("type_1_action_range", C.c_int32), ("type_2_action_range", C.c_int32),
         ("reproduction_cooldown_steps", C.c_int32), ("pad_", C.c_int32)] + [
-        (n, C.c_double * 2) for n, _ in _TYPED_REWARDS] + [(n, C.c_double) for n in _SCALARS]
+        (n, C.c_double * 2) for n, _ in _TYPED_REWARDS] + [(n, C.c_double) for n in _SCALARS] + [
+        (n, C.c_int32) for n in ("walls", "include_visibility_channel", "respect_los_for_movement",
+                                 "mask_observation_with_visibility")]
 
 
 class _Record(C.Structure):
     _fields_ = [("pool", C.c_int32), ("id", C.c_int32), ("reward", C.c_double), ("terminated", C.c_int32),
-                ("truncated", C.c_int32), ("obs_offset", C.c_int32), ("obs_len", C.c_int32)]
+                ("truncated", C.c_int32), ("obs_offset", C.c_int32), ("obs_len", C.c_int32),
+                ("block_reason", C.c_int32), ("pad_", C.c_int32)]
+
+
+BLOCK_REASONS = {1: "wall", 2: "occupied", 3: "corner_cut", 4: "los"}  # move_blocked_reason, WO:466-488
 
 
 class _StepOut(C.Structure):
@@ -118,6 +124,7 @@ def lib():
         L.rqo_create.argtypes = [C.POINTER(_Config)]
         L.rqo_destroy.argtypes = [C.c_void_p]
         L.rqo_set_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.rqo_set_walls.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.rqo_reset_from_placement.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_StepOut)]
         L.rqo_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                C.POINTER(_StepOut)]
@@ -159,12 +166,19 @@ def philox_uniform(seed: int, episode: int, step: int, draw: int) -> float:
 
 
 class RQOracleEnv:
-    """The red_queen reference env's interface on top of the C restatement."""
+    """The red_queen reference env's interface on top of the C restatement; with ``walls=True`` the walls_occlusion
+    env's (static walls in observation channel 0, line-of-sight options, per-agent infos)."""
 
-    def __init__(self, config: dict):
+    def __init__(self, config: dict, walls: bool = False):
         cfg = fill_config(config)
         self.config = cfg
+        self.walls = bool(walls)
         c = _Config()
+        c.walls = int(self.walls)
+        c.include_visibility_channel = int(bool((config or {}).get("include_visibility_channel", False)) and self.walls)
+        c.respect_los_for_movement = int(bool((config or {}).get("respect_los_for_movement", False)) and self.walls)
+        c.mask_observation_with_visibility = int(bool((config or {}).get("mask_observation_with_visibility", False)) and self.walls)
+        self.channels = 4 + c.include_visibility_channel
         for n in ("max_steps", "grid_size", "num_obs_channels", "predator_obs_range", "prey_obs_range",
                   "initial_num_grass", "type_1_action_range", "type_2_action_range", "reproduction_cooldown_steps"):
             setattr(c, n, int(cfg[n]))
@@ -197,12 +211,18 @@ class RQOracleEnv:
     def _records(self):
         o = self._out
         obs, rew, term, trunc = {}, {}, {}, {}
+        self.last_infos = {}
         for i in range(o.n_records):
             r = o.records[i]
             name = agent_name(r.pool, r.id)
             R = self._obs_range(r.pool)
             a = np.ctypeslib.as_array(o.obs, shape=(r.obs_offset + r.obs_len,))[r.obs_offset:]
-            obs[name] = a.reshape(4, R, R).copy()
+            obs[name] = a.reshape(self.channels, R, R).copy()
+            if r.block_reason >= 0:   # infos of the walls env, WO:766-778
+                info = {"los_rejected": int(r.block_reason == 4)}
+                if r.block_reason > 0:
+                    info["move_blocked_reason"] = BLOCK_REASONS[r.block_reason]
+                self.last_infos[name] = info
             rew[name] = float(r.reward)
             term[name] = bool(r.terminated)
             trunc[name] = bool(r.truncated)
@@ -212,6 +232,11 @@ class RQOracleEnv:
         return obs, rew, term, trunc
 
     # -- reference-shaped API ----------------------------------------
+    def set_walls(self, wall_xy):
+        w = np.ascontiguousarray(wall_xy, dtype=np.int32).reshape(-1)
+        if self._L.rqo_set_walls(self._h, w.size // 2, w.ctypes.data) != 0:
+            raise ValueError("wall outside the grid")
+
     def reset_from_placement(self, pred_xy, prey_xy, grass_xy):
         p = np.ascontiguousarray(pred_xy, dtype=np.int32).reshape(-1)
         q = np.ascontiguousarray(prey_xy, dtype=np.int32).reshape(-1)
@@ -251,9 +276,15 @@ class RQOracleEnv:
         if rc != 0:
             raise RuntimeError(f"oracle step failed rc={rc}")
         obs, rew, term, trunc = self._records()
+        if self.walls and not self._out.truncated_all:
+            # WO:370-395: the scalar dicts also carry every agent named in action_dict (defaults 0.0 / False); they are
+            # built from a Python set there, so their ORDER is arbitrary in the reference -- compare them as mappings
+            for name in action_dict:
+                if name not in rew:
+                    rew[name], term[name], trunc[name] = 0.0, False, False
         term["__all__"] = bool(self._out.terminated_all)
         trunc["__all__"] = bool(self._out.truncated_all)
-        return obs, rew, term, trunc, {}
+        return obs, rew, term, trunc, (dict(self.last_infos) if self.walls else {})
 
     def rollout_random(self, seed: int, n_calls: int) -> int:
         return int(self._L.rqo_rollout_random(self._h, seed, n_calls, C.byref(self._out)))
@@ -264,12 +295,24 @@ class RQOracleEnv:
                  o.records[i].truncated) for i in range(o.n_records)]
         return recs, bool(o.terminated_all), bool(o.truncated_all)
 
+    def infos_of_last_call(self):
+        """infos dict of the walls env for the last call (also after rollout_random)."""
+        o, out = self._out, {}
+        for i in range(o.n_records):
+            r = o.records[i]
+            if r.block_reason >= 0:
+                d = {"los_rejected": int(r.block_reason == 4)}
+                if r.block_reason > 0:
+                    d["move_blocked_reason"] = BLOCK_REASONS[r.block_reason]
+                out[agent_name(r.pool, r.id)] = d
+        return out
+
     def last_obs(self, i):
         o = self._out
         r = o.records[i]
         R = self._obs_range(r.pool)
         a = np.ctypeslib.as_array(o.obs, shape=(r.obs_offset + r.obs_len,))[r.obs_offset:]
-        return a.reshape(4, R, R).copy()
+        return a.reshape(self.channels, R, R).copy()
 
     # -- attributes --------------------------------------------------
     @property
@@ -330,7 +373,7 @@ class RQOracleEnv:
     def _get_observation(self, name):
         t, i = parse_agent(name)
         R = self._obs_range(t)
-        out = np.empty(4 * R * R, dtype=np.float32)
+        out = np.empty(self.channels * R * R, dtype=np.float32)
         if self._L.rqo_observe(self._h, t, i, out.ctypes.data) != 0:
             raise KeyError(name)
-        return out.reshape(4, R, R)
+        return out.reshape(self.channels, R, R)

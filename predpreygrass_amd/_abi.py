@@ -41,8 +41,9 @@ _DBL_FIELDS = [
 ]
 _BUF_FIELDS = [
     "row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "env_state", "env_seed",
-    "grass_xy", "grass_energy", "obs_pred", "obs_prey", "row_parent", "row_lastrep",
+    "grass_xy", "grass_energy", "obs_pred", "obs_prey", "row_parent", "row_lastrep", "wall_bits", "row_info",
 ]
+MOVE_REASONS = {1: "wall", 2: "occupied", 3: "corner_cut", 4: "los"}  # row_info - 1 -> move_blocked_reason (WO:466-488)
 
 
 class PpgConfig(C.Structure):
@@ -70,7 +71,9 @@ class PpgConfigGen2(C.Structure):
         ("n_possible", C.c_int32 * 4), ("n_initial", C.c_int32 * 4)] + [
         (n, C.c_int32) for n in ("n_grass", "pred_capacity", "prey_capacity", "grass_capacity", "obs_dtype",
                                  "type_1_action_range", "type_2_action_range", "reproduction_cooldown_steps")] + [
-        (n, C.c_double * 2) for n in GEN2_TYPED] + [(n, C.c_double) for n in GEN2_SCALARS]
+        (n, C.c_double * 2) for n in GEN2_TYPED] + [(n, C.c_double) for n in GEN2_SCALARS] + [
+        (n, C.c_int32) for n in ("walls", "include_visibility_channel", "respect_los_for_movement",
+                                 "mask_observation_with_visibility")]
 
 
 class PpgBuffers(C.Structure):

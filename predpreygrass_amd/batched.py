@@ -132,12 +132,15 @@ class BatchedPredPreyGrass:
         self.row_reward = z((B, S), torch.float64)
         self.row_parent = torch.full((B, S), -1, dtype=torch.int32, device=dev)
         self.row_lastrep = z((B, S), torch.int32)  # second generation only (agent_last_reproduction)
+        self.wall_bits = z((B, (self.grid_size * self.grid_size + 31) // 32), torch.int32)  # walls variant only
+        self.row_info = z((B, S), torch.uint8)                                               # walls variant only
         self.env_state = z((B, _abi.ENV_WORDS), torch.int32)
         self.env_seed = z((B,), torch.int64)
         self.grass_xy = z((B, NG), torch.int16)
         self.grass_energy = z((B, NG), torch.float64)
-        self.obs_pred = z((B, self.pred_capacity, 4, self.Rp, self.Rp), self.obs_dtype)
-        self.obs_prey = z((B, self.prey_capacity, 4, self.Rq, self.Rq), self.obs_dtype)
+        nc = getattr(self, "obs_channels", 4)
+        self.obs_pred = z((B, self.pred_capacity, nc, self.Rp, self.Rp), self.obs_dtype)
+        self.obs_prey = z((B, self.prey_capacity, nc, self.Rq, self.Rq), self.obs_dtype)
         self.actions = torch.full((B, S), _abi.ACTION_NONE, dtype=torch.int8, device=dev)
 
     def _create_handle(self, c, create_fn):

@@ -58,17 +58,21 @@ static uint32_t ppg_host_lexkey(uint32_t id) {
 // elements e = ch*128 + 2l and e+1 of the (4,R,R) block in C order.
 static int ppg_obs_chunks(int R) { return (4 * R * R + 127) / 128; }
 
-static void ppg_build_lut(int R, int G, int map_n, uint32_t *out) {
-    const int blk = 4 * R * R, off = (R - 1) / 2;
+static int ppg_obs_chunks_c(int R, int channels) { return (channels * R * R + 127) / 128; }
+
+// channels = 4, or 5 in the walls variant with the visibility channel (its elements: bit 28 set, channel bits 0)
+static void ppg_build_lut(int R, int G, int map_n, uint32_t *out, int channels = 4) {
+    const int blk = channels * R * R, off = (R - 1) / 2;
     const int W = 2 * off + 1;  // BASE:532-539: the window is x-off..x+off
-    const int nwords = ppg_obs_chunks(R) * 128;
+    const int nwords = ppg_obs_chunks_c(R, channels) * 128;
     for (int e = 0; e < nwords; ++e) {
         uint32_t d = 0;
         if (e < blk) {
             const int c = e / (R * R), rem = e % (R * R), i = rem / R, j = rem % R;
-            const int moff = c * map_n + (i - off) * G + (j - off);
+            const int cm = c < 4 ? c : 0;
+            const int moff = cm * map_n + (i - off) * G + (j - off);
             d = ((uint32_t)moff & 0xFFFFu) | ((uint32_t)(i - off + 8) << 16) | ((uint32_t)(j - off + 8) << 20) |
-                ((uint32_t)c << 24) | 0x4000000u | ((i < W && j < W) ? 0x8000000u : 0u);
+                ((uint32_t)cm << 24) | 0x4000000u | ((i < W && j < W) ? 0x8000000u : 0u) | (c == 4 ? 0x10000000u : 0u);
         }
         out[e] = d;
     }
@@ -132,8 +136,14 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.off_val = off; off += (1 + P.S + P.cap_grass) * 8;
     off = (off + 15) / 16 * 16;
     P.off_scr = off; off += (P.S * 8 > 1024 ? P.S * 8 : 1024);
-    P.nch_p = ppg_obs_chunks(P.Rp); P.nch_q = ppg_obs_chunks(P.Rq);
+    const int channels = (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
+    P.nch_p = ppg_obs_chunks_c(P.Rp, channels); P.nch_q = ppg_obs_chunks_c(P.Rq, channels);
     P.off_lut = off; off += (P.nch_p + P.nch_q) * 128 * 4;
+    if (h->gen2 && h->cfg2.walls) {  // wall bitmap
+        P.n_wall_words = (n + 31) / 32;
+        off = (off + 15) / 16 * 16;
+        P.off_wall = off; off += P.n_wall_words * 4;
+    }
     P.lds_bytes = off;
     if (const char *pad = getenv("PPG_DEBUG_LDS_BYTES")) { int v = atoi(pad); if (v > P.lds_bytes) P.lds_bytes = v; }  // occupancy experiments
     if (P.lds_bytes > 64 * 1024) return ppg_fail(h, PPG_EINVAL, "configuration needs %d bytes of LDS per wave (> 64 KiB)", P.lds_bytes);
@@ -146,8 +156,8 @@ static int ppg_validate_and_layout(ppg_handle *h) {
 
     if (3 * P.map_n + 8 * c.grid_size + 8 > 32767) return ppg_fail(h, PPG_EINVAL, "grid too large for 16-bit map offsets");
     h->lut_host.assign((size_t)(P.nch_p + P.nch_q) * 128, 0u);
-    ppg_build_lut(P.Rp, P.G, P.map_n, h->lut_host.data());
-    ppg_build_lut(P.Rq, P.G, P.map_n, h->lut_host.data() + (size_t)P.nch_p * 128);
+    ppg_build_lut(P.Rp, P.G, P.map_n, h->lut_host.data(), channels);
+    ppg_build_lut(P.Rq, P.G, P.map_n, h->lut_host.data() + (size_t)P.nch_p * 128, channels);
     return PPG_OK;
 }
 
@@ -169,6 +179,7 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
     if (g.reproduction_cooldown_steps < 0 || g.reproduction_cooldown_steps > 1000000)
         return ppg_fail(h, PPG_EINVAL, "reproduction_cooldown_steps outside 0..1000000");
     if (!h->bufs.row_lastrep) return ppg_fail(h, PPG_EINVAL, "row_lastrep is NULL");
+    if (g.walls && (!h->bufs.wall_bits || !h->bufs.row_info)) return ppg_fail(h, PPG_EINVAL, "walls need wall_bits and row_info");
     ppg_config &c = h->cfg;
     memset(&c, 0, sizeof c);
     c.abi_version = g.abi_version; c.grid_size = g.grid_size; c.predator_obs_range = g.predator_obs_range;
@@ -202,6 +213,11 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
     P.cap_g = g.max_energy_grass; P.eff_transfer = g.energy_transfer_efficiency; P.eff_repro = g.reproduction_energy_efficiency;
     P.chance_p = g.reproduction_chance_predator; P.chance_q = g.reproduction_chance_prey;
     P.mut_p = g.mutation_rate_predator; P.mut_q = g.mutation_rate_prey;
+    P.walls = g.walls ? 1 : 0;
+    P.vis_channel = (g.walls && g.include_visibility_channel) ? 1 : 0;
+    P.los_move = (g.walls && g.respect_los_for_movement) ? 1 : 0;
+    P.mask_obs = (g.walls && g.mask_observation_with_visibility) ? 1 : 0;
+    P.wall_bits = h->bufs.wall_bits; P.row_info = h->bufs.row_info;
     return PPG_OK;
 }
 

@@ -48,6 +48,10 @@ enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3, MO
 // turn before a predator of a later class caught it (RQ:225-233 runs in self.agents order, types interleaved).
 enum { EV_STARVED = 1, EV_CAUGHT = 2, EV_ATE = 4, EV_PARENT = 8, EV_BORN = 16, EV_TRUNC = 32, EV_REPRO = 64, EV_TURN = 128 };
 
+// walls variant: move_blocked_reason (WO:466-488) as kept in bits 0-2 of Env::keep / in row_info: 0 = the agent did not go
+// through the movement phase, otherwise 1 + code
+enum { MV_NONE = 1, MV_WALL = 2, MV_OCCUPIED = 3, MV_CORNER_CUT = 4, MV_LOS = 5 };
+
 constexpr uint32_t TAG_ACT = 0x41435431u;  // Philox key domains (see oracle/ppg_oracle.c)
 constexpr uint32_t TAG_RST = 0x52535431u;
 constexpr uint32_t TAG_SPW = 0x53505731u;
@@ -79,6 +83,13 @@ struct KParams {
     double move_factor, cap_gain_prey, cap_gain_grass, max_e_pred, max_e_prey, eff_transfer, eff_repro;
     double chance_p, chance_q, mut_p, mut_q;
     double cap_g;                 // grass regrowth cap: initial_energy_grass (BASE:254) / max_energy_grass (RQ:510)
+    // walls variant of the second generation (walls_occlusion/predpreygrass_rllib_env.py, "WO")
+    int32_t walls;                // 1: observation channel 0 = walls, wall-blocked moves, per-agent move infos
+    int32_t vis_channel;          // include_visibility_channel (WO:104): a fifth observation channel
+    int32_t los_move;             // respect_los_for_movement (WO:106)
+    int32_t mask_obs;             // mask_observation_with_visibility (WO:111)
+    int32_t n_wall_words;         // 32-bit words of the per-env wall bitmap: ceil(G*G / 32)
+    int32_t off_wall;             // LDS offset of the wall bitmap
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
     int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
@@ -103,6 +114,8 @@ struct KParams {
     void *obs_prey;
     int32_t *row_parent;
     int32_t *row_lastrep;     // second generation: agent_last_reproduction
+    uint32_t *wall_bits;      // walls variant: [B, n_wall_words], bit (x*G+y) set = wall
+    uint8_t *row_info;        // walls variant: [B,S] 0 = no move info, else 1 + move_blocked_reason code (WO:466-488)
     const uint32_t *obs_lut;  // library-owned, (nch_p + nch_q) * 128 words
     // per-launch
     const int8_t *actions;
@@ -196,7 +209,9 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // base path 11 % (register / SGPR pressure), so it has its own kernel variants.
 // GEN2: the second-generation step (two agent types per species, move cost, energy caps, stochastic reproduction:
 // red_queen/predpreygrass_rllib_env.py, "RQ").  Its own kernel variants; the base kernels compile none of it.
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, class KP, class KC>
+// WALLS (with GEN2): the walls_occlusion variant -- static walls in a per-env bitmap, observation channel 0 = walls,
+// optional line-of-sight mask / fifth channel, wall- and LOS-blocked moves, per-agent move infos.
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, class KP, class KC>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
@@ -210,6 +225,7 @@ struct Env {
     double *val;     // LDS
     uint64_t *scr;   // LDS
     uint32_t *lut;   // LDS
+    uint32_t *wallw; // LDS: wall bitmap (WALLS)
 
     // per-lane row fields
     uint32_t xy[T];
@@ -239,7 +255,7 @@ struct Env {
     PPG_MEMBER Env(KP &p, KC &c, int b_, unsigned char *lds, int lane)
         : P(p), C(c), b(b_), ln(lane),
           map((uint16_t *)(lds + p.off_map)), val((double *)(lds + p.off_val)),
-          scr((uint64_t *)(lds + p.off_scr)), lut((uint32_t *)(lds + p.off_lut)) {}
+          scr((uint64_t *)(lds + p.off_scr)), lut((uint32_t *)(lds + p.off_lut)), wallw((uint32_t *)(lds + c.off_wall)) {}
 
     // ---- index helpers -------------------------------------------------------------
     static PPG_MEMBER int type_of(int r) { return r ? 1 : 0; }
@@ -249,6 +265,49 @@ struct Env {
     PPG_MEMBER int grass_validx(int p) const { return 1 + P.S + p; }
     PPG_MEMBER int cell_of(uint32_t s_xy) const { return (int)(s_xy >> 8) * P.G + (int)(s_xy & 255u); }
     PPG_MEMBER uint16_t *chmap(int ch) const { return map + ch * P.map_n; }
+
+    // ---- walls (WO) ----------------------------------------------------------------------
+    PPG_MEMBER bool wall_at(int x, int y) const {
+        const int c = x * P.G + y;
+        return (wallw[c >> 5] >> (c & 31)) & 1u;
+    }
+    // _line_of_sight_clear (WO:492-525) == the bresenham walk of _get_observation (WO:550-589): no wall strictly between
+    // the two cells.  The reference's float error term dx/2.0 is carried doubled, as an integer.
+    PPG_MEMBER bool los_clear(int x0, int y0, int x1, int y1) const {
+        const int dx = x1 > x0 ? x1 - x0 : x0 - x1, dy = y1 > y0 ? y1 - y0 : y0 - y1;
+        const int sx = x1 > x0 ? 1 : -1, sy = y1 > y0 ? 1 : -1;
+        int x = x0, y = y0;
+        bool clear = true;
+        if (dx >= dy) {
+            int err2 = dx;
+            while (x != x1) {
+                if (!(x == x0 && y == y0) && !(x == x1 && y == y1) && wall_at(x, y)) clear = false;
+                err2 -= 2 * dy;
+                if (err2 < 0) { y += sy; err2 += 2 * dx; }
+                x += sx;
+            }
+        } else {
+            int err2 = dy;
+            while (y != y1) {
+                if (!(x == x0 && y == y0) && !(x == x1 && y == y1) && wall_at(x, y)) clear = false;
+                err2 -= 2 * dx;
+                if (err2 < 0) { x += sx; err2 += 2 * dy; }
+                y += sy;
+            }
+        }
+        return clear;
+    }
+    // What the walls do to a move from (x,y) to the clipped target (tx,ty): MV_WALL, MV_CORNER_CUT, MV_LOS or MV_NONE
+    // (WO:469-488; the occupancy test sits between the wall test and the line-of-sight tests and is applied by the caller).
+    PPG_MEMBER uint32_t wall_verdict(int x, int y, int tx, int ty) const {
+        if (wall_at(tx, ty)) return MV_WALL;
+        if (!C.los_move || (tx == x && ty == y)) return MV_NONE;
+        const int ddx = tx - x, ddy = ty - y;
+        if ((ddx == 1 || ddx == -1) && (ddy == 1 || ddy == -1))
+            return (wall_at(x + ddx, y) || wall_at(x, y + ddy)) ? (uint32_t)MV_CORNER_CUT : (uint32_t)MV_NONE;
+        return los_clear(x, y, tx, ty) ? (uint32_t)MV_NONE : (uint32_t)MV_LOS;
+    }
+    PPG_MEMBER void set_move_info(int r, uint32_t code) { keep[r] = (keep[r] & ~7u) | code; }
 
     // alive rows of `type` standing on s_xy, per register
     PPG_MEMBER void match(int type, uint32_t s_xy, uint64_t (&m)[T]) const {
@@ -402,6 +461,8 @@ struct Env {
         if (ln == 0) val[0] = 0.0;
         gxyr[0] = p.gxy[0];
         gxyr[1] = p.gxy[1];
+        if (WALLS)
+            for (int i = ln; i < C.n_wall_words; i += 64) wallw[i] = C.wall_bits[(size_t)b * C.n_wall_words + i];
     }
 
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
@@ -611,12 +672,24 @@ struct Env {
         int tx = (int)(s_xy >> 8) + dx, ty = (int)(s_xy & 255u) + dy;
         tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);  // np.clip, BASE:505
         ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
+        uint32_t verdict = MV_NONE;
+        if (WALLS) {  // WO:469-471: a wall cell is never entered -- the agent stays where it is
+            verdict = wall_verdict((int)(s_xy >> 8), (int)(s_xy & 255u), tx, ty);
+            if (verdict == MV_WALL) { tx = (int)(s_xy >> 8); ty = (int)(s_xy & 255u); }
+        }
         const uint32_t t_xy = ((uint32_t)tx << 8) | (uint32_t)ty;
         uint64_t mt[T], mo[T];
         match(type, t_xy, mt);
         uint64_t occ = 0;  // grid[type, target] > 0 (BASE:506): an owner with positive energy sits there
 #pragma unroll
         for (int q = 0; q < T; ++q) occ |= mt[q] & owns[q] & pos[q];
+        if (WALLS) {  // WO:466-488: wall, then occupied, then corner cutting / line of sight
+            const uint32_t reason = verdict == MV_WALL ? (uint32_t)MV_WALL : (occ ? (uint32_t)MV_OCCUPIED : verdict);
+#pragma unroll
+            for (int q = 0; q < T; ++q)
+                if (q == r && ln == k) set_move_info(q, reason);
+            if (verdict == MV_CORNER_CUT || verdict == MV_LOS) occ = 1;  // refused like an occupied target: stay
+        }
         if (t_xy == s_xy) {
 #pragma unroll
             for (int q = 0; q < T; ++q) mo[q] = mt[q];
@@ -684,7 +757,7 @@ struct Env {
             if (!cooc[type]) {
                 uint16_t *A = chmap(1 + type), *F = chmap(0);
                 const int G1 = P.G - 1;
-                uint32_t t_xy[T], rd[T];
+                uint32_t t_xy[T], rd[T], verdict[T];
                 bool mover[T];
 #pragma unroll
                 for (int r = 0; r < T; ++r) {
@@ -695,6 +768,11 @@ struct Env {
                     tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);
                     ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
                     t_xy[r] = ((uint32_t)tx << 8) | (uint32_t)ty;
+                    verdict[r] = MV_NONE;
+                    if (WALLS && ((acted[r] >> ln) & 1ull)) {
+                        verdict[r] = wall_verdict((int)(xy[r] >> 8), (int)(xy[r] & 255u), tx, ty);
+                        if (verdict[r] == MV_WALL) t_xy[r] = xy[r];   // WO:469-471
+                    }
                     mover[r] = ((acted[r] >> ln) & 1ull) && t_xy[r] != xy[r];
                     rd[r] = 0;
                     if ((alive[r] >> ln) & 1ull) A[cell_of(xy[r])] = (uint16_t)validx(r, ln);  // sitters
@@ -729,6 +807,9 @@ struct Env {
                     if (type_of(r) != type) continue;
                     bool c = false;
                     if ((alive[r] >> ln) & 1ull) c = F[cell_of(xy[r])] != 0 || (mover[r] && F[cell_of(t_xy[r])] != 0);
+                    // a move the walls refuse still has to see whether its target is occupied at its turn (the reported
+                    // reason depends on it, WO:472-488): ordered loop
+                    if (WALLS && (verdict[r] == MV_CORNER_CUT || verdict[r] == MV_LOS)) c = true;
                     cx[r] = wv::ballot(c) & acted[r];
                 }
 #pragma unroll
@@ -744,6 +825,9 @@ struct Env {
                 for (int r = 0; r < T; ++r) {
                     if (type_of(r) != type) continue;
                     const uint64_t simple = acted[r] & ~cx[r];
+                    if (WALLS && ((simple >> ln) & 1ull))  // nobody else touches its cells: the target is free, or its own cell
+                        set_move_info(r, verdict[r] == MV_WALL ? (uint32_t)MV_WALL
+                                         : (t_xy[r] == xy[r] && shown_positive(r)) ? (uint32_t)MV_OCCUPIED : (uint32_t)MV_NONE);
                     if (GEN2 && ((simple >> ln) & 1ull) && t_xy[r] != xy[r] && C.move_factor != 0.0) {  // RQ:301-313,526
                         const int ddx = (int)(t_xy[r] >> 8) - (int)(xy[r] >> 8), ddy = (int)(t_xy[r] & 255u) - (int)(xy[r] & 255u);
                         e[r] = e[r] - move_distance(ddx * ddx + ddy * ddy) * C.move_factor * e[r];
@@ -981,11 +1065,11 @@ struct Env {
         }
         wv::sync();  // LDS writes of the sequential phases -> visible
         const int R = type ? P.Rq : P.Rp;
-        const int blk = 4 * R * R;
+        const int blk = (WALLS && C.vis_channel ? 5 : 4) * R * R;
         const int off = (R - 1) / 2;
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;
-        const bool interior = (R & 1) && x >= off && y >= off && x + off < P.G && y + off < P.G;
+        const bool interior = !WALLS && (R & 1) && x >= off && y >= off && x + off < P.G && y + off < P.G;
         const uint2 *L = (const uint2 *)(lut + (type ? P.nch_p * 128 : 0));
         const int nch = type ? P.nch_q : P.nch_p;
         const size_t obase = ((size_t)b * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)blk;
@@ -1007,11 +1091,36 @@ struct Env {
                     const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
                     const int a = (int)(int16_t)(w & 0xFFFFu) + s_cell;
                     double t = val[map[inb ? a : 0]];        // map[0] (channel 0, cell 0) is always 0 -> val[0] = 0.0
-                    if (!inb && (w & 0x3000000u) == 0u) t = 1.0;  // channel 0: 1 outside the grid (BASE:522-523)
+                    if (!WALLS) {
+                        if (!inb && (w & 0x3000000u) == 0u) t = 1.0;  // channel 0: 1 outside the grid (BASE:522-523)
+                    } else {
+                        // _get_observation of the walls env (WO:527-601): channel 0 = walls inside the window (0 outside the
+                        // grid); channels 1-3 optionally multiplied -- in float32, like the reference -- by the line-of-
+                        // sight mask; optional last channel = the mask itself
+                        const bool vis_elem = (w & 0x10000000u) != 0u;
+                        // the mask is computed for every cell of the R x R array that maps into the grid (WO:577-589), also
+                        // for the last row / column of an even R, which the window copy (WO:543) leaves untouched
+                        const bool in_grid = (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+                        const bool need_vis = vis_elem ? in_grid : (inb && C.mask_obs && (w & 0x3000000u) != 0u);
+                        const float vis = (need_vis && los_clear(x, y, gx, gy)) ? 1.0f : 0.0f;
+                        if (vis_elem) t = (double)vis;
+                        else if ((w & 0x3000000u) == 0u) t = (inb && wall_at(gx, gy)) ? 1.0 : 0.0;
+                        else if (C.mask_obs) t = (double)((float)t * vis);
+                    }
                     v[h] = t;
                 }
             }
-            if (d.x & 0x4000000u) {
+            if (WALLS && (blk & 1)) {
+                // five channels x an odd window: blocks start at odd element offsets and the last pair of a block
+                // straddles the next agent's block -> element-wise stores
+                const size_t o = obase + (size_t)ch * 128 + 2 * (size_t)ln;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (!((h ? d.y : d.x) & 0x4000000u)) continue;
+                    if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred))[o + h] = (float)v[h];
+                    else ((double *)(type ? P.obs_prey : P.obs_pred))[o + h] = v[h];
+                }
+            } else if (d.x & 0x4000000u) {
                 const size_t o = obase + (size_t)ch * 128 + 2 * (size_t)ln;
                 if (P.obs_f32) {
                     float2 f; f.x = (float)v[0]; f.y = (float)v[1];
@@ -1525,6 +1634,7 @@ struct Env {
             C.row_reward[s] = rew_[r];
             if (KICK) C.row_parent[s] = par_[r];
             if (GEN2) C.row_lastrep[s] = lr[r];
+            if (WALLS) C.row_info[s] = (uint8_t)((transition && !(ev[r] & (EV_TRUNC | EV_BORN))) ? (keep[r] & 7u) : 0u);
             keep[r] = (keep[r] & ~0xFFu) | (fl_[r] & PPG_ROW_ATE);
         }
         obs_count[0] += n_rows[0];       // every row in use got an observation
@@ -1570,7 +1680,20 @@ struct Env {
         uint16_t *perm = chmap(1), *ent = chmap(2);
         uint32_t *rnd = (uint32_t *)scr;  // 256 words per round
         wv::sync();
-        for (int i = ln; i < n; i += 64) perm[i] = (uint16_t)i;
+        int n_free = n;
+        if (!WALLS) {
+            for (int i = ln; i < n; i += 64) perm[i] = (uint16_t)i;
+        } else {  // the cells that are not walls, in cell-index order (the walls stay; build contract, see oracle/rq_oracle.c)
+            n_free = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int c = base + ln;
+                const bool fr = c < n && !((wallw[c >> 5] >> (c & 31)) & 1u);
+                const uint64_t m = wv::ballot(fr);
+                if (fr) perm[n_free + (int)wv::prefix(m)] = (uint16_t)c;
+                n_free += wv::popc(m);
+            }
+            if (K > n_free) status |= PPG_STATUS_FAILED_SPAWN;  // more entities than free cells: the host validates this
+        }
         for (int base = 0; base < K; base += 256) {
             uint32_t w[4];
             philox4x32_10((uint32_t)(base >> 2) + (uint32_t)ln, 0u, 0u, episode, (uint32_t)seed,
@@ -1583,7 +1706,7 @@ struct Env {
             for (int kk = 0; kk < hi; ++kk) {
                 const int k = base + kk;
                 const uint32_t rr = wv::first(rnd[kk]);
-                const int j = k + (int)wv::mulhi(rr, (uint32_t)(n - k));
+                const int j = k + (int)wv::mulhi(rr, (uint32_t)(n_free - k));
                 const uint32_t a = wv::first(perm[k]);
                 const uint32_t bb = wv::first(perm[j]);
                 if (ln == 0) { perm[j] = (uint16_t)a; perm[k] = (uint16_t)bb; ent[k] = (uint16_t)bb; }
@@ -1685,7 +1808,7 @@ struct Env {
         uint64_t acted[T];
         load_actions(acted);
 #pragma unroll
-        for (int r = 0; r < T; ++r) keep[r] &= GEN2 ? ~(uint32_t)PPG_ROW_ATE : ~0xFFu;  // agents_just_ate.clear(), BASE:241
+        for (int r = 0; r < T; ++r) keep[r] &= GEN2 ? ~(uint32_t)(PPG_ROW_ATE | 7u) : ~0xFFu;  // agents_just_ate.clear(), BASE:241
         wv::sync();                                // LDS zeros visible
         PPG_STAMP(2);
         decay(acted);                              // BASE:244-250
@@ -1780,12 +1903,12 @@ struct Env {
         double *out = C.grid_out + (size_t)b * 4 * n;
         for (int i = ln; i < 4 * n; i += 64) {
             const int ch = i / n, c = i - ch * n;
-            out[i] = ch ? val[chmap(ch)[c]] : 0.0;
+            out[i] = ch ? val[chmap(ch)[c]] : ((WALLS && ((wallw[c >> 5] >> (c & 31)) & 1u)) ? 1.0 : 0.0);  // WO:271-273
         }
     }
 };
 
-template <int NQ, int MODE, bool FASTOBS, bool GEN2 = false>
+template <int NQ, int MODE, bool FASTOBS, bool GEN2 = false, bool WALLS = false>
 PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     const int b = PPG_BLOCK_INDEX();
     if (b >= P.batch) return;
@@ -1807,7 +1930,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
             PPG_LAUNDER_S(bb);
             PPG_LAUNDER_V(lane);
             PPG_LAUNDER_V(l);
-            Env<NQ, false, FASTOBS, true, false, false, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
+            Env<NQ, false, FASTOBS, true, false, false, false, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
             env.run_step(it);
             wv::sync();
         }
@@ -1815,7 +1938,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     }
     const PPG_CONSTANT_AS KParams *Pcold = PPG_KERNARG_PTR(KParams, P);  // KParams is the kernel's only argument
     Env<NQ, MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_ORDERED_KICK, FASTOBS, false,
-        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, GEN2, const KParams, const PPG_CONSTANT_AS KParams>
+        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, GEN2, WALLS, const KParams, const PPG_CONSTANT_AS KParams>
         env(P, *Pcold, b, lds, wv::lane());
     if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();

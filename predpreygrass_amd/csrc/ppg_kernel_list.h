@@ -20,6 +20,14 @@
     PPG_K(ppg_step_kick_q##NQ##g, NQ, ppg::MODE_STEP_KICK, false)     \
     PPG_K(ppg_step_ord_kick_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED_KICK, false)
 
+// walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>)
+#define PPG_DEFINE_KERNELS3(NQ)                                       \
+    PPG_K3(ppg3_step_q##NQ, NQ, ppg::MODE_STEP)                       \
+    PPG_K3(ppg3_reset_q##NQ, NQ, ppg::MODE_RESET)                     \
+    PPG_K3(ppg3_observe_q##NQ, NQ, ppg::MODE_OBSERVE)                 \
+    PPG_K3(ppg3_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID)                \
+    PPG_K3(ppg3_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED)
+
 #define PPG_DEFINE_KERNELS2(NQ)                                       \
     PPG_K2(ppg2_step_q##NQ, NQ, ppg::MODE_STEP, true)                 \
     PPG_K2(ppg2_reset_q##NQ, NQ, ppg::MODE_RESET, true)               \

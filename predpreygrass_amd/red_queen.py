@@ -121,9 +121,15 @@ class BatchedRedQueen(BatchedPredPreyGrass):
     ``row_id``.  Observations default to float32, the reference's dtype (RQ:352-355)."""
 
     def __init__(self, config, batch_size=1, device=None, obs_dtype=torch.float32, prey_capacity=128, seed=0,
-                 _library=None):
+                 walls=False, _library=None):
+        """walls=True selects the walls_occlusion env ("WO"): observation channel 0 shows walls, wall / line-of-sight
+        rules for moves and observations (config keys include_visibility_channel, respect_los_for_movement,
+        mask_observation_with_visibility), per-agent move infos in `row_info`.  Walls are given with `set_walls`."""
         cfg = resolve_config(config)
         self.config = cfg
+        self.walls = bool(walls)
+        self.vis_channel = self.walls and bool(cfg.get("include_visibility_channel", False))   # WO:104
+        self.obs_channels = 5 if self.vis_channel else 4
         self.batch_size = int(batch_size)
         self._init_device(device, obs_dtype, _library)
         self.grid_size = int(cfg["grid_size"])
@@ -154,6 +160,10 @@ class BatchedRedQueen(BatchedPredPreyGrass):
                 getattr(c, name)[t - 1] = typed_value(cfg[name], species, t)
         for name in _abi.GEN2_SCALARS:
             setattr(c, name, float(cfg[name]))
+        c.walls = int(self.walls)
+        c.include_visibility_channel = int(self.vis_channel)
+        c.respect_los_for_movement = int(self.walls and bool(cfg.get("respect_los_for_movement", False)))          # WO:106
+        c.mask_observation_with_visibility = int(self.walls and bool(cfg.get("mask_observation_with_visibility", False)))  # WO:111
         self._create_handle(c, self._lib.ppg_create_gen2)
         self.set_seeds(seed)
 
@@ -220,6 +230,23 @@ class BatchedRedQueen(BatchedPredPreyGrass):
         self.observe()
         return self
 
+    def set_walls(self, wall_xy):
+        """Wall cells of every env (walls variant): a list of (x, y) shared by all envs, or one list per env.  They stay in
+        place across device resets until replaced; call before `set_placement` / `reset`."""
+        if not self.walls:
+            raise RuntimeError("set_walls needs walls=True")
+        B, G = self.batch_size, self.grid_size
+        per_env = wall_xy if (len(wall_xy) == B and len(wall_xy) > 0 and np.asarray(wall_xy[0]).ndim == 2) else [wall_xy] * B
+        bits = np.zeros((B, self.wall_bits.shape[1]), dtype=np.uint32)
+        for b, cells in enumerate(per_env):
+            a = np.asarray(cells, dtype=np.int64).reshape(-1, 2)
+            if a.size and (a.min() < 0 or a.max() >= G):
+                raise ValueError("wall outside the grid")
+            c = a[:, 0] * G + a[:, 1]
+            np.bitwise_or.at(bits[b], c >> 5, (np.uint32(1) << (c & 31).astype(np.uint32)))
+        self.wall_bits.copy_(torch.from_numpy(bits.view(np.int32)))
+        return self
+
     def step(self, actions=None, random_actions=False, auto_reset=False, act_rank=None, uniforms=None, stream=None):
         """One transition of every env (RQ:197-299).
 
@@ -258,7 +285,7 @@ class BatchedRedQueen(BatchedPredPreyGrass):
     def host_tables(self, b=None):
         sl = slice(None) if b is None else slice(b, b + 1)
         names = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_lastrep",
-                 "env_state", "grass_xy", "grass_energy"]
+                 "row_info", "env_state", "grass_xy", "grass_energy"]
         return {n: getattr(self, n)[sl].cpu().numpy() for n in names}
 
     def records(self, b, tables=None):
@@ -326,11 +353,15 @@ class PredPreyGrass(_MultiAgentEnvBase):
     Not carried over: the per-agent analytics the reference accumulates on the side (unique_agent_stats,
     per_step_agent_data, death statistics, offspring lists, agent_ages)."""
 
+    _walls = False                 # walls_occlusion.PredPreyGrass sets this
+    _require_all_actions = True    # RQ:279 fails for a live agent without an action
+
     def __init__(self, config=None, *, device=None, prey_capacity: int | None = None, _library=None):
         super().__init__()
         cfg = resolve_config(config)
         self.config = config
-        b = BatchedRedQueen(cfg, batch_size=1, device=device, prey_capacity=prey_capacity or 128, _library=_library)
+        b = BatchedRedQueen(cfg, batch_size=1, device=device, prey_capacity=prey_capacity or 128, walls=self._walls,
+                            _library=_library)
         self._b = b
         self._cfg = cfg
         for k in ("max_steps", "grid_size", "num_obs_channels", "predator_obs_range", "prey_obs_range",
@@ -338,8 +369,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
             setattr(self, k, cfg[k])                                               # RQ:36-78
         self.type_1_act_range, self.type_2_act_range = b.action_ranges               # RQ:85-86
         self.possible_agents = [f"{POOLS[p]}_{i}" for p in (0, 1, 2, 3) for i in range(b.n_possible[p])]  # RQ:941-955
-        self._pspace = _box((4, b.Rp, b.Rp))
-        self._qspace = _box((4, b.Rq, b.Rq))
+        self._pspace = _box((b.obs_channels, b.Rp, b.Rp))
+        self._qspace = _box((b.obs_channels, b.Rq, b.Rq))
         self._aspace = {1: _discrete(self.type_1_act_range ** 2), 2: _discrete(self.type_2_act_range ** 2)}  # RQ:974-985
         self.observation_spaces = {a: (self._pspace if "predator" in a else self._qspace) for a in self.possible_agents}
         self.action_spaces = {a: self._aspace[int(a[5])] for a in self.possible_agents}
@@ -388,7 +419,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
             count[sp] += 1
             in_order = in_order and row >= last[sp]
             last[sp] = row
-        if not truncated_call and count[0] + count[1] != len(where):
+        self._last_action_names = list(action_dict)
+        if self._require_all_actions and not truncated_call and count[0] + count[1] != len(where):
             # the reference itself fails for a live agent without an action (KeyError in its per-step bookkeeping, RQ:279)
             missing = [n for n in where if n not in action_dict]
             raise KeyError(missing[0])
@@ -443,9 +475,13 @@ class PredPreyGrass(_MultiAgentEnvBase):
         self._pending_removal = [r[0] for r in recs if r[4]]
         if after_reset:
             return obs, {}
+        infos = self._finish_outputs(recs, t, rew, term, trunc, bool(fl & _abi.ENVF_TRUNC_ALL))
         term["__all__"] = bool(fl & _abi.ENVF_TERM_ALL)
         trunc["__all__"] = bool(fl & _abi.ENVF_TRUNC_ALL)
-        return obs, rew, term, trunc, {}
+        return obs, rew, term, trunc, infos
+
+    def _finish_outputs(self, recs, tables, rew, term, trunc, truncated_call):
+        return {}   # RQ:198,299: infos stays empty
 
     def _live(self):
         cp = self._b.pred_capacity

@@ -1,0 +1,114 @@
+"""The walls_occlusion environment: the second-generation env plus static walls, line-of-sight rules and per-agent move
+infos ("WO:n" = line n of predpreygrass/non_evolutionary/walls_occlusion/predpreygrass_rllib_env.py in the reference).
+
+    from predpreygrass_amd.walls_occlusion import PredPreyGrass
+    env = PredPreyGrass(config)          # same config keys: num_walls, wall_placement_mode, manual_wall_positions,
+    obs, _ = env.reset(seed=3)           # include_visibility_channel, respect_los_for_movement,
+                                         # mask_observation_with_visibility (WO:101-123)
+
+The transition runs in the `ppg3_*` kernels of libppg_hip.so (predpreygrass_amd/csrc/ppg_kernel.h, WALLS); this module is
+host plumbing on top of `red_queen.BatchedRedQueen(walls=True)`.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+from .red_queen import PredPreyGrass as _RedQueenPredPreyGrass
+
+
+class PredPreyGrass(_RedQueenPredPreyGrass):
+    """`PredPreyGrass(config)` of walls_occlusion/predpreygrass_rllib_env.py (class WO:41, reset WO:203, step WO:304).
+    `reset(seed=s)` draws the walls and the initial cells from `default_rng(s)` exactly like the reference (WO:246,260),
+    and that same generator then supplies the reproduction uniforms."""
+
+    _walls = True
+    _require_all_actions = False   # WO:406 tolerates live agents without an action
+
+    def __init__(self, config=None, **kw):
+        super().__init__(config, **kw)
+        cfg = self._cfg
+        self.num_walls = cfg.get("num_walls", 20)                                  # WO:118
+        self.wall_placement_mode = cfg.get("wall_placement_mode", "random")        # WO:121
+        self.manual_wall_positions = cfg.get("manual_wall_positions", None)        # WO:122
+        self.include_visibility_channel = bool(cfg.get("include_visibility_channel", False))
+        self.respect_los_for_movement = bool(cfg.get("respect_los_for_movement", False))
+        self.mask_observation_with_visibility = bool(cfg.get("mask_observation_with_visibility", False))
+        self.wall_positions = set()
+        self.los_rejected_moves_total = 0
+        self.los_rejected_moves_by_type = {"predator": 0, "prey": 0}
+
+    def reset(self, *, seed=None, options=None):
+        """WO:203-302.  ``options={"walls": [...], "placement": (pred_xy, prey_xy, grass_xy)}`` overrides the draw."""
+        b = self._b
+        G = b.grid_size
+        self.rng = np.random.default_rng(seed)                                      # WO:135
+        self.los_rejected_moves_total = 0
+        self.los_rejected_moves_by_type = {"predator": 0, "prey": 0}
+        opts = options if isinstance(options, dict) else {}
+        max_cells = G * G
+        if self.wall_placement_mode not in ("random", "manual"):
+            raise ValueError("wall_placement_mode must be 'random' or 'manual'")  # WO:213-214
+        walls = set()
+        if "walls" in opts:
+            walls = {(int(x), int(y)) for x, y in opts["walls"]}
+        elif self.wall_placement_mode == "manual":                                  # WO:216-241
+            for pos in (self.manual_wall_positions or []):
+                try:
+                    x, y = map(int, pos)
+                except Exception:
+                    continue
+                if 0 <= x < G and 0 <= y < G:
+                    walls.add((x, y))
+        else:                                                                       # WO:242-250
+            if self.num_walls >= max_cells:
+                raise ValueError("num_walls must be less than total grid cells")
+            if self.num_walls > 0:
+                for idx in self.rng.choice(max_cells, size=self.num_walls, replace=False):
+                    walls.add((int(idx) // G, int(idx) % G))
+        self.wall_positions = walls
+        placement = opts.get("placement")
+        if placement is None:
+            total = b.P0 + b.Q0 + b.n_grass
+            free_cells = max_cells - self.num_walls                                # WO:254 (num_walls, also in manual mode)
+            if total > free_cells:
+                raise ValueError(f"Too many agents+grass ({total}) for free cells ({free_cells}) given {self.num_walls} "
+                                 f"walls on {G}x{G} grid")
+            free_indices = [i for i in range(max_cells) if (i // G, i % G) not in walls]
+            cells = [(int(i) // G, int(i) % G) for i in self.rng.choice(free_indices, size=total, replace=False)] \
+                if total > 0 else []                                               # WO:258-262
+            placement = (cells[:b.P0], cells[b.P0:b.P0 + b.Q0], cells[b.P0 + b.Q0:])
+        b.set_walls(sorted(walls))
+        p, q, g = placement
+        b.set_placement(np.asarray(p).reshape(1, -1, 2), np.asarray(q).reshape(1, -1, 2), np.asarray(g).reshape(1, -1, 2))
+        self.cumulative_rewards = {}
+        self._insertion_order = []
+        self._last_action_names = []
+        return self._collect(after_reset=True)[0], {}
+
+    def _finish_outputs(self, recs, tables, rew, term, trunc, truncated_call):
+        """WO:370-395: the scalar dicts also name every agent of the action dict (defaults 0.0 / False); infos carry
+        `los_rejected` and `move_blocked_reason` for the agents that went through the movement phase.  (The reference
+        builds these dicts from a Python set, so their order is arbitrary there; here: observation order, then the rest.)"""
+        if truncated_call:
+            return {}
+        for a in self._last_action_names:
+            if a not in rew:
+                rew[a], term[a], trunc[a] = 0.0, False, False
+        infos = {}
+        cp = self._b.pred_capacity
+        for name, sp, row, *_ in recs:
+            code = int(tables["row_info"][0][cp * sp + row])
+            if code:
+                d = {"los_rejected": int(code - 1 == 4)}
+                if code > 1:
+                    d["move_blocked_reason"] = _abi.MOVE_REASONS[code - 1]
+                if code - 1 == 4:                                                   # WO:770-772
+                    self.los_rejected_moves_total += 1
+                    self.los_rejected_moves_by_type["prey" if sp else "predator"] += 1
+                infos[name] = d
+        return infos
+
+
+def env_creator(config):
+    return PredPreyGrass(config)

@@ -14,6 +14,14 @@ recorded; the env is then driven with the live-agent protocol (actions only for 
 last call and were not terminated), one `default_rng(action_seed).integers(n_actions)` per agent in dict order.
 A case that reaches the set-order dependent spawn fallback (RQ:396-401) is rejected.
 
+Cases with variant "walls_occlusion" (tests/golden/wo/*.npz) come from
+/root/reference/predpreygrass/non_evolutionary/walls_occlusion/predpreygrass_rllib_env.py ("WO": the same env plus static
+walls, line-of-sight rules and per-agent infos).  Extra fields: wall_xy (the episode's walls, sorted), info_off[T+1] /
+info_pool / info_id / info_reason (infos dict: 0 = {"los_rejected": 0}, 1 wall, 2 occupied, 3 corner_cut, 4 los), and
+extra_off[T+1] / extra_pool / extra_id: agents that appear in the scalar dicts only (named in action_dict but gone; reward
+0.0, False, False).  That env builds its scalar dicts from a Python set (WO:376-388), so their ORDER is arbitrary in the
+reference itself: rec_* keep the observation-dict order and the digest hashes the scalar dicts in sorted key order.
+
 Stored per case:
   config_json                      the complete config dict
   pred_xy/prey_xy/grass_xy         captured placement (predators / prey in creation order, grass in id order)
@@ -50,11 +58,13 @@ def parse_agent(name):
     return POOLS.index(kind), int(idx)
 
 
-def call_digest(grid, obs, rew, term, trunc) -> bytes:
+def call_digest(grid, obs, rew, term, trunc, sort_scalars=False) -> bytes:
     h = hashlib.sha256()
     h.update(np.ascontiguousarray(grid, dtype=np.float32).tobytes())
     for k, v in obs.items():
         h.update(k.encode() + np.ascontiguousarray(v, dtype=np.float32).tobytes())
+    if sort_scalars:
+        rew, term, trunc = ({k: d[k] for k in sorted(d)} for d in (rew, term, trunc))
     for k, v in rew.items():
         h.update(k.encode() + np.float64(v).tobytes())
     for k, v in term.items():
@@ -78,6 +88,9 @@ class RecordingRng:
 
     def integers(self, *a, **k):
         raise RuntimeError("golden case reached the set-order dependent spawn fallback (RQ:396-401); change its parameters")
+
+    def choice(self, *a, **k):
+        raise RuntimeError("rng.choice is only expected inside reset() (WO:246,260)")
 
 
 def _train_v1():
@@ -140,7 +153,25 @@ CASES = {
         max_energy_gain_per_grass=1.5, max_energy_gain_per_prey=5.0, max_energy_predator=20.0, max_energy_prey=14.0,
         energy_transfer_efficiency=0.9, reproduction_energy_efficiency=0.9), 5, 33, "shuffled", 6, 300),
     "rq_trunc_seed4": (lambda: dict(max_steps=25, move_energy_cost_factor=0.01), 4, 3, "live", 5, 40),
+    # ---- walls_occlusion env ----
+    "wo_zigzag_seed1": (lambda: reference_config("predpreygrass.non_evolutionary.walls_occlusion.config.config_env_zigzag_walls"),
+                        1, 0, "live", 10, 300, "walls_occlusion"),
+    "wo_perimeter_seed2": (lambda: reference_config(
+        "predpreygrass.non_evolutionary.walls_occlusion.config.config_env_perimeter_four_gaps_walls"), 2, 4, "live", 12, 200,
+        "walls_occlusion"),
+    "wo_base_random_walls_seed3": (lambda: {}, 3, 1, "live", 25, 150, "walls_occlusion"),
+    "wo_los_two_types_seed5": (lambda: dict(
+        _TYPED, num_walls=60, respect_los_for_movement=True, mask_observation_with_visibility=True,
+        include_visibility_channel=True, type_2_action_range=5, grid_size=14, initial_num_grass=40, max_steps=80,
+        n_initial_active_type_2_predator=4, n_possible_type_2_predators=40, energy_gain_per_step_grass=0.3,
+        predator_creation_energy_threshold=8.0, prey_creation_energy_threshold=4.5), 5, 2, "live", 8, 120, "walls_occlusion"),
+    "wo_mask_only_shuffled_seed6": (lambda: dict(
+        _TYPED, num_walls=45, respect_los_for_movement=True, mask_observation_with_visibility=True,
+        include_visibility_channel=False, predator_obs_range=6, prey_obs_range=8, type_2_action_range=5, grid_size=13,
+        initial_num_grass=35, max_steps=70, n_initial_active_type_2_predator=3, n_possible_type_2_predators=30,
+        energy_gain_per_step_grass=0.3, prey_creation_energy_threshold=4.5), 6, 3, "shuffled", 7, 100, "walls_occlusion"),
 }
+REASON_CODE = {None: 0, "wall": 1, "occupied": 2, "corner_cut": 3, "los": 4}
 
 
 def capture(env):
@@ -150,14 +181,18 @@ def capture(env):
     return pred, prey, grass
 
 
-def make_case(name, build_cfg, seed, action_seed, mode, full_every, max_calls):
-    cfg = reference_default_config("red_queen")
+def make_case(name, build_cfg, seed, action_seed, mode, full_every, max_calls, variant="red_queen"):
+    wo = variant == "walls_occlusion"
+    cfg = reference_default_config(variant)
     cfg.update(build_cfg())
-    env = make_reference_env(cfg, "red_queen")
+    env = make_reference_env(cfg, variant)
     cfg = dict(env.config)
     obs, _ = env.reset(seed=seed)
     env.rng = RecordingRng(env.rng)
     pred_xy, prey_xy, grass_xy = capture(env)
+    wall_xy = np.array(sorted(env.wall_positions), dtype=np.int32).reshape(-1, 2) if wo else np.zeros((0, 2), dtype=np.int32)
+    info_off, info_pool, info_id, info_reason = [0], [], [], []
+    extra_off, extra_pool, extra_id = [0], [], []
     reset_keys = list(obs)
     reset_obs = np.concatenate([obs[k].reshape(-1) for k in reset_keys]).astype(np.float32)
     arng = np.random.default_rng(action_seed)
@@ -188,8 +223,24 @@ def make_case(name, build_cfg, seed, action_seed, mode, full_every, max_calls):
             act_pool.append(p); act_id.append(i); act_val.append(v)
         act_off.append(len(act_val))
         before = dict(env._next_idx)
-        o, r, te, tr, _ = env.step(act)
+        o, r, te, tr, infos = env.step(act)
         uni_off.append(len(env.rng.values))
+        if wo:
+            for a in sorted(infos):
+                p, i = parse_agent(a)
+                assert set(infos[a]) <= {"los_rejected", "move_blocked_reason"}
+                code = REASON_CODE[infos[a].get("move_blocked_reason")]
+                assert infos[a]["los_rejected"] == int(code == 4)
+                info_pool.append(p); info_id.append(i); info_reason.append(code)
+            for a in sorted(r):
+                if a not in o:
+                    assert r[a] == 0.0 and te[a] is False and tr[a] is False
+                    p, i = parse_agent(a)
+                    extra_pool.append(p); extra_id.append(i)
+            assert set(r) == set(te) - {"__all__"} == set(tr) - {"__all__"}
+        else:
+            assert infos == {}
+        info_off.append(len(info_id)); extra_off.append(len(extra_id))
         for a in o:
             p, i = parse_agent(a)
             rec_pool.append(p); rec_id.append(i); rec_rew.append(float(r[a]))
@@ -198,7 +249,7 @@ def make_case(name, build_cfg, seed, action_seed, mode, full_every, max_calls):
                 stats["ate_then_caught"] += 1
         rec_off.append(len(rec_id))
         term_all.append(bool(te["__all__"])); trunc_all.append(bool(tr["__all__"]))
-        digests.append(np.frombuffer(call_digest(env.grid_world_state, o, r, te, tr), dtype=np.uint8))
+        digests.append(np.frombuffer(call_digest(env.grid_world_state, o, r, te, tr, sort_scalars=wo), dtype=np.uint8))
         agents_after.append(list(env.agents))
         stats["births"] += sum(env._next_idx[k] - before[k] for k in before)
         last = te["__all__"] or tr["__all__"] or t == max_calls - 1
@@ -226,9 +277,17 @@ def make_case(name, build_cfg, seed, action_seed, mode, full_every, max_calls):
             break
     for uid, st in env.unique_agent_stats.items():
         stats["mutations"] += bool(st.get("mutated"))
-    os.makedirs(OUT_DIR, exist_ok=True)
+    out_dir = os.path.join(HERE, "wo") if wo else OUT_DIR
+    os.makedirs(out_dir, exist_ok=True)
+    stats["los_rejected"] = int(sum(1 for v in info_reason if v == 4))
+    stats["blocked"] = {k: int(sum(1 for v in info_reason if v == c)) for k, c in REASON_CODE.items() if c}
     np.savez_compressed(
-        os.path.join(OUT_DIR, name + ".npz"),
+        os.path.join(out_dir, name + ".npz"),
+        variant=variant, wall_xy=wall_xy,
+        info_off=np.array(info_off, dtype=np.int64), info_pool=np.array(info_pool, dtype=np.int8),
+        info_id=np.array(info_id, dtype=np.int32), info_reason=np.array(info_reason, dtype=np.int8),
+        extra_off=np.array(extra_off, dtype=np.int64), extra_pool=np.array(extra_pool, dtype=np.int8),
+        extra_id=np.array(extra_id, dtype=np.int32),
         config_json=json.dumps(cfg), seed=seed, action_seed=action_seed,
         pred_xy=pred_xy, prey_xy=prey_xy, grass_xy=grass_xy,
         act_off=np.array(act_off, dtype=np.int64), act_pool=np.array(act_pool, dtype=np.int8),
@@ -250,7 +309,7 @@ def make_case(name, build_cfg, seed, action_seed, mode, full_every, max_calls):
         grass_energy=np.stack(grass_energy), next_idx=np.array(next_idx, dtype=np.int32),
         reset_keys=json.dumps(reset_keys), reset_obs_data=reset_obs,
     )
-    size = os.path.getsize(os.path.join(OUT_DIR, name + ".npz"))
+    size = os.path.getsize(os.path.join(out_dir, name + ".npz"))
     print(f"{name}: {len(term_all)} calls, {len(env.rng.values)} uniforms, {stats}, next_idx={dict(env._next_idx)}, "
           f"{size / 1024:.0f} KiB")
 

@@ -9,6 +9,8 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rq")
+WALLS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wo")   # walls_occlusion env
+MOVE_REASONS = {1: "wall", 2: "occupied", 3: "corner_cut", 4: "los"}
 POOLS = ("type_1_predator", "type_2_predator", "type_1_prey", "type_2_prey")
 
 
@@ -16,16 +18,18 @@ def agent_name(pool, i):
     return f"{POOLS[int(pool)]}_{int(i)}"
 
 
-def case_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+def case_names(walls=False):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(WALLS_DIR if walls else GOLDEN_DIR, "*.npz")))
 
 
-def call_digest(grid, obs, rew, term, trunc) -> bytes:
+def call_digest(grid, obs, rew, term, trunc, sort_scalars=False) -> bytes:
     """Same definition as tests/golden/make_golden_rq.py:call_digest."""
     h = hashlib.sha256()
     h.update(np.ascontiguousarray(grid, dtype=np.float32).tobytes())
     for k, v in obs.items():
         h.update(k.encode() + np.ascontiguousarray(v, dtype=np.float32).tobytes())
+    if sort_scalars:
+        rew, term, trunc = ({k: d[k] for k in sorted(d)} for d in (rew, term, trunc))
     for k, v in rew.items():
         h.update(k.encode() + np.float64(v).tobytes())
     for k, v in term.items():
@@ -38,8 +42,10 @@ def call_digest(grid, obs, rew, term, trunc) -> bytes:
 class RQGoldenCase:
     def __init__(self, name):
         self.name = name
-        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.walls = name.startswith("wo_")
+        z = np.load(os.path.join(WALLS_DIR if self.walls else GOLDEN_DIR, name + ".npz"))
         self.z = {k: z[k] for k in z.files}
+        self.wall_xy = self.z["wall_xy"] if self.walls else None
         self.config = json.loads(str(self.z["config_json"]))  # complete config (json's Infinity -> float inf)
         self.n_calls = len(self.z["term_all"])
         self.agents_after = json.loads(str(self.z["agents_after"]))
@@ -67,6 +73,30 @@ class RQGoldenCase:
     def flags(self, t):
         return bool(self.z["term_all"][t]), bool(self.z["trunc_all"][t])
 
+    def infos(self, t):
+        """infos dict of call t of the walls env (WO:766-778,393-395); {} for the red_queen env."""
+        if not self.walls:
+            return {}
+        out = {}
+        for k in range(self.z["info_off"][t], self.z["info_off"][t + 1]):
+            code = int(self.z["info_reason"][k])
+            d = {"los_rejected": int(code == 4)}
+            if code:
+                d["move_blocked_reason"] = MOVE_REASONS[code]
+            out[agent_name(self.z["info_pool"][k], self.z["info_id"][k])] = d
+        return out
+
+    def extras(self, t):
+        """agents that appear in the scalar dicts only (named in action_dict but gone): reward 0.0, False, False"""
+        if not self.walls:
+            return []
+        return [agent_name(self.z["extra_pool"][k], self.z["extra_id"][k])
+                for k in range(self.z["extra_off"][t], self.z["extra_off"][t + 1])]
+
+    @property
+    def channels(self):
+        return 5 if (self.walls and self.config.get("include_visibility_channel")) else 4
+
     def digest(self, t) -> bytes:
         return self.z["digest"][t].tobytes()
 
@@ -75,10 +105,11 @@ class RQGoldenCase:
 
     def reset_obs(self):
         out, off = {}, 0
+        C = self.channels
         for k in self.reset_keys:
             R = self.obs_range(k)
-            out[k] = self.z["reset_obs_data"][off:off + 4 * R * R].reshape(4, R, R)
-            off += 4 * R * R
+            out[k] = self.z["reset_obs_data"][off:off + C * R * R].reshape(C, R, R)
+            off += C * R * R
         return out
 
     def full(self, t):
@@ -88,10 +119,11 @@ class RQGoldenCase:
             return None
         off = int(self.z["obs_off"][k])
         obs = {}
+        C = self.channels
         for name, _, _, _ in self.records(t):
             R = self.obs_range(name)
-            obs[name] = self.z["obs_data"][off:off + 4 * R * R].reshape(4, R, R)
-            off += 4 * R * R
+            obs[name] = self.z["obs_data"][off:off + C * R * R].reshape(C, R, R)
+            off += C * R * R
         assert off == int(self.z["obs_off"][k + 1])
         lo, hi = self.z["st_off"][k], self.z["st_off"][k + 1]
         state = {

@@ -24,6 +24,19 @@ def collect(env: BatchedRedQueen, b, tables=None):
     return recs, obs, rew, term, trunc, bool(fl & _abi.ENVF_TERM_ALL), bool(fl & _abi.ENVF_TRUNC_ALL)
 
 
+def infos_of(env: BatchedRedQueen, b, recs, tables):
+    """infos dict of the walls env (WO:766-778) from row_info."""
+    out = {}
+    for name, sp, row, *_ in recs:
+        code = int(tables["row_info"][b][env.pred_capacity * sp + row])
+        if code:
+            d = {"los_rejected": int(code - 1 == 4)}
+            if code > 1:
+                d["move_blocked_reason"] = _abi.MOVE_REASONS[code - 1]
+            out[name] = d
+    return out
+
+
 def fill_actions(env: BatchedRedQueen, b, recs, action_dict, rank):
     """Write env b's action dict into env.actions (rows of the previous records) and the per-species action order
     into `rank`.  Actions naming agents that are no longer alive are dropped, like the reference does (RQ:467,521).
@@ -54,7 +67,9 @@ def replay_golden_case(make_env, name, max_calls=None, extra_uniforms=2):
     """One golden case through BatchedRedQueen (batch 1), every call compared with what the reference returned."""
     c = RQGoldenCase(name)
     cfg = c.config
-    env = make_env(cfg, 1)
+    env = make_env(cfg, 1, **({"walls": True} if c.walls else {}))
+    if c.walls:
+        env.set_walls(c.wall_xy)
     env.set_placement(*[np.asarray(a)[None] for a in c.placement])
     recs, obs, rew, term, trunc, ta, tra = collect(env, 0)
     want = c.reset_obs()
@@ -86,7 +101,14 @@ def replay_golden_case(make_env, name, max_calls=None, extra_uniforms=2):
             assert int(es[_abi.ENV_DRAWS]) == n_used, (name, t, "draws", int(es[_abi.ENV_DRAWS]), n_used)
         te_d = dict(term); te_d["__all__"] = ta
         tr_d = dict(trunc); tr_d["__all__"] = tra
-        assert call_digest(grid, obs, rew, te_d, tr_d) == c.digest(t), (name, t, "digest")
+        if c.walls:   # scalar dicts also carry the agents named in the action dict that are gone (WO:373-388)
+            assert infos_of(env, 0, recs, tables) == c.infos(t), (name, t, "infos", infos_of(env, 0, recs, tables), c.infos(t))
+            if not tra:
+                for a in c.actions(t):
+                    if a not in rew:
+                        rew[a], te_d[a], tr_d[a] = 0.0, False, False
+            assert sorted(a for a in rew if a not in obs) == sorted(c.extras(t)), (name, t, "extras")
+        assert call_digest(grid, obs, rew, te_d, tr_d, sort_scalars=c.walls) == c.digest(t), (name, t, "digest")
         full = c.full(t)
         if full is not None:
             fobs, fgrid, fstate, fgrass, next_idx = full
@@ -144,6 +166,8 @@ def compare_env_with_oracle(env: BatchedRedQueen, b, orc, tables, tag=""):
         assert int(tables["row_lastrep"][b][s]) == st["last_reproduction"], (tag, b, nm, "last_reproduction")
     gxy, ge = orc.grass_state()
     assert tables["grass_energy"][b][: env.n_grass].tobytes() == ge.tobytes(), (tag, b, "grass energy")
+    if env.walls:
+        assert infos_of(env, b, recs, tables) == orc.infos_of_last_call(), (tag, b, "infos")
     op = env.obs_pred[b].cpu().numpy()
     oq = env.obs_prey[b].cpu().numpy()
     for k, (nm, sp, row, _, _, _) in enumerate(recs):

@@ -76,3 +76,31 @@ def test_random_gen2_config_matches_oracle_on_gpu(seed):
     from predpreygrass_amd.red_queen import PredPreyGrass
     from tests.test_rq_random_configs import run_differential
     run_differential(lambda cfg: PredPreyGrass(cfg, device="cuda:0"), seed)
+
+
+# ---- walls_occlusion variant (ppg3_* kernels) -------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", case_names(walls=True))
+def test_walls_golden_cases_on_gpu(name):
+    replay_golden_case(make_env, name)
+
+
+def test_walls_random_rollout_matches_oracle_on_gpu():
+    case = RQGoldenCase("wo_los_two_types_seed5")
+    cfg, walls = case.config, case.wall_xy
+
+    def oracle():
+        o = RQOracleEnv(cfg, walls=True)
+        o.set_walls(walls)
+        return o
+    env = make_env(cfg, 64, walls=True)
+    env.set_walls(walls)
+    n_resets, stats = rollout_vs_oracle(env, oracle, seed0=31, n_calls=250, check_every=5, check_grid=True)
+    assert stats["births"] > 20 and n_resets > 10
+
+
+@pytest.mark.parametrize("seed", range(200, 220))
+def test_random_walls_config_matches_oracle_on_gpu(seed):
+    from predpreygrass_amd.walls_occlusion import PredPreyGrass as WallsEnv
+    from tests.test_rq_random_configs import run_differential
+    run_differential(lambda cfg: WallsEnv(cfg, device="cuda:0"), seed, walls=True)

@@ -12,7 +12,7 @@ from tests import emu_backend
 from tests.golden_io_rq import RQGoldenCase, case_names
 from tests.parity_utils_rq import replay_golden_case, rollout_vs_oracle
 
-CASES = case_names()
+CASES = case_names() + case_names(walls=True)
 
 
 def make_env(cfg, B, **kw):
@@ -48,3 +48,23 @@ def test_gen2_rejects_bad_configs():
         make_env(dict(cfg, n_possible_type_1_predators=70000), 1)
     with pytest.raises(ValueError):
         BatchedRedQueen(None, _library=emu_backend.library())
+
+
+def _walls_oracle(cfg, walls):
+    o = RQOracleEnv(cfg, walls=True)
+    o.set_walls(walls)
+    return o
+
+
+def test_emulated_random_rollout_with_walls_matches_oracle():
+    """Device reset around the walls (Philox over the free cells), wall / corner / line-of-sight rules, masked
+    observations with the visibility channel: every call against the oracle."""
+    case = RQGoldenCase("wo_los_two_types_seed5")
+    cfg, walls = case.config, case.wall_xy
+    env = make_env(cfg, 3, walls=True)
+    env.set_walls(walls)
+    n_resets, stats = rollout_vs_oracle(env, lambda: _walls_oracle(cfg, walls), seed0=11, n_calls=120, check_every=1,
+                                        check_grid=True)
+    assert n_resets >= 3 and stats["births"] > 5
+    info = env.row_info.numpy()
+    assert (info <= 5).all()

@@ -6,17 +6,19 @@ import pytest
 from oracle.rq_oracle import RQOracleEnv, philox_uniform
 from tests.golden_io_rq import RQGoldenCase, call_digest, case_names
 
-CASES = case_names()
+CASES = case_names() + case_names(walls=True)
 
 
 def test_golden_cases_present():
-    assert len(CASES) >= 7
+    assert len(case_names()) >= 7 and len(case_names(walls=True)) >= 5
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_replays_reference(name):
     case = RQGoldenCase(name)
-    env = RQOracleEnv(case.config)
+    env = RQOracleEnv(case.config, walls=case.walls)
+    if case.walls:
+        env.set_walls(case.wall_xy)
     obs, info = env.reset_from_placement(*case.placement)
     assert info == {}
     ref = case.reset_obs()
@@ -26,19 +28,21 @@ def test_oracle_replays_reference(name):
     for t in range(case.n_calls):
         u, n_used = case.uniforms(t, extra=3)
         obs, rew, term, trunc, infos = env.step(case.actions(t), uniforms=u)
-        assert infos == {}
+        assert infos == case.infos(t), t
         assert env.last_draws == n_used, (t, env.last_draws, n_used)
         assert env.last_fallback_spawns == 0 and env.last_failed_spawns == 0
         recs = case.records(t)
         assert list(obs) == [r[0] for r in recs], t
-        assert list(rew) == list(obs) and list(term)[:-1] == list(obs) and list(trunc)[:-1] == list(obs)
+        extra = case.extras(t)
+        assert list(rew) == list(obs) + extra and list(term)[:-1] == list(rew) and list(trunc)[:-1] == list(rew)
+        assert all(rew[a] == 0.0 and term[a] is False and trunc[a] is False for a in extra)
         for name_, r, te, tr in recs:
             assert rew[name_] == r, (t, name_)
             assert term[name_] == te and trunc[name_] == tr, (t, name_)
         assert (term["__all__"], trunc["__all__"]) == case.flags(t)
         grid = env.grid_world_state
         assert grid.dtype == np.float32
-        assert call_digest(grid, obs, rew, term, trunc) == case.digest(t), t
+        assert call_digest(grid, obs, rew, term, trunc, sort_scalars=case.walls) == case.digest(t), t
         assert env.agents == case.agents_after[t], t
         full = case.full(t)
         if full is not None:
