@@ -145,7 +145,22 @@ typedef struct ppg_config {
     int32_t kickback;                   /* 0 = base env */
     double kickback_reward_predator;
     double kickback_reward_prey;
+    /* drive-conditioned variant (drive_conditioned_environment/predpreygrass_rllib_env.py, "DRV"): n_drive[species] extra
+     * observation channels, each filled with one per-agent scalar (DRV:54-89,551-616); both 0 = base env.  The observation
+     * tensors then have 4 + n_drive[0] (predators) / 4 + n_drive[1] (prey) channels. */
+    int32_t n_drive[2];                 /* <= 4 each */
+    int32_t drive_kind[2][4];           /* PPG_DRIVE_* per channel, in the order of the reference's *_drive_channels lists */
+    double hunger_safe_energy[2];       /* DRV:76-77 */
+    double prey_opportunity_normalizer;    /* DRV:78 */
+    double predator_danger_normalizer;     /* DRV:79-82 */
+    double grass_opportunity_normalizer;   /* DRV:83-86 */
 } ppg_config;
+
+#define PPG_DRIVE_HUNGER_PRESSURE 0          /* clip01(1 - energy / hunger_safe_energy), DRV:591-593 */
+#define PPG_DRIVE_REPRODUCTIVE_READINESS 1   /* clip01(energy / creation threshold), DRV:595-599 */
+#define PPG_DRIVE_PREY_OPPORTUNITY 2         /* clip01(np.sum(window prey channel) / normalizer), DRV:601-602 */
+#define PPG_DRIVE_PREDATOR_DANGER 3          /* DRV:604-605 */
+#define PPG_DRIVE_GRASS_OPPORTUNITY 4        /* DRV:607-608 */
 
 /* Caller-owned device buffers.  B = batch, S = pred_capacity + prey_capacity,
  * NG = grass_capacity, Rp/Rq = predator/prey obs range. */

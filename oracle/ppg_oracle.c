@@ -208,6 +208,57 @@ static void observe_at(const ppo_env *e, int xp, int yp, int R, double *obs) {
         }
 }
 
+/* np.sum of n contiguous float64 values: numpy's pairwise summation (numpy/core/src/umath/loops_utils.h.src,
+ * pairwise_sum: plain loop below 8 elements, eight interleaved accumulators up to 128, halves above).  The drive
+ * features sum a whole (R,R) channel of the observation (DRV:601-608), so the order of the additions matters. */
+static double np_sum(const double *a, int n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int i;
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_sum(a, n2) + np_sum(a + n2, n - n2);
+    }
+}
+
+static int n_channels(const ppo_env *e, int type) { return 4 + e->c.n_drive[type]; }
+
+/* _safe_clip01, DRV:612-615 */
+static double safe_clip01(double v) {
+    if (!(v - v == 0.0)) return 0.0;   /* not finite */
+    return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+}
+
+/* _get_drive_features / _get_drive_feature (DRV:577-610) appended to an observation whose world channels are filled */
+static void add_drive_channels(const ppo_env *e, int type, double energy, int R, double *obs) {
+    const ppo_config *c = &e->c;
+    for (int k = 0; k < c->n_drive[type]; ++k) {
+        double v = 0.0;
+        switch (c->drive_kind[type][k]) {
+            case PPO_DRIVE_HUNGER: v = safe_clip01(1.0 - energy / c->hunger_safe_energy[type]); break;
+            case PPO_DRIVE_REPRO:
+                v = safe_clip01(energy / (type == PPO_PREDATOR ? c->predator_creation_energy_threshold
+                                                               : c->prey_creation_energy_threshold));
+                break;
+            case PPO_DRIVE_PREY_OPP: v = safe_clip01(np_sum(obs + 2 * R * R, R * R) / c->prey_opportunity_normalizer); break;
+            case PPO_DRIVE_PRED_DANGER: v = safe_clip01(np_sum(obs + 1 * R * R, R * R) / c->predator_danger_normalizer); break;
+            case PPO_DRIVE_GRASS_OPP: v = safe_clip01(np_sum(obs + 3 * R * R, R * R) / c->grass_opportunity_normalizer); break;
+        }
+        for (int i = 0; i < R * R; ++i) obs[(size_t)(4 + k) * R * R + i] = v;   /* DRV:566-569 */
+    }
+}
+
 static int entry_of(const ppo_env *e, int type, int id) {
     if (id < 0 || id > npos(e, type)) return -1;
     int k = e->ent_index[type][id];
@@ -219,19 +270,21 @@ int ppo_observe(const ppo_env *e, int32_t type, int32_t id, double *dst) {
     int k = entry_of(e, type, id);
     if (k < 0) return -1;
     observe_at(e, e->ent_x[k], e->ent_y[k], obs_range(e, type), dst);
+    add_drive_channels(e, type, e->energy[type][id], obs_range(e, type), dst);
     return 0;
 }
 
 /* observations[agent] = self._get_observation(agent) */
 static void put_obs(ppo_env *e, int type, int id) {
     int R = obs_range(e, type);
-    size_t len = (size_t)4 * R * R;
+    size_t len = (size_t)n_channels(e, type) * R * R;
     if (e->arena_len + len > e->arena_cap) {
         while (e->arena_len + len > e->arena_cap) e->arena_cap *= 2;
         e->arena = (double *)realloc(e->arena, e->arena_cap * sizeof(double));
     }
     int k = entry_of(e, type, id);
     observe_at(e, e->ent_x[k], e->ent_y[k], R, e->arena + e->arena_len);
+    add_drive_channels(e, type, e->energy[type][id], R, e->arena + e->arena_len);
     e->obs_at[type][id] = (int)e->arena_len;
     e->has_obs[type][id] = 1;
     e->arena_len += len;
@@ -299,7 +352,7 @@ static int emit_records(ppo_env *e, ppo_step_out *out) {
         r->terminated = e->term[t][id];
         r->truncated = e->trunc[t][id];
         r->obs_offset = e->obs_at[t][id];
-        r->obs_len = 4 * R * R;
+        r->obs_len = n_channels(e, t) * R * R;
     }
     out->n_records = n;
     out->records = e->rec;

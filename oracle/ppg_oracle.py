@@ -72,7 +72,35 @@ class _Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS] + [
         ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double),
         ("reward_mode", C.c_int32), ("kickback", C.c_int32), ("kickback_reward_predator", C.c_double),
-        ("kickback_reward_prey", C.c_double)]
+        ("kickback_reward_prey", C.c_double),
+        ("n_drive", C.c_int32 * 2), ("drive_kind", (C.c_int32 * 4) * 2), ("hunger_safe_energy", C.c_double * 2),
+        ("prey_opportunity_normalizer", C.c_double), ("predator_danger_normalizer", C.c_double),
+        ("grass_opportunity_normalizer", C.c_double)]
+
+
+DRIVE_KINDS = {"hunger_pressure": 0, "reproductive_readiness": 1, "prey_opportunity": 2, "predator_danger_pressure": 3,
+               "grass_opportunity": 4}
+# drive_conditioned_environment/predpreygrass_rllib_env.py:56-75
+DEFAULT_PREDATOR_DRIVES = ["hunger_pressure", "reproductive_readiness", "prey_opportunity"]
+DEFAULT_PREY_DRIVES = ["hunger_pressure", "reproductive_readiness", "predator_danger_pressure", "grass_opportunity"]
+
+
+def fill_drive_config(c, cfg, raw, enabled):
+    """The drive-channel settings of the drive-conditioned env (its :54-89) into a config struct `c`."""
+    lists = (raw.get("predator_drive_channels", DEFAULT_PREDATOR_DRIVES), raw.get("prey_drive_channels", DEFAULT_PREY_DRIVES))
+    on = enabled and bool(raw.get("enable_drive_channels", True))
+    for t in range(2):
+        c.n_drive[t] = len(lists[t]) if on else 0
+        for k, name in enumerate(lists[t] if on else []):
+            if name not in DRIVE_KINDS:
+                raise ValueError(f"Unknown drive feature: {name!r}")
+            c.drive_kind[t][k] = DRIVE_KINDS[name]
+    c.hunger_safe_energy[0] = float(raw.get("predator_hunger_safe_energy", cfg["initial_energy_predator"]))
+    c.hunger_safe_energy[1] = float(raw.get("prey_hunger_safe_energy", cfg["initial_energy_prey"]))
+    c.prey_opportunity_normalizer = float(raw.get("prey_opportunity_normalizer", cfg["initial_energy_prey"] * 3))
+    c.predator_danger_normalizer = float(raw.get("predator_danger_normalizer", cfg["initial_energy_predator"] * 2))
+    c.grass_opportunity_normalizer = float(raw.get("grass_opportunity_normalizer", raw.get("initial_energy_grass", 2.0) * 5))
+    return (4 + c.n_drive[0], 4 + c.n_drive[1])
 
 
 class _Record(C.Structure):
@@ -163,7 +191,11 @@ def random_action(seed: int, episode: int, step: int, type_: int, row: int) -> i
 class OracleEnv:
     """The reference env's interface on top of the C restatement."""
 
-    def __init__(self, config: dict | None = None):
+    def __init__(self, config: dict | None = None, drive: bool | None = None):
+        """drive: the drive-conditioned env (extra constant-filled observation channels); default: the config's
+        `enable_drive_channels` key (absent = base env)."""
+        if drive is None:
+            drive = bool((config or {}).get("enable_drive_channels", False))
         cfg = dict(DEFAULT_CONFIG)
         if config:
             cfg.update({k: v for k, v in config.items() if k in cfg})
@@ -183,6 +215,7 @@ class OracleEnv:
         c.kickback = int("kickback_reward_predator" in kb or "kickback_reward_prey" in kb)
         c.kickback_reward_predator = float(kb.get("kickback_reward_predator", 10.0))
         c.kickback_reward_prey = float(kb.get("kickback_reward_prey", 10.0))
+        self.channels = fill_drive_config(c, cfg, config or {}, drive)
         self._L = lib()
         self._h = self._L.ppo_create(C.byref(c))
         if not self._h:
@@ -209,7 +242,7 @@ class OracleEnv:
             name = agent_name(r.type, r.id)
             R = self._obs_range(r.type)
             a = np.ctypeslib.as_array(o.obs, shape=(r.obs_offset + r.obs_len,))[r.obs_offset:]
-            obs[name] = a.reshape(4, R, R).copy()
+            obs[name] = a.reshape(self.channels[r.type], R, R).copy()
             rew[name] = float(r.reward)
             term[name] = bool(r.terminated)
             trunc[name] = bool(r.truncated)
@@ -326,7 +359,7 @@ class OracleEnv:
     def _get_observation(self, name):
         t, i = parse_agent(name)
         R = self._obs_range(t)
-        out = np.empty(4 * R * R, dtype=np.float64)
+        out = np.empty(self.channels[t] * R * R, dtype=np.float64)
         if self._L.ppo_observe(self._h, t, i, out.ctypes.data) != 0:
             raise KeyError(name)
-        return out.reshape(4, R, R)
+        return out.reshape(self.channels[t], R, R)

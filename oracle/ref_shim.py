@@ -35,6 +35,7 @@ VARIANTS = {
     "dense_rewards": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_dense_rewards",
     "dense_rewards_additive": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_dense_rewards_additive",
     "sparse_rewards_plus_kickback": "predpreygrass/non_evolutionary/project_reward_shaping/base_environment_sparse_rewards_plus_kickback",
+    "drive_conditioned": "predpreygrass/non_evolutionary/drive_conditioned_environment",
     # second generation without walls / line of sight; its configs live in config/*.py
     "red_queen": "predpreygrass/non_evolutionary/red_queen",
     # the same plus static walls, line-of-sight masking and per-agent infos

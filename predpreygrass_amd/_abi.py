@@ -50,7 +50,16 @@ class PpgConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in _INT_FIELDS] + [(n, C.c_double) for n in _DBL_FIELDS] + [
         ("season_length_steps", C.c_int32), ("season_high_multiplier", C.c_double), ("season_low_multiplier", C.c_double),
         ("reward_mode", C.c_int32), ("kickback", C.c_int32), ("kickback_reward_predator", C.c_double),
-        ("kickback_reward_prey", C.c_double)]
+        ("kickback_reward_prey", C.c_double),
+        # drive-conditioned variant (drive_conditioned_environment/predpreygrass_rllib_env.py:54-89)
+        ("n_drive", C.c_int32 * 2), ("drive_kind", (C.c_int32 * 4) * 2), ("hunger_safe_energy", C.c_double * 2),
+        ("prey_opportunity_normalizer", C.c_double), ("predator_danger_normalizer", C.c_double),
+        ("grass_opportunity_normalizer", C.c_double)]
+
+DRIVE_KINDS = {"hunger_pressure": 0, "reproductive_readiness": 1, "prey_opportunity": 2, "predator_danger_pressure": 3,
+               "grass_opportunity": 4}
+DEFAULT_PREDATOR_DRIVES = ["hunger_pressure", "reproductive_readiness", "prey_opportunity"]                  # its :56-63
+DEFAULT_PREY_DRIVES = ["hunger_pressure", "reproductive_readiness", "predator_danger_pressure", "grass_opportunity"]  # :64-72
 
 
 # include/ppg.h: struct ppg_config_gen2 (red_queen/predpreygrass_rllib_env.py:28-86 and the config.get calls in step())

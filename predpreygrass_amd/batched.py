@@ -55,10 +55,31 @@ class BatchedPredPreyGrass:
         self.Rp, self.Rq = int(cfg["predator_obs_range"]), int(cfg["prey_obs_range"])
         self.P0, self.Q0 = int(cfg["n_initial_active_predator"]), int(cfg["n_initial_active_prey"])
         self.n_grass = int(cfg["initial_num_grass"])
+        # drive-conditioned variant (drive_conditioned_environment/predpreygrass_rllib_env.py:54-89): extra observation
+        # channels filled with per-agent scalars; absent / False = the base environment
+        drive = bool(cfg.get("enable_drive_channels", False))
+        drive_lists = (list(cfg.get("predator_drive_channels", _abi.DEFAULT_PREDATOR_DRIVES)) if drive else [],
+                       list(cfg.get("prey_drive_channels", _abi.DEFAULT_PREY_DRIVES)) if drive else [])
+        for lst in drive_lists:
+            for name in lst:
+                if name not in _abi.DRIVE_KINDS:
+                    raise ValueError(f"Unknown drive feature: {name!r}")   # its :610
+            if len(lst) > 4:
+                raise ValueError("at most 4 drive channels per species")
+        self.obs_channels_pred, self.obs_channels_prey = 4 + len(drive_lists[0]), 4 + len(drive_lists[1])
         self._alloc_buffers(prey_capacity)
         NG = self.grass_capacity
 
         c = _abi.PpgConfig()
+        for t in range(2):
+            c.n_drive[t] = len(drive_lists[t])
+            for k, name in enumerate(drive_lists[t]):
+                c.drive_kind[t][k] = _abi.DRIVE_KINDS[name]
+        c.hunger_safe_energy[0] = float(cfg.get("predator_hunger_safe_energy", cfg["initial_energy_predator"]))
+        c.hunger_safe_energy[1] = float(cfg.get("prey_hunger_safe_energy", cfg["initial_energy_prey"]))
+        c.prey_opportunity_normalizer = float(cfg.get("prey_opportunity_normalizer", cfg["initial_energy_prey"] * 3))
+        c.predator_danger_normalizer = float(cfg.get("predator_danger_normalizer", cfg["initial_energy_predator"] * 2))
+        c.grass_opportunity_normalizer = float(cfg.get("grass_opportunity_normalizer", cfg["initial_energy_grass"] * 5))
         c.abi_version = _abi.ABI_VERSION
         c.grid_size, c.predator_obs_range, c.prey_obs_range = self.grid_size, self.Rp, self.Rq
         c.max_steps = int(cfg["max_steps"])
@@ -139,8 +160,9 @@ class BatchedPredPreyGrass:
         self.grass_xy = z((B, NG), torch.int16)
         self.grass_energy = z((B, NG), torch.float64)
         nc = getattr(self, "obs_channels", 4)
-        self.obs_pred = z((B, self.pred_capacity, nc, self.Rp, self.Rp), self.obs_dtype)
-        self.obs_prey = z((B, self.prey_capacity, nc, self.Rq, self.Rq), self.obs_dtype)
+        ncp, ncq = getattr(self, "obs_channels_pred", nc), getattr(self, "obs_channels_prey", nc)
+        self.obs_pred = z((B, self.pred_capacity, ncp, self.Rp, self.Rp), self.obs_dtype)
+        self.obs_prey = z((B, self.prey_capacity, ncq, self.Rq, self.Rq), self.obs_dtype)
         self.actions = torch.full((B, S), _abi.ACTION_NONE, dtype=torch.int8, device=dev)
 
     def _create_handle(self, c, create_fn):

@@ -15,6 +15,7 @@
 #define PPG_K(name, NQ, MODE, FAST) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K2(name, NQ, MODE, FAST) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K3(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
+#define PPG_K4(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #include "ppg_kernel_list.h"
 
 PPG_DEFINE_KERNELS(1)
@@ -26,6 +27,9 @@ PPG_DEFINE_KERNELS2(4)
 PPG_DEFINE_KERNELS3(1)
 PPG_DEFINE_KERNELS3(2)
 PPG_DEFINE_KERNELS3(4)
+PPG_DEFINE_KERNELS4(1)
+PPG_DEFINE_KERNELS4(2)
+PPG_DEFINE_KERNELS4(4)
 
 typedef void (*ppg_kernel_fn)(const ppg::KParams);
 
@@ -46,6 +50,15 @@ static ppg_kernel_fn pick_kernel_walls(int nq, int mode) {
         {ppg3_step_q1, ppg3_reset_q1, ppg3_observe_q1, ppg3_grid_q1, ppg3_step_ord_q1},
         {ppg3_step_q2, ppg3_reset_q2, ppg3_observe_q2, ppg3_grid_q2, ppg3_step_ord_q2},
         {ppg3_step_q4, ppg3_reset_q4, ppg3_observe_q4, ppg3_grid_q4, ppg3_step_ord_q4},
+    };
+    return table[nq == 1 ? 0 : nq == 2 ? 1 : 2][mode];
+}
+
+static ppg_kernel_fn pick_kernel_drive(int nq, int mode) {
+    static const ppg_kernel_fn table[3][5] = {
+        {ppg4_step_q1, ppg4_reset_q1, ppg4_observe_q1, ppg4_grid_q1, ppg4_step_ord_q1},
+        {ppg4_step_q2, ppg4_reset_q2, ppg4_observe_q2, ppg4_grid_q2, ppg4_step_ord_q2},
+        {ppg4_step_q4, ppg4_reset_q4, ppg4_observe_q4, ppg4_grid_q4, ppg4_step_ord_q4},
     };
     return table[nq == 1 ? 0 : nq == 2 ? 1 : 2][mode];
 }
@@ -93,7 +106,8 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
     const bool fast = P.nch_p <= 2 && P.nch_q <= 3;
     if (h->gen2 && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for second-generation handles", mode);
-    const ppg_kernel_fn fn = !h->gen2 ? pick_kernel(h->nq, mode, fast)
+    if (h->drive && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for the drive-conditioned variant", mode);
+    const ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
                              : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);
     hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(64), (size_t)P.lds_bytes, (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());

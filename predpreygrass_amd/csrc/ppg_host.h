@@ -19,6 +19,7 @@
 #include "ppg_kernel.h"
 
 struct ppg_handle {
+    int32_t drive;  // drive-conditioned variant of the base family (cfg.n_drive)
     ppg_config cfg;
     ppg_config_gen2 cfg2;
     int32_t gen2;  // created by ppg_create_gen2
@@ -60,8 +61,9 @@ static int ppg_obs_chunks(int R) { return (4 * R * R + 127) / 128; }
 
 static int ppg_obs_chunks_c(int R, int channels) { return (channels * R * R + 127) / 128; }
 
-// channels = 4, or 5 in the walls variant with the visibility channel (its elements: bit 28 set, channel bits 0)
-static void ppg_build_lut(int R, int G, int map_n, uint32_t *out, int channels = 4) {
+// channels = 4; 5 in the walls variant with the visibility channel (its elements: bit 28 set, channel bits 0); 4 + n_drive
+// in the drive-conditioned variant (drive elements: bit 29 set, bits 24-25 = index of the drive channel)
+static void ppg_build_lut(int R, int G, int map_n, uint32_t *out, int channels = 4, bool drive = false) {
     const int blk = channels * R * R, off = (R - 1) / 2;
     const int W = 2 * off + 1;  // BASE:532-539: the window is x-off..x+off
     const int nwords = ppg_obs_chunks_c(R, channels) * 128;
@@ -72,7 +74,9 @@ static void ppg_build_lut(int R, int G, int map_n, uint32_t *out, int channels =
             const int cm = c < 4 ? c : 0;
             const int moff = cm * map_n + (i - off) * G + (j - off);
             d = ((uint32_t)moff & 0xFFFFu) | ((uint32_t)(i - off + 8) << 16) | ((uint32_t)(j - off + 8) << 20) |
-                ((uint32_t)cm << 24) | 0x4000000u | ((i < W && j < W) ? 0x8000000u : 0u) | (c == 4 ? 0x10000000u : 0u);
+                ((uint32_t)cm << 24) | 0x4000000u | ((i < W && j < W) ? 0x8000000u : 0u) |
+                ((c >= 4 && !drive) ? 0x10000000u : 0u);
+            if (c >= 4 && drive) d = 0x4000000u | 0x20000000u | ((uint32_t)(c - 4) << 24);
         }
         out[e] = d;
     }
@@ -136,9 +140,30 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.off_val = off; off += (1 + P.S + P.cap_grass) * 8;
     off = (off + 15) / 16 * 16;
     P.off_scr = off; off += (P.S * 8 > 1024 ? P.S * 8 : 1024);
+    const bool drive = !h->gen2 && (c.n_drive[0] > 0 || c.n_drive[1] > 0);
+    if (!h->gen2) {
+        for (int t = 0; t < 2; ++t) {
+            if (c.n_drive[t] < 0 || c.n_drive[t] > 4) return ppg_fail(h, PPG_EINVAL, "n_drive must be in 0..4");
+            for (int k = 0; k < c.n_drive[t]; ++k)
+                if (c.drive_kind[t][k] < 0 || c.drive_kind[t][k] > 4) return ppg_fail(h, PPG_EINVAL, "unknown drive feature %d", c.drive_kind[t][k]);
+        }
+        if (drive && c.kickback) return ppg_fail(h, PPG_EINVAL, "drive channels cannot be combined with the kickback variant");
+    }
     const int channels = (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
-    P.nch_p = ppg_obs_chunks_c(P.Rp, channels); P.nch_q = ppg_obs_chunks_c(P.Rq, channels);
+    const int ch_p = drive ? 4 + c.n_drive[0] : channels, ch_q = drive ? 4 + c.n_drive[1] : channels;
+    P.nch_p = ppg_obs_chunks_c(P.Rp, ch_p); P.nch_q = ppg_obs_chunks_c(P.Rq, ch_q);
     P.off_lut = off; off += (P.nch_p + P.nch_q) * 128 * 4;
+    if (drive) {  // staging area for the window sums of the drive features
+        for (int t = 0; t < 2; ++t) {
+            P.n_drive[t] = c.n_drive[t]; P.hunger_safe[t] = c.hunger_safe_energy[t];
+            for (int k = 0; k < 4; ++k) P.drive_kind[t][k] = c.drive_kind[t][k];
+        }
+        P.norm_prey_opp = c.prey_opportunity_normalizer; P.norm_pred_danger = c.predator_danger_normalizer;
+        P.norm_grass_opp = c.grass_opportunity_normalizer;
+        const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;
+        off = (off + 15) / 16 * 16;
+        P.off_win = off; off += rmax * rmax * 8;
+    }
     if (h->gen2 && h->cfg2.walls) {  // wall bitmap
         P.n_wall_words = (n + 31) / 32;
         off = (off + 15) / 16 * 16;
@@ -156,8 +181,8 @@ static int ppg_validate_and_layout(ppg_handle *h) {
 
     if (3 * P.map_n + 8 * c.grid_size + 8 > 32767) return ppg_fail(h, PPG_EINVAL, "grid too large for 16-bit map offsets");
     h->lut_host.assign((size_t)(P.nch_p + P.nch_q) * 128, 0u);
-    ppg_build_lut(P.Rp, P.G, P.map_n, h->lut_host.data(), channels);
-    ppg_build_lut(P.Rq, P.G, P.map_n, h->lut_host.data() + (size_t)P.nch_p * 128, channels);
+    ppg_build_lut(P.Rp, P.G, P.map_n, h->lut_host.data(), ch_p, drive);
+    ppg_build_lut(P.Rq, P.G, P.map_n, h->lut_host.data() + (size_t)P.nch_p * 128, ch_q, drive);
     return PPG_OK;
 }
 
@@ -240,6 +265,7 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     if (cfg) h->cfg = *cfg; else h->cfg2 = *cfg2;
     h->bufs = *bufs; h->batch = batch; h->device = device;
     h->lut_dev = nullptr; h->backend = nullptr; h->prof_dev = nullptr; h->err[0] = 0;
+    h->drive = (cfg && (cfg->n_drive[0] > 0 || cfg->n_drive[1] > 0)) ? 1 : 0;
     int rc = cfg2 ? ppg_validate_and_layout_gen2(h) : ppg_validate_and_layout(h);
     if (rc == PPG_OK) rc = backend_init(h, device);
     if (rc != PPG_OK) {
@@ -297,6 +323,7 @@ int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t 
     if (n_steps < 1) return ppg_fail(h, PPG_EINVAL, "n_steps must be >= 1");
     if (h->cfg.kickback) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support the kickback variant");
     if (h->gen2) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support second-generation handles");
+    if (h->drive) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support the drive-conditioned variant");
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
     ppg::KParams P = h->base;

@@ -90,6 +90,13 @@ struct KParams {
     int32_t mask_obs;             // mask_observation_with_visibility (WO:111)
     int32_t n_wall_words;         // 32-bit words of the per-env wall bitmap: ceil(G*G / 32)
     int32_t off_wall;             // LDS offset of the wall bitmap
+    // drive-conditioned variant of the base family (drive_conditioned_environment/predpreygrass_rllib_env.py, "DRV")
+    int32_t n_drive[2];           // extra constant-filled observation channels per species (DRV:70-75), <= 4
+    int32_t drive_kind[2][4];     // 0 hunger_pressure, 1 reproductive_readiness, 2 prey_opportunity, 3 predator_danger_pressure,
+                                  // 4 grass_opportunity (DRV:587-608)
+    int32_t off_win;              // LDS offset of the window staging area (one float64 per window cell)
+    int32_t pad3_;
+    double hunger_safe[2], norm_prey_opp, norm_pred_danger, norm_grass_opp;   // DRV:76-86
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
     int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
@@ -211,7 +218,8 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // red_queen/predpreygrass_rllib_env.py, "RQ").  Its own kernel variants; the base kernels compile none of it.
 // WALLS (with GEN2): the walls_occlusion variant -- static walls in a per-env bitmap, observation channel 0 = walls,
 // optional line-of-sight mask / fifth channel, wall- and LOS-blocked moves, per-agent move infos.
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, class KP, class KC>
+// DRIVE (base family): the drive-conditioned variant -- extra observation channels filled with per-agent scalars.
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, class KP, class KC>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
@@ -1057,7 +1065,78 @@ struct Env {
         wv::sync();
     }
 
-    PPG_MEMBER void obs_row(int type, int j, uint32_t s_xy) {
+    // ---- drive channels (DRV:551-616) ------------------------------------------------------------
+    // np.sum over the n staged float64 values win[lo .. lo+n): numpy's pairwise summation (plain loop below 8 elements,
+    // eight interleaved accumulators up to 128, two halves above) -- the order of the additions is part of the result.
+    PPG_MEMBER double np_sum_block(const double *win, int lo, int n) const {
+        if (n < 8) {
+            double res = 0.0;
+            for (int i = 0; i < n; ++i) res += first_f64(win[lo + i]);
+            return res;
+        }
+        const int n8 = n - (n & 7);
+        double acc = 0.0;
+        if (ln < 8) {
+            acc = win[lo + ln];
+            for (int i = 8 + ln; i < n8; i += 8) acc += win[lo + i];
+        }
+        double r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = readlane_f64(acc, q);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int i = n8; i < n; ++i) res += first_f64(win[lo + i]);
+        return res;
+    }
+    // np.sum(observation[ch]) for the agent of `type` standing on s_xy (DRV:601-608)
+    PPG_MEMBER double window_sum(int type, int ch, uint32_t s_xy) {
+        const int R = type ? P.Rq : P.Rp, n = R * R;
+        const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
+        const int s_cell = x * P.G + y;
+        double *win = (double *)((unsigned char *)map + C.off_win - P.off_map);
+        const uint32_t *L = lut + (type ? P.nch_p * 128 : 0) + ch * n;
+        wv::sync();
+        for (int i = ln; i < n; i += 64) {
+            const uint32_t w = L[i];
+            const int gx = x + (int)((w >> 16) & 15u) - 8, gy = y + (int)((w >> 20) & 15u) - 8;
+            const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+            win[i] = val[map[inb ? (int)(int16_t)(w & 0xFFFFu) + s_cell : 0]];
+        }
+        wv::sync();
+        double res;
+        if (n <= 128) {
+            res = np_sum_block(win, 0, n);
+        } else {
+            int n2 = n / 2;
+            n2 -= n2 & 7;
+            const double a = np_sum_block(win, 0, n2);
+            res = a + np_sum_block(win, n2, n - n2);
+        }
+        wv::sync();
+        return res;
+    }
+    // _safe_clip01 (DRV:612-615)
+    static PPG_MEMBER double safe_clip01(double v) {
+        if (!(v - v == 0.0)) return 0.0;
+        return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    }
+    // the drive features of one agent (DRV:577-610); s_e = its energy at this moment
+    PPG_MEMBER void drive_features(int type, double s_e, uint32_t s_xy, double (&dv)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dv[k] = 0.0;
+            if (k >= (type ? C.n_drive[1] : C.n_drive[0])) continue;
+            const int kind = type ? C.drive_kind[1][k] : C.drive_kind[0][k];
+            double v;
+            if (kind == 0) v = 1.0 - s_e / (type ? C.hunger_safe[1] : C.hunger_safe[0]);
+            else if (kind == 1) v = s_e / (type ? C.thr_q : C.thr_p);
+            else if (kind == 2) v = window_sum(type, 2, s_xy) / C.norm_prey_opp;
+            else if (kind == 3) v = window_sum(type, 1, s_xy) / C.norm_pred_danger;
+            else v = window_sum(type, 3, s_xy) / C.norm_grass_opp;
+            dv[k] = safe_clip01(v);
+        }
+    }
+
+    PPG_MEMBER void obs_row(int type, int j, uint32_t s_xy, double s_e = 0.0) {
         if (FASTOBS) {
             if (type) obs_row_fast<1>(j, s_xy);
             else obs_row_fast<0>(j, s_xy);
@@ -1065,11 +1144,13 @@ struct Env {
         }
         wv::sync();  // LDS writes of the sequential phases -> visible
         const int R = type ? P.Rq : P.Rp;
-        const int blk = (WALLS && C.vis_channel ? 5 : 4) * R * R;
+        double dv[4] = {0.0, 0.0, 0.0, 0.0};
+        if (DRIVE) drive_features(type, s_e, s_xy, dv);
+        const int blk = (DRIVE ? 4 + (type ? C.n_drive[1] : C.n_drive[0]) : (WALLS && C.vis_channel ? 5 : 4)) * R * R;
         const int off = (R - 1) / 2;
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;
-        const bool interior = !WALLS && (R & 1) && x >= off && y >= off && x + off < P.G && y + off < P.G;
+        const bool interior = !WALLS && !DRIVE && (R & 1) && x >= off && y >= off && x + off < P.G && y + off < P.G;
         const uint2 *L = (const uint2 *)(lut + (type ? P.nch_p * 128 : 0));
         const int nch = type ? P.nch_q : P.nch_p;
         const size_t obase = ((size_t)b * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)blk;
@@ -1091,7 +1172,10 @@ struct Env {
                     const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
                     const int a = (int)(int16_t)(w & 0xFFFFu) + s_cell;
                     double t = val[map[inb ? a : 0]];        // map[0] (channel 0, cell 0) is always 0 -> val[0] = 0.0
-                    if (!WALLS) {
+                    if (DRIVE && (w & 0x20000000u)) {       // a drive channel: the whole (R,R) plane holds one scalar (DRV:566-569)
+                        const uint32_t k = (w >> 24) & 3u;
+                        t = k == 0 ? dv[0] : k == 1 ? dv[1] : k == 2 ? dv[2] : dv[3];
+                    } else if (!WALLS) {
                         if (!inb && (w & 0x3000000u) == 0u) t = 1.0;  // channel 0: 1 outside the grid (BASE:522-523)
                     } else {
                         // _get_observation of the walls env (WO:527-601): channel 0 = walls inside the window (0 outside the
@@ -1110,7 +1194,7 @@ struct Env {
                     v[h] = t;
                 }
             }
-            if (WALLS && (blk & 1)) {
+            if ((WALLS || DRIVE) && (blk & 1)) {
                 // five channels x an odd window: blocks start at odd element offsets and the last pair of a block
                 // straddles the next agent's block -> element-wise stores
                 const size_t o = obase + (size_t)ch * 128 + 2 * (size_t)ln;
@@ -1141,7 +1225,7 @@ struct Env {
             while (m) {
                 const int k = wv::ctz(m);
                 m &= m - 1;
-                obs_row(type_of(r), row_of(r, k), wv::readlane(xy[r], k));
+                obs_row(type_of(r), row_of(r, k), wv::readlane(xy[r], k), DRIVE ? readlane_f64(e[r], k) : 0.0);
             }
         }
     }
@@ -1149,7 +1233,7 @@ struct Env {
     // ---- step 3: engagement in self.agents order (BASE:279-380) ----------------------
     PPG_MEMBER void starve(int r, int k, uint32_t s_xy) {  // BASE:284-301
         const int type = type_of(r);
-        obs_row(type, row_of(r, k), s_xy);
+        obs_row(type, row_of(r, k), s_xy, DRIVE ? e_at(r, k) : 0.0);
         if (ln == k) ev[r] |= EV_STARVED;
         n_alive[type] -= 1;
         grid_zero(type, s_xy, true);
@@ -1199,7 +1283,7 @@ struct Env {
             e[0] = writelane_f64(e[0], k, ne);
             if (ln == k) ev[0] |= EV_ATE;                   // BASE:319
             grid_set(0, k, s_xy, ne, true);                 // BASE:325
-            obs_row(1, row_of(cr, ck), s_xy);               // BASE:327 (before the prey is erased)
+            obs_row(1, row_of(cr, ck), s_xy, pe);           // BASE:327 (before the prey is erased)
             n_alive[1] -= 1;
 #pragma unroll
             for (int q = 1; q < T; ++q) {
@@ -1908,7 +1992,7 @@ struct Env {
     }
 };
 
-template <int NQ, int MODE, bool FASTOBS, bool GEN2 = false, bool WALLS = false>
+template <int NQ, int MODE, bool FASTOBS, bool GEN2 = false, bool WALLS = false, bool DRIVE = false>
 PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     const int b = PPG_BLOCK_INDEX();
     if (b >= P.batch) return;
@@ -1930,7 +2014,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
             PPG_LAUNDER_S(bb);
             PPG_LAUNDER_V(lane);
             PPG_LAUNDER_V(l);
-            Env<NQ, false, FASTOBS, true, false, false, false, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
+            Env<NQ, false, FASTOBS, true, false, false, false, false, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
             env.run_step(it);
             wv::sync();
         }
@@ -1938,7 +2022,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     }
     const PPG_CONSTANT_AS KParams *Pcold = PPG_KERNARG_PTR(KParams, P);  // KParams is the kernel's only argument
     Env<NQ, MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_ORDERED_KICK, FASTOBS, false,
-        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, GEN2, WALLS, const KParams, const PPG_CONSTANT_AS KParams>
+        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, GEN2, WALLS, DRIVE, const KParams, const PPG_CONSTANT_AS KParams>
         env(P, *Pcold, b, lds, wv::lane());
     if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();

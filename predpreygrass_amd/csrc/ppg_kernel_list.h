@@ -28,6 +28,14 @@
     PPG_K3(ppg3_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID)                \
     PPG_K3(ppg3_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED)
 
+// drive-conditioned variant of the base family: generic observation geometry only (ppg4_<mode>_q<NQ>)
+#define PPG_DEFINE_KERNELS4(NQ)                                       \
+    PPG_K4(ppg4_step_q##NQ, NQ, ppg::MODE_STEP)                       \
+    PPG_K4(ppg4_reset_q##NQ, NQ, ppg::MODE_RESET)                     \
+    PPG_K4(ppg4_observe_q##NQ, NQ, ppg::MODE_OBSERVE)                 \
+    PPG_K4(ppg4_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID)                \
+    PPG_K4(ppg4_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED)
+
 #define PPG_DEFINE_KERNELS2(NQ)                                       \
     PPG_K2(ppg2_step_q##NQ, NQ, ppg::MODE_STEP, true)                 \
     PPG_K2(ppg2_reset_q##NQ, NQ, ppg::MODE_RESET, true)               \

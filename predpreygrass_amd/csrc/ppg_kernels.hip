@@ -1,6 +1,6 @@
 // ppg_kernels.hip -- one group of gfx950 kernels of libppg_hip.so per compilation:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -c -DPPG_TU_GEN=<1|2|3> -DPPG_TU_NQ=<1|2|4> ppg_kernels.hip
-// (1 = base family, 2 = second generation, 3 = second generation with walls; NQ = prey row registers).  Host code: ppg_hip.hip.
+// (1 = base family, 2 = second generation, 3 = second generation with walls, 4 = base family with drive channels; NQ = prey row registers).  Host code: ppg_hip.hip.
 #include <hip/hip_runtime.h>
 
 #include "ppg_kernel.h"
@@ -15,6 +15,8 @@
     PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, FAST, true>(P, lds); }
 #define PPG_K3(name, NQ, MODE)                                                               \
     PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, false, true, true>(P, lds); }
+#define PPG_K4(name, NQ, MODE)                                                               \
+    PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, false, false, false, true>(P, lds); }
 #include "ppg_kernel_list.h"
 
 #define PPG_APPLY(M, NQ) M(NQ)  // expands PPG_TU_NQ before the list pastes it into the kernel names
@@ -22,6 +24,8 @@
 PPG_APPLY(PPG_DEFINE_KERNELS, PPG_TU_NQ)
 #elif PPG_TU_GEN == 2
 PPG_APPLY(PPG_DEFINE_KERNELS2, PPG_TU_NQ)
-#else
+#elif PPG_TU_GEN == 3
 PPG_APPLY(PPG_DEFINE_KERNELS3, PPG_TU_NQ)
+#else
+PPG_APPLY(PPG_DEFINE_KERNELS4, PPG_TU_NQ)
 #endif

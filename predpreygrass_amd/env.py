@@ -98,8 +98,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
         self.agents = [f"predator_{i}" for i in range(self.n_initial_active_predator)] + \
                       [f"prey_{j}" for j in range(self.n_initial_active_prey)]
         self.grass_agents = [f"grass_{k}" for k in range(self.initial_num_grass)]
-        pshape = (4, self.predator_obs_range, self.predator_obs_range)
-        qshape = (4, self.prey_obs_range, self.prey_obs_range)
+        pshape = (batched.obs_pred.shape[2], self.predator_obs_range, self.predator_obs_range)
+        qshape = (batched.obs_prey.shape[2], self.prey_obs_range, self.prey_obs_range)
         self._pspace, self._qspace, self._aspace = _box(pshape), _box(qshape), _discrete(9)
         self.observation_spaces = _SpaceDict(self._pspace, self._qspace, self)
         self.action_spaces = _SpaceDict(self._aspace, self._aspace, self)

@@ -103,6 +103,17 @@ CASES = {
     "kickback_fast_seed5": ({"max_steps": 110, "prey_creation_energy_threshold": 4.5, "predator_creation_energy_threshold": 7.0,
                              "energy_gain_per_step_grass": 0.12, "kickback_reward_predator": 3.0, "kickback_reward_prey": 1.25,
                              "initial_num_grass": 110}, 5, 1005, False, 10, "sparse_rewards_plus_kickback"),
+    # drive_conditioned_environment: the base step with extra constant-filled "drive" observation channels
+    "drive_default_seed2": ({"max_steps": 120}, 2, 1006, False, 20, "drive_conditioned"),
+    "drive_dense_seed3": ({"grid_size": 9, "n_initial_active_predator": 12, "n_initial_active_prey": 20,
+                           "initial_num_grass": 25, "predator_obs_range": 5, "prey_obs_range": 7, "max_steps": 150},
+                          3, 1007, True, 6, "drive_conditioned"),
+    "drive_custom_lists_big_windows_seed4": ({"predator_obs_range": 13, "prey_obs_range": 15, "grid_size": 30,
+                                              "n_initial_active_prey": 40, "max_steps": 60,
+                                              "predator_drive_channels": ["grass_opportunity", "prey_opportunity"],
+                                              "prey_drive_channels": ["predator_danger_pressure"],
+                                              "predator_hunger_safe_energy": 4.0, "grass_opportunity_normalizer": 7.5},
+                                             4, 1008, False, 10, "drive_conditioned"),
 }
 
 

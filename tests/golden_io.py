@@ -39,7 +39,19 @@ def call_digest(grid, obs, rew, term, trunc) -> bytes:
 VARIANT_CONFIG = {
     "dense_rewards": {"reward_mode": "dense_energy_delta"},
     "dense_rewards_additive": {"reward_mode": "dense_energy_delta_plus_reproduction"},
+    "drive_conditioned": {"enable_drive_channels": True},
 }
+# drive_conditioned_environment/predpreygrass_rllib_env.py:56-75
+_DEFAULT_DRIVES = {"predator": 3, "prey": 4}
+
+
+def obs_channels(name, cfg):
+    """Channels of an agent's observation: 4, plus the drive channels of the drive-conditioned variant."""
+    if not cfg.get("enable_drive_channels", False):
+        return 4
+    kind = "predator" if name.startswith("predator") else "prey"
+    lst = cfg.get(f"{kind}_drive_channels")
+    return 4 + (len(lst) if lst is not None else _DEFAULT_DRIVES[kind])
 
 
 class GoldenCase:
@@ -90,9 +102,9 @@ class GoldenCase:
     def reset_obs(self, cfg):
         out, off = {}, 0
         for k in self.reset_keys:
-            R = self.obs_range(k, cfg)
-            out[k] = self.z["reset_obs_data"][off:off + 4 * R * R].reshape(4, R, R)
-            off += 4 * R * R
+            R, C = self.obs_range(k, cfg), obs_channels(k, cfg)
+            out[k] = self.z["reset_obs_data"][off:off + C * R * R].reshape(C, R, R)
+            off += C * R * R
         return out
 
     def full(self, t, cfg):
@@ -103,9 +115,9 @@ class GoldenCase:
         off = int(self.z["obs_off"][k])
         obs = {}
         for name, _, _, _ in self.records(t):
-            R = self.obs_range(name, cfg)
-            obs[name] = self.z["obs_data"][off:off + 4 * R * R].reshape(4, R, R)
-            off += 4 * R * R
+            R, C = self.obs_range(name, cfg), obs_channels(name, cfg)
+            obs[name] = self.z["obs_data"][off:off + C * R * R].reshape(C, R, R)
+            off += C * R * R
         assert off == int(self.z["obs_off"][k + 1])
         lo, hi = self.z["st_off"][k], self.z["st_off"][k + 1]
         state = {

@@ -30,6 +30,8 @@ def make_env(cfg, B, **kw):
     (["dense_additive_seed4"], None),      # ...base_environment_dense_rewards_additive's own file
     (["kickback_seed0"], None),            # ...base_environment_sparse_rewards_plus_kickback's own file
     (["kickback_fast_seed5"], None),       # 194 grandparent rewards incl. double kicks and kick-after-own-reproduction
+    (["drive_default_seed2"], None),       # ...drive_conditioned_environment's own file (3 + 4 drive channels)
+    (["drive_custom_lists_big_windows_seed4"], None),   # 13x13 / 15x15 windows (numpy's pairwise sum splits), custom lists
 ])
 def test_golden_cases_through_emulated_kernel(names, max_calls):
     replay_golden_cases(make_env, names, config_env, max_calls=max_calls)
@@ -168,3 +170,14 @@ def test_fused_rollout_equals_single_steps_action_tape():
         a.step(tape[t].contiguous())
     b.rollout(K, actions=tape)
     _assert_same_state(_state(a), _state(b), a)
+
+
+def test_emulated_random_rollout_with_drive_channels_matches_oracle():
+    """drive-conditioned variant: device reset, Philox actions, auto-reset; observations incl. the drive channels
+    (window sums in numpy's pairwise order) against the oracle every call."""
+    cfg = {**config_env, "enable_drive_channels": True, "grid_size": 12, "initial_num_grass": 40,
+           "n_initial_active_predator": 6, "n_initial_active_prey": 14, "max_steps": 60,
+           "predator_hunger_safe_energy": 4.0, "energy_gain_per_step_grass": 0.2}
+    env = make_env(cfg, 3)
+    assert env.obs_pred.shape[2] == 7 and env.obs_prey.shape[2] == 8
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=77, n_calls=120, check_every=1)

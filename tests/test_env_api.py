@@ -57,6 +57,19 @@ def test_dict_api_replays_golden_case(name):
     replay_through_dict_api(name, make)
 
 
+@pytest.mark.parametrize("name", ["drive_default_seed2", "drive_dense_seed3", "drive_custom_lists_big_windows_seed4"])
+def test_drive_conditioned_class_replays_its_reference(name):
+    """drive_conditioned_environment/predpreygrass_rllib_env.py: episodes recorded from that file, replayed from the seed
+    through predpreygrass_amd.drive_conditioned.PredPreyGrass (drive channels on by default, like there)."""
+    from predpreygrass_amd.drive_conditioned import PredPreyGrass as DriveEnv
+
+    def make_drive(cfg, **kw):
+        cfg = {k: v for k, v in cfg.items() if k != "enable_drive_channels"}   # the class switches them on itself
+        return DriveEnv(cfg, _library=library(), **kw)
+    env = replay_through_dict_api(name, make_drive, max_calls=80)
+    assert env.observation_spaces["predator_0"].shape[0] >= 5 and env.observation_spaces["prey_0"].shape[0] >= 5
+
+
 def test_dict_api_honours_shuffled_action_dict_order():
     """dense_shuffled_seed17: the action dict is shuffled every call; movement order follows the dict
     (predpreygrass_rllib_env.py:259) and changes who gets a contested / ghost cell."""

@@ -23,6 +23,7 @@ def make_env(cfg, B, **kw):
     ["rewards_seed3"], ["pool_seed3"], ["even_obs_seed0"],
     ["seasonal_short_seed0"], ["seasonal_default_seed1"], ["plus_eating_seed2"],
     ["dense_rewards_seed0"], ["dense_additive_seed4"], ["kickback_seed0"], ["kickback_fast_seed5"],
+    ["drive_default_seed2"], ["drive_custom_lists_big_windows_seed4"],
 ])
 def test_golden_cases_on_gpu(names):
     replay_golden_cases(make_env, names, config_env)
@@ -205,3 +206,16 @@ def test_32768_envs_on_one_gpu_sampled_oracle():
     assert (es[:, _abi.ENV_CALLS] == 120).all()
     del env
     torch.cuda.empty_cache()
+
+
+def test_drive_conditioned_variant_on_gpu():
+    """drive channels (window sums in numpy's pairwise order): random rollouts vs the oracle, 64 envs, and the shuffled
+    golden episode through the drive-conditioned dict class."""
+    cfg = {**config_env, "enable_drive_channels": True}
+    env = make_env(cfg, 64)
+    assert env.obs_pred.shape[2] == 7 and env.obs_prey.shape[2] == 8
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=99, n_calls=200, check_every=10)
+    from predpreygrass_amd.drive_conditioned import PredPreyGrass as DriveEnv
+    from tests.test_env_api import replay_through_dict_api
+    replay_through_dict_api("drive_dense_seed3", lambda c, **kw: DriveEnv({k: v for k, v in c.items() if k != "enable_drive_channels"},
+                                                                       device="cuda:0", **kw))

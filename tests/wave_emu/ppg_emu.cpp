@@ -65,8 +65,26 @@ static void run_mode3(const ppg::KParams &P, int mode) {
     }
 }
 
+template <int NQ>
+static void run_mode4(const ppg::KParams &P, int mode) {
+    PPG_DYNAMIC_LDS(lds);
+    switch (mode) {
+        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true>(P, lds); break;
+        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET, false, false, false, true>(P, lds); break;
+        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, false, false, false, true>(P, lds); break;
+        case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, false, false, false, true>(P, lds); break;
+        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, false, false, false, true>(P, lds); break;
+    }
+}
+
 template <bool FAST>
 static void run_nq(const EmuLaunch *L) {
+    if (L->gen2 == 3) {  // drive-conditioned variant of the base family: generic observation geometry only
+        if (L->nq == 1) run_mode4<1>(*L->P, L->mode);
+        else if (L->nq == 2) run_mode4<2>(*L->P, L->mode);
+        else run_mode4<4>(*L->P, L->mode);
+        return;
+    }
     if (L->gen2 == 2) {  // walls variant: generic observation geometry only
         if (L->nq == 1) run_mode3<1>(*L->P, L->mode);
         else if (L->nq == 2) run_mode3<2>(*L->P, L->mode);
@@ -102,7 +120,7 @@ static void backend_release(ppg_handle *h) {
     h->lut_dev = nullptr;
 }
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *) {
-    EmuLaunch L{&P, h->nq, mode, h->gen2 ? (h->cfg2.walls ? 2 : 1) : 0};
+    EmuLaunch L{&P, h->nq, mode, h->drive ? 3 : h->gen2 ? (h->cfg2.walls ? 2 : 1) : 0};
     for (int b = 0; b < h->batch; ++b) wv::run_block(lane_entry, &L, b, (size_t)P.lds_bytes);
     return PPG_OK;
 }
