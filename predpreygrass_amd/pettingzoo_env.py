@@ -24,8 +24,9 @@ except Exception:
 class PredPreyGrassParallelEnv(_ParallelBase):
     metadata = {"name": "predpreygrass_amd_v0", "render_modes": []}
 
-    def __init__(self, config=None, **kw):
-        self._env = PredPreyGrass(config, **kw)
+    def __init__(self, config=None, env_class=None, **kw):
+        # env_class: the dict env to wrap (default: the base env; red_queen / walls_occlusion / drive_conditioned .PredPreyGrass)
+        self._env = (env_class or PredPreyGrass)(config, **kw)
         self.possible_agents = list(self._env.possible_agents)
         self.agents = []
 
@@ -41,11 +42,12 @@ class PredPreyGrassParallelEnv(_ParallelBase):
         return obs, {a: {} for a in obs}
 
     def step(self, actions):
-        obs, rew, term, trunc, _ = self._env.step({a: actions[a] for a in self.agents if a in actions})
-        term = {k: v for k, v in term.items() if k != "__all__"}
-        trunc = {k: v for k, v in trunc.items() if k != "__all__"}
+        obs, rew, term, trunc, infos = self._env.step({a: actions[a] for a in self.agents if a in actions})
+        rew = {k: rew[k] for k in obs}   # (the walls env also reports agents that are gone; PettingZoo dicts follow obs)
+        term = {k: term[k] for k in obs}
+        trunc = {k: trunc[k] for k in obs}
         self.agents = [a for a in obs if not term[a] and not trunc[a]]
-        return obs, rew, term, trunc, {a: {} for a in obs}
+        return obs, rew, term, trunc, {a: dict(infos.get(a, {})) for a in obs}
 
     def state(self):
         return self._env.grid_world_state

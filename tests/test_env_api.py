@@ -239,3 +239,17 @@ def test_vector_env_auto_reset_and_shuffled_orders():
                 assert vec.envs[i].current_step == 0 and all(v == 0.0 for v in r.values())
             live[i] = [a for a in o if not te[a]] if not (te["__all__"] or tr["__all__"]) else []
     assert n_resets >= 3
+
+
+def test_pettingzoo_parallel_wraps_the_other_env_classes():
+    from predpreygrass_amd import red_queen, walls_occlusion
+    for cls, cfg in ((red_queen.PredPreyGrass, red_queen.config_env_base),
+                     (walls_occlusion.PredPreyGrass, dict(red_queen.config_env_base, respect_los_for_movement=True))):
+        par = PredPreyGrassParallelEnv(cfg, env_class=cls, _library=library())
+        obs, infos = par.reset(seed=4)
+        assert par.agents == list(obs) and len(obs) == 32
+        for _ in range(12):
+            obs, rew, term, trunc, infos = par.step({a: par.action_space(a).sample() for a in par.agents})
+            assert set(obs) == set(rew) == set(term) == set(trunc) == set(infos)
+        if cls is walls_occlusion.PredPreyGrass:
+            assert any("los_rejected" in v for v in infos.values())
