@@ -313,6 +313,12 @@ int ppg_step_uniforms(ppg_handle *h, const int8_t *actions, const uint8_t *act_r
 int ppg_step_many(ppg_handle *const *handles, int32_t n, const int8_t *const *actions, uint32_t flags,
                   void *const *streams);
 
+/* Scheduling hint: this handle's launches overlap with launches of other handles on the same GPU (sub-batches on other
+ * streams); envs_in_flight = envs of all of them together (default: the handle's own batch).  Used to choose between the
+ * one-wave-per-env step kernel and the four-waves-per-env one (wave 0 steps, all four write the final observations), which is
+ * faster while the GPU is not full: up to about 3072 envs in flight, or when LDS admits at most 4 envs per CU. */
+int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight);
+
 /* grid_world_state (BASE:124): dense float64 [B,4,G,G] rebuilt from the rows. */
 int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream);
 

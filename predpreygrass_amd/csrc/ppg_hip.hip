@@ -16,6 +16,8 @@
 #define PPG_K2(name, NQ, MODE, FAST) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K3(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K4(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
+#define PPG_KW(name, NQ, FAST) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
+#define PPG_KW2(name, NQ, FAST) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
 #include "ppg_kernel_list.h"
 
 PPG_DEFINE_KERNELS(1)
@@ -30,6 +32,12 @@ PPG_DEFINE_KERNELS3(4)
 PPG_DEFINE_KERNELS4(1)
 PPG_DEFINE_KERNELS4(2)
 PPG_DEFINE_KERNELS4(4)
+PPG_DEFINE_KERNELSW(1)
+PPG_DEFINE_KERNELSW(2)
+PPG_DEFINE_KERNELSW(4)
+PPG_DEFINE_KERNELSW2(1)
+PPG_DEFINE_KERNELSW2(2)
+PPG_DEFINE_KERNELSW2(4)
 
 typedef void (*ppg_kernel_fn)(const ppg::KParams);
 
@@ -107,9 +115,18 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     const bool fast = P.nch_p <= 2 && P.nch_q <= 3;
     if (h->gen2 && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for second-generation handles", mode);
     if (h->drive && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for the drive-conditioned variant", mode);
-    const ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
-                             : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);
-    hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(64), (size_t)P.lds_bytes, (hipStream_t)stream, P);
+    ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
+                       : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);
+    unsigned block = 64;
+    if (mode == ppg::MODE_STEP && !h->drive && !(h->gen2 && h->cfg2.walls) && ppg_use_multiwave(h)) {
+        // one wave per env cannot fill the GPU: 4 waves per env, wave 0 steps, all 4 write the final observations
+        static const ppg_kernel_fn w[2][2][3] = {
+            {{ppgw_step_q1g, ppgw_step_q2g, ppgw_step_q4g}, {ppgw_step_q1, ppgw_step_q2, ppgw_step_q4}},
+            {{ppgw2_step_q1g, ppgw2_step_q2g, ppgw2_step_q4g}, {ppgw2_step_q1, ppgw2_step_q2, ppgw2_step_q4}}};
+        fn = w[h->gen2 ? 1 : 0][fast ? 1 : 0][h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
+        block = 256;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(block), (size_t)P.lds_bytes, (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());
     return PPG_OK;
 }

@@ -20,6 +20,7 @@
 
 struct ppg_handle {
     int32_t drive;  // drive-conditioned variant of the base family (cfg.n_drive)
+    int32_t envs_in_flight;  // scheduling hint (ppg_set_envs_in_flight); 0 = the handle's own batch
     ppg_config cfg;
     ppg_config_gen2 cfg2;
     int32_t gen2;  // created by ppg_create_gen2
@@ -246,6 +247,17 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
     return PPG_OK;
 }
 
+// Multi-wave step kernels pay off while single-wave workgroups leave wave slots of the CUs empty (256 CUs x 16 slots):
+// measured on MI355X, 4 waves per env win up to about 3072 envs in flight (256 envs: 1.8x, 1024: 1.7x, 2048: 1.3x,
+// 3072: 1.02x, 4096: 0.93x), and whenever the LDS footprint admits at most 4 envs per CU (64x64 grids: 1.4x).
+// PPG_MULTIWAVE=0/1 forces (experiments).
+static bool ppg_use_multiwave(const ppg_handle *h) {
+    if (const char *f = getenv("PPG_MULTIWAVE")) return atoi(f) != 0;
+    const int lds_envs = h->base.lds_bytes > 0 ? (160 * 1024) / h->base.lds_bytes : 16;
+    const int in_flight = h->envs_in_flight > 0 ? h->envs_in_flight : h->batch;
+    return in_flight <= 3072 || lds_envs <= 4;
+}
+
 static int backend_init(ppg_handle *h, int device);
 static void backend_release(ppg_handle *h);
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream);
@@ -265,6 +277,7 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     if (cfg) h->cfg = *cfg; else h->cfg2 = *cfg2;
     h->bufs = *bufs; h->batch = batch; h->device = device;
     h->lut_dev = nullptr; h->backend = nullptr; h->prof_dev = nullptr; h->err[0] = 0;
+    h->envs_in_flight = 0;
     h->drive = (cfg && (cfg->n_drive[0] > 0 || cfg->n_drive[1] > 0)) ? 1 : 0;
     int rc = cfg2 ? ppg_validate_and_layout_gen2(h) : ppg_validate_and_layout(h);
     if (rc == PPG_OK) rc = backend_init(h, device);
@@ -365,6 +378,13 @@ int ppg_step_uniforms(ppg_handle *h, const int8_t *actions, const uint8_t *act_r
     P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
     P.uniforms = uniforms; P.uniforms_per_env = uniforms_per_env;
     return backend_launch(h, mode, P, stream);
+}
+
+int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight) {
+    if (!h) return PPG_EINVAL;
+    if (envs_in_flight < 0) return ppg_fail(h, PPG_EINVAL, "envs_in_flight < 0");
+    h->envs_in_flight = envs_in_flight;
+    return PPG_OK;
 }
 
 int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream) {

@@ -219,7 +219,11 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // WALLS (with GEN2): the walls_occlusion variant -- static walls in a per-env bitmap, observation channel 0 = walls,
 // optional line-of-sight mask / fifth channel, wall- and LOS-blocked moves, per-agent move infos.
 // DRIVE (base family): the drive-conditioned variant -- extra observation channels filled with per-agent scalars.
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, class KP, class KC>
+// NW: wavefronts per environment.  1 everywhere except the multi-wave step kernels (ppgw_*): there wave 0 runs the
+// whole transition and all NW waves of the workgroup write the final observations (the phase that dominates a wave's
+// run time) -- for launches that cannot fill the GPU with one wave per env (small batches; large grids whose LDS
+// footprint allows only a few envs per CU).
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, int NW, class KP, class KC>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
 
@@ -1218,7 +1222,44 @@ struct Env {
         wv::sync();  // reads done before the caller touches the maps again
     }
 
+    // multi-wave variants: rows of the published list, every NW-th one starting at `w`
+    PPG_MEMBER void obs_shared(int w) {
+        const uint32_t *lst = (const uint32_t *)scr;
+        const int n = (int)wv::first(lst[0]);
+        for (int i = w; i < n; i += NW) {
+            const uint32_t en = wv::first(lst[1 + i]);
+            obs_row((int)(en >> 31), (int)((en >> 16) & 0x7FFFu), en & 0xFFFFu);
+        }
+    }
+    // a helper wave of a multi-wave workgroup: wait until wave 0 has finished the transition, then write its share
+    PPG_MEMBER void run_helper(int w) {
+        if (FASTOBS) {
+            const uint2 *L2 = (const uint2 *)C.obs_lut;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { uint2 d; d.x = 0; d.y = 0; if (c < P.nch_p) d = L2[c * 64 + ln]; lutr[2 * c] = d.x; lutr[2 * c + 1] = d.y; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { uint2 d; d.x = 0; d.y = 0; if (c < P.nch_q) d = L2[(P.nch_p + c) * 64 + ln]; lutr[4 + 2 * c] = d.x; lutr[5 + 2 * c] = d.y; }
+        }
+        wv::wg_barrier();
+        obs_shared(w);
+    }
+
     PPG_MEMBER void obs_all_alive() {
+        if (NW > 1) {  // publish (type, row, cell) of every live row, then all waves of the workgroup share the rows
+            uint32_t *lst = (uint32_t *)scr;
+            int n = 0;
+            wv::sync();
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                if ((alive[r] >> ln) & 1ull)
+                    lst[1 + n + (int)wv::prefix(alive[r])] = ((uint32_t)type_of(r) << 31) | ((uint32_t)row_of(r, ln) << 16) | xy[r];
+                n += wv::popc(alive[r]);
+            }
+            if (ln == 0) lst[0] = (uint32_t)n;
+            wv::wg_barrier();
+            obs_shared(0);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             uint64_t m = alive[r];
@@ -1992,7 +2033,7 @@ struct Env {
     }
 };
 
-template <int NQ, int MODE, bool FASTOBS, bool GEN2 = false, bool WALLS = false, bool DRIVE = false>
+template <int NQ, int MODE, bool FASTOBS, bool GEN2 = false, bool WALLS = false, bool DRIVE = false, int NW = 1>
 PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     const int b = PPG_BLOCK_INDEX();
     if (b >= P.batch) return;
@@ -2014,7 +2055,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
             PPG_LAUNDER_S(bb);
             PPG_LAUNDER_V(lane);
             PPG_LAUNDER_V(l);
-            Env<NQ, false, FASTOBS, true, false, false, false, false, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
+            Env<NQ, false, FASTOBS, true, false, false, false, false, 1, const PPG_CONSTANT_AS KParams, const PPG_CONSTANT_AS KParams> env(*Pc, *Pc, bb, l, lane);
             env.run_step(it);
             wv::sync();
         }
@@ -2022,8 +2063,12 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     }
     const PPG_CONSTANT_AS KParams *Pcold = PPG_KERNARG_PTR(KParams, P);  // KParams is the kernel's only argument
     Env<NQ, MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_ORDERED_KICK, FASTOBS, false,
-        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, GEN2, WALLS, DRIVE, const KParams, const PPG_CONSTANT_AS KParams>
+        MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK, GEN2, WALLS, DRIVE, NW, const KParams, const PPG_CONSTANT_AS KParams>
         env(P, *Pcold, b, lds, wv::lane());
+    if (NW > 1) {
+        const int w = wv::wave_index();
+        if (w != 0) { env.run_helper(w); return; }
+    }
     if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();
     else if (MODE == MODE_OBSERVE) env.run_observe();

@@ -20,6 +20,15 @@
     PPG_K(ppg_step_kick_q##NQ##g, NQ, ppg::MODE_STEP_KICK, false)     \
     PPG_K(ppg_step_ord_kick_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED_KICK, false)
 
+// multi-wave step kernels of the base family (4 wavefronts per env; see Env's NW): ppgw_step_q<NQ>[g]
+#define PPG_DEFINE_KERNELSW(NQ)                                       \
+    PPG_KW(ppgw_step_q##NQ, NQ, true)                                 \
+    PPG_KW(ppgw_step_q##NQ##g, NQ, false)
+
+#define PPG_DEFINE_KERNELSW2(NQ)                                      \
+    PPG_KW2(ppgw2_step_q##NQ, NQ, true)                               \
+    PPG_KW2(ppgw2_step_q##NQ##g, NQ, false)
+
 // walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>)
 #define PPG_DEFINE_KERNELS3(NQ)                                       \
     PPG_K3(ppg3_step_q##NQ, NQ, ppg::MODE_STEP)                       \

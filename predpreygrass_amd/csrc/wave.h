@@ -16,6 +16,8 @@
 // 64 threads = one wavefront per workgroup; W = waves per SIMD the register allocator must allow
 // (4 -> <= 128 VGPRs -> 16 waves per CU = 4096 co-resident envs per MI355X)
 #define PPG_KERNEL(name, W) extern "C" __global__ void __launch_bounds__(64, W) name
+// NW wavefronts per workgroup: wave 0 steps the env, all NW waves write the final observations (small batches, large grids)
+#define PPG_KERNEL_NW(name, W, NW) extern "C" __global__ void __launch_bounds__(64 * NW, W) name
 #define PPG_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define PPG_BLOCK_INDEX() ((int)blockIdx.x)
 // kernel parameters read in place from the kernarg segment (constant address space -> s_load)
@@ -27,7 +29,11 @@
 
 namespace wv {
 
-PPG_DEVICE int lane() { return (int)threadIdx.x; }
+PPG_DEVICE int lane() { return (int)(threadIdx.x & 63u); }
+// index of this wavefront within its workgroup (0 unless the kernel is a multi-wave variant), as a scalar
+PPG_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// workgroup barrier of the multi-wave variants (LDS writes of every wave visible afterwards)
+PPG_DEVICE void wg_barrier() { __syncthreads(); }
 
 // 64-bit mask of lanes whose predicate is true (s_* result: lives in SGPRs).
 PPG_DEVICE uint64_t ballot(bool p) { return __ballot(p); }

@@ -31,6 +31,8 @@ class SubBatchedPredPreyGrass:
         self.offsets = [shard_range(self.batch_size, k, n_sub) for k in range(n_sub)]
         self.subs = [env_class(config, batch_size=hi - lo, device=device, seed=seed + lo, **kw)
                      for lo, hi in self.offsets]
+        for e in self.subs:   # the sub-batches run concurrently: kernel selection should look at all of them together
+            e._lib.ppg_set_envs_in_flight(e._handle, self.batch_size)
         cuda = self.device.type == "cuda"   # (the CPU case exists only for the emulated-kernel tests)
         self.streams = [torch.cuda.Stream(device=self.device) if cuda else None for _ in self.subs]
 

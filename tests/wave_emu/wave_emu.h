@@ -168,6 +168,8 @@ inline uint32_t shfl_up1(uint32_t v) {
     int l = lane();
     return (uint32_t)s[l ? l - 1 : 0];
 }
+inline int wave_index() { return 0; }                 // the emulator runs single-wave workgroups only
+inline void wg_barrier() { (void)exchange(0); }
 inline void sync() { (void)exchange(0); }
 inline void drain_loads() { (void)exchange(0); }  // lanes run one after another here: a collective orders reads before writes
 inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
