@@ -12,8 +12,8 @@ variants.update({k: v for k, v in [a.split("=", 1) for a in sys.argv[1:] if "=" 
 for name, flags in variants.items():
     lib_path = os.path.join(ROOT, "gpurun_out", f"libppg_exp_{name}.so")
     os.makedirs(os.path.dirname(lib_path), exist_ok=True)
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
-                    *flags, "-o", lib_path, os.path.join(CSRC, "ppg_hip.hip")], check=True, cwd=CSRC)
+    import __graft_entry__ as graft   # the library is built from several translation units
+    graft.build_hip(force=True, extra_flags=flags, out=lib_path)
     code = f"""
 import ctypes, sys, time, torch
 sys.path.insert(0, {ROOT!r})
