@@ -244,6 +244,11 @@ def main():
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
     except Exception:
         traffic = None
+    # which step kernel the library picked (predpreygrass_amd/csrc/ppg_host.h: ppg_use_multiwave): four waves per env while the
+    # GPU is not full (<= 3072 envs in flight) or when LDS admits at most 4 envs per CU
+    multiwave = (B <= 3072) or (160 * 1024 // max(env.lds_bytes, 1) <= 4)
+    if os.environ.get("PPG_MULTIWAVE") is not None:
+        multiwave = os.environ["PPG_MULTIWAVE"] != "0"
     kernel_s = dev_ms / 1e3 / args.steps          # per launch; n_sub launches are in flight concurrently
     achieved = alg_bytes / args.steps / kernel_s / 1e9   # all n_sub concurrent launches together
     value = n_gpus * env_steps_rank / wall
@@ -288,7 +293,7 @@ def main():
                 "achieved_from_pmc_traffic": round(traffic * n_sub / kernel_s / 1e9, 1) if traffic else None,
                 "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
                                          "launch = 4.85 TB/s (profiles/r01/c_store_pattern_ceiling.txt); linear fill 6.5 TB/s",
-                "kernel": "ppg2_step_q2" if rq else "ppg_step_q2",
+                "kernel": ("ppgw2_step_q2" if multiwave else "ppg2_step_q2") if rq else ("ppgw_step_q2" if multiwave else "ppg_step_q2"),
                 "kernel_ms": round(kernel_s * 1e3, 5),
                 "concurrent_launches": n_sub,
                 "algorithmic_bytes_per_launch": int(alg_bytes / args.steps / n_sub),
