@@ -68,3 +68,36 @@ def test_emulated_random_rollout_with_walls_matches_oracle():
     assert n_resets >= 3 and stats["births"] > 5
     info = env.row_info.numpy()
     assert (info <= 5).all()
+
+
+def test_second_generation_kernels_are_clean_under_ubsan():
+    """The second-generation, walls and drive code paths in the UBSan build of the emulated kernel (traps on signed
+    overflow, bad shifts, misaligned access -- e.g. the odd-sized observation blocks of 5- and 7-channel variants)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from tests.emu_backend import library\n"
+        "from tests.parity_utils_rq import replay_golden_case, rollout_vs_oracle\n"
+        "from tests.parity_utils import rollout_vs_oracle as rollout_base\n"
+        "from tests.golden_io_rq import RQGoldenCase\n"
+        "from predpreygrass_amd.red_queen import BatchedRedQueen\n"
+        "from predpreygrass_amd.batched import BatchedPredPreyGrass\n"
+        "from predpreygrass_amd.config import config_env\n"
+        "from oracle.rq_oracle import RQOracleEnv\n"
+        "from oracle.ppg_oracle import OracleEnv\n"
+        "lib = library(sanitize=True)\n"
+        "mk = lambda cfg, B, **kw: BatchedRedQueen(cfg, batch_size=B, _library=lib, **kw)\n"
+        "replay_golden_case(mk, 'rq_mixed_types_seed7')\n"
+        "replay_golden_case(mk, 'rq_shuffled_seed5')\n"
+        "replay_golden_case(mk, 'wo_los_two_types_seed5')\n"
+        "replay_golden_case(mk, 'wo_mask_only_shuffled_seed6')\n"
+        "cfg = RQGoldenCase('rq_pool_exhaust_seed2').config\n"
+        "rollout_vs_oracle(mk(cfg, 2), lambda: RQOracleEnv(cfg), seed0=3, n_calls=120)\n"
+        "drv = {**config_env, 'enable_drive_channels': True, 'grid_size': 11, 'initial_num_grass': 30, 'max_steps': 50}\n"
+        "rollout_base(BatchedPredPreyGrass(drv, batch_size=2, _library=lib), lambda: OracleEnv(drv), seed0=5, n_calls=80)\n"
+        "print('UBSAN-CLEAN')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "UBSAN-CLEAN" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
