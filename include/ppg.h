@@ -315,8 +315,9 @@ int ppg_step_many(ppg_handle *const *handles, int32_t n, const int8_t *const *ac
 
 /* Scheduling hint: this handle's launches overlap with launches of other handles on the same GPU (sub-batches on other
  * streams); envs_in_flight = envs of all of them together (default: the handle's own batch).  Used to choose between the
- * one-wave-per-env step kernel and the four-waves-per-env one (wave 0 steps, all four write the final observations), which is
- * faster while the GPU is not full: up to about 3072 envs in flight, or when LDS admits at most 4 envs per CU. */
+ * one-wave-per-env step kernel and the four- / eight-waves-per-env ones (wave 0 steps, all waves write the final observations),
+ * which are faster while the GPU is not full: eight up to 512 envs in flight, four up to about 3072 or when LDS admits at most
+ * 4 envs per CU. */
 int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight);
 
 /* grid_world_state (BASE:124): dense float64 [B,4,G,G] rebuilt from the rows. */

@@ -16,8 +16,8 @@
 #define PPG_K2(name, NQ, MODE, FAST) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K3(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K4(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
-#define PPG_KW(name, NQ, FAST) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
-#define PPG_KW2(name, NQ, FAST) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
+#define PPG_KW(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
+#define PPG_KW2(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #include "ppg_kernel_list.h"
 
 PPG_DEFINE_KERNELS(1)
@@ -120,11 +120,16 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     unsigned block = 64;
     if (mode == ppg::MODE_STEP && !h->drive && !(h->gen2 && h->cfg2.walls) && ppg_use_multiwave(h)) {
         // one wave per env cannot fill the GPU: 4 waves per env, wave 0 steps, all 4 write the final observations
-        static const ppg_kernel_fn w[2][2][3] = {
-            {{ppgw_step_q1g, ppgw_step_q2g, ppgw_step_q4g}, {ppgw_step_q1, ppgw_step_q2, ppgw_step_q4}},
-            {{ppgw2_step_q1g, ppgw2_step_q2g, ppgw2_step_q4g}, {ppgw2_step_q1, ppgw2_step_q2, ppgw2_step_q4}}};
-        fn = w[h->gen2 ? 1 : 0][fast ? 1 : 0][h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
-        block = 256;
+        static const ppg_kernel_fn w[2][2][2][3] = {
+            {{{ppgw_step_q1g, ppgw_step_q2g, ppgw_step_q4g}, {ppgw_step_q1, ppgw_step_q2, ppgw_step_q4}},
+             {{ppgw2_step_q1g, ppgw2_step_q2g, ppgw2_step_q4g}, {ppgw2_step_q1, ppgw2_step_q2, ppgw2_step_q4}}},
+            {{{ppgw8_step_q1g, ppgw8_step_q2g, ppgw8_step_q4g}, {ppgw8_step_q1, ppgw8_step_q2, ppgw8_step_q4}},
+             {{ppgw28_step_q1g, ppgw28_step_q2g, ppgw28_step_q4g}, {ppgw28_step_q1, ppgw28_step_q2, ppgw28_step_q4}}}};
+        const int in_flight = h->envs_in_flight > 0 ? h->envs_in_flight : h->batch;
+        const char *force8 = getenv("PPG_MULTIWAVE8");
+        const bool eight = force8 ? atoi(force8) != 0 : in_flight <= 512;   // even emptier GPU: 8 waves per env
+        fn = w[eight ? 1 : 0][h->gen2 ? 1 : 0][fast ? 1 : 0][h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
+        block = eight ? 512 : 256;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(block), (size_t)P.lds_bytes, (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());

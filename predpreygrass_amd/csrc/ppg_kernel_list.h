@@ -20,14 +20,18 @@
     PPG_K(ppg_step_kick_q##NQ##g, NQ, ppg::MODE_STEP_KICK, false)     \
     PPG_K(ppg_step_ord_kick_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED_KICK, false)
 
-// multi-wave step kernels of the base family (4 wavefronts per env; see Env's NW): ppgw_step_q<NQ>[g]
+// multi-wave step kernels of the base family (4 or 8 wavefronts per env; see Env's NW): ppgw_step_q<NQ>[g], ppgw8_step_*
 #define PPG_DEFINE_KERNELSW(NQ)                                       \
-    PPG_KW(ppgw_step_q##NQ, NQ, true)                                 \
-    PPG_KW(ppgw_step_q##NQ##g, NQ, false)
+    PPG_KW(ppgw_step_q##NQ, NQ, true, 4)                              \
+    PPG_KW(ppgw_step_q##NQ##g, NQ, false, 4)                          \
+    PPG_KW(ppgw8_step_q##NQ, NQ, true, 8)                             \
+    PPG_KW(ppgw8_step_q##NQ##g, NQ, false, 8)
 
 #define PPG_DEFINE_KERNELSW2(NQ)                                      \
-    PPG_KW2(ppgw2_step_q##NQ, NQ, true)                               \
-    PPG_KW2(ppgw2_step_q##NQ##g, NQ, false)
+    PPG_KW2(ppgw2_step_q##NQ, NQ, true, 4)                            \
+    PPG_KW2(ppgw2_step_q##NQ##g, NQ, false, 4)                        \
+    PPG_KW2(ppgw28_step_q##NQ, NQ, true, 8)                           \
+    PPG_KW2(ppgw28_step_q##NQ##g, NQ, false, 8)
 
 // walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>)
 #define PPG_DEFINE_KERNELS3(NQ)                                       \

@@ -17,10 +17,10 @@
     PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, false, true, true>(P, lds); }
 #define PPG_K4(name, NQ, MODE)                                                               \
     PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, false, false, false, true>(P, lds); }
-#define PPG_KW(name, NQ, FAST)                                                               \
-    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, false, false, false, 4>(P, lds); }
-#define PPG_KW2(name, NQ, FAST)                                                              \
-    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, true, false, false, 4>(P, lds); }
+#define PPG_KW(name, NQ, FAST, NW)                                                           \
+    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, false, false, false, NW>(P, lds); }
+#define PPG_KW2(name, NQ, FAST, NW)                                                          \
+    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, true, false, false, NW>(P, lds); }
 #include "ppg_kernel_list.h"
 
 #define PPG_APPLY(M, NQ) M(NQ)  // expands PPG_TU_NQ before the list pastes it into the kernel names
