@@ -194,7 +194,7 @@ def main():
     assert ((es[:, _abi.ENV_CALLS] - calls0) == args.steps).all()
 
     # ---- optional leg: the RCCL observation all-gather north_star specifies (N > 1 only) ----
-    gather_info = None
+    gather_info = gather_overlapped = None
     if distributed and args.gather_steps > 0:
         try:
             from predpreygrass_amd.distributed import ObservationGatherer
@@ -220,6 +220,52 @@ def main():
                            "what": "step + synchronous all-gather (RCCL) of the compacted float64 observations, ids, rewards, flags"}
         except Exception as ex:  # never lose the main measurement to the optional leg
             gather_info = {"error": repr(ex)[:300]}
+        # the same with the gather of step t overlapped with step t+1: the rows in use are packed (copied) on each
+        # sub-batch's stream right after its step, the next step is enqueued behind the copy, and the collective runs on a
+        # side stream that only waits for the copies
+        try:
+            from predpreygrass_amd.distributed import ObservationGatherer
+            gs = [ObservationGatherer(e) for e in group.subs]
+            cuda = not dry
+            side = torch.cuda.Stream(device=device) if cuda else None
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            tg = time.perf_counter()
+            nbytes = 0
+            for _ in range(args.gather_steps):
+                packed, events = [], []
+                for g, s in zip(gs, group.streams):
+                    if cuda:
+                        with torch.cuda.stream(s):
+                            packed.append(g.pack_local())
+                            ev = torch.cuda.Event()
+                            ev.record(s)
+                            events.append(ev)
+                    else:
+                        packed.append(g.pack_local())
+                one_step()                               # step t+1 runs while obs(t) travel
+                if cuda:
+                    for ev in events:
+                        side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        for g, loc in zip(gs, packed):
+                            g.gather(loc)
+                            nbytes += g.last_bytes
+                else:
+                    for g, loc in zip(gs, packed):
+                        g.gather(loc)
+                        nbytes += g.last_bytes
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            tg = time.perf_counter() - tg
+            t = torch.tensor([tg], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gather_overlapped = {"value": round(n_gpus * B * args.gather_steps / float(t.item()), 1), "unit": "env-steps/s",
+                                 "steps": args.gather_steps, "ms_per_step": round(float(t.item()) / args.gather_steps * 1e3, 4),
+                                 "gathered_bytes_per_step_per_rank": int(nbytes / args.gather_steps),
+                                 "what": "all-gather of step t's compacted observations overlapped with step t+1 (packed copies, side stream)"}
+        except Exception as ex:
+            gather_overlapped = {"error": repr(ex)[:300]}
 
     # ---- accounting ------------------------------------------------------------------
     status = int((es[:, _abi.ENV_STATUS]).max())
@@ -307,6 +353,8 @@ def main():
         }
         if gather_info is not None:
             out["obs_gather"] = gather_info
+        if gather_overlapped is not None:
+            out["obs_gather_overlapped"] = gather_overlapped
         if not args.no_cpu_baseline and n_gpus == 1 and not dry:
             out["cpu_baseline"] = cpu_baseline(cfg, args.seed, seconds=args.cpu_seconds, workload=args.workload)
         print(json.dumps(out), flush=True)

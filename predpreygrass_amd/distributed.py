@@ -65,9 +65,14 @@ class ObservationGatherer:
         dist.all_gather_into_tensor(out, pad, group=self.group)
         return [out[r * n_max: r * n_max + counts[r]] for r in range(self.world)]
 
-    def gather(self):
-        """Every rank receives every shard's packed observation data (list indexed by rank)."""
-        local = self.pack_local()
+    def gather(self, local=None):
+        """Every rank receives every shard's packed observation data (list indexed by rank).
+
+        local: a dict from an earlier `pack_local()`.  Packing copies the rows in use out of the env's buffers, so the
+        env can already run its next step while this gather moves the copies: pack on the env's stream, enqueue the next
+        step, then call `gather(local)` on another stream (`bench.py`'s obs_gather_overlapped leg)."""
+        if local is None:
+            local = self.pack_local()
         cnt = torch.tensor([local["obs_pred"].shape[0], local["obs_prey"].shape[0], self.env.batch_size],
                            dtype=torch.int64, device=self.env.device)
         allc = torch.empty((self.world * 3,), dtype=torch.int64, device=self.env.device)

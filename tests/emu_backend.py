@@ -22,11 +22,13 @@ def build(sanitize=False):
     out = EMU_LIB if not sanitize else EMU_LIB.replace(".so", "_ubsan.so")
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in _SOURCES):
         return out
+    tmp = f"{out}.{os.getpid()}.tmp"   # concurrent builders (multi-process tests) must never see a half-written library
     cmd = ["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fno-omit-frame-pointer", "-Wall",
-           "-Wno-unknown-pragmas", "-Wno-unused-function", "-fPIC", "-shared", "-o", out, _SOURCES[0]]
+           "-Wno-unknown-pragmas", "-Wno-unused-function", "-fPIC", "-shared", "-o", tmp, _SOURCES[0]]
     if sanitize:
         cmd[3:3] = ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"]
     subprocess.run(cmd, check=True)
+    os.replace(tmp, out)
     return out
 
 

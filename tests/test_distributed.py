@@ -8,6 +8,10 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests import emu_backend
+
+emu_backend.build()   # once, in the parent: the ranks below must not all start compiling the emulator library
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -105,3 +109,5 @@ def test_bench_two_ranks_dry_run_with_gather_leg():
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 5
     assert "obs_gather" in d and "error" not in d["obs_gather"], d.get("obs_gather")
     assert d["obs_gather"]["steps"] == 3 and d["obs_gather"]["gathered_bytes_per_step_per_rank"] > 0
+    assert "error" not in d["obs_gather_overlapped"], d["obs_gather_overlapped"]
+    assert d["obs_gather_overlapped"]["gathered_bytes_per_step_per_rank"] > 0
