@@ -219,3 +219,30 @@ def test_drive_conditioned_variant_on_gpu():
     from tests.test_env_api import replay_through_dict_api
     replay_through_dict_api("drive_dense_seed3", lambda c, **kw: DriveEnv({k: v for k, v in c.items() if k != "enable_drive_channels"},
                                                                        device="cuda:0", **kw))
+
+
+@pytest.mark.parametrize("cls_name", ["base", "red_queen"])
+def test_multiwave_step_kernels_give_identical_results(cls_name, monkeypatch):
+    """One, four and eight wavefronts per env (ppg_step / ppgw_step / ppgw8_step; the library picks by batch size, the
+    environment variables force a choice) must produce the same tables and observations, bit for bit."""
+    if cls_name == "base":
+        mk = lambda: make_env(dict(config_env), 300)
+    else:
+        from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
+        mk = lambda: BatchedRedQueen(config_env_base, batch_size=300, device="cuda:0")
+    results = []
+    for multi, eight in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("PPG_MULTIWAVE", multi)
+        monkeypatch.setenv("PPG_MULTIWAVE8", eight)
+        env = mk()
+        env.reset(seed=11)
+        for _ in range(150):
+            env.step(random_actions=True, auto_reset=True)
+        torch.cuda.synchronize()
+        results.append({n: getattr(env, n).clone() for n in
+                        ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state",
+                         "grass_energy", "obs_pred", "obs_prey")})
+    for other in results[1:]:
+        for n, t in results[0].items():
+            a, b = (t[:, : _abi.ENV_CALLS], other[n][:, : _abi.ENV_CALLS]) if n == "env_state" else (t, other[n])
+            assert torch.equal(a, b), n
