@@ -249,6 +249,8 @@ def main():
                         side.wait_event(ev)
                     with torch.cuda.stream(side):
                         for g, loc in zip(gs, packed):
+                            for v in loc.values():
+                                v.record_stream(side)   # allocated on the sub-batch's stream, consumed on the side stream
                             g.gather(loc)
                             nbytes += g.last_bytes
                 else:
