@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=3,
                     help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even for one rank, so that the gather legs run (needs torchrun)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="TEST ONLY: run the control flow on CPU (gloo, wave-emulator build of the kernel); numbers are meaningless")
     ap.add_argument("--gather-steps", type=int, default=50,
@@ -101,7 +103,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist   # --force-dist: exercise the RCCL legs with a world of one rank (test hook)
     dry = args.dry_run_cpu
     if dry:
         from tests.emu_backend import library as _emu_library

@@ -47,11 +47,18 @@ class ObservationGatherer:
         mp = self._rows_p < nP
         mq = self._rows_q < nQ
         cp = e.pred_capacity
+        # row indices of the slots in use; whole-row index_select copies (a boolean-mask gather of the 5-D observation
+        # tensors is ~30x slower)
+        ip = mp.reshape(-1).nonzero().squeeze(1)
+        iq = mq.reshape(-1).nonzero().squeeze(1)
+
+        def rows(t, idx):
+            return t.reshape((t.shape[0] * t.shape[1],) + tuple(t.shape[2:])).index_select(0, idx)
         out = {
-            "obs_pred": e.obs_pred[mp], "obs_prey": e.obs_prey[mq],
-            "id_pred": e.row_id[:, :cp][mp], "id_prey": e.row_id[:, cp:][mq],
-            "reward_pred": e.row_reward[:, :cp][mp], "reward_prey": e.row_reward[:, cp:][mq],
-            "flags_pred": e.row_flags[:, :cp][mp], "flags_prey": e.row_flags[:, cp:][mq],
+            "obs_pred": rows(e.obs_pred, ip), "obs_prey": rows(e.obs_prey, iq),
+            "id_pred": rows(e.row_id[:, :cp].contiguous(), ip), "id_prey": rows(e.row_id[:, cp:].contiguous(), iq),
+            "reward_pred": rows(e.row_reward[:, :cp].contiguous(), ip), "reward_prey": rows(e.row_reward[:, cp:].contiguous(), iq),
+            "flags_pred": rows(e.row_flags[:, :cp].contiguous(), ip), "flags_prey": rows(e.row_flags[:, cp:].contiguous(), iq),
             "env_state": es.clone(),
         }
         return out
@@ -59,8 +66,11 @@ class ObservationGatherer:
     def _all_gather_var(self, t: torch.Tensor, counts):
         """All-gather tensors whose first dimension differs per rank (counts known on every rank)."""
         n_max = max(counts)
-        pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        pad[: t.shape[0]] = t
+        if t.shape[0] == n_max:
+            pad = t.contiguous()
+        else:   # (the tail is never read: the receivers slice by counts)
+            pad = torch.empty((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[: t.shape[0]] = t
         out = torch.empty((self.world * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, pad, group=self.group)
         return [out[r * n_max: r * n_max + counts[r]] for r in range(self.world)]
