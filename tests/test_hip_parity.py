@@ -246,3 +246,23 @@ def test_multiwave_step_kernels_give_identical_results(cls_name, monkeypatch):
         for n, t in results[0].items():
             a, b = (t[:, : _abi.ENV_CALLS], other[n][:, : _abi.ENV_CALLS]) if n == "env_state" else (t, other[n])
             assert torch.equal(a, b), n
+
+
+def test_bench_rccl_gather_legs_with_one_rank():
+    """bench.py under torch.distributed.run with a world of ONE rank and --force-dist: process-group init on RCCL,
+    barrier / max-over-ranks timing, the synchronous and the overlapped observation-gather legs on the real device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "50",
+           "--envs", "1024", "--force-dist", "--no-cpu-baseline", "--gather-steps", "5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 1e6
+    for leg in ("obs_gather", "obs_gather_overlapped"):
+        assert "error" not in d[leg], d[leg]
+        assert d[leg]["gathered_bytes_per_step_per_rank"] > 1e6
