@@ -24,6 +24,21 @@ class PredPreyGrass(_RedQueenPredPreyGrass):
 
     _walls = True
     _require_all_actions = False   # WO:406 tolerates live agents without an action
+    _STATE_TENSORS = _RedQueenPredPreyGrass._STATE_TENSORS + ["wall_bits", "row_info"]
+
+    def get_state_snapshot(self):
+        snap = super().get_state_snapshot()
+        snap["wall_positions"] = set(self.wall_positions)   # static within an episode; kept so a restore after another reset works
+        snap["los_rejected_moves_total"] = self.los_rejected_moves_total
+        snap["los_rejected_moves_by_type"] = dict(self.los_rejected_moves_by_type)
+        return snap
+
+    def restore_state_snapshot(self, snapshot):
+        self.wall_positions = set(snapshot["wall_positions"])
+        self.los_rejected_moves_total = snapshot["los_rejected_moves_total"]
+        self.los_rejected_moves_by_type = dict(snapshot["los_rejected_moves_by_type"])
+        self._last_action_names = []
+        super().restore_state_snapshot(snapshot)
 
     def __init__(self, config=None, **kw):
         super().__init__(config, **kw)

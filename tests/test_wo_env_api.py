@@ -74,3 +74,40 @@ def test_wall_sanity_like_the_reference_script():
     assert env.grid_world_state[0].sum() == 20.0
     with pytest.raises(ValueError, match="Too many agents"):
         make(dict(cfg, num_walls=95)).reset(seed=1)
+
+
+def test_snapshot_restore_survives_a_reset_with_other_walls():
+    case = RQGoldenCase("wo_los_two_types_seed5")
+    env = make(case.config)
+    env.reset(seed=int(case.z["seed"]))
+    for t in range(15):
+        env.step(case.actions(t))
+    snap = env.get_state_snapshot()
+    a = [env.step(case.actions(t)) for t in range(15, 25)]
+    env.reset(seed=999)                       # other walls, other cells
+    assert env.wall_positions != snap["wall_positions"]
+    env.restore_state_snapshot(snap)
+    assert env.wall_positions == snap["wall_positions"]
+    b = [env.step(case.actions(t)) for t in range(15, 25)]
+    for x, y in zip(a, b):
+        assert list(x[0]) == list(y[0]) and x[1] == y[1] and x[2] == y[2] and x[4] == y[4]
+        for k in x[0]:
+            assert x[0][k].tobytes() == y[0][k].tobytes()
+
+
+def test_batched_per_env_walls():
+    import torch
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+    case = RQGoldenCase("wo_base_random_walls_seed3")
+    env = BatchedRedQueen(case.config, batch_size=2, walls=True, _library=library())
+    env.set_walls([case.wall_xy, case.wall_xy[:5]])        # one list per env
+    env.reset(seed=3)
+    g = env.export_grid().numpy()
+    assert g[0, 0].sum() == len(case.wall_xy) and g[1, 0].sum() == 5
+    # nobody is placed on a wall
+    es = env.env_state.numpy()
+    for b, walls in enumerate((case.wall_xy, case.wall_xy[:5])):
+        ws = {(int(x), int(y)) for x, y in walls}
+        n = int(es[b, 0])
+        xy = env.row_xy[b, :n].numpy().astype(np.int64) & 0xFFFF
+        assert not any(((int(v) >> 8), int(v) & 255) in ws for v in xy)
