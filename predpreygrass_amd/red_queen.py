@@ -230,13 +230,15 @@ class BatchedRedQueen(BatchedPredPreyGrass):
         self.observe()
         return self
 
-    def set_walls(self, wall_xy):
-        """Wall cells of every env (walls variant): a list of (x, y) shared by all envs, or one list per env.  They stay in
-        place across device resets until replaced; call before `set_placement` / `reset`."""
+    def set_walls(self, wall_xy, per_env=False):
+        """Wall cells (walls variant): a list of (x, y) shared by all envs, or with per_env=True one such list per env.
+        They stay in place across device resets until replaced; call before `set_placement` / `reset`."""
         if not self.walls:
             raise RuntimeError("set_walls needs walls=True")
         B, G = self.batch_size, self.grid_size
-        per_env = wall_xy if (len(wall_xy) == B and len(wall_xy) > 0 and np.asarray(wall_xy[0]).ndim == 2) else [wall_xy] * B
+        if per_env and len(wall_xy) != B:
+            raise ValueError("per_env=True needs one wall list per env")
+        per_env = list(wall_xy) if per_env else [wall_xy] * B
         bits = np.zeros((B, self.wall_bits.shape[1]), dtype=np.uint32)
         for b, cells in enumerate(per_env):
             a = np.asarray(cells, dtype=np.int64).reshape(-1, 2)

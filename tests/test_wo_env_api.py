@@ -100,7 +100,7 @@ def test_batched_per_env_walls():
     from predpreygrass_amd.red_queen import BatchedRedQueen
     case = RQGoldenCase("wo_base_random_walls_seed3")
     env = BatchedRedQueen(case.config, batch_size=2, walls=True, _library=library())
-    env.set_walls([case.wall_xy, case.wall_xy[:5]])        # one list per env
+    env.set_walls([case.wall_xy, case.wall_xy[:5]], per_env=True)
     env.reset(seed=3)
     g = env.export_grid().numpy()
     assert g[0, 0].sum() == len(case.wall_xy) and g[1, 0].sum() == 5
