@@ -1,6 +1,6 @@
 // Calibration kernel (not product code): the observation WRITE PATTERN of ppg_step without any compute.
 // One 64-lane workgroup per env writes rows[b] blocks of `blk` doubles (16-byte stores, 128 doubles per
-// wave instruction) into its own stride-`cap*blk` region.  Usage: ./a.out B rows_mean iters
+// wave instruction) into its own stride-`cap*blk` region.  Usage: ./a.out B rows_mean iters [cap]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(64) pattern(double *obs, const int *rows, int 
 }
 int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4096, mean = argc > 2 ? atoi(argv[2]) : 36, iters = argc > 3 ? atoi(argv[3]) : 200;
-    const int cap = 128, blk = 324;
+    const int cap = argc > 4 ? atoi(argv[4]) : 128, blk = 324;   // cap = rows per env slot (stride between envs = cap * blk doubles)
     double *obs; int *rows;
     hipMalloc(&obs, (size_t)B * cap * blk * 8);
     hipMalloc(&rows, B * sizeof(int));
