@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=3,
                     help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step)")
+    ap.add_argument("--rebalance-every", type=int, default=64,
+                    help="call ppg_rebalance every that many steps (0 = never): heavy envs are assigned to workgroups first")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even for one rank, so that the gather legs run (needs torchrun)")
     ap.add_argument("--dry-run-cpu", action="store_true",
@@ -152,7 +154,14 @@ def main():
     group.synchronize()
     env = group.subs[0]
 
+    step_no = [0]
+
     def one_step():
+        # every --rebalance-every steps the library re-sorts the env -> workgroup assignment by the envs' current number of
+        # agents (ppg_rebalance: scheduling only, part of the timed loop)
+        if args.rebalance_every > 0 and step_no[0] % args.rebalance_every == 0:
+            group.rebalance()
+        step_no[0] += 1
         group.step(random_actions=True, auto_reset=True)
 
     for _ in range(args.warmup):

@@ -320,6 +320,12 @@ int ppg_step_many(ppg_handle *const *handles, int32_t n, const int8_t *const *ac
  * 4 envs per CU. */
 int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight);
 
+/* Scheduling only, results are unaffected: recompute the order in which the handle's envs are assigned to workgroups --
+ * envs with many agent rows (much observation data to write) first, so that the load is spread evenly over the CUs.
+ * Stream-ordered like a step; populations drift slowly, calling it every few dozen steps is enough (bench.py: every 32).
+ * The order is used by every later launch of the handle. */
+int ppg_rebalance(ppg_handle *h, void *stream);
+
 /* grid_world_state (BASE:124): dense float64 [B,4,G,G] rebuilt from the rows. */
 int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream);
 

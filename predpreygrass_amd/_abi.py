@@ -91,7 +91,7 @@ class PpgBuffers(C.Structure):
 
 EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
-    "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight",
+    "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_rebalance",
     "ppg_export_grid",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_last_error",
 ]
@@ -120,6 +120,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_create_gen2.argtypes = [C.POINTER(PpgConfigGen2), C.c_int32, C.c_int32, C.POINTER(PpgBuffers), C.POINTER(C.c_void_p)]
     lib.ppg_step_uniforms.restype = C.c_int
     lib.ppg_step_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
+    lib.ppg_rebalance.restype = C.c_int
+    lib.ppg_rebalance.argtypes = [C.c_void_p, C.c_void_p]
     lib.ppg_set_envs_in_flight.restype = C.c_int
     lib.ppg_set_envs_in_flight.argtypes = [C.c_void_p, C.c_int32]
     lib.ppg_export_grid.restype = C.c_int

@@ -279,6 +279,12 @@ class BatchedPredPreyGrass:
         self.observe()
         return self
 
+    def rebalance(self, stream=None):
+        """Scheduling only (results are unaffected): let envs with many agents start first so that the observation
+        writing is spread evenly over the CUs; call every few dozen steps (`ppg_rebalance`)."""
+        self._check(self._lib.ppg_rebalance(self._handle, self._stream(stream)), "ppg_rebalance")
+        return self
+
     def observe(self):
         """Recompute the observations of all live rows from the current state tensors."""
         self._check(self._lib.ppg_observe(self._handle, self._stream()), "ppg_observe")

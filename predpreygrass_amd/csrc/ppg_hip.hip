@@ -106,6 +106,38 @@ static int backend_init(ppg_handle *h, int device) {
 static void backend_release(ppg_handle *h) {
     if (h->lut_dev) (void)hipFree(h->lut_dev);
     h->lut_dev = nullptr;
+    if (h->order_dev) (void)hipFree(h->order_dev);
+    h->order_dev = nullptr;
+}
+
+// order[rank(i)] = i, rank by descending key (rows weighted by observation size), ties by index: a counting sort that
+// needs no scratch.  Every workgroup stages all keys in LDS (4 bytes per env) and each thread ranks one env.
+extern "C" __global__ void __launch_bounds__(256) ppg_rank_envs(const int32_t *env_state, int batch, int wp, int wq, int32_t *order) {
+    extern __shared__ int32_t keys[];
+    for (int j = (int)threadIdx.x; j < batch; j += (int)blockDim.x)
+        keys[j] = env_state[(size_t)j * PPG_ENV_WORDS + PPG_ENV_N_PRED_ROWS] * wp + env_state[(size_t)j * PPG_ENV_WORDS + PPG_ENV_N_PREY_ROWS] * wq;
+    __syncthreads();
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= batch) return;
+    const int ki = keys[i];
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < batch; ++j) {
+        const int kj = keys[j];
+        rank += (kj > ki) || (kj == ki && j < i);
+    }
+    order[rank] = i;
+}
+
+static int backend_rebalance(ppg_handle *h, int weight_pred, int weight_prey, void *stream) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->order_dev) PPG_HIP_TRY(h, hipMalloc((void **)&h->order_dev, (size_t)h->batch * sizeof(int32_t)));
+    if (h->batch > 16000) return ppg_fail(h, PPG_EINVAL, "ppg_rebalance supports up to 16000 envs per handle (use sub-batches)");
+    hipLaunchKernelGGL(ppg_rank_envs, dim3((unsigned)((h->batch + 255) / 256)), dim3(256), (size_t)h->batch * sizeof(int32_t), (hipStream_t)stream,
+                       (const int32_t *)h->bufs.env_state, (int)h->batch, weight_pred, weight_prey, h->order_dev);
+    PPG_HIP_TRY(h, hipGetLastError());
+    return PPG_OK;
 }
 
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream) {

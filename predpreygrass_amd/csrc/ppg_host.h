@@ -21,6 +21,7 @@
 struct ppg_handle {
     int32_t drive;  // drive-conditioned variant of the base family (cfg.n_drive)
     int32_t envs_in_flight;  // scheduling hint (ppg_set_envs_in_flight); 0 = the handle's own batch
+    int32_t *order_dev;      // library-owned [batch]: env order of ppg_rebalance (NULL until first used)
     ppg_config cfg;
     ppg_config_gen2 cfg2;
     int32_t gen2;  // created by ppg_create_gen2
@@ -261,6 +262,9 @@ static bool ppg_use_multiwave(const ppg_handle *h) {
 static int backend_init(ppg_handle *h, int device);
 static void backend_release(ppg_handle *h);
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream);
+// (re)compute h->order_dev (allocating it on first use): envs sorted by descending weight_pred * predator rows +
+// weight_prey * prey rows, ties by env index -- always a permutation of 0..batch-1
+static int backend_rebalance(ppg_handle *h, int weight_pred, int weight_prey, void *stream);
 
 extern "C" {
 
@@ -278,6 +282,7 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     h->bufs = *bufs; h->batch = batch; h->device = device;
     h->lut_dev = nullptr; h->backend = nullptr; h->prof_dev = nullptr; h->err[0] = 0;
     h->envs_in_flight = 0;
+    h->order_dev = nullptr;
     h->drive = (cfg && (cfg->n_drive[0] > 0 || cfg->n_drive[1] > 0)) ? 1 : 0;
     int rc = cfg2 ? ppg_validate_and_layout_gen2(h) : ppg_validate_and_layout(h);
     if (rc == PPG_OK) rc = backend_init(h, device);
@@ -378,6 +383,14 @@ int ppg_step_uniforms(ppg_handle *h, const int8_t *actions, const uint8_t *act_r
     P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
     P.uniforms = uniforms; P.uniforms_per_env = uniforms_per_env;
     return backend_launch(h, mode, P, stream);
+}
+
+int ppg_rebalance(ppg_handle *h, void *stream) {
+    if (!h) return PPG_EINVAL;
+    const ppg::KParams &P = h->base;
+    const int rc = backend_rebalance(h, P.nch_p, P.nch_q, stream);   // weight = 128-element chunks per observation
+    if (rc == PPG_OK) h->base.env_order = h->order_dev;
+    return rc;
 }
 
 int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight) {

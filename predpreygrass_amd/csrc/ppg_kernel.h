@@ -131,6 +131,7 @@ struct KParams {
     const double *uniforms;   // second generation, ppg_step_uniforms: [B, uniforms_per_env]
     double *grid_out;
     unsigned long long *prof;  // diagnostic build only
+    const int32_t *env_order;  // optional permutation of 0..batch-1 (ppg_rebalance): workgroup i steps env env_order[i]
     uint32_t flags;
     uint32_t reset_episode;
     int32_t n_steps;   // transitions per launch (ppg_step: 1; ppg_rollout: n)
@@ -2035,8 +2036,12 @@ struct Env {
 
 template <int NQ, int MODE, bool FASTOBS, bool GEN2 = false, bool WALLS = false, bool DRIVE = false, int NW = 1>
 PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
-    const int b = PPG_BLOCK_INDEX();
+    int b = PPG_BLOCK_INDEX();
     if (b >= P.batch) return;
+    {   // scheduling only: heavy envs first, so that consecutive workgroups (which land on different CUs) spread the load
+        const PPG_CONSTANT_AS KParams *Pk = PPG_KERNARG_PTR(KParams, P);
+        if (Pk->env_order) b = (int)wv::first((uint32_t)Pk->env_order[b]);   // (kept scalar: b feeds every address)
+    }
     if (MODE == MODE_ROLLOUT) {
         // ppg_rollout: n_steps transitions in one launch.  Every lane always loads and stores the same slots
         // (its rows, its env words, its grass patches), so a fused step reads its state back through memory

@@ -77,6 +77,12 @@ class SubBatchedPredPreyGrass:
             raise RuntimeError(f"ppg_step_many failed ({rc})")
         return self
 
+    def rebalance(self):
+        """ppg_rebalance of every sub-batch on its own stream (scheduling only)."""
+        for e, s in zip(self.subs, self.streams):
+            e.rebalance(stream=s)
+        return self
+
     def rollout(self, n_steps, random_actions=True, auto_reset=False):
         """`n_steps` fused transitions per sub-batch (one launch each, on its own stream)."""
         for e, s in zip(self.subs, self.streams):

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from oracle.ppg_oracle import OracleEnv
+from predpreygrass_amd import _abi
 from predpreygrass_amd.batched import BatchedPredPreyGrass, lexkey
 from predpreygrass_amd.config import config_env
 from tests.emu_backend import library
@@ -181,3 +182,19 @@ def test_emulated_random_rollout_with_drive_channels_matches_oracle():
     env = make_env(cfg, 3)
     assert env.obs_pred.shape[2] == 7 and env.obs_prey.shape[2] == 8
     rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=77, n_calls=120, check_every=1)
+
+
+def test_rebalance_changes_scheduling_only():
+    """ppg_rebalance re-orders the assignment of envs to workgroups (heavy envs first); every result must stay the same."""
+    import torch
+    cfg = {**config_env, "grid_size": 12, "initial_num_grass": 40, "max_steps": 40}
+    envs = [make_env(cfg, 7), make_env(cfg, 7)]
+    for k, env in enumerate(envs):
+        env.reset(seed=21)
+        for t in range(60):
+            if k == 1 and t % 5 == 0:
+                env.rebalance()
+            env.step(random_actions=True, auto_reset=True)
+    for n in ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
+        assert torch.equal(getattr(envs[0], n), getattr(envs[1], n)), n
+    assert torch.equal(envs[0].env_state[:, : _abi.ENV_CALLS], envs[1].env_state[:, : _abi.ENV_CALLS])

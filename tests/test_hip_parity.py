@@ -266,3 +266,18 @@ def test_bench_rccl_gather_legs_with_one_rank():
     for leg in ("obs_gather", "obs_gather_overlapped"):
         assert "error" not in d[leg], d[leg]
         assert d[leg]["gathered_bytes_per_step_per_rank"] > 1e6
+
+
+def test_rebalance_changes_scheduling_only_on_gpu():
+    """ppg_rebalance (heavy envs are assigned to workgroups first) must not change any result: 2048 envs, 200 calls."""
+    envs = [make_env(dict(config_env), 2048), make_env(dict(config_env), 2048)]
+    for k, env in enumerate(envs):
+        env.reset(seed=77)
+        for t in range(200):
+            if k == 1 and t % 16 == 0:
+                env.rebalance()
+            env.step(random_actions=True, auto_reset=True)
+    torch.cuda.synchronize()
+    for n in ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
+        assert torch.equal(getattr(envs[0], n), getattr(envs[1], n)), n
+    assert torch.equal(envs[0].env_state[:, : _abi.ENV_CALLS], envs[1].env_state[:, : _abi.ENV_CALLS])

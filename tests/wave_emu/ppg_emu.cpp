@@ -118,6 +118,22 @@ static int backend_init(ppg_handle *h, int) {
 static void backend_release(ppg_handle *h) {
     free(h->lut_dev);
     h->lut_dev = nullptr;
+    free(h->order_dev);
+    h->order_dev = nullptr;
+}
+static int backend_rebalance(ppg_handle *h, int wp, int wq, void *) {
+    if (!h->order_dev) h->order_dev = (int32_t *)malloc((size_t)h->batch * sizeof(int32_t));
+    const int32_t *es = h->bufs.env_state;
+    for (int i = 0; i < h->batch; ++i) {
+        const int ki = es[(size_t)i * PPG_ENV_WORDS + PPG_ENV_N_PRED_ROWS] * wp + es[(size_t)i * PPG_ENV_WORDS + PPG_ENV_N_PREY_ROWS] * wq;
+        int rank = 0;
+        for (int j = 0; j < h->batch; ++j) {
+            const int kj = es[(size_t)j * PPG_ENV_WORDS + PPG_ENV_N_PRED_ROWS] * wp + es[(size_t)j * PPG_ENV_WORDS + PPG_ENV_N_PREY_ROWS] * wq;
+            rank += (kj > ki) || (kj == ki && j < i);
+        }
+        h->order_dev[rank] = i;
+    }
+    return PPG_OK;
 }
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *) {
     EmuLaunch L{&P, h->nq, mode, h->drive ? 3 : h->gen2 ? (h->cfg2.walls ? 2 : 1) : 0};
