@@ -298,7 +298,7 @@ def main():
     # MI355X_MICROARCH.md HBM section); only quoted when the settings match the profiled run.
     traffic = None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "e_bench_default_summary.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "f_bench_default_summary.json")))
         if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry and args.workload == "base":
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
     except Exception:
@@ -347,7 +347,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_source": "profiles/r01/e_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "traffic_source": "profiles/r01/f_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                   "bytes per launch)" if traffic else None,
                 "achieved_from_pmc_traffic": round(traffic * n_sub / kernel_s / 1e9, 1) if traffic else None,
                 "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
