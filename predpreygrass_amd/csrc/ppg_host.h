@@ -170,6 +170,10 @@ static int ppg_validate_and_layout(ppg_handle *h) {
         P.n_wall_words = (n + 31) / 32;
         off = (off + 15) / 16 * 16;
         P.off_wall = off; off += P.n_wall_words * 4;
+        // line-of-sight staging: one float per window cell, one area per wave of a multi-wave workgroup (4)
+        const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;
+        off = (off + 15) / 16 * 16;
+        P.off_win = off; off += 4 * rmax * rmax * 4;
     }
     P.lds_bytes = off;
     if (const char *pad = getenv("PPG_DEBUG_LDS_BYTES")) { int v = atoi(pad); if (v > P.lds_bytes) P.lds_bytes = v; }  // occupancy experiments

@@ -233,6 +233,7 @@ struct Env {
              // kernarg segment at their single use sites, so they do not occupy SGPRs for the whole kernel
     const int b;
     const int ln;
+    int wave_idx = 0;  // index of this wavefront in its workgroup (multi-wave kernels; 0 otherwise)
 
     uint16_t *map;   // LDS
     double *val;     // LDS
@@ -1158,6 +1159,20 @@ struct Env {
         const bool interior = !WALLS && !DRIVE && (R & 1) && x >= off && y >= off && x + off < P.G && y + off < P.G;
         const uint2 *L = (const uint2 *)(lut + (type ? P.nch_p * 128 : 0));
         const int nch = type ? P.nch_q : P.nch_p;
+        // walls variant: the line-of-sight mask of this agent, one value per cell of the R x R array (WO:577-589), staged in
+        // LDS once and used by up to four channels (every wave of a multi-wave workgroup has its own staging area)
+        const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;   // (areas are strided by the larger window: waves work on both species)
+        float *visb = (float *)((unsigned char *)map + C.off_win - P.off_map) + wave_idx * rmax * rmax;
+        const bool want_vis = WALLS && (C.mask_obs || C.vis_channel);
+        if (want_vis) {
+            for (int i = ln; i < R * R; i += 64) {
+                const int ci = i / R, cj = i - ci * R;
+                const int gx = x - off + ci, gy = y - off + cj;
+                const bool in_grid = (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+                visb[i] = (in_grid && los_clear(x, y, gx, gy)) ? 1.0f : 0.0f;
+            }
+            wv::sync();
+        }
         const size_t obase = ((size_t)b * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)blk;
         for (int ch = 0; ch < nch; ++ch) {
             const uint2 d = L[ch * 64 + ln];
@@ -1191,7 +1206,8 @@ struct Env {
                         // for the last row / column of an even R, which the window copy (WO:543) leaves untouched
                         const bool in_grid = (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
                         const bool need_vis = vis_elem ? in_grid : (inb && C.mask_obs && (w & 0x3000000u) != 0u);
-                        const float vis = (need_vis && los_clear(x, y, gx, gy)) ? 1.0f : 0.0f;
+                        const int vcell = ((int)((w >> 16) & 15u) - 8 + off) * R + ((int)((w >> 20) & 15u) - 8 + off);
+                        const float vis = need_vis ? visb[vcell] : 0.0f;
                         if (vis_elem) t = (double)vis;
                         else if ((w & 0x3000000u) == 0u) t = (inb && wall_at(gx, gy)) ? 1.0 : 0.0;
                         else if (C.mask_obs) t = (double)((float)t * vis);
@@ -2072,6 +2088,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
         env(P, *Pcold, b, lds, wv::lane());
     if (NW > 1) {
         const int w = wv::wave_index();
+        env.wave_idx = w;
         if (w != 0) { env.run_helper(w); return; }
     }
     if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();

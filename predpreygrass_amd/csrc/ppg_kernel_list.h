@@ -33,8 +33,9 @@
     PPG_KW2(ppgw28_step_q##NQ, NQ, true, 8)                           \
     PPG_KW2(ppgw28_step_q##NQ##g, NQ, false, 8)
 
-// walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>)
+// walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>; ppgw3_step: 4 waves per env)
 #define PPG_DEFINE_KERNELS3(NQ)                                       \
+    PPG_KW3(ppgw3_step_q##NQ, NQ)                                     \
     PPG_K3(ppg3_step_q##NQ, NQ, ppg::MODE_STEP)                       \
     PPG_K3(ppg3_reset_q##NQ, NQ, ppg::MODE_RESET)                     \
     PPG_K3(ppg3_observe_q##NQ, NQ, ppg::MODE_OBSERVE)                 \
