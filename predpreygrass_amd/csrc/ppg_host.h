@@ -69,7 +69,11 @@ static void ppg_build_lut(int R, int G, int map_n, uint32_t *out, int channels =
     const int blk = channels * R * R, off = (R - 1) / 2;
     const int W = 2 * off + 1;  // BASE:532-539: the window is x-off..x+off
     const int nwords = ppg_obs_chunks_c(R, channels) * 128;
-    for (int e = 0; e < nwords; ++e) {
+    // odd-sized blocks (an odd number of channels x an odd window) cannot be stored as aligned element pairs: their
+    // descriptors are laid out so that lane l of chunk c handles elements c*128 + l and c*128 + 64 + l (see Env::obs_row)
+    const bool strided = (blk & 1) != 0;
+    for (int slot = 0; slot < nwords; ++slot) {
+        const int e = strided ? (slot & ~127) + ((slot & 127) >> 1) + 64 * (slot & 1) : slot;
         uint32_t d = 0;
         if (e < blk) {
             const int c = e / (R * R), rem = e % (R * R), i = rem / R, j = rem % R;
@@ -80,7 +84,7 @@ static void ppg_build_lut(int R, int G, int map_n, uint32_t *out, int channels =
                 ((c >= 4 && !drive) ? 0x10000000u : 0u);
             if (c >= 4 && drive) d = 0x4000000u | 0x20000000u | ((uint32_t)(c - 4) << 24);
         }
-        out[e] = d;
+        out[slot] = d;
     }
 }
 

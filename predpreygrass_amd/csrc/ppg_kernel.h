@@ -1099,10 +1099,12 @@ struct Env {
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;
         double *win = (double *)((unsigned char *)map + C.off_win - P.off_map);
-        const uint32_t *L = lut + (type ? P.nch_p * 128 : 0) + ch * n;
+        const uint32_t *L = lut + (type ? P.nch_p * 128 : 0);
+        const bool strided = (((4 + (type ? C.n_drive[1] : C.n_drive[0])) * n) & 1) != 0;   // see obs_row / ppg_build_lut
         wv::sync();
         for (int i = ln; i < n; i += 64) {
-            const uint32_t w = L[i];
+            const int el = ch * n + i, w7 = el & 127;
+            const uint32_t w = L[strided ? (el & ~127) + (w7 & 63) * 2 + (w7 >> 6) : el];
             const int gx = x + (int)((w >> 16) & 15u) - 8, gy = y + (int)((w >> 20) & 15u) - 8;
             const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
             win[i] = val[map[inb ? (int)(int16_t)(w & 0xFFFFu) + s_cell : 0]];
@@ -1216,14 +1218,16 @@ struct Env {
                 }
             }
             if ((WALLS || DRIVE) && (blk & 1)) {
-                // five channels x an odd window: blocks start at odd element offsets and the last pair of a block
-                // straddles the next agent's block -> element-wise stores
-                const size_t o = obase + (size_t)ch * 128 + 2 * (size_t)ln;
+                // an odd number of channels x an odd window: blocks start at odd element offsets, so element pairs cannot be
+                // stored as aligned vectors.  For these geometries the host lays the descriptors out "strided": this lane's
+                // two elements are ch*128 + ln and ch*128 + 64 + ln, i.e. each store instruction writes 64 consecutive
+                // elements (ppg_build_lut)
+                const size_t o = obase + (size_t)ch * 128 + (size_t)ln;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (!((h ? d.y : d.x) & 0x4000000u)) continue;
-                    if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred))[o + h] = (float)v[h];
-                    else ((double *)(type ? P.obs_prey : P.obs_pred))[o + h] = v[h];
+                    if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred))[o + 64 * h] = (float)v[h];
+                    else ((double *)(type ? P.obs_prey : P.obs_pred))[o + 64 * h] = v[h];
                 }
             } else if (d.x & 0x4000000u) {
                 const size_t o = obase + (size_t)ch * 128 + 2 * (size_t)ln;
