@@ -17,6 +17,7 @@
 #define PPG_K3(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K4(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_KW3(name, NQ) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
+#define PPG_KW4(name, NQ) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
 #define PPG_KW(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KW2(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #include "ppg_kernel_list.h"
@@ -151,7 +152,11 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
                        : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);
     unsigned block = 64;
-    if (mode == ppg::MODE_STEP && h->gen2 && h->cfg2.walls && ppg_use_multiwave(h)) {
+    if (mode == ppg::MODE_STEP && h->drive && ppg_use_multiwave(h)) {
+        static const ppg_kernel_fn w4[3] = {ppgw4_step_q1, ppgw4_step_q2, ppgw4_step_q4};
+        fn = w4[h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
+        block = 256;
+    } else if (mode == ppg::MODE_STEP && h->gen2 && h->cfg2.walls && ppg_use_multiwave(h)) {
         static const ppg_kernel_fn w3[3] = {ppgw3_step_q1, ppgw3_step_q2, ppgw3_step_q4};
         fn = w3[h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
         block = 256;

@@ -168,7 +168,7 @@ static int ppg_validate_and_layout(ppg_handle *h) {
         P.norm_grass_opp = c.grass_opportunity_normalizer;
         const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;
         off = (off + 15) / 16 * 16;
-        P.off_win = off; off += rmax * rmax * 8;
+        P.off_win = off; off += 4 * rmax * rmax * 8;   // one area per wave of a multi-wave workgroup
     }
     if (h->gen2 && h->cfg2.walls) {  // wall bitmap
         P.n_wall_words = (n + 31) / 32;

@@ -1098,7 +1098,8 @@ struct Env {
         const int R = type ? P.Rq : P.Rp, n = R * R;
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;
-        double *win = (double *)((unsigned char *)map + C.off_win - P.off_map);
+        const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;   // one staging area per wave of a multi-wave workgroup
+        double *win = (double *)((unsigned char *)map + C.off_win - P.off_map) + wave_idx * rmax * rmax;
         const uint32_t *L = lut + (type ? P.nch_p * 128 : 0);
         const bool strided = (((4 + (type ? C.n_drive[1] : C.n_drive[0])) * n) & 1) != 0;   // see obs_row / ppg_build_lut
         wv::sync();
@@ -1249,7 +1250,10 @@ struct Env {
         const int n = (int)wv::first(lst[0]);
         for (int i = w; i < n; i += NW) {
             const uint32_t en = wv::first(lst[1 + i]);
-            obs_row((int)(en >> 31), (int)((en >> 16) & 0x7FFFu), en & 0xFFFFu);
+            const int ty = (int)(en >> 31), row = (int)((en >> 16) & 0x7FFFu);
+            // (drive variant: the agent's energy is its entry of the LDS value table -- row energies are kept current there)
+            const double s_e = DRIVE ? first_f64(val[1 + (ty ? P.cap_pred + row : row)]) : 0.0;
+            obs_row(ty, row, en & 0xFFFFu, s_e);
         }
     }
     // a helper wave of a multi-wave workgroup: wait until wave 0 has finished the transition, then write its share

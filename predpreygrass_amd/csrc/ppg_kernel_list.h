@@ -44,6 +44,7 @@
 
 // drive-conditioned variant of the base family: generic observation geometry only (ppg4_<mode>_q<NQ>)
 #define PPG_DEFINE_KERNELS4(NQ)                                       \
+    PPG_KW4(ppgw4_step_q##NQ, NQ)                                     \
     PPG_K4(ppg4_step_q##NQ, NQ, ppg::MODE_STEP)                       \
     PPG_K4(ppg4_reset_q##NQ, NQ, ppg::MODE_RESET)                     \
     PPG_K4(ppg4_observe_q##NQ, NQ, ppg::MODE_OBSERVE)                 \

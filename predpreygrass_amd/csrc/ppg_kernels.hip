@@ -23,6 +23,8 @@
     PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, true, false, false, NW>(P, lds); }
 #define PPG_KW3(name, NQ)                                                                    \
     PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, true, true, false, 4>(P, lds); }
+#define PPG_KW4(name, NQ)                                                                    \
+    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, 4>(P, lds); }
 #include "ppg_kernel_list.h"
 
 #define PPG_APPLY(M, NQ) M(NQ)  // expands PPG_TU_NQ before the list pastes it into the kernel names
