@@ -152,11 +152,11 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
                        : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);
     unsigned block = 64;
-    if (mode == ppg::MODE_STEP && h->drive && ppg_use_multiwave(h)) {
+    if (mode == ppg::MODE_STEP && h->drive && ppg_use_multiwave(h, true)) {
         static const ppg_kernel_fn w4[3] = {ppgw4_step_q1, ppgw4_step_q2, ppgw4_step_q4};
         fn = w4[h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
         block = 256;
-    } else if (mode == ppg::MODE_STEP && h->gen2 && h->cfg2.walls && ppg_use_multiwave(h)) {
+    } else if (mode == ppg::MODE_STEP && h->gen2 && h->cfg2.walls && ppg_use_multiwave(h, true)) {
         static const ppg_kernel_fn w3[3] = {ppgw3_step_q1, ppgw3_step_q2, ppgw3_step_q4};
         fn = w3[h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
         block = 256;

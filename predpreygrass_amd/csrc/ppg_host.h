@@ -260,8 +260,11 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
 // measured on MI355X, 4 waves per env win up to about 3072 envs in flight (256 envs: 1.8x, 1024: 1.7x, 2048: 1.3x,
 // 3072: 1.02x, 4096: 0.93x), and whenever the LDS footprint admits at most 4 envs per CU (64x64 grids: 1.4x).
 // PPG_MULTIWAVE=0/1 forces (experiments).
-static bool ppg_use_multiwave(const ppg_handle *h) {
+// compute_bound: the walls and drive variants (Bresenham walks / window sums per observation) are never limited by HBM:
+// four waves per env pay off at every batch size (4096 envs: 1.7-1.9x).
+static bool ppg_use_multiwave(const ppg_handle *h, bool compute_bound = false) {
     if (const char *f = getenv("PPG_MULTIWAVE")) return atoi(f) != 0;
+    if (compute_bound) return true;
     const int lds_envs = h->base.lds_bytes > 0 ? (160 * 1024) / h->base.lds_bytes : 16;
     const int in_flight = h->envs_in_flight > 0 ? h->envs_in_flight : h->batch;
     return in_flight <= 3072 || lds_envs <= 4;
