@@ -78,9 +78,11 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--obs-dtype", choices=["f64", "f32"], default=None,
                     help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen)")
-    ap.add_argument("--workload", choices=["base", "c4", "red_queen"], default="base",
+    ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls"], default="base",
                     help="base: BASELINE.json configs[2] (the headline); c4: configs[3] (64x64 grid, 16 predators / 32 prey, "
-                         "7x7 windows); red_queen: the second-generation env (SURVEY 8(f) N2) with its reference config")
+                         "7x7 windows); red_queen: the second-generation env (SURVEY 8(f) N2) with its reference config; "
+                         "drive: the drive-conditioned variant of the default config; walls: the walls variant with the "
+                         "reference's zigzag layout and every line-of-sight option on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=3,
@@ -133,10 +135,15 @@ def main():
         torch.cuda.set_device(device)
     n_gpus = world if distributed else 1
 
-    rq = args.workload == "red_queen"
+    rq = args.workload in ("red_queen", "walls")
+    extra_kw = {}
     if args.obs_dtype is None:
         args.obs_dtype = "f32" if rq else "f64"
-    if rq:
+    if args.workload == "walls":
+        from predpreygrass_amd.red_queen import BatchedRedQueen
+        from predpreygrass_amd.walls_occlusion import config_env_zigzag_walls
+        cfg, env_class, extra_kw = dict(config_env_zigzag_walls), BatchedRedQueen, {"walls": True}
+    elif rq:
         from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
         cfg, env_class = dict(config_env_base), BatchedRedQueen
     else:
@@ -144,12 +151,17 @@ def main():
         if args.workload == "c4":   # BASELINE.json configs[3]
             cfg.update({"grid_size": 64, "n_initial_active_predator": 16, "n_initial_active_prey": 32,
                         "predator_obs_range": 7, "prey_obs_range": 7})
+        if args.workload == "drive":
+            cfg["enable_drive_channels"] = True
     B = args.envs
     obs_dtype = torch.float64 if args.obs_dtype == "f64" else torch.float32
     from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
     n_sub = max(1, args.streams)
     group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype, env_class=env_class,
-                                    seed=args.seed + rank * B, **({"_library": _emu_library()} if dry else {}))
+                                    seed=args.seed + rank * B, **extra_kw, **({"_library": _emu_library()} if dry else {}))
+    if args.workload == "walls":
+        for e in group.subs:
+            e.set_walls(cfg["manual_wall_positions"])
     group.reset()
     group.synchronize()
     env = group.subs[0]
@@ -288,11 +300,12 @@ def main():
     osz = 8 if obs_dtype == torch.float64 else 4
     env_steps_rank = B * args.steps
     # 2*(3*G^2*8) + sum_obs(4*R^2*osz) + 64*L per env-step, L = rows in use
-    alg_bytes = env_steps_rank * 2 * 3 * G * G * 8 + n_obs_pred * 4 * Rp * Rp * osz + \
-        n_obs_prey * 4 * Rq * Rq * osz + 64 * (n_obs_pred + n_obs_prey)
+    cp, cq = env.obs_pred.shape[2], env.obs_prey.shape[2]   # observation channels (4; more in the drive / walls variants)
+    alg_bytes = env_steps_rank * 2 * 3 * G * G * 8 + n_obs_pred * cp * Rp * Rp * osz + \
+        n_obs_prey * cq * Rq * Rq * osz + 64 * (n_obs_pred + n_obs_prey)
     # bytes this implementation has to move at minimum (no dense grid exists in HBM): observations +
     # row tables r/w (27 B read, 35 B written per row) + grass table (8 B r/w, 2 B read) + env words
-    min_bytes = n_obs_pred * 4 * Rp * Rp * osz + n_obs_prey * 4 * Rq * Rq * osz + \
+    min_bytes = n_obs_pred * cp * Rp * Rp * osz + n_obs_prey * cq * Rq * Rq * osz + \
         62 * (n_obs_pred + n_obs_prey) + env_steps_rank * (env.n_grass * 18 + 2 * 64 + 8)
     # HBM bytes per launch from rocprofv3 PMC passes of this very command (FETCH_SIZE x2 + WRITE_SIZE,
     # MI355X_MICROARCH.md HBM section); only quoted when the settings match the profiled run.
@@ -305,7 +318,7 @@ def main():
         traffic = None
     # which step kernel the library picked (predpreygrass_amd/csrc/ppg_host.h: ppg_use_multiwave): four waves per env while the
     # GPU is not full (<= 3072 envs in flight) or when LDS admits at most 4 envs per CU
-    multiwave = (B <= 3072) or (160 * 1024 // max(env.lds_bytes, 1) <= 4)
+    multiwave = (B <= 3072) or (160 * 1024 // max(env.lds_bytes, 1) <= 4) or args.workload in ("drive", "walls")
     if os.environ.get("PPG_MULTIWAVE") is not None:
         multiwave = os.environ["PPG_MULTIWAVE"] != "0"
     kernel_s = dev_ms / 1e3 / args.steps          # per launch; n_sub launches are in flight concurrently
@@ -331,6 +344,9 @@ def main():
                              f"{cfg['n_initial_active_prey']} prey / 100 grass, "
                              f"obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), device-side uniform random actions, "
                              f"auto-reset, observations written every step (BASELINE.json configs[{3 if args.workload == 'c4' else 2}])") if not rq else
+                            (f"WALLS variant of the second-generation env (walls_occlusion zigzag layout, mask + visibility channel + "
+                             f"line-of-sight moves, obs {cp}x{Rp}x{Rp} / {cq}x{Rq}x{Rq} {args.obs_dtype}), {B} envs x {G}x{G} grid per GPU; "
+                             "NOT the BASELINE.json headline config") if args.workload == "walls" else
                             (f"SECOND-GENERATION env (red_queen config_env_base: 12 predators / 10+10 prey of two types / 100 "
                              f"grass, obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), {B} envs x {G}x{G} grid per GPU, device-side "
                              "random actions and reproduction uniforms, auto-reset; NOT the BASELINE.json headline config"),
@@ -352,7 +368,10 @@ def main():
                 "achieved_from_pmc_traffic": round(traffic * n_sub / kernel_s / 1e9, 1) if traffic else None,
                 "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
                                          "launch = 4.85 TB/s (profiles/r01/c_store_pattern_ceiling.txt); linear fill 6.5 TB/s",
-                "kernel": ("ppgw2_step_q2" if multiwave else "ppg2_step_q2") if rq else ("ppgw_step_q2" if multiwave else "ppg_step_q2"),
+                "kernel": {"walls": "ppgw3_step_q2" if multiwave else "ppg3_step_q2",
+                           "drive": "ppgw4_step_q2" if multiwave else "ppg4_step_q2",
+                           "red_queen": "ppgw2_step_q2" if multiwave else "ppg2_step_q2"}.get(
+                               args.workload, "ppgw_step_q2" if multiwave else "ppg_step_q2"),
                 "kernel_ms": round(kernel_s * 1e3, 5),
                 "concurrent_launches": n_sub,
                 "algorithmic_bytes_per_launch": int(alg_bytes / args.steps / n_sub),

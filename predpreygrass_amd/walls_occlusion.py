@@ -17,6 +17,34 @@ from . import _abi
 from .red_queen import PredPreyGrass as _RedQueenPredPreyGrass
 
 
+# walls_occlusion/config/config_env_zigzag_walls.py (values restated): the eval-style second-generation settings with two
+# zigzag wall rows and every line-of-sight option switched on
+config_env_zigzag_walls = {
+    "max_steps": 1000, "grid_size": 25, "num_obs_channels": 4, "predator_obs_range": 7, "prey_obs_range": 9,
+    "type_1_action_range": 3, "type_2_action_range": 0,
+    "reward_predator_catch_prey": 0.0, "reward_prey_eat_grass": 0.0, "reward_predator_step": 0.0, "reward_prey_step": 0.0,
+    "penalty_prey_caught": 0.0,
+    "reproduction_reward_predator": {"type_1_predator": 10.0, "type_2_predator": 0.0},
+    "reproduction_reward_prey": {"type_1_prey": 10.0, "type_2_prey": 0.0},
+    "energy_loss_per_step_predator": 0.15, "energy_loss_per_step_prey": 0.05,
+    "predator_creation_energy_threshold": 12.0, "prey_creation_energy_threshold": 8.0, "move_energy_cost_factor": 0.0,
+    "initial_energy_predator": 5.0, "initial_energy_prey": 3.0,
+    "n_possible_type_1_predators": 2000, "n_possible_type_2_predators": 0,
+    "n_possible_type_1_prey": 2000, "n_possible_type_2_prey": 0,
+    "n_initial_active_type_1_predator": 6, "n_initial_active_type_2_predator": 0,
+    "n_initial_active_type_1_prey": 8, "n_initial_active_type_2_prey": 0,
+    "mutation_rate_predator": 0.0, "mutation_rate_prey": 0.0,
+    "initial_num_grass": 100, "initial_energy_grass": 2.0, "energy_gain_per_step_grass": 0.04,
+    "mask_observation_with_visibility": True, "include_visibility_channel": True, "respect_los_for_movement": True,
+    "max_energy_gain_per_grass": float("inf"), "max_energy_gain_per_prey": float("inf"),
+    "max_energy_predator": float("inf"), "max_energy_prey": float("inf"), "max_energy_grass": 2.0,
+    "reproduction_cooldown_steps": 0, "reproduction_chance_predator": 1.0, "reproduction_chance_prey": 1.0,
+    "energy_transfer_efficiency": 1.0, "reproduction_energy_efficiency": 1.0,
+    "wall_placement_mode": "manual",
+    "manual_wall_positions": [(x, 6 + (x % 2)) for x in range(6, 18)] + [(x, 17 - (x % 2)) for x in range(6, 18)],
+}
+
+
 class PredPreyGrass(_RedQueenPredPreyGrass):
     """`PredPreyGrass(config)` of walls_occlusion/predpreygrass_rllib_env.py (class WO:41, reset WO:203, step WO:304).
     `reset(seed=s)` draws the walls and the initial cells from `default_rng(s)` exactly like the reference (WO:246,260),
