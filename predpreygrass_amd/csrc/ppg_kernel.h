@@ -7,6 +7,8 @@
 // self.agents order, spawning) run as wave-uniform scalar loops over mask bits that read
 // a row with v_readlane and test cell occupancy with one v_cmp + ballot; order-free
 // phases (decay, grass regrowth, observation extraction, reward assembly) are lane-parallel.
+// The multi-wave step kernels (NW = 4 / 8) add helper wavefronts to the workgroup that do nothing
+// but share the final observation writing once wave 0 has finished the transition.
 //
 // The reference's dense float64 grid (4,G,G) is never materialised.  Every non-zero write
 // the reference makes to grid[1|2] stores the writer's *current* energy at the writer's
