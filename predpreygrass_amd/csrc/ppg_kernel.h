@@ -1097,7 +1097,8 @@ struct Env {
     }
     // np.sum(observation[ch]) for the agent of `type` standing on s_xy (DRV:601-608)
     PPG_MEMBER double window_sum(int type, int ch, uint32_t s_xy) {
-        const int R = type ? P.Rq : P.Rp, n = R * R;
+        // (not `type ? P.Rq : P.Rp`: with a run-time type hipcc selects the fields' ADDRESSES and spills both to scratch)
+        const int R = P.Rp + (type ? P.Rq - P.Rp : 0), n = R * R;
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;
         const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;   // one staging area per wave of a multi-wave workgroup
@@ -1154,7 +1155,7 @@ struct Env {
             return;
         }
         wv::sync();  // LDS writes of the sequential phases -> visible
-        const int R = type ? P.Rq : P.Rp;
+        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);   // (arithmetic, not a select of fields: see window_sum)
         double dv[4] = {0.0, 0.0, 0.0, 0.0};
         if (DRIVE) drive_features(type, s_e, s_xy, dv);
         const int blk = (DRIVE ? 4 + (type ? C.n_drive[1] : C.n_drive[0]) : (WALLS && C.vis_channel ? 5 : 4)) * R * R;
