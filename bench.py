@@ -311,7 +311,7 @@ def main():
     # MI355X_MICROARCH.md HBM section); only quoted when the settings match the profiled run.
     traffic = None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "f_bench_default_summary.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "g_bench_default_summary.json")))
         if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry and args.workload == "base":
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
     except Exception:
@@ -362,8 +362,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # the same with the bytes this design has to touch (no dense grid in HBM): the honest utilisation figure
+                # when the SURVEY 8(d) model's dense-grid term dominates (64x64 grids: frac > 1)
+                "frac_of_touched_bytes": round(min_bytes / args.steps / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_source": "profiles/r01/f_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                "traffic_source": "profiles/r01/g_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                   "bytes per launch)" if traffic else None,
                 "achieved_from_pmc_traffic": round(traffic * n_sub / kernel_s / 1e9, 1) if traffic else None,
                 "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
@@ -376,7 +379,7 @@ def main():
                 "concurrent_launches": n_sub,
                 "algorithmic_bytes_per_launch": int(alg_bytes / args.steps / n_sub),
                 "implementation_min_bytes_per_launch": int(min_bytes / args.steps / n_sub),
-                "note": "kernel_ms = mean launch-to-launch time of ppg_step_q2 on its stream (HIP events on that "
+                "note": "kernel_ms = mean launch-to-launch time of the step kernel on its stream (HIP events on that "
                         "stream); concurrent_launches such kernels (one per sub-batch of envs_per_gpu/concurrent_"
                         "launches envs) overlap in time, so achieved = concurrent_launches x algorithmic_bytes_per_"
                         "launch / kernel_ms. Algorithmic bytes follow SURVEY 8(d); its dense-grid term is never moved "

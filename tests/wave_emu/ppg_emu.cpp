@@ -24,7 +24,24 @@ __asm__(
 struct EmuLaunch {
     const ppg::KParams *P;
     int nq, mode, gen2;
+    int nw;  // wavefronts per workgroup: 1, or 4 / 8 for the multi-wave step kernels (MODE_STEP only)
 };
+
+// the multi-wave step kernels (ppgw*_step_*): family 0 base, 1 second generation, 2 walls, 3 drive
+template <int NQ, bool FAST, int NW>
+static void run_step_nw(const ppg::KParams &P, int family) {
+    PPG_DYNAMIC_LDS(lds);
+    if (family == 3) ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, NW>(P, lds);
+    else if (family == 2) ppg::env_main<NQ, ppg::MODE_STEP, false, true, true, false, NW>(P, lds);
+    else if (family == 1) ppg::env_main<NQ, ppg::MODE_STEP, FAST, true, false, false, NW>(P, lds);
+    else ppg::env_main<NQ, ppg::MODE_STEP, FAST, false, false, false, NW>(P, lds);
+}
+template <bool FAST, int NW>
+static void run_step_nq(const EmuLaunch *L) {
+    if (L->nq == 1) run_step_nw<1, FAST, NW>(*L->P, L->gen2);
+    else if (L->nq == 2) run_step_nw<2, FAST, NW>(*L->P, L->gen2);
+    else run_step_nw<4, FAST, NW>(*L->P, L->gen2);
+}
 
 template <int NQ, bool FAST>
 static void run_mode(const ppg::KParams &P, int mode) {
@@ -79,6 +96,8 @@ static void run_mode4(const ppg::KParams &P, int mode) {
 
 template <bool FAST>
 static void run_nq(const EmuLaunch *L) {
+    if (L->nw == 4) { run_step_nq<FAST, 4>(L); return; }
+    if (L->nw == 8) { run_step_nq<FAST, 8>(L); return; }
     if (L->gen2 == 3) {  // drive-conditioned variant of the base family: generic observation geometry only
         if (L->nq == 1) run_mode4<1>(*L->P, L->mode);
         else if (L->nq == 2) run_mode4<2>(*L->P, L->mode);
@@ -106,7 +125,7 @@ static void lane_entry(void *arg) {
     const EmuLaunch *L = (const EmuLaunch *)arg;
     // same selection rule as the HIP backend; PPG_EMU_FORCE_GENERIC_OBS=1 exercises the LDS-descriptor path
     static const bool force_generic = getenv("PPG_EMU_FORCE_GENERIC_OBS") != nullptr;
-    if (L->P->nch_p <= 2 && L->P->nch_q <= 3 && !force_generic) run_nq<true>(L);
+    if (L->P->nch_p <= 2 && L->P->nch_q <= 3 && !force_generic && L->gen2 < 2) run_nq<true>(L);
     else run_nq<false>(L);
 }
 
@@ -136,8 +155,17 @@ static int backend_rebalance(ppg_handle *h, int wp, int wq, void *) {
     return PPG_OK;
 }
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *) {
-    EmuLaunch L{&P, h->nq, mode, h->drive ? 3 : h->gen2 ? (h->cfg2.walls ? 2 : 1) : 0};
-    for (int b = 0; b < h->batch; ++b) wv::run_block(lane_entry, &L, b, (size_t)P.lds_bytes);
+    EmuLaunch L{&P, h->nq, mode, h->drive ? 3 : h->gen2 ? (h->cfg2.walls ? 2 : 1) : 0, 1};
+    // The HIP backend picks the multi-wave step kernels from the batch size (ppg_use_multiwave); here the tests ask for
+    // them explicitly: PPG_EMU_WAVES=4|8 (walls / drive have a four-wave kernel only, as in the library).
+    if (mode == ppg::MODE_STEP) {
+        const char *w = getenv("PPG_EMU_WAVES");
+        const int nw = w ? atoi(w) : 1;
+        if (nw == 4 || (nw == 8 && L.gen2 < 2)) L.nw = nw;
+        else if (nw == 8) L.nw = 4;
+        else if (nw != 1 && nw != 0) return ppg_fail(h, PPG_EINVAL, "PPG_EMU_WAVES=%d (1, 4 or 8)", nw);
+    }
+    for (int b = 0; b < h->batch; ++b) wv::run_block(lane_entry, &L, b, (size_t)P.lds_bytes, L.nw);
     return PPG_OK;
 }
 

@@ -3,13 +3,15 @@
 // g++ and debugged on a machine without a GPU (asan/ubsan/gdb).  It is never part of the
 // product: predpreygrass_amd loads libppg_hip.so only and fails loudly without it.
 //
-// Model: the 64 lanes of a workgroup are 64 cooperative fibers.  A fiber runs until its
+// Model: the 64 lanes of each wavefront of a workgroup are cooperative fibers (64 x nwaves of them).  A fiber runs until its
 // next wave primitive (a "collective"), publishes its operand and yields; when all 64
 // have arrived the scheduler resumes them -- in a RANDOM order each round, so code that
 // silently relies on lane execution order or on which lane wins a same-address LDS
 // write fails here.  The emulator is stricter than hardware about LDS visibility:
 // a value written to LDS by one lane is only guaranteed visible to the others after a
 // collective, which is exactly the discipline the kernels document.
+// A workgroup of several wavefronts (the multi-wave step kernels) runs as nwaves x 64 fibers: wave collectives involve
+// the 64 lanes of one wave only; wg_barrier() parks a wave until every wave that has not finished has arrived.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -31,17 +33,21 @@
 namespace wv {
 
 constexpr int W = 64;
+constexpr int MAXW = 8;           // wavefronts per workgroup
+constexpr int NF = W * MAXW;      // fibers
 
 extern "C" void ppg_emu_ctx_switch(void **save_sp, void *load_sp);
 
 struct Emu {
     void *main_sp = nullptr;
-    void *fiber_sp[W];
+    void *fiber_sp[NF];
     unsigned char *stacks = nullptr;
-    bool done[W];
-    uint64_t phase[W];
-    uint64_t slot[2][W];
+    bool done[NF];
+    bool at_barrier[NF];
+    uint64_t phase[NF];
+    uint64_t slot[2][NF];
     int cur = 0;
+    int nwaves = 1;
     int block = 0;
     unsigned char *lds = nullptr;
     size_t lds_bytes = 0;
@@ -64,7 +70,7 @@ static void fiber_main() {
     abort();  // never resumed
 }
 
-// Publish `mine`, wait for the whole wave, return the 64 published operands.
+// Publish `mine`, wait for the whole wave, return the 64 operands published by the lanes of this wave.
 inline const uint64_t *exchange(uint64_t mine) {
     Emu &e = emu();
     int me = e.cur;
@@ -72,15 +78,16 @@ inline const uint64_t *exchange(uint64_t mine) {
     e.slot[ph & 1][me] = mine;
     ppg_emu_ctx_switch(&e.fiber_sp[me], e.main_sp);
     e.cur = me;
-    return e.slot[ph & 1];
+    return e.slot[ph & 1] + (me & ~(W - 1));
 }
 
 constexpr size_t STACK_BYTES = 512 * 1024;
 
-// Run one workgroup (64 lanes) of `entry(arg)` with `lds_bytes` of shared memory.
-inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_bytes) {
+// Run one workgroup (nwaves x 64 lanes) of `entry(arg)` with `lds_bytes` of shared memory.
+inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_bytes, int nwaves = 1) {
     Emu &e = emu();
-    if (!e.stacks) e.stacks = (unsigned char *)aligned_alloc(64, STACK_BYTES * W);
+    if (nwaves < 1 || nwaves > MAXW) { fprintf(stderr, "wave_emu: %d waves per workgroup\n", nwaves); abort(); }
+    if (!e.stacks) e.stacks = (unsigned char *)aligned_alloc(64, STACK_BYTES * NF);  // (untouched pages stay virtual)
     if (e.lds_bytes < lds_bytes + 64) {
         free(e.lds);
         e.lds = (unsigned char *)aligned_alloc(64, (lds_bytes + 127) / 64 * 64);
@@ -91,8 +98,11 @@ inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_by
     e.entry = entry;
     e.arg = arg;
     e.block = block;
-    for (int l = 0; l < W; ++l) {
+    e.nwaves = nwaves;
+    const int nf = nwaves * W;
+    for (int l = 0; l < nf; ++l) {
         e.done[l] = false;
+        e.at_barrier[l] = false;
         e.phase[l] = 0;
         uint64_t *top = (uint64_t *)(e.stacks + STACK_BYTES * (l + 1));
         top[-1] = 0;                       // fake return address of fiber_main
@@ -100,13 +110,20 @@ inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_by
         for (int k = 3; k <= 8; ++k) top[-k] = 0;  // rbp rbx r12 r13 r14 r15
         e.fiber_sp[l] = (void *)(top - 8);
     }
-    int order[W];
+    static int order[NF];
     for (;;) {
-        int n = 0;
-        for (int l = 0; l < W; ++l)
-            if (!e.done[l]) order[n++] = l;
-        if (n == 0) break;
-        for (int i = n - 1; i > 0; --i) {  // random resume order
+        int n = 0, live = 0;
+        for (int l = 0; l < nf; ++l) {
+            if (e.done[l]) continue;
+            live++;
+            if (!e.at_barrier[l]) order[n++] = l;
+        }
+        if (live == 0) break;
+        if (n == 0) {  // every wave that is still running waits at the workgroup barrier: release them
+            for (int l = 0; l < nf; ++l) e.at_barrier[l] = false;
+            continue;
+        }
+        for (int i = n - 1; i > 0; --i) {  // random resume order (across lanes AND waves)
             e.rng ^= e.rng << 13; e.rng ^= e.rng >> 7; e.rng ^= e.rng << 17;
             int j = (int)(e.rng % (uint64_t)(i + 1));
             int t = order[i]; order[i] = order[j]; order[j] = t;
@@ -115,25 +132,28 @@ inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_by
             e.cur = order[i];
             ppg_emu_ctx_switch(&e.main_sp, e.fiber_sp[order[i]]);
         }
-        // all lanes must now sit at the same collective, or all be done
-        int nd = 0;
-        uint64_t ph = 0;
-        bool have = false, bad = false;
-        for (int l = 0; l < W; ++l) {
-            if (e.done[l]) { nd++; continue; }
-            if (!have) { ph = e.phase[l]; have = true; }
-            else if (e.phase[l] != ph) bad = true;
-        }
-        if (bad || (nd != 0 && nd != W)) {
-            fprintf(stderr, "wave_emu: divergent collective in block %d (done=%d)\n", block, nd);
-            abort();
+        // the lanes of a wave must now sit at the same collective / the barrier, or all be done
+        for (int w = 0; w < nwaves; ++w) {
+            int nd = 0, nb = 0;
+            uint64_t ph = 0;
+            bool have = false, bad = false;
+            for (int l = w * W; l < (w + 1) * W; ++l) {
+                if (e.done[l]) { nd++; continue; }
+                if (e.at_barrier[l]) nb++;
+                if (!have) { ph = e.phase[l]; have = true; }
+                else if (e.phase[l] != ph) bad = true;
+            }
+            if (bad || (nd != 0 && nd != W) || (nb != 0 && nb != W - nd)) {
+                fprintf(stderr, "wave_emu: divergent collective in block %d wave %d (done=%d, at barrier=%d)\n", block, w, nd, nb);
+                abort();
+            }
         }
         e.n_collectives++;
     }
 }
 
 // ---- the primitives of wave.h ----
-inline int lane() { return emu().cur; }
+inline int lane() { return emu().cur & (W - 1); }
 
 inline uint64_t ballot(bool p) {
     const uint64_t *s = exchange(p ? 1 : 0);
@@ -168,8 +188,16 @@ inline uint32_t shfl_up1(uint32_t v) {
     int l = lane();
     return (uint32_t)s[l ? l - 1 : 0];
 }
-inline int wave_index() { return 0; }                 // the emulator runs single-wave workgroups only
-inline void wg_barrier() { (void)exchange(0); }
+inline int wave_index() { return emu().cur / W; }
+// workgroup barrier: the fiber parks until every fiber of the workgroup that has not finished is parked too (a wave that
+// has ended no longer takes part, as on hardware)
+inline void wg_barrier() {
+    Emu &e = emu();
+    int me = e.cur;
+    e.at_barrier[me] = true;
+    ppg_emu_ctx_switch(&e.fiber_sp[me], e.main_sp);
+    e.cur = me;
+}
 inline void sync() { (void)exchange(0); }
 inline void drain_loads() { (void)exchange(0); }  // lanes run one after another here: a collective orders reads before writes
 inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
