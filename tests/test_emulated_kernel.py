@@ -112,6 +112,12 @@ def test_kernel_source_is_clean_under_ubsan():
         "       'initial_num_grass': 8, 'predator_obs_range': 3, 'prey_obs_range': 5, 'max_steps': 60,\n"
         "       'energy_gain_per_step_grass': 0.5}\n"
         "rollout_vs_oracle(mk(cfg, 3), lambda: OracleEnv(cfg), seed0=9, n_calls=150)\n"
+        "import os\n"
+        "for w in ('4', '8'):\n"                      # the multi-wave step kernels (helper-wave code paths)
+        "    os.environ['PPG_EMU_WAVES'] = w\n"
+        "    for name in ['default_seed0', 'drive_default_seed2'][:1 if w == '8' else 2]:\n"
+        "        replay_golden_cases(mk, [name], config_env, max_calls=80)\n"
+        "    rollout_vs_oracle(mk(cfg, 2), lambda: OracleEnv(cfg), seed0=10, n_calls=80)\n"
         "print('UBSAN-CLEAN')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "UBSAN-CLEAN" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])

@@ -170,3 +170,5 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
 }
 
 extern "C" uint64_t ppg_emu_collectives(void) { return wv::emu().n_collectives; }
+// wavefronts per workgroup of the most recent launch (the tests check that PPG_EMU_WAVES really took effect)
+extern "C" int ppg_emu_last_waves(void) { return wv::emu().nwaves; }
