@@ -221,6 +221,23 @@ def test_drive_conditioned_variant_on_gpu():
                                                                        device="cuda:0", **kw))
 
 
+@pytest.mark.parametrize("cap,G,prey0,grass0", [(64, 14, 8, 30), (128, 14, 80, 100), (256, 18, 170, 140)])
+@pytest.mark.parametrize("multi", ["0", "1"])
+def test_drive_variant_every_register_count_on_gpu(cap, G, prey0, grass0, multi, monkeypatch):
+    """ppg4_step_q{1,2,4} and ppgw4_step_q{1,2,4}: 64 / 128 / 256 prey rows per env (1, 2, 4 prey registers; the configs
+    start with 8 / 80 / 170 prey so that the upper registers are in use), one and four waves per env; every fourth call
+    against the oracle."""
+    monkeypatch.setenv("PPG_MULTIWAVE", multi)
+    cfg = {**config_env, "enable_drive_channels": True, "grid_size": G, "initial_num_grass": grass0,
+           "n_initial_active_predator": 6, "n_initial_active_prey": prey0, "max_steps": 80,
+           "predator_creation_energy_threshold": 30.0, "prey_creation_energy_threshold": 12.0}
+    if cap == 64:
+        cfg.update(energy_gain_per_step_grass=0.4, predator_creation_energy_threshold=12.0, prey_creation_energy_threshold=8.0)
+    env = make_env(cfg, 16, prey_capacity=cap)
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=1234 + cap, n_calls=100, check_every=4)
+    assert not (env.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_PREY_OVERFLOW).any()
+
+
 @pytest.mark.parametrize("cls_name", ["base", "red_queen"])
 def test_multiwave_step_kernels_give_identical_results(cls_name, monkeypatch):
     """One, four and eight wavefronts per env (ppg_step / ppgw_step / ppgw8_step; the library picks by batch size, the
