@@ -343,7 +343,9 @@ def main():
                 "workload": (f"{B} envs x {G}x{G} grid per GPU, default config ({cfg['n_initial_active_predator']} predators / "
                              f"{cfg['n_initial_active_prey']} prey / 100 grass, "
                              f"obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), device-side uniform random actions, "
-                             f"auto-reset, observations written every step (BASELINE.json configs[{3 if args.workload == 'c4' else 2}])") if not rq else
+                             f"auto-reset, observations written every step (BASELINE.json configs[{3 if args.workload == 'c4' else 2}])"
+                             + (f"; DRIVE-CONDITIONED variant ({cp} / {cq} observation channels incl. the per-agent drive planes), "
+                                "NOT the BASELINE.json headline config" if args.workload == "drive" else "")) if not rq else
                             (f"WALLS variant of the second-generation env (walls_occlusion zigzag layout, mask + visibility channel + "
                              f"line-of-sight moves, obs {cp}x{Rp}x{Rp} / {cq}x{Rq}x{Rq} {args.obs_dtype}), {B} envs x {G}x{G} grid per GPU; "
                              "NOT the BASELINE.json headline config") if args.workload == "walls" else
