@@ -1099,6 +1099,9 @@ struct Env {
     PPG_MEMBER double window_sum(int type, int ch, uint32_t s_xy) {
         // (not `type ? P.Rq : P.Rp`: with a run-time type hipcc selects the fields' ADDRESSES and spills both to scratch)
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0), n = R * R;
+#ifdef PPG_EXP_DRIVE_NO_SUM  // ablation build only: what the window sums cost altogether
+        if (P.batch > 0) return 0.0;
+#endif
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;
         const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;   // one staging area per wave of a multi-wave workgroup
@@ -1115,6 +1118,9 @@ struct Env {
         }
         wv::sync();
         double res;
+#ifdef PPG_EXP_DRIVE_NO_REDUCE  // ablation build only: staging without the ordered reduction
+        if (P.batch > 0) { res = first_f64(win[0]); wv::sync(); return res; }
+#endif
         if (n <= 128) {
             res = np_sum_block(win, 0, n);
         } else {
