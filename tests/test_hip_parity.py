@@ -298,3 +298,44 @@ def test_rebalance_changes_scheduling_only_on_gpu():
     for n in ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
         assert torch.equal(getattr(envs[0], n), getattr(envs[1], n)), n
     assert torch.equal(envs[0].env_state[:, : _abi.ENV_CALLS], envs[1].env_state[:, : _abi.ENV_CALLS])
+
+
+def test_steps_captured_in_a_hip_graph_replay_bit_identically():
+    """ppg_step keeps no host-side state between calls (call counters, RNG keys and row tables live in HBM), so a sequence
+    of steps can be captured in a hipGraph (torch.cuda.graph) and replayed: 12 replays of an 8-step graph == 96 eager steps,
+    with device-side random actions and with an action buffer that is refilled between replays."""
+    cfg = dict(config_env)
+    a, b = make_env(cfg, 256), make_env(cfg, 256)
+    for env in (a, b):
+        env.reset(seed=5)
+        env.step(random_actions=True, auto_reset=True)      # first launch (code object load) outside the capture
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        for _ in range(8):
+            a.step(random_actions=True, auto_reset=True)
+    for _ in range(12):
+        graph.replay()
+    for _ in range(96):
+        b.step(random_actions=True, auto_reset=True)
+    torch.cuda.synchronize()
+    names = ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey")
+    for n in names:
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+    assert torch.equal(a.env_state[:, : _abi.ENV_CALLS + 1], b.env_state[:, : _abi.ENV_CALLS + 1])
+
+    # explicit actions: the graph holds the POINTER of the action buffer; its contents change between replays
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=side):
+        a.step(a.actions, auto_reset=True)
+    gen = torch.Generator(device="cuda:0").manual_seed(3)
+    for _ in range(40):
+        acts = torch.randint(0, 9, a.actions.shape, generator=gen, device="cuda:0", dtype=torch.int8)
+        a.actions.copy_(acts)
+        b.actions.copy_(acts)
+        graph2.replay()
+        b.step(b.actions, auto_reset=True)
+    torch.cuda.synchronize()
+    for n in names:
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
