@@ -11,11 +11,17 @@ float64 observations written for every agent -- with auto-reset of finished epis
 and observation buffers are resident in HBM; nothing crosses PCIe inside the timed region.
 
 Workload (BASELINE.json configs[2], the headline): 4096 envs x 25x25 grid per GPU, default
-config (6 predators / 8 prey / 100 grass, obs 7x7 / 9x9).  N GPUs = N independent shards of 4096
-envs (weak scaling, no data-path collective: envs never interact).  For N>1 an extra leg measures
-the step followed by the RCCL all-gather of the compacted observations that north_star specifies
-and reports it under "obs_gather" (it is bandwidth-bound on xGMI).  Within one GPU the
-4096 envs are stepped as --streams (default 3) independent sub-batches on separate HIP streams.
+config (6 predators / 8 prey / 100 grass, obs 7x7 / 9x9), in its STEADY STATE: before the W warm-up and
+K timed steps an untimed pre-roll steps the envs until the mean number of agent rows per env is
+stationary ("after 200 warm-up"; right after a reset every env holds its 14 initial
+agents and a step writes 2.7x fewer observation bytes than the workload defines).
+
+N GPUs = N independent shards of 4096 envs (weak scaling, no data-path collective: envs never
+interact).  `python bench.py --gpus N` without a torch.distributed launcher starts the N ranks itself.
+For N>1 two extra legs measure the step followed by the ONE RCCL all-gather of the packed observation
+image that north_star specifies ("obs_gather", "obs_gather_overlapped"; bandwidth-bound on xGMI, see
+DESIGN.md).  Within one GPU the 4096 envs are stepped as --streams (default 3) independent sub-batches on
+separate HIP streams.
 
 Prints ONE JSON line (rank 0).
 """
@@ -32,13 +38,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_driver_summary.json")
 
 
 def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
     """The CPU oracle (C restatement of the reference step(), kind "port") timed on this host on a
     bounded sample of the same workload: one env per thread, random actions, auto-reset."""
     import concurrent.futures as cf
-    if workload == "red_queen":
+    if workload in ("red_queen", "walls"):
         from oracle.rq_oracle import RQOracleEnv as OracleEnv
     else:
         from oracle.ppg_oracle import OracleEnv
@@ -46,7 +53,11 @@ def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
     chunk = 2000
 
     def work(i):
-        env = OracleEnv(cfg)
+        if workload == "walls":
+            env = OracleEnv(cfg, walls=True)
+            env.set_walls(cfg["manual_wall_positions"])
+        else:
+            env = OracleEnv(cfg)
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds:
             n += env.rollout_random(seed0 + i, chunk)
@@ -61,15 +72,73 @@ def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
     return {
         "value": round(tot / wall, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
         "single_thread_value": round(n1 / t1, 1),
-        "sample": f"{threads} threads x 1 env each, {'red_queen config_env_base' if workload == 'red_queen' else 'default config'}, "
+        "sample": f"{threads} threads x 1 env each, {'red_queen config_env_base' if workload == 'red_queen' else 'walls_occlusion zigzag config' if workload == 'walls' else 'default config'}, "
                   f"Philox random actions + auto-reset, {seconds:.0f} s per thread ({tot} env-steps); "
-                  f"oracle/{'rq_oracle.c' if workload == 'red_queen' else 'ppg_oracle.c'} (-O2 -ffp-contract=off)",
+                  f"oracle/{'rq_oracle.c' if workload in ('red_queen', 'walls') else 'ppg_oracle.c'} (-O2 -ffp-contract=off)",
         "reference_python_fixed": "reference Python step(): 45 env-steps/s on 1 core, ~400 on 8 cores "
                                   "(measured in the survey container, BASELINE.md section 2)",
     }
 
 
-def main():
+class HipBackend:
+    """Where the bench runs: the MI355X of this rank.  (tests/bench_dry.py substitutes a CPU stand-in that drives the same
+    control flow through the emulated kernel; nothing of it lives here.)"""
+    dry = False
+    dist_backend = "nccl"
+
+    def setup(self, distributed, local_rank):
+        import torch
+        import torch.distributed as dist
+        if local_rank >= torch.cuda.device_count():   # (device_count does not initialise the GPU)
+            raise SystemExit(f"bench.py: rank with LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPUs are visible")
+        if distributed:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        device = torch.device("cuda", local_rank if distributed else 0)
+        torch.cuda.set_device(device)
+        return device
+
+    def env_kwargs(self):
+        return {}
+
+    def event(self):
+        import torch
+        return torch.cuda.Event(enable_timing=True)
+
+    def synchronize(self, device):
+        import torch
+        torch.cuda.synchronize(device)
+
+    def current_stream(self, device):
+        import torch
+        return torch.cuda.current_stream(device)
+
+    def new_stream(self, device):
+        import torch
+        return torch.cuda.Stream(device=device)
+
+    def stream_ctx(self, stream):
+        import torch
+        return torch.cuda.stream(stream)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks (one per GPU) with torch.distributed.run as
+    CHILD processes.  Nothing in this parent has touched the GPU (torch is not even imported yet), so no process that has
+    initialised HIP is ever replaced; the parent only forwards the children's output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
@@ -89,50 +158,46 @@ def main():
                     help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step)")
     ap.add_argument("--rebalance-every", type=int, default=64,
                     help="call ppg_rebalance every that many steps (0 = never): heavy envs are assigned to workgroups first")
+    ap.add_argument("--preroll-min", type=int, default=512,
+                    help="untimed steps before --warmup that bring the envs into the steady state the workload is defined on")
+    ap.add_argument("--preroll-max", type=int, default=4096,
+                    help="the pre-roll continues in 64-step windows until the mean rows per env of two consecutive windows "
+                         "differ by < 1 %%, at most this many steps (0 = no pre-roll: measures the post-reset transient)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even for one rank, so that the gather legs run (needs torchrun)")
-    ap.add_argument("--dry-run-cpu", action="store_true",
-                    help="TEST ONLY: run the control flow on CPU (gloo, wave-emulator build of the kernel); numbers are meaningless")
     ap.add_argument("--gather-steps", type=int, default=50,
-                    help="N>1 only: extra leg of this many steps with the RCCL observation all-gather after each step")
-    args = ap.parse_args()
+                    help="N>1 only: extra legs of this many steps with the RCCL all-gather of the packed observation image")
+    ap.add_argument("--gather-wire", choices=["f32", "native"], default="native",
+                    help="observation dtype on the wire in the gather legs (f32 halves the bytes of float64 observations)")
+    return ap.parse_args(argv)
 
+
+def main(argv=None, backend=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    backend = backend or HipBackend()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args, argv))      # before anything touches the GPU
+    world = int(env_world or "1")
+    if env_world is not None and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     from predpreygrass_amd import _abi
     from predpreygrass_amd.batched import BatchedPredPreyGrass
     from predpreygrass_amd.config import config_env
+    from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or args.force_dist   # --force-dist: exercise the RCCL legs with a world of one rank (test hook)
-    dry = args.dry_run_cpu
-    if dry:
-        from tests.emu_backend import library as _emu_library
-        if distributed:
-            dist.init_process_group("gloo")
-        device = torch.device("cpu")
-
-        class _NoEvent:
-            def __init__(self, **kw):
-                self.t = 0.0
-
-            def record(self, stream=None):
-                self.t = time.perf_counter()
-
-            def elapsed_time(self, other):
-                return (other.t - self.t) * 1e3
-
-        torch.cuda.synchronize = lambda *a, **k: None   # nothing asynchronous on the CPU path
-        torch.cuda.Event = _NoEvent
-    else:
-        if distributed:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        device = torch.device("cuda", local_rank if distributed else 0)
-        torch.cuda.set_device(device)
+    dry = backend.dry
+    device = backend.setup(distributed, local_rank)
     n_gpus = world if distributed else 1
 
     rq = args.workload in ("red_queen", "walls")
@@ -155,10 +220,9 @@ def main():
             cfg["enable_drive_channels"] = True
     B = args.envs
     obs_dtype = torch.float64 if args.obs_dtype == "f64" else torch.float32
-    from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
     n_sub = max(1, args.streams)
     group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype, env_class=env_class,
-                                    seed=args.seed + rank * B, **extra_kw, **({"_library": _emu_library()} if dry else {}))
+                                    seed=args.seed + rank * B, **extra_kw, **backend.env_kwargs())
     if args.workload == "walls":
         for e in group.subs:
             e.set_walls(cfg["manual_wall_positions"])
@@ -176,21 +240,46 @@ def main():
         step_no[0] += 1
         group.step(random_actions=True, auto_reset=True)
 
+    def zero_obs_counters():
+        for e in group.subs:
+            e.env_state[:, _abi.ENV_OBS_PRED:_abi.ENV_OBS_PREY + 1] = 0
+
+    def rows_written():
+        return sum(int(e.env_state[:, _abi.ENV_OBS_PRED:_abi.ENV_OBS_PREY + 1].sum().item()) for e in group.subs)
+
+    # ---- untimed pre-roll to the steady-state population -------------------------------------------
+    WINDOW = 64
+    preroll, trace = 0, []
+    if args.preroll_max > 0:
+        while preroll < args.preroll_max:
+            backend.synchronize(device)
+            zero_obs_counters()
+            for _ in range(WINDOW):
+                one_step()
+            backend.synchronize(device)
+            preroll += WINDOW
+            trace.append(rows_written() / (B * WINDOW))
+            stationary = len(trace) >= 3 and all(abs(trace[-k] - trace[-k - 1]) <= 0.01 * trace[-k - 1] for k in (1, 2))
+            if distributed:   # every rank has to leave the pre-roll after the same number of steps
+                t = torch.tensor([0 if stationary else 1], dtype=torch.int64, device=device)
+                dist.all_reduce(t)
+                stationary = int(t.item()) == 0
+            if preroll >= args.preroll_min and stationary:
+                break
+
     for _ in range(args.warmup):
         one_step()
-    torch.cuda.synchronize(device)
+    backend.synchronize(device)
     # zero the observation counters (bandwidth accounting) -- outside the timed region
-    calls0 = []
-    for e in group.subs:
-        e.env_state[:, _abi.ENV_OBS_PRED:_abi.ENV_OBS_PREY + 1] = 0
-        calls0.append(e.env_state[:, _abi.ENV_CALLS].clone())
-    torch.cuda.synchronize(device)
+    zero_obs_counters()
+    calls0 = [e.env_state[:, _abi.ENV_CALLS].clone() for e in group.subs]
+    backend.synchronize(device)
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize(device)
+    backend.synchronize(device)
     # HIP events on the streams the kernels are launched on
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in group.streams]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in group.streams]
+    ev0 = [backend.event() for _ in group.streams]
+    ev1 = [backend.event() for _ in group.streams]
     t0 = time.perf_counter()
     for s, e in zip(group.streams, ev0):
         e.record(s)
@@ -198,10 +287,10 @@ def main():
         one_step()
     for s, e in zip(group.streams, ev1):
         e.record(s)
-    torch.cuda.synchronize(device)
+    backend.synchronize(device)
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize(device)
+    backend.synchronize(device)
     wall = time.perf_counter() - t0
     # mean launch-to-launch time of the step kernel on each stream (the n_sub streams run concurrently)
     dev_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / len(ev0)
@@ -211,86 +300,66 @@ def main():
         wall = float(t.item())
 
     # counters of the timed region, snapshotted before anything else steps the envs
-    import numpy as np
     es = np.concatenate([e.env_state.cpu().numpy() for e in group.subs]).astype("int64")
     calls0 = np.concatenate([c.cpu().numpy() for c in calls0])
     assert ((es[:, _abi.ENV_CALLS] - calls0) == args.steps).all()
 
-    # ---- optional leg: the RCCL observation all-gather north_star specifies (N > 1 only) ----
+    # ---- optional legs: the ONE RCCL all-gather per step north_star specifies (N > 1 only) -------------------------
     gather_info = gather_overlapped = None
     if distributed and args.gather_steps > 0:
-        try:
-            from predpreygrass_amd.distributed import ObservationGatherer
-            gs = [ObservationGatherer(e) for e in group.subs]
-            torch.cuda.synchronize(device)
+        from predpreygrass_amd.distributed import ObservationGatherer
+        wire = torch.float32 if args.gather_wire == "f32" else None
+        rows_now = (es[:, _abi.ENV_N_PRED_ROWS].mean(), es[:, _abi.ENV_N_PREY_ROWS].mean())
+        # image sized from the current population with 30 % head room (every rank computes its own and the maximum is used)
+        want = torch.tensor([rows_now[0] * 1.3 + 1, rows_now[1] * 1.3 + 1], dtype=torch.float64, device=device)
+        dist.all_reduce(want, op=dist.ReduceOp.MAX)
+        rows_per_env = tuple(float(v) for v in want.tolist())
+
+        def leg(overlapped):
+            g = ObservationGatherer(group.subs, wire_dtype=wire, rows_per_env=rows_per_env)
+            cuda = not dry
+            cur = backend.current_stream(device) if cuda else None
+            side = backend.new_stream(device) if (cuda and overlapped) else None
+            backend.synchronize(device)
             dist.barrier()
             tg = time.perf_counter()
-            nbytes = 0
             for _ in range(args.gather_steps):
                 one_step()
-                group.synchronize()
-                for g in gs:
-                    g.gather()
-                    nbytes += g.last_bytes
-            torch.cuda.synchronize(device)
-            dist.barrier()
-            tg = time.perf_counter() - tg
-            t = torch.tensor([tg], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gather_info = {"value": round(n_gpus * B * args.gather_steps / float(t.item()), 1), "unit": "env-steps/s",
-                           "steps": args.gather_steps, "ms_per_step": round(float(t.item()) / args.gather_steps * 1e3, 4),
-                           "gathered_bytes_per_step_per_rank": int(nbytes / args.gather_steps),
-                           "what": "step + synchronous all-gather (RCCL) of the compacted float64 observations, ids, rewards, flags"}
-        except Exception as ex:  # never lose the main measurement to the optional leg
-            gather_info = {"error": repr(ex)[:300]}
-        # the same with the gather of step t overlapped with step t+1: the rows in use are packed (copied) on each
-        # sub-batch's stream right after its step, the next step is enqueued behind the copy, and the collective runs on a
-        # side stream that only waits for the copies
-        try:
-            from predpreygrass_amd.distributed import ObservationGatherer
-            gs = [ObservationGatherer(e) for e in group.subs]
-            cuda = not dry
-            side = torch.cuda.Stream(device=device) if cuda else None
-            torch.cuda.synchronize(device)
-            dist.barrier()
-            tg = time.perf_counter()
-            nbytes = 0
-            for _ in range(args.gather_steps):
-                packed, events = [], []
-                for g, s in zip(gs, group.streams):
-                    if cuda:
-                        with torch.cuda.stream(s):
-                            packed.append(g.pack_local())
-                            ev = torch.cuda.Event()
-                            ev.record(s)
-                            events.append(ev)
-                    else:
-                        packed.append(g.pack_local())
-                one_step()                               # step t+1 runs while obs(t) travel
                 if cuda:
-                    for ev in events:
-                        side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        for g, loc in zip(gs, packed):
-                            for v in loc.values():
-                                v.record_stream(side)   # allocated on the sub-batch's stream, consumed on the side stream
-                            g.gather(loc)
-                            nbytes += g.last_bytes
+                    group.wait(cur)                 # the pack reads what the sub-batch streams have just written
+                slot = g.pack(stream=cur)
+                if side is not None:
+                    # the collective of step t runs on a side stream while step t+1 (which only waits for the pack) computes
+                    side.wait_stream(cur)
+                    with backend.stream_ctx(side):
+                        g.gather(slot, pack=False)
                 else:
-                    for g, loc in zip(gs, packed):
-                        g.gather(loc)
-                        nbytes += g.last_bytes
-            torch.cuda.synchronize(device)
+                    g.gather(slot, pack=False)
+            backend.synchronize(device)
             dist.barrier()
             tg = time.perf_counter() - tg
             t = torch.tensor([tg], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gather_overlapped = {"value": round(n_gpus * B * args.gather_steps / float(t.item()), 1), "unit": "env-steps/s",
-                                 "steps": args.gather_steps, "ms_per_step": round(float(t.item()) / args.gather_steps * 1e3, 4),
-                                 "gathered_bytes_per_step_per_rank": int(nbytes / args.gather_steps),
-                                 "what": "all-gather of step t's compacted observations overlapped with step t+1 (packed copies, side stream)"}
-        except Exception as ex:
-            gather_overlapped = {"error": repr(ex)[:300]}
+            hs = g.headers()
+            return {"value": round(n_gpus * B * args.gather_steps / float(t.item()), 1), "unit": "env-steps/s",
+                    "steps": args.gather_steps, "ms_per_step": round(float(t.item()) / args.gather_steps * 1e3, 4),
+                    "collectives_per_step": 1,
+                    "wire_bytes_per_step_per_rank": int(g.capacity),
+                    "image_bytes_used_last_step": [int(h.bytes_used) for h in hs],
+                    "image_overflows": int(sum(h.overflow for h in hs)),
+                    "wire_obs_dtype": "f32" if (wire is not None or obs_dtype == torch.float32) else "f64",
+                    "what": ("one all_gather_into_tensor (RCCL) of the packed observation image per step" +
+                             (", the collective of step t overlapped with step t+1 (side stream, two image slots)" if overlapped
+                              else ", synchronous: the next step waits for it"))}
+        for name, ov in (("sync", False), ("overlapped", True)):
+            try:   # never lose the main measurement to an optional leg
+                res = leg(ov)
+            except Exception as ex:
+                res = {"error": repr(ex)[:300]}
+            if ov:
+                gather_overlapped = res
+            else:
+                gather_info = res
 
     # ---- accounting ------------------------------------------------------------------
     status = int((es[:, _abi.ENV_STATUS]).max())
@@ -299,33 +368,69 @@ def main():
     G, Rp, Rq = env.grid_size, env.Rp, env.Rq
     osz = 8 if obs_dtype == torch.float64 else 4
     env_steps_rank = B * args.steps
-    # 2*(3*G^2*8) + sum_obs(4*R^2*osz) + 64*L per env-step, L = rows in use
     cp, cq = env.obs_pred.shape[2], env.obs_prey.shape[2]   # observation channels (4; more in the drive / walls variants)
-    alg_bytes = env_steps_rank * 2 * 3 * G * G * 8 + n_obs_pred * cp * Rp * Rp * osz + \
-        n_obs_prey * cq * Rq * Rq * osz + 64 * (n_obs_pred + n_obs_prey)
-    # bytes this implementation has to move at minimum (no dense grid exists in HBM): observations +
-    # row tables r/w (27 B read, 35 B written per row) + grass table (8 B r/w, 2 B read) + env words
-    min_bytes = n_obs_pred * cp * Rp * Rp * osz + n_obs_prey * cq * Rq * Rq * osz + \
-        62 * (n_obs_pred + n_obs_prey) + env_steps_rank * (env.n_grass * 18 + 2 * 64 + 8)
-    # HBM bytes per launch from rocprofv3 PMC passes of this very command (FETCH_SIZE x2 + WRITE_SIZE,
-    # MI355X_MICROARCH.md HBM section); only quoted when the settings match the profiled run.
-    traffic = None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "g_bench_default_summary.json")))
-        if B == 4096 and n_sub == prof["concurrent_launches"] and obs_dtype == torch.float64 and not dry and args.workload == "base":
-            traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"])
-    except Exception:
-        traffic = None
+    obs_bytes = n_obs_pred * cp * Rp * Rp * osz + n_obs_prey * cq * Rq * Rq * osz
+    # Bytes THIS RUN moved, counted by the kernel (rows in use per env and call): observations + row tables r/w (27 B read,
+    # 35 B written per row) + grass table (8 B r/w + 2 B read per patch) + env words.  No dense grid exists in HBM.
+    run_bytes = obs_bytes + 62 * (n_obs_pred + n_obs_prey) + env_steps_rank * (env.n_grass * 18 + 2 * 64 + 8)
+    # SURVEY.md section 8(d)'s model of the REFERENCE's data structures: 2*(3*G^2*8) + sum_obs(4*R^2*osz) + 64*L per env-step
+    # (its first term is a dense-grid read+write this design never performs) -- kept for comparison only
+    survey_bytes = env_steps_rank * 2 * 3 * G * G * 8 + obs_bytes + 64 * (n_obs_pred + n_obs_prey)
     # which step kernel the library picked (predpreygrass_amd/csrc/ppg_host.h: ppg_use_multiwave): four waves per env while the
     # GPU is not full (<= 3072 envs in flight) or when LDS admits at most 4 envs per CU
     multiwave = (B <= 3072) or (160 * 1024 // max(env.lds_bytes, 1) <= 4) or args.workload in ("drive", "walls")
     if os.environ.get("PPG_MULTIWAVE") is not None:
         multiwave = os.environ["PPG_MULTIWAVE"] != "0"
     kernel_s = dev_ms / 1e3 / args.steps          # per launch; n_sub launches are in flight concurrently
-    achieved = alg_bytes / args.steps / kernel_s / 1e9   # all n_sub concurrent launches together
+    achieved = run_bytes / args.steps / kernel_s / 1e9   # all n_sub concurrent launches together
     value = n_gpus * env_steps_rank / wall
+    # HBM bytes per launch from rocprofv3 PMC passes of the driver's command (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md
+    # HBM section), scaled by this run's own counted bytes relative to the profiled run's (same workload, same pre-roll)
+    traffic = traffic_src = None
+    try:
+        prof = json.load(open(PROFILE_SUMMARY))
+        same = (prof["envs_per_gpu"] == B and prof["concurrent_launches"] == n_sub and prof["obs_dtype"] == args.obs_dtype
+                and prof["workload"] == args.workload and not dry)
+        if same:
+            scale = (run_bytes / args.steps / n_sub) / prof["counted_bytes_per_launch"]
+            traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"] * scale)
+            traffic_src = (f"profiles/r02/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                           f"{prof['hbm_traffic_per_launch_bytes']['total_corrected']} B per launch at "
+                           f"{prof['mean_agents_per_env']} agents/env, scaled x{scale:.4f} by this run's counted bytes")
+    except Exception:
+        traffic = None
 
     if rank == 0:
+        roof = {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "bytes_counted": "observations + row tables + grass table + env words actually moved, from the kernel's own row counters "
+                             "of the timed region",
+            # SURVEY 8(d)'s formula adds a dense-grid read+write (30 KB per env-step at 25x25, 197 KB at 64x64) that this
+            # design never moves; with it the figure can exceed 1 (64x64 grids), so it is a comparison number, not `frac`
+            "frac_survey_formula": round(survey_bytes / args.steps / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
+                                     "launch = 4.85 TB/s (profiles/r01/c_store_pattern_ceiling.txt); linear fill 6.5 TB/s",
+            "kernel": {"walls": "ppgw3_step_q2" if multiwave else "ppg3_step_q2",
+                       "drive": "ppgw4_step_q2" if multiwave else "ppg4_step_q2",
+                       "red_queen": "ppgw2_step_q2" if multiwave else "ppg2_step_q2"}.get(
+                           args.workload, "ppgw_step_q2" if multiwave else "ppg_step_q2"),
+            "kernel_ms": round(kernel_s * 1e3, 5),
+            "concurrent_launches": n_sub,
+            "counted_bytes_per_launch": int(run_bytes / args.steps / n_sub),
+            "survey_formula_bytes_per_launch": int(survey_bytes / args.steps / n_sub),
+            "note": "kernel_ms = mean launch-to-launch time of the step kernel on its stream (HIP events on that "
+                    "stream); concurrent_launches such kernels (one per sub-batch of envs_per_gpu/concurrent_"
+                    "launches envs) overlap in time, so achieved = concurrent_launches x counted_bytes_per_"
+                    "launch / kernel_ms.",
+        }
+        if not dry and achieved > HBM_PEAK_GBS:
+            raise SystemExit(f"bench.py: achieved {achieved:.0f} GB/s exceeds the HBM peak -- the timing or the byte count is broken")
         out = {
             "metric": "env-steps/sec at 4096x(25x25) grids, 1/2/4/8 MI355X; % HBM roofline",
             "value": round(value, 1),
@@ -337,13 +442,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.obs_dtype,
             "data": "synthetic" if not dry else "DRY RUN ON CPU (emulated kernel) -- not a measurement",
             "config": {
                 "workload": (f"{B} envs x {G}x{G} grid per GPU, default config ({cfg['n_initial_active_predator']} predators / "
                              f"{cfg['n_initial_active_prey']} prey / 100 grass, "
                              f"obs {Rp}x{Rp} / {Rq}x{Rq} {args.obs_dtype}), device-side uniform random actions, "
-                             f"auto-reset, observations written every step (BASELINE.json configs[{3 if args.workload == 'c4' else 2}])"
+                             f"auto-reset, observations written every step, steady-state population after an untimed pre-roll "
+                             f"(BASELINE.json configs[{3 if args.workload == 'c4' else 2}])"
                              + (f"; DRIVE-CONDITIONED variant ({cp} / {cq} observation channels incl. the per-agent drive planes), "
                                 "NOT the BASELINE.json headline config" if args.workload == "drive" else "")) if not rq else
                             (f"WALLS variant of the second-generation env (walls_occlusion zigzag layout, mask + visibility channel + "
@@ -355,38 +461,12 @@ def main():
                 "envs_per_gpu": B,
                 "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
                 "sub_batches_per_gpu": n_sub,
+                "preroll_steps": preroll,
+                "preroll_mean_agents_per_env_by_64_step_window": [round(v, 2) for v in trace[-8:]],
                 "mean_agents_per_env": round((n_obs_pred + n_obs_prey) / env_steps_rank, 2),
                 "status_bits": status,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # the same with the bytes this design has to touch (no dense grid in HBM): the honest utilisation figure
-                # when the SURVEY 8(d) model's dense-grid term dominates (64x64 grids: frac > 1)
-                "frac_of_touched_bytes": round(min_bytes / args.steps / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "traffic_source": "profiles/r01/g_bench_default_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                  "bytes per launch)" if traffic else None,
-                "achieved_from_pmc_traffic": round(traffic * n_sub / kernel_s / 1e9, 1) if traffic else None,
-                "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
-                                         "launch = 4.85 TB/s (profiles/r01/c_store_pattern_ceiling.txt); linear fill 6.5 TB/s",
-                "kernel": {"walls": "ppgw3_step_q2" if multiwave else "ppg3_step_q2",
-                           "drive": "ppgw4_step_q2" if multiwave else "ppg4_step_q2",
-                           "red_queen": "ppgw2_step_q2" if multiwave else "ppg2_step_q2"}.get(
-                               args.workload, "ppgw_step_q2" if multiwave else "ppg_step_q2"),
-                "kernel_ms": round(kernel_s * 1e3, 5),
-                "concurrent_launches": n_sub,
-                "algorithmic_bytes_per_launch": int(alg_bytes / args.steps / n_sub),
-                "implementation_min_bytes_per_launch": int(min_bytes / args.steps / n_sub),
-                "note": "kernel_ms = mean launch-to-launch time of the step kernel on its stream (HIP events on that "
-                        "stream); concurrent_launches such kernels (one per sub-batch of envs_per_gpu/concurrent_"
-                        "launches envs) overlap in time, so achieved = concurrent_launches x algorithmic_bytes_per_"
-                        "launch / kernel_ms. Algorithmic bytes follow SURVEY 8(d); its dense-grid term is never moved "
-                        "by this design -- implementation_min_bytes_per_launch is what the kernel must actually touch.",
-            },
+            "roofline": roof,
         }
         if gather_info is not None:
             out["obs_gather"] = gather_info

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PPG_ABI_VERSION 3
+#define PPG_ABI_VERSION 4
 
 /* error codes */
 #define PPG_OK 0
@@ -328,6 +328,58 @@ int ppg_rebalance(ppg_handle *h, void *stream);
 
 /* grid_world_state (BASE:124): dense float64 [B,4,G,G] rebuilt from the rows. */
 int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream);
+
+/* ---- snapshot of one env (get_state_snapshot / restore_state_snapshot, BASE:768-804; consumers
+ * evaluate_ppo_from_checkpoint_debug.py:164-182) ------------------------------------------------------------
+ * A snapshot is a versioned POD image in HOST memory: struct ppg_state_header followed by env `env`'s slice of every
+ * state tensor of ppg_buffers in the order of ppg_state_field[] below (row tables, env words, Philox key + episode,
+ * grass table, and for the variants row_parent / row_lastrep / row_info / wall_bits).  Observations, rewards of the last
+ * call included, are NOT part of it: ppg_observe() recomputes the observations of the live rows after an import.
+ * Both calls are synchronous: they enqueue the copies on `stream` and wait for them. */
+#define PPG_STATE_MAGIC 0x53475050u /* "PPGS" */
+#define PPG_STATE_VERSION 1u
+typedef struct ppg_state_header {
+    uint32_t magic, version;
+    uint32_t bytes;            /* size of the whole image incl. this header */
+    uint32_t gen2, walls;      /* which ppg_create* made the handle */
+    uint32_t grid_size, pred_capacity, prey_capacity, grass_capacity, n_wall_words;
+    uint32_t reserved[6];
+} ppg_state_header;
+
+/* bytes an image of one env of this handle takes */
+uint64_t ppg_state_bytes(const ppg_handle *h);
+/* env `env` -> blob (host memory, *size bytes available; on return *size = bytes written).  blob == NULL: only report the size. */
+int ppg_export_state(ppg_handle *h, int32_t env, void *blob, uint64_t *size, void *stream);
+/* blob -> env `env`; the image must come from a handle with the same geometry (checked through the header). */
+int ppg_import_state(ppg_handle *h, int32_t env, const void *blob, uint64_t size, void *stream);
+
+/* ---- packed observation image (ONE collective per step for the returned observation dict) --------
+ * ppg_pack writes what the last call of the n handles (sub-batches of one GPU, envs concatenated in handle order)
+ * returned -- env words, per-row ids / rewards / flags and the observations of the rows IN USE, compacted -- into one
+ * contiguous device buffer that a single all-gather (RCCL) can move.  Layout, every section 16-byte aligned, in this order:
+ *   ppg_pack_header | env_state int32[n_envs][PPG_ENV_WORDS] | row_off uint32[n_envs][2] (exclusive prefix sums of the
+ *   predator / prey row counts) | id_pred int32[Np] | id_prey int32[Nq] | reward_pred double[Np] | reward_prey double[Nq] |
+ *   flags_pred uint8[Np] | flags_prey uint8[Nq] | obs_pred elem[Np][blk_pred] | obs_prey elem[Nq][blk_prey]
+ * (Np / Nq = rows in use over all envs, env-major, row order = dict order).  If the image does not fit in `capacity`
+ * bytes the header has overflow = 1 and bytes_used = the size it needs; the row sections are then not written. */
+#define PPG_PACK_MAGIC 0x4B475050u /* "PPGK" */
+#define PPG_PACK_VERSION 1u
+#define PPG_PACK_F32 0x1u /* float64 observations travel as float32 (observations that already are float32 are copied) */
+#define PPG_PACK_MAX_HANDLES 8
+typedef struct ppg_pack_header {
+    uint32_t magic, version;
+    uint32_t n_envs, n_pred_rows, n_prey_rows;
+    uint32_t obs_elem_bytes;       /* 4 or 8 */
+    uint32_t blk_pred, blk_prey;   /* elements per observation: channels * R * R */
+    uint64_t bytes_used, capacity;
+    uint32_t overflow, env_words;
+    uint32_t reserved[2];
+} ppg_pack_header;                 /* 64 bytes */
+
+/* size of an image with the given totals (host helper; h gives the geometry) */
+uint64_t ppg_pack_bytes(const ppg_handle *h, int32_t n_envs, int64_t n_pred_rows, int64_t n_prey_rows, uint32_t flags);
+/* asynchronous on `stream`, which the caller has ordered behind the handles' last step (two small launches) */
+int ppg_pack(ppg_handle *const *handles, int32_t n, void *out, uint64_t capacity, uint32_t flags, void *stream);
 
 /* Sort key of the decimal string of `id` (digits d: sum (d+1)*11^(5-pos)); host helper. */
 uint32_t ppg_lexkey(uint32_t id);

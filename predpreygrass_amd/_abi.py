@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libppg_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # row_flags bits
 ROW_DIED, ROW_OWNS, ROW_NEWBORN, ROW_ATE, ROW_TRUNC, ROW_GRID_E0 = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
@@ -85,6 +85,33 @@ class PpgConfigGen2(C.Structure):
                                  "mask_observation_with_visibility")]
 
 
+PACK_MAGIC, PACK_VERSION, PACK_F32, PACK_MAX_HANDLES = 0x4B475050, 1, 0x1, 8
+STATE_MAGIC, STATE_VERSION = 0x53475050, 1
+
+
+class PpgPackHeader(C.Structure):
+    """include/ppg.h: struct ppg_pack_header (64 bytes, little endian)."""
+    _fields_ = [(n, C.c_uint32) for n in ("magic", "version", "n_envs", "n_pred_rows", "n_prey_rows", "obs_elem_bytes",
+                                          "blk_pred", "blk_prey")] + [("bytes_used", C.c_uint64), ("capacity", C.c_uint64),
+                                                                      ("overflow", C.c_uint32), ("env_words", C.c_uint32),
+                                                                      ("reserved", C.c_uint32 * 2)]
+
+
+def pack_layout(n_envs, n_pred, n_prey, blk_pred, blk_prey, elem):
+    """Byte offsets of the sections of a packed observation image (mirror of ppg::pack_layout, csrc/ppg_pack.h)."""
+    def al(v):
+        return (v + 15) & ~15
+    L, o = {}, C.sizeof(PpgPackHeader)
+    for name, size in (("env_state", n_envs * ENV_WORDS * 4), ("row_off", n_envs * 8), ("id_pred", n_pred * 4),
+                       ("id_prey", n_prey * 4), ("reward_pred", n_pred * 8), ("reward_prey", n_prey * 8),
+                       ("flags_pred", n_pred), ("flags_prey", n_prey), ("obs_pred", n_pred * blk_pred * elem),
+                       ("obs_prey", n_prey * blk_prey * elem)):
+        L[name] = o
+        o = al(o + size)
+    L["total"] = o
+    return L
+
+
 class PpgBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _BUF_FIELDS]
 
@@ -92,7 +119,7 @@ class PpgBuffers(C.Structure):
 EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
     "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_rebalance",
-    "ppg_export_grid",
+    "ppg_export_grid", "ppg_state_bytes", "ppg_export_state", "ppg_import_state", "ppg_pack_bytes", "ppg_pack",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_last_error",
 ]
 
@@ -126,6 +153,16 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_set_envs_in_flight.argtypes = [C.c_void_p, C.c_int32]
     lib.ppg_export_grid.restype = C.c_int
     lib.ppg_export_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ppg_state_bytes.restype = C.c_uint64
+    lib.ppg_state_bytes.argtypes = [C.c_void_p]
+    lib.ppg_export_state.restype = C.c_int
+    lib.ppg_export_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    lib.ppg_import_state.restype = C.c_int
+    lib.ppg_import_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.ppg_pack_bytes.restype = C.c_uint64
+    lib.ppg_pack_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_uint32]
+    lib.ppg_pack.restype = C.c_int
+    lib.ppg_pack.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
     lib.ppg_lexkey.restype = C.c_uint32
     lib.ppg_lexkey.argtypes = [C.c_uint32]
     lib.ppg_lds_bytes.restype = C.c_int32

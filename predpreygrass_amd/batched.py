@@ -342,6 +342,24 @@ class BatchedPredPreyGrass:
         self._check(self._lib.ppg_export_grid(self._handle, C.c_void_p(out.data_ptr()), self._stream()), "ppg_export_grid")
         return out
 
+    def export_state(self, b=0) -> bytes:
+        """Versioned image of env b's state (`ppg_export_state`): row tables, env words, Philox key, grass table --
+        what get_state_snapshot of the reference captures (predpreygrass_rllib_env.py:768-786), as one POD blob."""
+        size = C.c_uint64(int(self._lib.ppg_state_bytes(self._handle)))
+        blob = C.create_string_buffer(size.value)
+        self._check(self._lib.ppg_export_state(self._handle, int(b), blob, C.byref(size), self._stream()), "ppg_export_state")
+        return blob.raw[: size.value]
+
+    def import_state(self, blob: bytes, b=0):
+        """Write an image from `export_state` into env b (`ppg_import_state`, predpreygrass_rllib_env.py:788-804); the
+        geometry of the handle it came from must match.  Call `observe()` afterwards for the observations."""
+        buf = C.create_string_buffer(bytes(blob), len(blob))
+        rc = self._lib.ppg_import_state(self._handle, int(b), buf, len(blob), self._stream())
+        if rc == -1:
+            raise ValueError(self._lib.ppg_last_error(self._handle).decode())
+        self._check(rc, "ppg_import_state")
+        return self
+
     # ------------------------------------------------------------------
     # host views (one device->host copy each; used by the dict API and by tests)
     def host_tables(self, b=None):

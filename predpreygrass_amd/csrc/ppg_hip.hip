@@ -142,6 +142,36 @@ static int backend_rebalance(ppg_handle *h, int weight_pred, int weight_prey, vo
     return PPG_OK;
 }
 
+// ---- ppg_pack: the packed observation image (ppg_pack.h) --------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) ppg_pack_scan(const ppg::PackParams K) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[512];
+    ppg::pack_scan_main(*PPG_KERNARG_PTR(ppg::PackParams, K), lds);
+}
+extern "C" __global__ void __launch_bounds__(64) ppg_pack_rows(const ppg::PackParams K) {
+    ppg::pack_rows_main(*PPG_KERNARG_PTR(ppg::PackParams, K));
+}
+
+static int backend_pack(ppg_handle *h, const ppg::PackParams &K, void *stream) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(ppg_pack_scan, dim3(1), dim3(64), 0, (hipStream_t)stream, K);
+    hipLaunchKernelGGL(ppg_pack_rows, dim3((unsigned)K.n_envs), dim3(64), 0, (hipStream_t)stream, K);
+    PPG_HIP_TRY(h, hipGetLastError());
+    return PPG_OK;
+}
+
+static int backend_copy(ppg_handle *h, void *dst, const void *src, size_t bytes, bool to_device, void *stream) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
+    PPG_HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return PPG_OK;
+}
+
+static int backend_sync(ppg_handle *h, void *stream) {
+    PPG_HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    return PPG_OK;
+}
+
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *stream) {
     // one workgroup = one wavefront = one environment
     int cur = -1;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "ppg_kernel.h"
+#include "ppg_pack.h"
 
 struct ppg_handle {
     int32_t drive;  // drive-conditioned variant of the base family (cfg.n_drive)
@@ -276,6 +277,28 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
 // (re)compute h->order_dev (allocating it on first use): envs sorted by descending weight_pred * predator rows +
 // weight_prey * prey rows, ties by env index -- always a permutation of 0..batch-1
 static int backend_rebalance(ppg_handle *h, int weight_pred, int weight_prey, void *stream);
+// snapshot plumbing: a copy between host memory and a caller-owned device tensor, enqueued on `stream`; and the wait
+static int backend_copy(ppg_handle *h, void *dst, const void *src, size_t bytes, bool to_device, void *stream);
+static int backend_sync(ppg_handle *h, void *stream);
+// the two launches of ppg_pack (ppg_pack.h)
+static int backend_pack(ppg_handle *h, const ppg::PackParams &K, void *stream);
+
+// The state tensors of one env, in image order (include/ppg.h: ppg_state_header): pointer, bytes per env.
+struct ppg_state_field { void *base; size_t bytes; };
+static int ppg_state_fields(const ppg_handle *h, ppg_state_field (&f)[16]) {
+    const ppg_buffers &b = h->bufs;
+    const size_t S = (size_t)h->base.S, NG = (size_t)h->base.cap_grass, W = (size_t)h->base.n_wall_words;
+    const bool walls = h->gen2 && h->cfg2.walls;
+    int n = 0;
+    f[n++] = {b.row_xy, S * 2}; f[n++] = {b.row_energy, S * 8}; f[n++] = {b.row_id, S * 4}; f[n++] = {b.row_key, S * 4};
+    f[n++] = {b.row_cumrew, S * 8}; f[n++] = {b.row_flags, S}; f[n++] = {b.row_reward, S * 8};
+    f[n++] = {b.row_parent, S * 4};
+    f[n++] = {b.env_state, (size_t)PPG_ENV_WORDS * 4}; f[n++] = {b.env_seed, 8};
+    f[n++] = {b.grass_xy, NG * 2}; f[n++] = {b.grass_energy, NG * 8};
+    if (h->gen2) f[n++] = {b.row_lastrep, S * 4};
+    if (walls) { f[n++] = {b.row_info, S}; f[n++] = {b.wall_bits, W * 4}; }
+    return n;
+}
 
 extern "C" {
 
@@ -420,6 +443,123 @@ int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream) {
 }
 
 int32_t ppg_lds_bytes(const ppg_handle *h) { return h ? h->base.lds_bytes : 0; }
+
+uint64_t ppg_state_bytes(const ppg_handle *h) {
+    if (!h) return 0;
+    ppg_state_field f[16];
+    const int n = ppg_state_fields(h, f);
+    uint64_t tot = sizeof(ppg_state_header);
+    for (int i = 0; i < n; ++i) tot += (f[i].bytes + 7) / 8 * 8;
+    return tot;
+}
+
+static void ppg_fill_state_header(const ppg_handle *h, ppg_state_header &H) {
+    memset(&H, 0, sizeof H);
+    H.magic = PPG_STATE_MAGIC; H.version = PPG_STATE_VERSION; H.bytes = (uint32_t)ppg_state_bytes(h);
+    H.gen2 = h->gen2 ? 1u : 0u; H.walls = (h->gen2 && h->cfg2.walls) ? 1u : 0u;
+    H.grid_size = (uint32_t)h->base.G; H.pred_capacity = (uint32_t)h->base.cap_pred; H.prey_capacity = (uint32_t)h->base.cap_prey;
+    H.grass_capacity = (uint32_t)h->base.cap_grass; H.n_wall_words = (uint32_t)h->base.n_wall_words;
+}
+
+int ppg_export_state(ppg_handle *h, int32_t env, void *blob, uint64_t *size, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!size) return ppg_fail(h, PPG_EINVAL, "size is NULL");
+    const uint64_t need = ppg_state_bytes(h);
+    if (!blob) { *size = need; return PPG_OK; }
+    if (env < 0 || env >= h->batch) return ppg_fail(h, PPG_EINVAL, "env %d not in 0..%d", env, h->batch - 1);
+    if (*size < need) return ppg_fail(h, PPG_EINVAL, "blob holds %llu bytes, the image needs %llu", (unsigned long long)*size, (unsigned long long)need);
+    ppg_state_header H;
+    ppg_fill_state_header(h, H);
+    memcpy(blob, &H, sizeof H);
+    ppg_state_field f[16];
+    const int n = ppg_state_fields(h, f);
+    unsigned char *dst = (unsigned char *)blob + sizeof H;
+    for (int i = 0; i < n; ++i) {
+        const int rc = backend_copy(h, dst, (const unsigned char *)f[i].base + (size_t)env * f[i].bytes, f[i].bytes, false, stream);
+        if (rc != PPG_OK) return rc;
+        dst += (f[i].bytes + 7) / 8 * 8;
+    }
+    *size = need;
+    return backend_sync(h, stream);
+}
+
+int ppg_import_state(ppg_handle *h, int32_t env, const void *blob, uint64_t size, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!blob) return ppg_fail(h, PPG_EINVAL, "blob is NULL");
+    if (env < 0 || env >= h->batch) return ppg_fail(h, PPG_EINVAL, "env %d not in 0..%d", env, h->batch - 1);
+    ppg_state_header want, got;
+    ppg_fill_state_header(h, want);
+    if (size < sizeof got) return ppg_fail(h, PPG_EINVAL, "blob of %llu bytes is shorter than a header", (unsigned long long)size);
+    memcpy(&got, blob, sizeof got);
+    if (got.magic != PPG_STATE_MAGIC || got.version != PPG_STATE_VERSION)
+        return ppg_fail(h, PPG_EINVAL, "not a ppg state image (magic 0x%x, version %u)", got.magic, got.version);
+    if (memcmp(&got, &want, sizeof got) != 0 || size < want.bytes)
+        return ppg_fail(h, PPG_EINVAL, "state image was taken from a handle with another geometry (grid %u, rows %u+%u, grass %u, gen2 %u, walls %u)",
+                        got.grid_size, got.pred_capacity, got.prey_capacity, got.grass_capacity, got.gen2, got.walls);
+    ppg_state_field f[16];
+    const int n = ppg_state_fields(h, f);
+    const unsigned char *src = (const unsigned char *)blob + sizeof got;
+    for (int i = 0; i < n; ++i) {
+        const int rc = backend_copy(h, (unsigned char *)f[i].base + (size_t)env * f[i].bytes, src, f[i].bytes, true, stream);
+        if (rc != PPG_OK) return rc;
+        src += (f[i].bytes + 7) / 8 * 8;
+    }
+    return backend_sync(h, stream);   // the blob may be freed by the caller as soon as this returns
+}
+
+static int ppg_pack_geometry(const ppg_handle *h, uint32_t flags, int &blk_p, int &blk_q, int &src_elem, int &dst_elem) {
+    const ppg::KParams &P = h->base;
+    const bool drive = h->drive != 0;
+    const int channels = (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
+    blk_p = (drive ? 4 + P.n_drive[0] : channels) * P.Rp * P.Rp;
+    blk_q = (drive ? 4 + P.n_drive[1] : channels) * P.Rq * P.Rq;
+    src_elem = P.obs_f32 ? 4 : 8;
+    dst_elem = (flags & PPG_PACK_F32) ? 4 : src_elem;
+    return PPG_OK;
+}
+
+uint64_t ppg_pack_bytes(const ppg_handle *h, int32_t n_envs, int64_t n_pred_rows, int64_t n_prey_rows, uint32_t flags) {
+    if (!h || n_envs < 0 || n_pred_rows < 0 || n_prey_rows < 0) return 0;
+    int bp, bq, se, de;
+    ppg_pack_geometry(h, flags, bp, bq, se, de);
+    return ppg::pack_layout((uint64_t)n_envs, (uint64_t)n_pred_rows, (uint64_t)n_prey_rows, (uint64_t)bp, (uint64_t)bq, (uint64_t)de).total;
+}
+
+int ppg_pack(ppg_handle *const *handles, int32_t n, void *out, uint64_t capacity, uint32_t flags, void *stream) {
+    if (!handles || n < 1 || !handles[0]) return PPG_EINVAL;
+    ppg_handle *h0 = handles[0];
+    if (n > PPG_PACK_MAX_HANDLES) return ppg_fail(h0, PPG_EINVAL, "ppg_pack takes at most %d handles", PPG_PACK_MAX_HANDLES);
+    if (!out || ((uintptr_t)out & 15u)) return ppg_fail(h0, PPG_EINVAL, "out must be a 16-byte aligned device pointer");
+    if (flags & ~PPG_PACK_F32) return ppg_fail(h0, PPG_EINVAL, "unknown pack flags 0x%x", flags);
+    ppg::PackParams K;
+    memset(&K, 0, sizeof K);
+    ppg_pack_geometry(h0, flags, K.blk_pred, K.blk_prey, K.src_elem, K.dst_elem);
+    K.S = h0->base.S; K.cap_pred = h0->base.cap_pred; K.cap_prey = h0->base.cap_prey;
+    K.n_handles = n;
+    int total = 0;
+    for (int k = 0; k < n; ++k) {
+        const ppg_handle *h = handles[k];
+        if (!h) return ppg_fail(h0, PPG_EINVAL, "handle %d is NULL", k);
+        int bp, bq, se, de;
+        ppg_pack_geometry(h, flags, bp, bq, se, de);
+        if (bp != K.blk_pred || bq != K.blk_prey || se != K.src_elem || h->base.S != K.S || h->base.cap_pred != K.cap_pred || h->device != h0->device)
+            return ppg_fail(h0, PPG_EINVAL, "handle %d has another geometry / device than handle 0", k);
+        K.env_base[k] = total;
+        total += h->batch;
+        K.env_state[k] = h->bufs.env_state; K.row_id[k] = h->bufs.row_id; K.row_reward[k] = h->bufs.row_reward;
+        K.row_flags[k] = h->bufs.row_flags;
+        K.obs_pred[k] = (const unsigned char *)h->bufs.obs_pred; K.obs_prey[k] = (const unsigned char *)h->bufs.obs_prey;
+    }
+    for (int k = n; k <= PPG_PACK_MAX_HANDLES; ++k) K.env_base[k] = total;
+    K.n_envs = total;
+    K.capacity = capacity;
+    K.out = (unsigned char *)out;
+    // the header, the env words and the row offsets are always written: the caller learns the size an overflowing image needs
+    const uint64_t fixed = ppg::pack_layout((uint64_t)total, 0, 0, 0, 0, 4).id_p;
+    if (capacity < fixed) return ppg_fail(h0, PPG_EINVAL, "capacity %llu is below the fixed part of the image (%llu bytes for %d envs)",
+                                          (unsigned long long)capacity, (unsigned long long)fixed, total);
+    return backend_pack(h0, K, stream);
+}
 
 #ifdef PPG_PROFILE_PHASES
 // diagnostic build only: device buffer [B,16] of shader-clock stamps (see PPG_STAMP)

@@ -1851,9 +1851,13 @@ struct Env {
                 if (fr) perm[n_free + (int)wv::prefix(m)] = (uint16_t)c;
                 n_free += wv::popc(m);
             }
-            if (K > n_free) status |= PPG_STATUS_FAILED_SPAWN;  // more entities than free cells: the host validates this
         }
-        for (int base = 0; base < K; base += 256) {
+        // more entities than free cells (walls set after create; ppg_create rejects it for the open grid, BASE:167-168): flagged,
+        // and only the entities that fit are placed -- the Fisher-Yates below must never index past the free cells
+        const int Kp = K < n_free ? K : n_free;
+        if (K > n_free) status |= PPG_STATUS_FAILED_SPAWN;
+        for (int i = Kp + ln; i < K; i += 64) ent[i] = perm[0];  // (defined, never meaningful: the status bit is set)
+        for (int base = 0; base < Kp; base += 256) {
             uint32_t w[4];
             philox4x32_10((uint32_t)(base >> 2) + (uint32_t)ln, 0u, 0u, episode, (uint32_t)seed,
                           (uint32_t)(seed >> 32) ^ TAG_RST, w);
@@ -1861,7 +1865,7 @@ struct Env {
 #pragma unroll
             for (int q = 0; q < 4; ++q) rnd[4 * ln + q] = w[q];
             wv::sync();
-            const int hi = (K - base) < 256 ? (K - base) : 256;
+            const int hi = (Kp - base) < 256 ? (Kp - base) : 256;
             for (int kk = 0; kk < hi; ++kk) {
                 const int k = base + kk;
                 const uint32_t rr = wv::first(rnd[kk]);

@@ -13,6 +13,7 @@
 
 #define PPG_DEVICE __device__ __forceinline__
 #define PPG_MEMBER __device__ __forceinline__
+#define PPG_HOST_DEVICE __host__ __device__ inline
 // 64 threads = one wavefront per workgroup; W = waves per SIMD the register allocator must allow
 // (4 -> <= 128 VGPRs -> 16 waves per CU = 4096 co-resident envs per MI355X)
 #define PPG_KERNEL(name, W) extern "C" __global__ void __launch_bounds__(64, W) name

@@ -2,16 +2,26 @@
 
 The transition needs no collective at all (envs are independent).  What a
 central consumer (a learner on rank 0, a logger) may need is the *returned observation dict* of every
-env; `ObservationGatherer` moves exactly that -- the observations of the rows in use plus their ids /
-rewards / flags -- with ONE variable-length all-gather per tensor over RCCL (backend "nccl" on ROCm;
-"gloo" in the CPU tests).  Rows are compacted first so that padding slots never cross xGMI.
+env.  `ObservationGatherer` moves exactly that with ONE collective per step:
+
+  1. `ppg_pack` (HIP, csrc/ppg_pack.h) compacts what the shard's last call returned -- env words, ids /
+     rewards / flags and the observations of the rows IN USE -- into one contiguous byte image
+     (include/ppg.h: ppg_pack_header), optionally with float64 observations narrowed to float32;
+  2. one `all_gather_into_tensor` of that image (RCCL: backend "nccl" on ROCm; "gloo" in the CPU tests).
+
+No host synchronisation is involved: the image has a fixed capacity (bytes) that every rank agrees on,
+its header says how much of it is used, and a consumer parses the header where it needs the data
+(`views()`, one small device->host copy) or hands the image to a device-side consumer as it is.
 
 Bandwidth note: float64 observations are ~2.4 KB per agent; at ~36 agents per env a
-4096-env shard emits ~360 MB per step, so a synchronous gather over xGMI (7 links x ~153 GB/s per
-GPU) caps the aggregate far below the compute rate -- gather only when a single consumer really
-needs every observation, and prefer float32 observations on the wire.
+4096-env shard emits ~360 MB per step, so a gather over xGMI (7 links x ~153 GB/s per GPU) caps the
+aggregate far below the compute rate -- gather only when a single consumer really needs every
+observation, prefer float32 on the wire, and overlap the collective of step t with step t+1
+(`pack()` on the env's stream, `gather()` on a side stream; two image slots alternate).
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.distributed as dist
@@ -27,70 +37,146 @@ def shard_range(total_envs: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_SECTION_DTYPES = {"id_pred": torch.int32, "id_prey": torch.int32, "reward_pred": torch.float64,
+                   "reward_prey": torch.float64, "flags_pred": torch.uint8, "flags_prey": torch.uint8}
+
+
+def parse_image(image: torch.Tensor, header: _abi.PpgPackHeader = None):
+    """Zero-copy views into one packed observation image (a uint8 tensor): dict with env_state [n,20] int32,
+    row_off [n,2] int32, id_* / reward_* / flags_* [N], obs_pred [Np, blk_pred], obs_prey [Nq, blk_prey].
+    Reads the 64-byte header on the host unless it is given."""
+    if header is None:
+        header = _abi.PpgPackHeader.from_buffer_copy(image[:64].cpu().numpy().tobytes())
+    if header.magic != _abi.PACK_MAGIC or header.version != _abi.PACK_VERSION:
+        raise ValueError("not a packed observation image")
+    if header.overflow:
+        raise OverflowError(f"the image needs {header.bytes_used} bytes, its capacity is {header.capacity}")
+    n, np_, nq = header.n_envs, header.n_pred_rows, header.n_prey_rows
+    elem = header.obs_elem_bytes
+    L = _abi.pack_layout(n, np_, nq, header.blk_pred, header.blk_prey, elem)
+    odt = torch.float32 if elem == 4 else torch.float64
+
+    def view(name, count, dtype):
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return image[L[name]: L[name] + nbytes].view(dtype)
+
+    out = {"header": header,
+           "env_state": view("env_state", n * _abi.ENV_WORDS, torch.int32).view(n, _abi.ENV_WORDS),
+           "row_off": view("row_off", n * 2, torch.int32).view(n, 2)}
+    for name, dt in _SECTION_DTYPES.items():
+        out[name] = view(name, np_ if name.endswith("pred") else nq, dt)
+    out["obs_pred"] = view("obs_pred", np_ * header.blk_pred, odt).view(np_, header.blk_pred)
+    out["obs_prey"] = view("obs_prey", nq * header.blk_prey, odt).view(nq, header.blk_prey)
+    return out
+
+
 class ObservationGatherer:
-    def __init__(self, env: BatchedPredPreyGrass, group=None):
-        self.env = env
+    """Packed observation images of one rank's envs and their all-gather.
+
+    envs: a `BatchedPredPreyGrass` (or subclass) or a list of them (the sub-batches of one GPU, at most 8);
+    wire_dtype: torch.float32 narrows float64 observations on the wire (None = the envs' own dtype);
+    rows_per_env: sizing of the image in (predator, prey) rows per env -- None = three times the initial
+    population, at most the row capacity; `grow()` enlarges it when a header reports an overflow."""
+
+    def __init__(self, envs, group=None, wire_dtype=None, rows_per_env=None, slots=2):
+        self.envs = list(envs) if isinstance(envs, (list, tuple)) else [envs]
+        e0 = self.envs[0]
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        dev = env.device
-        self._rows_p = torch.arange(env.pred_capacity, device=dev)[None, :]
-        self._rows_q = torch.arange(env.prey_capacity, device=dev)[None, :]
+        self.device = e0.device
+        self._lib = e0._lib
+        self.n_envs = sum(e.batch_size for e in self.envs)
+        self.flags = _abi.PACK_F32 if (wire_dtype == torch.float32 and e0.obs_dtype == torch.float64) else 0
+        if wire_dtype not in (None, torch.float32, e0.obs_dtype):
+            raise ValueError("wire_dtype must be None, torch.float32 or the envs' observation dtype")
+        self._handles = (C.c_void_p * len(self.envs))(*[e._handle for e in self.envs])
+        if rows_per_env is None:
+            rows_per_env = (min(e0.pred_capacity, 3 * max(e0.P0, 2)), min(e0.prey_capacity, 3 * max(e0.Q0, 2)))
+        # every rank must use the same capacity (all_gather_into_tensor): size it for the largest shard
+        n_max = -(-self._total_envs() // self.world)
+        self._set_capacity(int(self._lib.ppg_pack_bytes(e0._handle, n_max, int(n_max * rows_per_env[0]),
+                                                        int(n_max * rows_per_env[1]), self.flags)), slots)
+        self.last_bytes = 0
+
+    def _total_envs(self):
+        t = torch.tensor([self.n_envs], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def _set_capacity(self, capacity, slots=None):
+        self.capacity = (int(capacity) + 255) // 256 * 256
+        slots = slots or len(self._local)
+        self._local = [torch.zeros(self.capacity, dtype=torch.uint8, device=self.device) for _ in range(slots)]
+        self._all = [torch.zeros(self.world * self.capacity, dtype=torch.uint8, device=self.device) for _ in range(slots)]
+        self._slot = 0
+        self._cuda = self.device.type == "cuda"
+        self._done = [None] * slots
+
+    # ------------------------------------------------------------------
+    def pack(self, stream=None):
+        """`ppg_pack` of the envs' last call into the next image slot; asynchronous on `stream` (default: torch's current
+        stream), which must be ordered behind the envs' step.  Returns the slot index."""
+        self._slot = (self._slot + 1) % len(self._local)
+        buf = self._local[self._slot]
+        if self._cuda and self._done[self._slot] is not None:
+            # the collective that last read this slot (possibly on another stream) must have finished
+            (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_event(self._done[self._slot])
+        rc = self._lib.ppg_pack(self._handles, len(self.envs), C.c_void_p(buf.data_ptr()), self.capacity, self.flags,
+                                self.envs[0]._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"ppg_pack failed ({rc}): {self._lib.ppg_last_error(self.envs[0]._handle).decode()}")
+        return self._slot
+
+    def gather(self, slot=None, pack=True):
+        """THE collective of a step: every rank receives every shard's image.  Returns the slot; `views(rank)` parses it.
+        pack=False gathers an image packed earlier (`pack()` on the env's stream, `gather(slot, pack=False)` on a side
+        stream while the next step runs)."""
+        if pack:
+            slot = self.pack()
+        elif slot is None:
+            slot = self._slot
+        dist.all_gather_into_tensor(self._all[slot], self._local[slot], group=self.group)
+        if self._cuda:   # (the calling stream waits for the collective; an event behind it marks the slot as free again)
+            self._done[slot] = torch.cuda.Event()
+            self._done[slot].record(torch.cuda.current_stream(self.device))
+        self.last_bytes = self.world * self.capacity
+        self._gathered = slot
+        return slot
+
+    def image(self, rank, slot=None):
+        slot = self._gathered if slot is None else slot
+        return self._all[slot][rank * self.capacity: (rank + 1) * self.capacity]
+
+    def headers(self, slot=None):
+        """The headers of all ranks' images (one device->host copy of world x 64 bytes)."""
+        slot = self._gathered if slot is None else slot
+        h = self._all[slot].view(self.world, self.capacity)[:, :64].cpu().numpy()
+        return [_abi.PpgPackHeader.from_buffer_copy(h[r].tobytes()) for r in range(self.world)]
+
+    def views(self, rank, slot=None):
+        return parse_image(self.image(rank, slot))
+
+    def grow(self, slot=None, margin=1.25):
+        """If any rank's image overflowed, enlarge the capacity on every rank (same decision everywhere: all ranks hold
+        all headers).  Returns True if it grew -- the overflowing step has to be packed and gathered again."""
+        need = max(int(h.bytes_used) for h in self.headers(slot))
+        if need <= self.capacity:
+            return False
+        self._set_capacity(int(need * margin))
+        return True
+
+    # ------------------------------------------------------------------
+    def gather_dict(self):
+        """Convenience for tests and small consumers: pack + gather (repeated once if the image had to grow) and the
+        result as {section: [tensor of rank 0, tensor of rank 1, ...]}."""
+        slot = self.gather()
+        if self.grow(slot):
+            slot = self.gather()
+        per_rank = [self.views(r, slot) for r in range(self.world)]
+        return {k: [v[k] for v in per_rank] for k in per_rank[0] if k != "header"}
 
     def pack_local(self):
-        """Compacted view of this shard's last call: observations and per-row tables of the rows in
-        use, env-major, predators and prey separately, plus the per-env row counts."""
-        e = self.env
-        es = e.env_state
-        nP = es[:, _abi.ENV_N_PRED_ROWS:_abi.ENV_N_PRED_ROWS + 1]
-        nQ = es[:, _abi.ENV_N_PREY_ROWS:_abi.ENV_N_PREY_ROWS + 1]
-        mp = self._rows_p < nP
-        mq = self._rows_q < nQ
-        cp = e.pred_capacity
-        # row indices of the slots in use; whole-row index_select copies (a boolean-mask gather of the 5-D observation
-        # tensors is ~30x slower)
-        ip = mp.reshape(-1).nonzero().squeeze(1)
-        iq = mq.reshape(-1).nonzero().squeeze(1)
-
-        def rows(t, idx):
-            return t.reshape((t.shape[0] * t.shape[1],) + tuple(t.shape[2:])).index_select(0, idx)
-        out = {
-            "obs_pred": rows(e.obs_pred, ip), "obs_prey": rows(e.obs_prey, iq),
-            "id_pred": rows(e.row_id[:, :cp].contiguous(), ip), "id_prey": rows(e.row_id[:, cp:].contiguous(), iq),
-            "reward_pred": rows(e.row_reward[:, :cp].contiguous(), ip), "reward_prey": rows(e.row_reward[:, cp:].contiguous(), iq),
-            "flags_pred": rows(e.row_flags[:, :cp].contiguous(), ip), "flags_prey": rows(e.row_flags[:, cp:].contiguous(), iq),
-            "env_state": es.clone(),
-        }
-        return out
-
-    def _all_gather_var(self, t: torch.Tensor, counts):
-        """All-gather tensors whose first dimension differs per rank (counts known on every rank)."""
-        n_max = max(counts)
-        if t.shape[0] == n_max:
-            pad = t.contiguous()
-        else:   # (the tail is never read: the receivers slice by counts)
-            pad = torch.empty((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            pad[: t.shape[0]] = t
-        out = torch.empty((self.world * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, pad, group=self.group)
-        return [out[r * n_max: r * n_max + counts[r]] for r in range(self.world)]
-
-    def gather(self, local=None):
-        """Every rank receives every shard's packed observation data (list indexed by rank).
-
-        local: a dict from an earlier `pack_local()`.  Packing copies the rows in use out of the env's buffers, so the
-        env can already run its next step while this gather moves the copies: pack on the env's stream, enqueue the next
-        step, then call `gather(local)` on another stream (`bench.py`'s obs_gather_overlapped leg)."""
-        if local is None:
-            local = self.pack_local()
-        cnt = torch.tensor([local["obs_pred"].shape[0], local["obs_prey"].shape[0], self.env.batch_size],
-                           dtype=torch.int64, device=self.env.device)
-        allc = torch.empty((self.world * 3,), dtype=torch.int64, device=self.env.device)
-        dist.all_gather_into_tensor(allc, cnt, group=self.group)
-        allc = allc.cpu().view(self.world, 3).tolist()   # the one host sync of the gather
-        counts = {"pred": [c[0] for c in allc], "prey": [c[1] for c in allc], "state": [c[2] for c in allc]}
-        res = {}
-        for k, v in local.items():
-            res[k] = self._all_gather_var(v, counts[k.rsplit("_", 1)[1]])
-        self.last_bytes = sum(t.numel() * t.element_size() for k, v in res.items() for t in v)
-        return res
+        """This rank's own image, parsed (no collective)."""
+        slot = self.pack()
+        return parse_image(self._local[slot])

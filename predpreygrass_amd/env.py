@@ -315,9 +315,6 @@ class PredPreyGrass(_MultiAgentEnvBase):
         return t[self._i, row].cpu().numpy().astype(np.float64)
 
     # snapshot / restore (predpreygrass_rllib_env.py:768-804)
-    _STATE_TENSORS = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_parent",
-                      "env_state", "env_seed", "grass_xy", "grass_energy"]
-
     def get_state_snapshot(self):
         b, i = self._b, self._i
         snap = {
@@ -339,7 +336,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
             "next_prey_idx": self._next_prey_idx,
             "agent_parent": self.agent_parent,
             # device state of this implementation
-            "_device_state": {n: getattr(b, n)[i].cpu().clone() for n in self._STATE_TENSORS},
+            "_device_state": b.export_state(i),   # ppg_export_state: the versioned POD image of include/ppg.h
             "_records": list(self._records),
             "_insertion_order": list(self._insertion_order),
         }
@@ -347,8 +344,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
 
     def restore_state_snapshot(self, snapshot):
         b, i = self._b, self._i
-        for n, v in snapshot["_device_state"].items():
-            getattr(b, n)[i].copy_(v)
+        b.import_state(snapshot["_device_state"], i)
         self.cumulative_rewards = dict(snapshot["cumulative_rewards"])
         self._insertion_order = list(snapshot["_insertion_order"])
         b.observe()

@@ -107,18 +107,17 @@ class PredPreyGrassAECEnv(_AECBase):
     def step(self, action):
         a = self.agent_selection
         if self.terminations[a] or self.truncations[a]:
-            # dead-step: the agent is removed (PettingZoo's _was_dead_step); action must be None
+            # dead-step: the agent is removed (PettingZoo's _was_dead_step); action must be None.  The cursor stays: the
+            # next agent of the cycle has moved into this position.
             self.agents.remove(a)
-            self._order = [x for x in self._order if x != a]
-            if self._cursor >= len(self._order):
-                self._cursor = 0
-            self.agent_selection = self._order[self._cursor] if self._order else None
-            return
-        self._cumulative_rewards[a] = 0.0
-        self._pending[a] = action
-        self._cursor += 1
-        live = [x for x in self._order if not (self.terminations[x] or self.truncations[x])]
-        if all(x in self._pending for x in live):
+            del self._order[self._cursor]
+        else:
+            self._cumulative_rewards[a] = 0.0
+            self._pending[a] = action
+            self._cursor += 1
+        if self._cursor >= len(self._order) and self._order:
+            # the cycle is complete: every live agent has acted and every agent that was reported dead has been
+            # dead-stepped, so no terminated agent can be left behind in `agents` when the order is rebuilt
             obs, rew, term, trunc, infos = self._par.step(self._pending)
             self._pending = {}
             for k in obs:
@@ -129,8 +128,6 @@ class PredPreyGrassAECEnv(_AECBase):
                 self._cumulative_rewards[k] = self._cumulative_rewards.get(k, 0.0) + rew[k]
                 self.terminations[k], self.truncations[k], self.infos[k] = term[k], trunc[k], infos[k]
             self._order = list(obs)
-            self._cursor = 0
-        if self._cursor >= len(self._order):
             self._cursor = 0
         self.agent_selection = self._order[self._cursor] if self._order else None
 

@@ -246,6 +246,10 @@ class BatchedRedQueen(BatchedPredPreyGrass):
                 raise ValueError("wall outside the grid")
             c = a[:, 0] * G + a[:, 1]
             np.bitwise_or.at(bits[b], c >> 5, (np.uint32(1) << (c & 31).astype(np.uint32)))
+            n_free = G * G - len(np.unique(c))
+            if n_free < self.P0 + self.Q0 + self.n_grass:   # the device reset places every entity on its own free cell
+                raise ValueError(f"env {b}: {n_free} cells are free of walls but {self.P0 + self.Q0 + self.n_grass} "
+                                 "entities have to be placed")
         self.wall_bits.copy_(torch.from_numpy(bits.view(np.int32)))
         return self
 
@@ -548,9 +552,6 @@ class PredPreyGrass(_MultiAgentEnvBase):
         return out
 
     # snapshot / restore (RQ:893-939)
-    _STATE_TENSORS = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_lastrep",
-                      "env_state", "env_seed", "grass_xy", "grass_energy"]
-
     def get_state_snapshot(self):
         b = self._b
         return {
@@ -562,14 +563,13 @@ class PredPreyGrass(_MultiAgentEnvBase):
             "active_num_predators": self.active_num_predators, "active_num_prey": self.active_num_prey,
             "agents_just_ate": set(self.agents_just_ate), "agent_last_reproduction": self.agent_last_reproduction,
             "pending_removal": list(self._pending_removal), "next_idx": dict(self._next_idx),
-            "_device_state": {n: getattr(b, n)[0].cpu().clone() for n in self._STATE_TENSORS},
+            "_device_state": b.export_state(0),   # ppg_export_state (incl. row_lastrep; walls: row_info + wall bitmap)
             "_insertion_order": list(self._insertion_order), "_rng_state": self.rng.bit_generator.state,
         }
 
     def restore_state_snapshot(self, snapshot):
         b = self._b
-        for n, v in snapshot["_device_state"].items():
-            getattr(b, n)[0].copy_(v)
+        b.import_state(snapshot["_device_state"], 0)
         self._insertion_order = list(snapshot["_insertion_order"])
         self.rng.bit_generator.state = snapshot["_rng_state"]
         b.observe()

@@ -71,15 +71,34 @@ class SubBatchedPredPreyGrass:
                         not a.is_contiguous() or a.device != self.subs[k].device:
                     raise ValueError("actions[k] must be a contiguous int8 tensor [B_k, S] on the env's device")
             acts = (C.c_void_p * n)(*[a.data_ptr() for a in actions])
+        # whatever the caller enqueued on the current stream (a policy writing the action tensors, edits of env_state)
+        # happens before the step kernels of the sub-batch streams
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
         lib = self.subs[0]._lib
         rc = lib.ppg_step_many(self._c_handles, n, acts, flags, self._c_streams)
         if rc != 0:
-            raise RuntimeError(f"ppg_step_many failed ({rc})")
+            msgs = [lib.ppg_last_error(e._handle).decode() for e in self.subs]
+            raise RuntimeError(f"ppg_step_many failed ({rc}): {'; '.join(m for m in msgs if m)}")
+        return self
+
+    def wait(self, stream=None):
+        """Make `stream` (default: torch's current stream) wait for everything the sub-batch streams have been given so
+        far -- call it before a consumer on that stream reads observations / rewards (no host synchronisation)."""
+        if self.streams[0] is None:
+            return self
+        stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            stream.wait_stream(s)
         return self
 
     def rebalance(self):
-        """ppg_rebalance of every sub-batch on its own stream (scheduling only)."""
+        """ppg_rebalance of every sub-batch on its own stream (scheduling only; reads env_state, so it is ordered behind
+        the caller's current stream like a step)."""
         for e, s in zip(self.subs, self.streams):
+            if s is not None:
+                s.wait_stream(torch.cuda.current_stream(self.device))
             e.rebalance(stream=s)
         return self
 

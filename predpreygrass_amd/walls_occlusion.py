@@ -52,7 +52,6 @@ class PredPreyGrass(_RedQueenPredPreyGrass):
 
     _walls = True
     _require_all_actions = False   # WO:406 tolerates live agents without an action
-    _STATE_TENSORS = _RedQueenPredPreyGrass._STATE_TENSORS + ["wall_bits", "row_info"]
 
     def get_state_snapshot(self):
         snap = super().get_state_snapshot()

@@ -1,4 +1,4 @@
-"""World-size-2 `gloo` test of the batch-sharded path + observation gather (CPU, emulated kernel)."""
+"""World-size-2 / -4 `gloo` tests of the batch-sharded path + the single-collective observation gather (CPU, emulated kernel)."""
 import os
 import sys
 
@@ -8,6 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from predpreygrass_amd import _abi as _ABI
 from tests import emu_backend
 
 emu_backend.build()   # once, in the parent: the ranks below must not all start compiling the emulator library
@@ -15,7 +16,22 @@ emu_backend.build()   # once, in the parent: the ranks below must not all start 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmpdir):
+def local_rows_reference(env):
+    """What `ppg_pack` must produce for one env object, computed with plain torch indexing (tests)."""
+    es = env.env_state
+    cp = env.pred_capacity
+    mp = torch.arange(env.pred_capacity, device=env.device)[None, :] < es[:, _ABI.ENV_N_PRED_ROWS:_ABI.ENV_N_PRED_ROWS + 1]
+    mq = torch.arange(env.prey_capacity, device=env.device)[None, :] < es[:, _ABI.ENV_N_PREY_ROWS:_ABI.ENV_N_PREY_ROWS + 1]
+    return {
+        "env_state": es.clone(),
+        "id_pred": env.row_id[:, :cp][mp], "id_prey": env.row_id[:, cp:][mq],
+        "reward_pred": env.row_reward[:, :cp][mp], "reward_prey": env.row_reward[:, cp:][mq],
+        "flags_pred": env.row_flags[:, :cp][mp], "flags_prey": env.row_flags[:, cp:][mq],
+        "obs_pred": env.obs_pred[mp].reshape(int(mp.sum()), -1), "obs_prey": env.obs_prey[mq].reshape(int(mq.sum()), -1),
+    }
+
+
+def _worker(rank, world, port, tmpdir, n_sub, wire_f32):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -25,22 +41,37 @@ def _worker(rank, world, port, tmpdir):
     from predpreygrass_amd.distributed import ObservationGatherer, shard_range
     from tests.emu_backend import library
 
-    total = 5
+    total = 2 * world + 1
     lo, hi = shard_range(total, rank, world)
-    env = BatchedPredPreyGrass(config_env, batch_size=hi - lo, _library=library(), seed=100 + lo)
-    env.reset()
-    g = ObservationGatherer(env)
+    # the shard as n_sub sub-batches (handles) -- ppg_pack concatenates them in handle order
+    spans = [shard_range(hi - lo, k, n_sub) for k in range(n_sub)]
+    envs = [BatchedPredPreyGrass(config_env, batch_size=b - a, _library=library(), seed=100 + lo + a) for a, b in spans if b > a]
+    for e in envs:
+        e.reset()
+    # deliberately tiny image: the first gather overflows on every rank and grow() has to enlarge it everywhere
+    g = ObservationGatherer(envs, wire_dtype=torch.float32 if wire_f32 else None, rows_per_env=(1, 1))
     for _ in range(25):
-        env.step(random_actions=True, auto_reset=True)
-    res = g.gather()
-    # every rank holds every shard; compare with what the owning rank sees locally
-    local = g.pack_local()
-    np.savez(os.path.join(tmpdir, f"local{rank}.npz"), **{k: v.numpy() for k, v in local.items()})
+        for e in envs:
+            e.step(random_actions=True, auto_reset=True)
+    slot = g.gather()                      # ONE collective
+    assert all(h.overflow == 1 for h in g.headers(slot))
+    assert g.grow(slot)
+    res = g.gather_dict()
+    want = [local_rows_reference(e) for e in envs]
+    mine = {k: torch.cat([w[k] for w in want]) for k in want[0]}
+    if wire_f32:
+        mine["obs_pred"], mine["obs_prey"] = mine["obs_pred"].float(), mine["obs_prey"].float()
+    np.savez(os.path.join(tmpdir, f"local{rank}.npz"), **{k: v.numpy() for k, v in mine.items()})
     dist.barrier()
     for r in range(world):
-        want = np.load(os.path.join(tmpdir, f"local{r}.npz"))
-        for k in want.files:
-            assert np.array_equal(res[k][r].numpy(), want[k]), (rank, r, k)
+        ref = np.load(os.path.join(tmpdir, f"local{r}.npz"))
+        for k in ref.files:
+            assert np.array_equal(res[k][r].numpy(), ref[k]), (rank, r, k)
+        # row_off = exclusive prefix sums of the row counts
+        es = res["env_state"][r]
+        for col, w in ((0, _abi.ENV_N_PRED_ROWS), (1, _abi.ENV_N_PREY_ROWS)):
+            c = es[:, w].to(torch.int64)
+            assert torch.equal(res["row_off"][r][:, col].to(torch.int64), torch.cumsum(c, 0) - c)
     # shards are the same envs a single process would own: seeds 100 + global index
     if rank == 0:
         ref = BatchedPredPreyGrass(config_env, batch_size=total, _library=library(), seed=100)
@@ -50,16 +81,16 @@ def _worker(rank, world, port, tmpdir):
         es = torch.cat([res["env_state"][r] for r in range(world)])
         assert torch.equal(es[:, :13], ref.env_state[:, :13])
         cat = torch.cat([res["obs_prey"][r] for r in range(world)])
-        nQ = ref.env_state[:, _abi.ENV_N_PREY_ROWS]
-        mask = torch.arange(ref.prey_capacity)[None, :] < nQ[:, None]
-        assert torch.equal(cat, ref.obs_prey[mask])
+        want_all = local_rows_reference(ref)["obs_prey"]
+        assert torch.equal(cat, want_all.float() if wire_f32 else want_all)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_observation_gather(tmp_path):
-    port = 29500 + os.getpid() % 500
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("world,n_sub,wire_f32", [(2, 1, False), (2, 3, True), (4, 2, False)])
+def test_sharding_and_single_collective_observation_gather(tmp_path, world, n_sub, wire_f32):
+    port = 29500 + (os.getpid() * 7 + world * 3 + n_sub) % 500
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n_sub, wire_f32), nprocs=world, join=True)
 
 
 def test_shard_range_partitions_exactly():
@@ -73,16 +104,18 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _run_bench(args, nproc):
+def _run_bench(args, nproc, launcher=True):
+    """tests/bench_dry.py = bench.main() on the CPU stand-in (emulated kernel, gloo); same flags as bench.py."""
     import json
     import subprocess
     env = dict(os.environ, PYTHONPATH=ROOT)
-    if nproc == 1:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    env.pop("WORLD_SIZE", None)
+    script = os.path.join(ROOT, "tests", "bench_dry.py")
+    if nproc == 1 or not launcher:
+        cmd = [sys.executable, script] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-               "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200),
-               os.path.join(ROOT, "bench.py")] + args
+               "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), script] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -92,22 +125,37 @@ def _run_bench(args, nproc):
 
 def test_bench_contract_single_process_dry_run():
     """bench.py's control flow and JSON contract on CPU (emulated kernel; numbers meaningless)."""
-    d = _run_bench(["--dry-run-cpu", "--gpus", "1", "--steps", "6", "--warmup", "2", "--envs", "6", "--streams", "2"], 1)
+    d = _run_bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--envs", "6", "--streams", "2",
+                    "--preroll-min", "64", "--preroll-max", "128"], 1)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert d["dtype"] == "f64" and set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_survey_formula"}
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert 64 <= d["config"]["preroll_steps"] <= 128 and d["config"]["mean_agents_per_env"] > 0
+    d = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--envs", "4", "--streams", "1", "--workload", "red_queen",
+                    "--preroll-max", "0"], 1)
+    assert d["dtype"] == "f32" and d["config"]["preroll_steps"] == 0
 
 
-def test_bench_two_ranks_dry_run_with_gather_leg():
-    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver launches it (gloo on CPU):
-    barrier + max-over-ranks timing, rank-0 JSON, the obs_gather leg."""
-    d = _run_bench(["--dry-run-cpu", "--gpus", "2", "--steps", "5", "--warmup", "2", "--envs", "5", "--streams", "2",
-                    "--gather-steps", "3"], 2)
+@pytest.mark.parametrize("launcher", [True, False])
+def test_bench_two_ranks_dry_run_with_gather_leg(launcher):
+    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver launches it, and plain
+    `bench.py --gpus 2` (which starts its two ranks itself), gloo on CPU: barrier + max-over-ranks timing, rank-0 JSON,
+    the single-collective obs_gather legs."""
+    d = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--envs", "5", "--streams", "2",
+                    "--gather-steps", "3", "--preroll-min", "64", "--preroll-max", "64"], 2, launcher=launcher)
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 5
-    assert "obs_gather" in d and "error" not in d["obs_gather"], d.get("obs_gather")
-    assert d["obs_gather"]["steps"] == 3 and d["obs_gather"]["gathered_bytes_per_step_per_rank"] > 0
-    assert "error" not in d["obs_gather_overlapped"], d["obs_gather_overlapped"]
-    assert d["obs_gather_overlapped"]["gathered_bytes_per_step_per_rank"] > 0
+    for leg in ("obs_gather", "obs_gather_overlapped"):
+        assert leg in d and "error" not in d[leg], d.get(leg)
+        assert d[leg]["steps"] == 3 and d[leg]["collectives_per_step"] == 1 and d[leg]["image_overflows"] == 0
+        assert d[leg]["wire_bytes_per_step_per_rank"] > 0 and len(d[leg]["image_bytes_used_last_step"]) == 2
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry.py"), "--gpus", "4", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr

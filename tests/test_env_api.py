@@ -145,30 +145,128 @@ def test_random_policy_loop_like_the_reference_driver():
     assert steps > 10
 
 
-def test_snapshot_restore_roundtrip():
-    """get_state_snapshot / restore_state_snapshot (predpreygrass_rllib_env.py:768-804; used by the
-    viewer's step-back, evaluate_ppo_from_checkpoint_debug.py:164-182)."""
-    case = GoldenCase("dense_seed0")
+def _golden_step_matches(case, t, out):
+    o, r, te, tr, _ = out
+    recs = case.records(t)
+    assert list(o) == [x[0] for x in recs] == list(r), (case.name, t)
+    for k, rew, term, trunc in recs:
+        assert np.float64(r[k]).tobytes() == np.float64(rew).tobytes() and te[k] is term and tr[k] is trunc
+    assert (te["__all__"], tr["__all__"]) == case.flags(t)
+
+
+def check_snapshot_against_golden(make_env, name="dense_seed0", at=20, n=10):
+    """get_state_snapshot / restore_state_snapshot (predpreygrass_rllib_env.py:768-804; used by the viewer's step-back,
+    evaluate_ppo_from_checkpoint_debug.py:164-182): snapshot at call `at`, n more steps, restore, the same n steps again --
+    bit-identical to the first pass AND to the reference's golden episode (dicts, digests incl. the rebuilt grid)."""
+    case = GoldenCase(name)
     cfg = case.config(config_env)
-    env = make(cfg)
+    env = make_env(cfg)
     env.reset(options={"placement": case.placement})
-    for t in range(20):
+    for t in range(at):
         env.step(case.actions(t))
     snap = env.get_state_snapshot()
     for key in ["current_step", "agent_positions", "agent_energies", "grass_positions", "grass_energies",
                 "grid_world_state", "agents", "cumulative_rewards", "current_num_predators", "current_num_prey",
                 "agents_just_ate", "pending_removal", "next_predator_idx", "next_prey_idx"]:
         assert key in snap
-    later = [env.step(case.actions(t)) for t in range(20, 30)]
+    assert isinstance(snap["_device_state"], bytes)     # the C ABI's versioned image, not a list of tensors
+    later = [env.step(case.actions(t)) for t in range(at, at + n)]
     env.restore_state_snapshot(snap)
-    assert env.current_step == 20 and env.agents == snap["agents"]
-    obs0 = env._get_observation(env.agents[0]) if env.agents[0] in env.agent_positions else None
-    again = [env.step(case.actions(t)) for t in range(20, 30)]
-    for a, b in zip(later, again):
-        assert list(a[0]) == list(b[0]) and a[1] == b[1] and a[2] == b[2]
-        for k in a[0]:
-            assert a[0][k].tobytes() == b[0][k].tobytes()
-    assert env.agents == case.agents_after[29]
+    assert env.current_step == at and env.agents == snap["agents"]
+    if env.agents[0] in env.agent_positions:
+        env._get_observation(env.agents[0])
+    for k, t in enumerate(range(at, at + n)):
+        out = env.step(case.actions(t))
+        a = later[k]
+        assert list(a[0]) == list(out[0]) and a[1] == out[1] and a[2] == out[2] and a[3] == out[3]
+        for key in a[0]:
+            assert a[0][key].tobytes() == out[0][key].tobytes()
+        _golden_step_matches(case, t, out)
+        assert call_digest(env.grid_world_state, out[0], out[1], out[2], out[3]) == case.digest(t), (name, t)
+        assert env.agents == case.agents_after[t]
+    return env
+
+
+def check_state_image_moves_between_handles(make_env, name="dense_seed0", at=25):
+    """ppg_export_state of one handle -> ppg_import_state of ANOTHER handle with the same geometry: the second env continues
+    the golden episode; an image from another geometry is refused."""
+    case = GoldenCase(name)
+    cfg = case.config(config_env)
+    a = make_env(cfg)
+    a.reset(options={"placement": case.placement})
+    for t in range(at):
+        a.step(case.actions(t))
+    snap = a.get_state_snapshot()
+    b = make_env(cfg)
+    b.reset(seed=123)
+    b.restore_state_snapshot(snap)
+    for t in range(at, min(at + 10, case.n_calls)):
+        out = b.step(case.actions(t))
+        _golden_step_matches(case, t, out)
+        assert call_digest(b.grid_world_state, out[0], out[1], out[2], out[3]) == case.digest(t), (name, t)
+    other = make_env({**cfg, "grid_size": cfg["grid_size"] + 1})
+    other.reset(seed=1)
+    with pytest.raises(ValueError):
+        other._b.import_state(snap["_device_state"], 0)
+    with pytest.raises(ValueError):
+        b._b.import_state(snap["_device_state"][:40], 0)
+
+
+def test_snapshot_restore_roundtrip():
+    check_snapshot_against_golden(make)
+    check_snapshot_against_golden(make, name="default_seed0", at=30, n=12)
+
+
+def test_state_image_moves_between_handles():
+    check_state_image_moves_between_handles(make)
+
+
+def check_parallel_env_replays_golden(kw, name="c1_seed0"):
+    """The ParallelEnv facade adds nothing to the transition: driven with the reference's action stream it returns the
+    reference's observations / rewards / terminations (minus "__all__")."""
+    case = GoldenCase(name)
+    cfg = case.config(config_env)
+    par = PredPreyGrassParallelEnv(cfg, **kw)
+    obs, infos = par.reset(seed=int(case.z["seed"]))
+    want = case.reset_obs(cfg)
+    assert list(obs) == list(want) and all(obs[k].tobytes() == want[k].tobytes() for k in want)
+    for t in range(case.n_calls):
+        obs, rew, term, trunc, infos = par.step(case.actions(t))
+        recs = case.records(t)
+        assert list(obs) == [x[0] for x in recs] == list(rew) == list(term) == list(trunc)
+        for k, r, te, tr in recs:
+            assert np.float64(rew[k]).tobytes() == np.float64(r).tobytes() and term[k] is te and trunc[k] is tr
+        assert call_digest(par.state(), obs, rew, {**term, "__all__": case.flags(t)[0]},
+                           {**trunc, "__all__": case.flags(t)[1]}) == case.digest(t)
+        assert par.agents == [k for k, _, te, tr in recs if not te and not tr]
+    par.close()
+
+
+def check_aec_runs_to_exhaustion(kw):
+    """agent_iter() to the end of an episode: every agent reported dead is dead-stepped exactly once, `agents` ends empty
+    (the round-1 facade left a terminated agent behind: default config, max_steps=150, seed 0)."""
+    aec = PredPreyGrassAECEnv({**config_env, "max_steps": 150}, **kw)
+    aec.reset(seed=0)
+    n = dead_steps = 0
+    seen_dead = set()
+    for agent in aec.agent_iter(max_iter=20000):
+        assert agent is not None and agent in aec.agents
+        o, r, te, tr, info = aec.last()
+        assert o.shape == aec.observation_space(agent).shape
+        if te or tr:
+            assert agent not in seen_dead
+            seen_dead.add(agent)
+            dead_steps += 1
+        aec.step(None if (te or tr) else aec.action_space(agent).sample())
+        n += 1
+    assert aec.agents == [] and aec.agent_selection is None
+    assert n > 1000 and dead_steps > 10
+    aec.close()
+
+
+def test_pettingzoo_parallel_replays_golden_and_aec_runs_to_exhaustion():
+    check_parallel_env_replays_golden(dict(_library=library()))
+    check_aec_runs_to_exhaustion(dict(_library=library()))
 
 
 def test_pettingzoo_parallel_and_aec_shapes():

@@ -75,12 +75,18 @@ def test_full_size_4096_envs_properties_and_sampled_oracle():
     env2.env_state[:, _abi.ENV_EPISODE] = -1
     for _ in range(400):
         env2.step(random_actions=True, auto_reset=True)
-    for name in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "grass_energy"):
+    torch.cuda.synchronize()
+    assert torch.equal(env.env_state[:, : _abi.ENV_CALLS], env2.env_state[:, : _abi.ENV_CALLS])
+    nP, nQ = env.env_state[:, _abi.ENV_N_PRED_ROWS], env.env_state[:, _abi.ENV_N_PREY_ROWS]
+    cp = env.pred_capacity
+    mp = torch.arange(cp, device="cuda:0")[None, :] < nP[:, None]                    # predator rows in use
+    mq = torch.arange(env.prey_capacity, device="cuda:0")[None, :] < nQ[:, None]     # prey rows in use
+    for name in ("row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward"):
         a, b = getattr(env, name), getattr(env2, name)
-        nP = env.env_state[:, _abi.ENV_N_PRED_ROWS]
-        assert torch.equal(env.env_state[:, :13], env2.env_state[:, :13])
-        if name.startswith("grass"):
-            assert torch.equal(a, b), name
+        assert torch.equal(a[:, :cp][mp], b[:, :cp][mp]) and torch.equal(a[:, cp:][mq], b[:, cp:][mq]), name
+    for name in ("grass_xy", "grass_energy"):
+        assert torch.equal(getattr(env, name), getattr(env2, name)), name
+    assert torch.equal(env.obs_pred[mp], env2.obs_pred[mp]) and torch.equal(env.obs_prey[mq], env2.obs_prey[mq])
     # invariants: alive counts match flags; every live agent inside the grid; energies of live agents > 0
     G = cfg["grid_size"]
     flags = env.row_flags.cpu().numpy()
@@ -267,7 +273,8 @@ def test_multiwave_step_kernels_give_identical_results(cls_name, monkeypatch):
 
 def test_bench_rccl_gather_legs_with_one_rank():
     """bench.py under torch.distributed.run with a world of ONE rank and --force-dist: process-group init on RCCL,
-    barrier / max-over-ranks timing, the synchronous and the overlapped observation-gather legs on the real device."""
+    barrier / max-over-ranks timing, the synchronous and the overlapped single-collective observation-gather legs on the
+    real device (ppg_pack + one all_gather_into_tensor per step)."""
     import json
     import os
     import subprocess
@@ -275,14 +282,79 @@ def test_bench_rccl_gather_legs_with_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "50",
-           "--envs", "1024", "--force-dist", "--no-cpu-baseline", "--gather-steps", "5"]
+           "--envs", "1024", "--force-dist", "--no-cpu-baseline", "--gather-steps", "5", "--preroll-max", "400"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["value"] > 1e6
+    assert d["roofline"]["achieved"] <= d["roofline"]["peak"]
     for leg in ("obs_gather", "obs_gather_overlapped"):
         assert "error" not in d[leg], d[leg]
-        assert d[leg]["gathered_bytes_per_step_per_rank"] > 1e6
+        assert d[leg]["collectives_per_step"] == 1 and d[leg]["image_overflows"] == 0
+        assert d[leg]["wire_bytes_per_step_per_rank"] > 1e6
+
+
+def test_snapshot_restore_on_gpu_base_and_second_generation():
+    """get_state_snapshot / restore_state_snapshot through ppg_export_state / ppg_import_state on the device
+    (BASE:768-804, evaluate_ppo_from_checkpoint_debug.py:164-182): snapshot at call 20 -> 10 steps -> restore -> the same 10
+    steps bit-identical AND equal to the reference's golden episode; red_queen incl. its PCG64 stream; walls variant."""
+    from predpreygrass_amd.env import PredPreyGrass
+    from tests.test_env_api import check_snapshot_against_golden, check_state_image_moves_between_handles
+    check_snapshot_against_golden(lambda cfg, **kw: PredPreyGrass(cfg, device="cuda:0", **kw))
+    check_state_image_moves_between_handles(lambda cfg, **kw: PredPreyGrass(cfg, device="cuda:0", **kw))
+    from predpreygrass_amd import red_queen, walls_occlusion
+    from tests.test_rq_env_api import check_rq_snapshot_against_golden
+    check_rq_snapshot_against_golden(lambda cfg, **kw: red_queen.PredPreyGrass(cfg, device="cuda:0", **kw), "rq_mixed_types_seed7")
+    check_rq_snapshot_against_golden(lambda cfg, **kw: walls_occlusion.PredPreyGrass(cfg, device="cuda:0", **kw),
+                                     "wo_los_two_types_seed5", walls=True)
+
+
+def test_pettingzoo_facades_on_gpu():
+    """ParallelEnv driven with the reference's golden action stream returns the reference's observations; the AEC cycle
+    runs an episode to exhaustion without leaking a terminated agent."""
+    from predpreygrass_amd.env import PredPreyGrass
+    from tests.test_env_api import check_aec_runs_to_exhaustion, check_parallel_env_replays_golden
+    check_parallel_env_replays_golden(dict(device="cuda:0"))
+    check_aec_runs_to_exhaustion(dict(device="cuda:0"))
+    assert PredPreyGrass is not None
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_packed_observation_image_on_gpu(f32):
+    """ppg_pack on the device: 3 sub-batches of 1365/1365/1366 envs -> one image; every section equals plain torch indexing
+    of the env tensors; a too small capacity is reported through the header and leaves the row sections alone."""
+    import ctypes as C
+    from predpreygrass_amd.distributed import parse_image
+    from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
+    from tests.test_distributed import local_rows_reference
+    grp = SubBatchedPredPreyGrass(dict(config_env), batch_size=4096, n_sub=3, device="cuda:0", seed=3)
+    grp.reset()
+    for _ in range(120):
+        grp.step(random_actions=True, auto_reset=True)
+    grp.synchronize()
+    lib, e0 = grp.subs[0]._lib, grp.subs[0]
+    handles = (C.c_void_p * 3)(*[e._handle for e in grp.subs])
+    want = [local_rows_reference(e) for e in grp.subs]
+    want = {k: torch.cat([w[k] for w in want]) for k in want[0]}
+    flags = _abi.PACK_F32 if f32 else 0
+    need = int(lib.ppg_pack_bytes(e0._handle, 4096, want["id_pred"].numel(), want["id_prey"].numel(), flags))
+    img = torch.zeros(need + 4096, dtype=torch.uint8, device="cuda:0")
+    assert lib.ppg_pack(handles, 3, C.c_void_p(img.data_ptr()), img.numel(), flags, e0._stream()) == 0
+    torch.cuda.synchronize()
+    got = parse_image(img)
+    assert got["header"].bytes_used == need and got["header"].n_envs == 4096
+    for k, v in want.items():
+        v = v.float() if (f32 and k.startswith("obs")) else v
+        assert torch.equal(got[k], v), k
+    small = torch.full((need // 2,), 7, dtype=torch.uint8, device="cuda:0")
+    assert lib.ppg_pack(handles, 3, C.c_void_p(small.data_ptr()), small.numel(), flags, e0._stream()) == 0
+    torch.cuda.synchronize()
+    hdr = _abi.PpgPackHeader.from_buffer_copy(small[:64].cpu().numpy().tobytes())
+    assert hdr.overflow == 1 and hdr.bytes_used == need
+    L = _abi.pack_layout(4096, 0, 0, 0, 0, 4)
+    assert bool((small[L["id_pred"]:] == 7).all())          # nothing behind the fixed part was touched
+    with pytest.raises(OverflowError):
+        parse_image(small)
 
 
 def test_rebalance_changes_scheduling_only_on_gpu():

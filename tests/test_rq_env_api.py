@@ -73,17 +73,36 @@ def test_missing_or_bad_actions_raise_like_the_reference():
         PredPreyGrass(None, _library=library())
 
 
-def test_snapshot_restore_roundtrip():
-    case = RQGoldenCase("rq_mixed_types_seed7")
-    env = make(case.config)
+def check_rq_snapshot_against_golden(make_env, name, at=20, n=10, walls=False):
+    """snapshot at call `at` -> n steps -> restore -> the same n steps: identical to the first pass and to the reference's
+    golden episode -- device state through ppg_export_state / ppg_import_state (incl. agent_last_reproduction; walls: the
+    bitmap and the move infos) and the PCG64 stream that supplies the reproduction uniforms (RQ:893-939)."""
+    case = RQGoldenCase(name)
+    env = make_env(case.config)
     env.reset(seed=int(case.z["seed"]))
-    for t in range(20):
+    n = min(n, case.n_calls - at)
+    assert n > 0
+    for t in range(at):
         env.step(case.actions(t))
     snap = env.get_state_snapshot()
-    a = [env.step(case.actions(t)) for t in range(20, 30)]
+    assert isinstance(snap["_device_state"], bytes)
+    a = [env.step(case.actions(t)) for t in range(at, at + n)]
     env.restore_state_snapshot(snap)
-    b = [env.step(case.actions(t)) for t in range(20, 30)]
-    for x, y in zip(a, b):
-        assert list(x[0]) == list(y[0]) and x[1] == y[1] and x[2] == y[2]
-        for k in x[0]:
-            assert x[0][k].tobytes() == y[0][k].tobytes()
+    for k, t in enumerate(range(at, at + n)):
+        y = env.step(case.actions(t))
+        x = a[k]
+        assert list(x[0]) == list(y[0]) and x[1] == y[1] and x[2] == y[2] and x[3] == y[3] and x[4] == y[4]
+        for key in x[0]:
+            assert x[0][key].tobytes() == y[0][key].tobytes()
+        recs = case.records(t)
+        assert list(y[0]) == [r[0] for r in recs]
+        for key, rew, term, trunc in recs:
+            assert np.float64(y[1][key]).tobytes() == np.float64(rew).tobytes() and y[2][key] is term and y[3][key] is trunc
+        if walls:   # (the walls reference builds its scalar dicts from a set: order unpinned, WO:376-388)
+            assert y[4] == case.infos(t), (name, t)
+        assert call_digest(env.grid_world_state, y[0], y[1], y[2], y[3], sort_scalars=walls) == case.digest(t), (name, t)
+        assert env.agents == case.agents_after[t]
+
+
+def test_snapshot_restore_roundtrip():
+    check_rq_snapshot_against_golden(make, "rq_mixed_types_seed7")

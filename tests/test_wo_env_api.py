@@ -111,3 +111,9 @@ def test_batched_per_env_walls():
         n = int(es[b, 0])
         xy = env.row_xy[b, :n].numpy().astype(np.int64) & 0xFFFF
         assert not any(((int(v) >> 8), int(v) & 255) in ws for v in xy)
+
+
+def test_snapshot_restore_roundtrip_with_walls():
+    """ppg_export_state / ppg_import_state carry the wall bitmap and the move infos of the walls variant."""
+    from tests.test_rq_env_api import check_rq_snapshot_against_golden
+    check_rq_snapshot_against_golden(lambda cfg, **kw: PredPreyGrass(cfg, _library=library(), **kw), "wo_los_two_types_seed5", walls=True)

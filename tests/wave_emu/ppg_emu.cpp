@@ -169,6 +169,19 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     return PPG_OK;
 }
 
+static void pack_scan_entry(void *arg) { ppg::pack_scan_main(*(const ppg::PackParams *)arg, wv::emu().lds); }
+static void pack_rows_entry(void *arg) { ppg::pack_rows_main(*(const ppg::PackParams *)arg); }
+static int backend_pack(ppg_handle *, const ppg::PackParams &K, void *) {
+    wv::run_block(pack_scan_entry, (void *)&K, 0, 512, 1);
+    for (int e = 0; e < K.n_envs; ++e) wv::run_block(pack_rows_entry, (void *)&K, e, 16, 1);
+    return PPG_OK;
+}
+static int backend_copy(ppg_handle *, void *dst, const void *src, size_t bytes, bool, void *) {
+    memcpy(dst, src, bytes);
+    return PPG_OK;
+}
+static int backend_sync(ppg_handle *, void *) { return PPG_OK; }
+
 extern "C" uint64_t ppg_emu_collectives(void) { return wv::emu().n_collectives; }
 // wavefronts per workgroup of the most recent launch (the tests check that PPG_EMU_WAVES really took effect)
 extern "C" int ppg_emu_last_waves(void) { return wv::emu().nwaves; }

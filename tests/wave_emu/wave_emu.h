@@ -21,6 +21,7 @@
 #define PPG_WAVE_EMU 1
 #define PPG_DEVICE static inline
 #define PPG_MEMBER inline
+#define PPG_HOST_DEVICE static inline
 #define PPG_KERNEL(name, W) static void name
 #define PPG_DYNAMIC_LDS(name) unsigned char *name = wv::emu().lds
 #define PPG_BLOCK_INDEX() (wv::emu().block)

@@ -1,60 +1,79 @@
 #!/usr/bin/env python3
-"""Assemble profiles/<round>/<tag>_bench_default_summary.json from the rocprofv3 outputs of the default bench command.
-Run on the GPU box after (see profiles/README.md):
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_trace -o t -- python3 bench.py --no-cpu-baseline
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/p_w -o w -- python3 bench.py --no-cpu-baseline --steps 300 --warmup 300
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p_f -o f -- python3 bench.py --no-cpu-baseline --steps 300 --warmup 300
-  python3 bench.py > gpurun_out/bench_default.json ; python3 bench.py --no-cpu-baseline --streams 1 > gpurun_out/bench_s1.json
-usage: make_profile_summary.py <kernel name> <out.json>"""
+"""Assemble profiles/<round>/bench_driver_summary.json from rocprofv3 runs of THE DRIVER'S bench command
+(`python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`: untimed pre-roll to the steady state, 5 warm-up steps, 20 timed
+steps, 3 sub-batches), taken on the GPU box by tools/gpu_profile_driver_cmd.sh:
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/<tag>_trace -o t -- python3 bench.py <args>
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/<tag>_w -o w -- python3 bench.py <args>
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/<tag>_f -o f -- python3 bench.py <args>
+  python3 bench.py <args without --no-cpu-baseline> > gpurun_out/<tag>_bench.json        (unprofiled, same box)
+The timed region of each run = its last steps x streams dispatches of the step kernel.
+usage: make_profile_summary.py <tag> <kernel name> <out.json> [steps=20] [streams=3]"""
 import csv
+import glob
 import json
 import sys
 
-kernel, out = sys.argv[1], sys.argv[2]
+tag, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+streams = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+last = steps * streams
+
+
+def one(pattern):
+    files = glob.glob(pattern, recursive=True)
+    assert files, pattern
+    return files[0]
+
+
 durs = []
-grid = wg = scratch = vgpr = lds = None
-for r in csv.DictReader(open("gpurun_out/p_trace/t_kernel_trace.csv")):
+info = {}
+for r in csv.DictReader(open(one(f"gpurun_out/{tag}_trace/**/*kernel_trace.csv"))):
     if r["Kernel_Name"] == kernel:
         durs.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-        grid = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
-        wg = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)
-        scratch = int(r.get("Scratch_Size", 0) or 0)
-        vgpr, lds = int(r.get("VGPR_Count", 0) or 0), int(r.get("LDS_Block_Size", 0) or 0)
+        info = {"grid_threads": int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0),
+                "workgroup": int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0),
+                "scratch": int(r.get("Scratch_Size", 0) or 0), "vgpr": int(r.get("VGPR_Count", 0) or 0),
+                "lds": int(r.get("LDS_Block_Size", 0) or 0)}
 durs.sort()
 d = [x[1] for x in durs]
 
 
-def pmc_mean(path, name, last):
+def pmc_mean(path, name):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
             if r["Kernel_Name"] == kernel and r["Counter_Name"] == name]
     vals = vals[-last:]
     return sum(vals) / len(vals), len(vals)
 
 
-w, nw = pmc_mean("gpurun_out/p_w/w_counter_collection.csv", "WRITE_SIZE", 900)
-f, nf = pmc_mean("gpurun_out/p_f/f_counter_collection.csv", "FETCH_SIZE", 900)
-b = json.loads(open("gpurun_out/bench_default.json").read().strip().splitlines()[-1])
-b1 = json.loads(open("gpurun_out/bench_s1.json").read().strip().splitlines()[-1])
+w, nw = pmc_mean(one(f"gpurun_out/{tag}_w/**/*counter_collection.csv"), "WRITE_SIZE")
+f, nf = pmc_mean(one(f"gpurun_out/{tag}_f/**/*counter_collection.csv"), "FETCH_SIZE")
+b = json.loads(open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1])
+bt = json.loads(open(f"gpurun_out/{tag}_bench_under_trace.json").read().strip().splitlines()[-1])
+total = w * 1024 + 2 * f * 1024
+kernel_us = sum(d[-last:]) / len(d[-last:]) / 1e3
 summary = {
-    "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (defaults: --gpus 1 "
-               "--steps 3000 --warmup 300 --envs 4096 --streams 3)",
+    "command": f"python3 bench.py --steps {steps} --warmup 5 --no-cpu-baseline   (the driver's command; defaults --gpus 1 --envs 4096 "
+               f"--streams {streams}; untimed pre-roll of {b['config']['preroll_steps']} steps)",
+    "workload": "base", "envs_per_gpu": b["config"]["envs_per_gpu"], "obs_dtype": b["dtype"],
     "kernel": kernel,
-    "envs_per_launch": 4096 / 3,
-    "concurrent_launches": 3,
-    "kernel_trace": {"dispatches": len(d), "mean_us_all": sum(d) / len(d) / 1e3,
-                     "mean_us_timed_region_last_9000": sum(d[-9000:]) / len(d[-9000:]) / 1e3,
-                     "grid_threads": grid, "workgroup": wg, "scratch": scratch},
-    "bench_py_same_box_unprofiled": {"value": b["value"], "ms_per_step": b["ms_per_step"],
-                                     "kernel_ms": b["roofline"]["kernel_ms"], "frac": b["roofline"]["frac"],
+    "concurrent_launches": streams,
+    "mean_agents_per_env": bt["config"]["mean_agents_per_env"],
+    "counted_bytes_per_launch": bt["roofline"]["counted_bytes_per_launch"],
+    "kernel_trace": dict(info, dispatches=len(d), mean_us_all=sum(d) / len(d) / 1e3, mean_us_timed_region=kernel_us,
+                         timed_dispatches=len(d[-last:])),
+    "bench_py_under_trace": {"kernel_ms": bt["roofline"]["kernel_ms"], "value": bt["value"], "frac": bt["roofline"]["frac"]},
+    "bench_py_same_box_unprofiled": {"value": b["value"], "ms_per_step": b["ms_per_step"], "kernel_ms": b["roofline"]["kernel_ms"],
+                                     "frac": b["roofline"]["frac"], "mean_agents_per_env": b["config"]["mean_agents_per_env"],
                                      "cpu_baseline": b.get("cpu_baseline")},
-    "bench_py_streams_1_same_box": {"value": b1["value"], "ms_per_step": b1["ms_per_step"], "frac": b1["roofline"]["frac"]},
-    "pmc_passes": "separate runs (bench.py --steps 300 --warmup 300): --pmc FETCH_SIZE | --pmc WRITE_SIZE; means over the last 900 dispatches",
+    "pmc_passes": f"separate runs of the same command: --pmc FETCH_SIZE | --pmc WRITE_SIZE; means over the last {last} dispatches",
     "pmc_mean_per_launch": {"FETCH_SIZE": f, "WRITE_SIZE": w, "dispatches_used": [nf, nw]},
     "hbm_traffic_per_launch_bytes": {
-        "write": w * 1024, "fetch_raw": f * 1024, "fetch_corrected_x2_gfx950": 2 * f * 1024,
-        "total_corrected": w * 1024 + 2 * f * 1024,
+        "write": w * 1024, "fetch_raw": f * 1024, "fetch_corrected_x2_gfx950": 2 * f * 1024, "total_corrected": total,
         "note": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reads exactly 1/2 of a wide coalesced read on gfx950 (doubled "
                 "here); WRITE_SIZE is exact for 16-B-per-lane streaming stores. Units KB -> x1024."},
+    "roofline_check": {
+        "frac_from_pmc_bytes_and_rocprof_duration": streams * total / (kernel_us * 1e-6) / 8e12,
+        "frac_bench_py_under_trace": bt["roofline"]["frac"], "frac_bench_py_unprofiled": b["roofline"]["frac"]},
 }
 json.dump(summary, open(out, "w"), indent=1)
-print(json.dumps({k: summary[k] for k in ("kernel_trace", "hbm_traffic_per_launch_bytes")}, indent=1))
+print(json.dumps({k: summary[k] for k in ("kernel_trace", "hbm_traffic_per_launch_bytes", "roofline_check")}, indent=1))
