@@ -158,9 +158,12 @@ def parse_args(argv):
                     help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step)")
     ap.add_argument("--rebalance-every", type=int, default=64,
                     help="call ppg_rebalance every that many steps (0 = never): heavy envs are assigned to workgroups first")
-    ap.add_argument("--preroll-min", type=int, default=512,
-                    help="untimed steps before --warmup that bring the envs into the steady state the workload is defined on")
-    ap.add_argument("--preroll-max", type=int, default=4096,
+    ap.add_argument("--preroll-min", type=int, default=3072,
+                    help="untimed steps before --warmup that bring the envs into the steady state the workload is defined on "
+                         "(all envs are reset together, so the population first overshoots to 41 rows/env, drops to 34 when the "
+                         "survivors are truncated together at max_steps = 1000, and is within 1 %% of its long-run mean of 36.5 "
+                         "from about step 2900 on: tools/exp_population.py)")
+    ap.add_argument("--preroll-max", type=int, default=8192,
                     help="the pre-roll continues in 64-step windows until the mean rows per env of two consecutive windows "
                          "differ by < 1 %%, at most this many steps (0 = no pre-roll: measures the post-reset transient)")
     ap.add_argument("--force-dist", action="store_true",

@@ -73,15 +73,25 @@ class SubBatchedPredPreyGrass:
             acts = (C.c_void_p * n)(*[a.data_ptr() for a in actions])
         # whatever the caller enqueued on the current stream (a policy writing the action tensors, edits of env_state)
         # happens before the step kernels of the sub-batch streams
-        cur = torch.cuda.current_stream(self.device)
-        for s in self.streams:
-            s.wait_stream(cur)
+        self._order_behind_current()
         lib = self.subs[0]._lib
         rc = lib.ppg_step_many(self._c_handles, n, acts, flags, self._c_streams)
         if rc != 0:
             msgs = [lib.ppg_last_error(e._handle).decode() for e in self.subs]
             raise RuntimeError(f"ppg_step_many failed ({rc}): {'; '.join(m for m in msgs if m)}")
         return self
+
+    def _order_behind_current(self):
+        """Sub-batch streams wait for the work the caller has enqueued on torch's current stream.  If that stream is idle
+        (hipStreamQuery: everything given to it so far has completed -- the normal case when the actions come from the
+        device-side random policy) there is nothing to wait for and no barrier packets are put into the queues: they cost
+        ~3 us per launch, 10 % of a step."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.query():
+            return
+        ev = cur.record_event()
+        for s in self.streams:
+            s.wait_event(ev)
 
     def wait(self, stream=None):
         """Make `stream` (default: torch's current stream) wait for everything the sub-batch streams have been given so
@@ -96,9 +106,9 @@ class SubBatchedPredPreyGrass:
     def rebalance(self):
         """ppg_rebalance of every sub-batch on its own stream (scheduling only; reads env_state, so it is ordered behind
         the caller's current stream like a step)."""
+        if self.streams[0] is not None:
+            self._order_behind_current()
         for e, s in zip(self.subs, self.streams):
-            if s is not None:
-                s.wait_stream(torch.cuda.current_stream(self.device))
             e.rebalance(stream=s)
         return self
 
