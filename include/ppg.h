@@ -381,6 +381,42 @@ uint64_t ppg_pack_bytes(const ppg_handle *h, int32_t n_envs, int64_t n_pred_rows
 /* asynchronous on `stream`, which the caller has ordered behind the handles' last step (two small launches) */
 int ppg_pack(ppg_handle *const *handles, int32_t n, void *out, uint64_t capacity, uint32_t flags, void *stream);
 
+/* ---- policy inference next to the env (base_environment/tune_ppo_base_environment.py:106-141) ----------
+ * The reference trains two PPO policies (predator_policy / prey_policy) whose network is: conv 3x3 stride 1 "same" with
+ * 16, 32, 64 filters (ReLU), flatten, fully connected 256, 256 (ReLU), n_actions logits.  ppg_policy_act evaluates such a
+ * network for EVERY row in use of the handles' last call, reading the observation rows in place (obs_pred / obs_prey of
+ * ppg_buffers, float64 or float32) and writing the chosen action into actions[b][slot] -- the observations never leave
+ * the GPU and what a consumer has to move per agent is one byte.  Arithmetic: bf16 operands, fp32 accumulation, on the
+ * matrix cores (v_mfma_f32_32x32x16_bf16); activations are rounded to bf16 between layers.  The reference's own module
+ * (ray.rllib DefaultPPOTorchRLModule) is not importable here: parity is pinned against a float32 PyTorch module of the
+ * architecture above on the same weights, within the tolerance the tests state. */
+typedef struct ppg_policy_weights {   /* HOST pointers, float32, PyTorch layouts */
+    const float *conv_w[3];  /* Conv2d.weight [cout][cin][3][3]: cin = 4 / 16 / 32, cout = 16 / 32 / 64 */
+    const float *conv_b[3];  /* Conv2d.bias [cout] */
+    const float *fc_w[3];    /* Linear.weight [out][in]: [256][64*R*R] (input flattened channel-major), [256][256], [n_actions][256] */
+    const float *fc_b[3];    /* Linear.bias [out] */
+} ppg_policy_weights;
+
+typedef struct ppg_policy ppg_policy;
+
+#define PPG_POLICY_ARGMAX 0x0u  /* action = argmax of the logits (first maximum) */
+#define PPG_POLICY_SAMPLE 0x1u  /* action ~ softmax(logits): Gumbel-max with Philox4x32-10 keyed by (seed, env, row) */
+
+/* obs_range: the R of the species' (4,R,R) observations; n_actions <= 32.  The weights are repacked into MFMA fragment
+ * order (bf16) on the device; the host arrays may be freed afterwards. */
+int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, const ppg_policy_weights *w, ppg_policy **out);
+int ppg_policy_destroy(ppg_policy *p);
+/* One forward pass of `pred` over the predator rows in use and of `prey` over the prey rows in use of all n handles (either
+ * may be NULL: that species keeps whatever actions[] holds).  actions[k]: device int8 [B_k, S] of handle k.
+ * logits_pred / logits_prey: optional device float [rows in use over all envs][n_actions], env-major in row order (the
+ * order of ppg_pack); NULL = not wanted.  seed: Philox key of PPG_POLICY_SAMPLE (use a fresh value per step).
+ * Asynchronous on `stream`, which the caller has ordered behind the handles' last step. */
+int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handles, int32_t n, int8_t *const *actions,
+                   uint32_t flags, uint64_t seed, float *logits_pred, float *logits_prey, void *stream);
+/* multiply-accumulates one observation costs in this network (for FLOP accounting: 2 flops each) */
+uint64_t ppg_policy_macs_per_observation(const ppg_policy *p);
+const char *ppg_policy_last_error(const ppg_policy *p);
+
 /* Sort key of the decimal string of `id` (digits d: sum (d+1)*11^(5-pos)); host helper. */
 uint32_t ppg_lexkey(uint32_t id);
 

@@ -116,12 +116,22 @@ class PpgBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _BUF_FIELDS]
 
 
+class PpgPolicyWeights(C.Structure):
+    """include/ppg.h: struct ppg_policy_weights (host float32 pointers, PyTorch layouts)."""
+    _fields_ = [("conv_w", C.c_void_p * 3), ("conv_b", C.c_void_p * 3), ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3)]
+
+
+POLICY_ARGMAX, POLICY_SAMPLE = 0x0, 0x1
+POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_destroy", "ppg_policy_act", "ppg_policy_macs_per_observation",
+                  "ppg_policy_last_error"]
+
+
 EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
     "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_rebalance",
     "ppg_export_grid", "ppg_state_bytes", "ppg_export_state", "ppg_import_state", "ppg_pack_bytes", "ppg_pack",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_last_error",
-]
+] + POLICY_SYMBOLS
 
 
 def bind(lib: C.CDLL) -> C.CDLL:
@@ -163,6 +173,18 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_pack_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_uint32]
     lib.ppg_pack.restype = C.c_int
     lib.ppg_pack.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    if hasattr(lib, "ppg_policy_create"):   # (the MFMA kernels exist in the HIP library only, not in the CPU test build)
+        lib.ppg_policy_create.restype = C.c_int
+        lib.ppg_policy_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(PpgPolicyWeights), C.POINTER(C.c_void_p)]
+        lib.ppg_policy_destroy.restype = C.c_int
+        lib.ppg_policy_destroy.argtypes = [C.c_void_p]
+        lib.ppg_policy_act.restype = C.c_int
+        lib.ppg_policy_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ppg_policy_macs_per_observation.restype = C.c_uint64
+        lib.ppg_policy_macs_per_observation.argtypes = [C.c_void_p]
+        lib.ppg_policy_last_error.restype = C.c_char_p
+        lib.ppg_policy_last_error.argtypes = [C.c_void_p]
     lib.ppg_lexkey.restype = C.c_uint32
     lib.ppg_lexkey.argtypes = [C.c_uint32]
     lib.ppg_lds_bytes.restype = C.c_int32

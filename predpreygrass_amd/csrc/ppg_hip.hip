@@ -207,3 +207,6 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     PPG_HIP_TRY(h, hipGetLastError());
     return PPG_OK;
 }
+
+// policy inference next to the env (MFMA kernels + their host side)
+#include "ppg_policy.h"
