@@ -147,11 +147,13 @@ def parse_args(argv):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--obs-dtype", choices=["f64", "f32"], default=None,
                     help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen)")
-    ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls"], default="base",
+    ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls", "policy_rollout"], default="base",
                     help="base: BASELINE.json configs[2] (the headline); c4: configs[3] (64x64 grid, 16 predators / 32 prey, "
                          "7x7 windows); red_queen: the second-generation env (SURVEY 8(f) N2) with its reference config; "
                          "drive: the drive-conditioned variant of the default config; walls: the walls variant with the "
-                         "reference's zigzag layout and every line-of-sight option on")
+                         "reference's zigzag layout and every line-of-sight option on; policy_rollout: the headline envs driven by "
+                         "the two policy networks of the reference's PPO setup evaluated on the matrix cores next to the env "
+                         "(SURVEY 8(f) N4; no observation leaves the GPU, roofline = bf16 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=3,
@@ -173,6 +175,115 @@ def parse_args(argv):
     ap.add_argument("--gather-wire", choices=["f32", "native"], default="native",
                     help="observation dtype on the wire in the gather legs (f32 halves the bytes of float64 observations)")
     return ap.parse_args(argv)
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
+
+
+def policy_rollout(args, backend, device, distributed, rank, n_gpus):
+    """`--workload policy_rollout`: every step = ppg_policy_act (both species' networks of tune_ppo_base_environment.py:106-141,
+    random-initialised weights, actions sampled from the softmax) + ppg_step with those actions, auto-reset.  Not the headline
+    config: the same envs with the policy closed around them on the device.  Roofline: bf16 MFMA, real (unpadded) flops of
+    the six layers over the policy kernels' time (HIP events around ppg_policy_act on the launch stream)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from predpreygrass_amd import _abi
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.config import config_env
+    from predpreygrass_amd.policy import FusedPolicy, PolicyNet
+    if backend.dry:
+        raise SystemExit("policy_rollout needs the MFMA kernels: no dry run")
+    cfg = dict(config_env)
+    B = args.envs
+    obs_dtype = torch.float64 if (args.obs_dtype or "f64") == "f64" else torch.float32
+    args.obs_dtype = "f64" if obs_dtype == torch.float64 else "f32"
+    env = BatchedPredPreyGrass(cfg, batch_size=B, device=device, obs_dtype=obs_dtype, seed=args.seed + rank * B)
+    torch.manual_seed(1234)
+    nets = [PolicyNet(env.Rp), PolicyNet(env.Rq)]
+    fused = FusedPolicy(nets[0], nets[1], device=device)
+    env.reset()
+    t_step = [0]
+
+    def one_step(timed=None):
+        if timed is not None:
+            timed[0].record()
+        fused.act(env, sample=True, seed=args.seed * 1000003 + t_step[0])
+        if timed is not None:
+            timed[1].record()
+        t_step[0] += 1
+        env.step(env.actions, auto_reset=True)
+
+    preroll = min(args.preroll_min, 512) if args.preroll_max > 0 else 0    # (a forward pass costs ~10x a step: shorter pre-roll)
+    for _ in range(preroll + args.warmup):
+        one_step()
+    torch.cuda.synchronize(device)
+    env.env_state[:, _abi.ENV_OBS_PRED:_abi.ENV_OBS_PREY + 1] = 0
+    torch.cuda.synchronize(device)
+    if distributed:
+        dist.barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(evs[k])
+    torch.cuda.synchronize(device)
+    if distributed:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    pol_ms = sum(a.elapsed_time(b) for a, b in evs)
+    es = env.env_state.cpu().numpy().astype("int64")
+    n_pred, n_prey = int(es[:, _abi.ENV_OBS_PRED].sum()), int(es[:, _abi.ENV_OBS_PREY].sum())
+    flops = 2.0 * (n_pred * fused.macs_per_observation(0) + n_prey * fused.macs_per_observation(1))
+    achieved = flops / (pol_ms * 1e-3) / 1e12
+    if rank == 0:
+        out = {
+            "metric": "env-steps/sec at 4096x(25x25) grids, 1/2/4/8 MI355X; % HBM roofline",
+            "value": round(n_gpus * B * args.steps / wall, 1), "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": (f"POLICY ROLLOUT, NOT the BASELINE.json headline config: {B} envs x {env.grid_size}x{env.grid_size} grid per GPU, "
+                             f"default config, every step = the two policy networks of the reference's PPO setup (conv 3x3 16/32/64 + FC "
+                             f"256/256/9, random-initialised, bf16 MFMA with fp32 accumulation) evaluated on the {args.obs_dtype} observation rows "
+                             "in place, actions sampled on the device, then ppg_step with those actions and auto-reset"),
+                "envs_per_gpu": B, "parallelism": f"batch-sharded x{n_gpus}, no data-path collective", "preroll_steps": preroll,
+                "mean_agents_per_env": round((n_pred + n_prey) / (B * args.steps), 2),
+                "bytes_per_agent_a_consumer_has_to_move": 1,
+            },
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "ppg_policy_forward_f64" if obs_dtype == torch.float64 else "ppg_policy_forward_f32",
+                         "kernel_ms": round(pol_ms / args.steps, 5),
+                         "flops_per_step": int(flops / args.steps),
+                         "note": "flops = 2 x multiply-accumulates of the six layers (no padding counted) x observations evaluated; "
+                                 "kernel_ms = both species' forward launches + their plan launches per step (HIP events on the stream)"},
+        }
+        if not args.no_cpu_baseline and n_gpus == 1:
+            torch.set_num_threads(os.cpu_count() or 1)
+            x = [torch.rand(256, 4, env.Rp, env.Rp), torch.rand(1024, 4, env.Rq, env.Rq)]
+            cost = []   # seconds per observation on the host, per species (bounded: --cpu-seconds in total)
+            with torch.no_grad():
+                for net, xx in zip(nets, x):
+                    net = net.to("cpu")
+                    net(xx)
+                    tc, reps = time.perf_counter(), 0
+                    while time.perf_counter() - tc < args.cpu_seconds / 2:
+                        net(xx)
+                        reps += 1
+                    cost.append((time.perf_counter() - tc) / reps / xx.shape[0])
+            tp, tq = cost
+            mp, mq = n_pred / (B * args.steps), n_prey / (B * args.steps)
+            out["cpu_baseline"] = {"value": round(1.0 / (mp * tp + mq * tq), 1), "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"the same two networks as float32 PyTorch modules on the host ({os.cpu_count()} threads): "
+                                             f"{tp * 1e6:.1f} us per predator observation, {tq * 1e6:.1f} us per prey observation, x {mp:.1f} / {mq:.1f} "
+                                             "observations per env-step; the env transition itself (0.5 M env-steps/s on these cores) is not included"}
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
 
 
 def main(argv=None, backend=None):
@@ -203,6 +314,8 @@ def main(argv=None, backend=None):
     device = backend.setup(distributed, local_rank)
     n_gpus = world if distributed else 1
 
+    if args.workload == "policy_rollout":
+        return policy_rollout(args, backend, device, distributed, rank, n_gpus)
     rq = args.workload in ("red_queen", "walls")
     extra_kw = {}
     if args.obs_dtype is None:

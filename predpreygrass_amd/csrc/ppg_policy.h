@@ -7,16 +7,18 @@
 // row.  gfx950 only: every layer is a GEMM on the matrix cores, v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate).
 //
 // ORIENTATION (all six layers): M = output features / channels (the A operand = weights), N = samples or positions (the B
-// operand = activations).  With the 32x32 result layout (column = lane & 31, rows in the 16 registers: row = i + 8g + 4h for
-// register 4g+i, h = lane >> 5) a lane then holds, for ONE sample/position, four groups of four consecutive features: the
-// epilogue writes them as four 8-byte bf16x4 vectors into an activation image whose inner dimension is the feature index --
-// which is exactly the 16-byte-per-lane B fragment the next layer reads (k = 8h + j: eight consecutive features).
+// operand = activations).  In the 32x32 result a lane holds ONE column (sample / position, = lane & 31) and 16 of the 32 rows:
+// register 4g+i of lane half h = lane >> 5 is MFMA row i + 8g + 4h.  Which output feature an MFMA row computes is free -- it is
+// decided by the order in which the host packs the weight rows -- so row i + 8g + 4h is given feature 16h + 4g + i of its
+// 32-feature tile: a lane's 16 registers are then 16 CONSECUTIVE features (32 bytes of bf16), written by two 16-byte stores
+// into an activation image whose inner dimension is the feature index -- exactly the 16-byte-per-lane B fragment the next
+// layer reads (k = 8h + j: eight consecutive features).
 //
 // ONE persistent launch per species.  A workgroup (4 wavefronts) takes tiles of 128 samples:
 //   A. convolutions in sub-groups of ST samples: activations live in LDS as [sample][channel block of 8][padded position][8]
 //      bf16 with a zero halo ring (so the nine taps of the implicit GEMM are plain offsets); each wavefront keeps the layer's
 //      weight fragments in registers (conv3: 144 VGPRs) and walks over 32-position tiles.  conv3 writes its output to the
-//      workgroup's scratch slot in HBM/L2 as X[sample][position][64]  (= the K order the repacked FC1 weights expect).
+//      workgroup's scratch slot in HBM/L2 as X[sample][row tile][position][32]  (= the K order the repacked FC1 weights expect).
 //   B. FC1 over the whole tile (K = 64 R^2): weight fragments stream from L2, X fragments from the scratch slot (the slot was
 //      written by this workgroup and is re-read after a workgroup barrier + ONE agent-scope acquire that drops stale L1 lines);
 //      ReLU -> H[sample][256] in LDS.   C. FC2 from H, result back into H.   D. logits (M = actions padded to 32), the two
@@ -36,6 +38,8 @@ namespace ppgpol {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define GLOBAL_AS __attribute__((address_space(1)))   // pointers known to be global memory: global_* instead of flat_* instructions
 
 constexpr int TILE = 128;         // samples per workgroup tile
 constexpr int HSTRIDE = 264;      // H[sample][256 + 8] bf16: rows 528 B apart -> conflict-free 16-byte fragment reads
@@ -50,6 +54,8 @@ struct PolParams {
     int32_t species;              // 0 predators, 1 prey
     int32_t obs_f32;
     int32_t sample;               // PPG_POLICY_SAMPLE
+    int32_t debug_skip;           // timing experiments only (env PPG_POLICY_SKIP, results are then meaningless): 1 no convolutions,
+                                  // 2 no FC1, 4 no observation staging, 8 no conv3, 16 no conv1/conv2, 32 no conv3 stores
     uint32_t seed_lo, seed_hi;
     // weights in fragment order (device, bf16) and biases (float)
     const bf16x8 *wc1, *wc2, *wc3, *w1, *w2, *w3;
@@ -63,6 +69,8 @@ struct PolParams {
     int32_t S, cap, slot0;        // rows per env of the action tensor; row capacity of this species; its first slot
     // scratch
     const uint32_t *plan;         // [0] = total rows of this species, [1 + e] = exclusive prefix sum of env e
+    const uint32_t *tile_env;     // [tile] = env of sample tile * 128
+    uint32_t magic_P, magic_R;    // ceil(2^32 / P), ceil(2^32 / R): n / P == mulhi(n, magic_P) for the small n used here
     __bf16 *xg;                   // [gridDim.x][TILE][K1]
     float *logits;                // optional [rows][n_actions]
 };
@@ -72,6 +80,7 @@ struct PlanParams {
     int32_t env_base[MAX_HANDLES + 1];
     const int32_t *env_state[MAX_HANDLES];
     uint32_t *plan;
+    uint32_t *tile_env;
 };
 
 template <class P>
@@ -82,27 +91,47 @@ __device__ __forceinline__ int handle_of(P env_base, int n_handles, int e) {
     return k;
 }
 
-// exclusive prefix sums of one env_state word over the concatenated envs of all handles (one wavefront)
-extern "C" __global__ void __launch_bounds__(64) ppg_policy_plan(const PlanParams K) {
-    __shared__ uint32_t tot[64];
-    const int ln = (int)threadIdx.x;
-    const int per = (K.n_envs + 63) / 64;
-    const int lo = ln * per, hi = (lo + per) < K.n_envs ? (lo + per) : K.n_envs;
+// Exclusive prefix sums of one env_state word over the concatenated envs of all handles, and for every 128-sample tile the env
+// its first sample belongs to.  One workgroup of 1024 threads: thread t sums a contiguous run of envs, the 1024 partial sums are
+// scanned in LDS, then every thread bisects for its tiles.
+extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan(const PlanParams K) {
+    __shared__ uint32_t part[1024];
+    const int t = (int)threadIdx.x;
+    const int per = (K.n_envs + 1023) / 1024;
+    const int lo = t * per < K.n_envs ? t * per : K.n_envs, hi = (lo + per) < K.n_envs ? (lo + per) : K.n_envs;
     uint32_t s = 0;
     for (int e = lo; e < hi; ++e) {
         const int k = handle_of(K.env_base, K.n_handles, e);
         s += (uint32_t)K.env_state[k][(size_t)(e - K.env_base[k]) * PPG_ENV_WORDS + K.word];
     }
-    tot[ln] = s;
+    part[t] = s;
     __syncthreads();
-    uint32_t before = 0, all = 0;
-    for (int l = 0; l < 64; ++l) { const uint32_t a = tot[l]; if (l < ln) before += a; all += a; }
+    for (int d = 1; d < 1024; d <<= 1) {   // inclusive Hillis-Steele scan
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t before = part[t] - s;
+    const uint32_t all = part[1023];
     for (int e = lo; e < hi; ++e) {
         const int k = handle_of(K.env_base, K.n_handles, e);
         K.plan[1 + e] = before;
         before += (uint32_t)K.env_state[k][(size_t)(e - K.env_base[k]) * PPG_ENV_WORDS + K.word];
     }
-    if (ln == 0) K.plan[0] = all;
+    if (t == 0) K.plan[0] = all;
+    __threadfence_block();
+    __syncthreads();   // (the prefix sums are re-read below by other threads of this workgroup: same CU, written through L1)
+    const int n_tiles = (int)((all + TILE - 1) / TILE);
+    for (int tile = t; tile < n_tiles; tile += 1024) {
+        const uint32_t n = (uint32_t)tile * TILE;
+        int a = 0, b = K.n_envs - 1;
+        while (a < b) {   // the last env whose prefix sum is <= n
+            const int mid = (a + b + 1) >> 1;
+            if (__builtin_nontemporal_load(&K.plan[1 + mid]) <= n) a = mid; else b = mid - 1;
+        }
+        K.tile_env[tile] = (uint32_t)a;
+    }
 }
 
 __device__ __forceinline__ bf16x8 zero8() {
@@ -112,94 +141,194 @@ __device__ __forceinline__ bf16x8 zero8() {
     return v;
 }
 
-__device__ __forceinline__ bf16x4 relu_pack(float a, float b, float c, float d) {
-    bf16x4 v;
-    v[0] = (__bf16)(a > 0.f ? a : 0.f); v[1] = (__bf16)(b > 0.f ? b : 0.f);
-    v[2] = (__bf16)(c > 0.f ? c : 0.f); v[3] = (__bf16)(d > 0.f ? d : 0.f);
+// ReLU + round 8 accumulator registers to bf16
+__device__ __forceinline__ bf16x8 relu_pack8(const f32x16 &a, int r0) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float x = a[r0 + j]; v[j] = (__bf16)(x > 0.f ? x : 0.f); }
     return v;
 }
 
-// One convolution layer over the `ns` samples of a sub-group, this wavefront's share of the 32-position tiles.
+// The weight fragments of one convolution layer and, per k-step, the offset of this lane half's K block: in registers.
 //   CBIN   channel blocks (of 8) of the input image: 1 (4 real channels), 2, 4        K = 9 taps x CBIN blocks
 //   MT     32-row tiles of output channels: 1 (16 real for conv1 / 32 for conv2), 2 (conv3)
+template <int CBIN, int MT>
+struct ConvW {
+    static constexpr int Q = 9 * CBIN, KS = (Q + 1) / 2;
+    bf16x8 a[MT][KS];
+    const GLOBAL_AS f32x4 *bias;    // of this lane half's 16 consecutive channels: bias[8 * mt + g], g < 4 (read per position tile)
+    int koff1[CBIN == 1 ? KS : 1];   // CBIN == 1 only: the tap of a k-step depends on the lane half -> per-lane offsets
+    template <class KP>
+    __device__ __forceinline__ void load(const KP &K, const bf16x8 *wfrag, const float *b, int lane, int mt_base = 0) {
+        const int h = lane >> 5;
+        bias = (const GLOBAL_AS f32x4 *)(b + 32 * mt_base + 16 * h);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt][ks] = wfrag[((mt_base + mt) * KS + ks) * 64 + lane];
+            if (CBIN == 1) {
+                const int q = 2 * ks + h;
+                const int tap = q < Q ? q : 0;        // (a padding block: its weights are zero, any in-bounds address will do)
+                koff1[ks] = ((tap / 3 - 1) * K.Wp + tap % 3 - 1) * 8;
+            }
+        }
+    }
+    // element offset of k-step ks relative to (image of the sample, padded position, channel block h * [CBIN > 1]):
+    // K block q = 2 ks + h = tap * CBIN + cb.  For CBIN = 2: tap = ks, cb = h; for CBIN = 4: tap = ks >> 1, cb = 2 (ks & 1) + h --
+    // the lane half only selects the channel block, which the caller folds into the base address, the rest is wave-uniform.
+    template <class KP>
+    __device__ __forceinline__ int offset(const KP &K, int ks) const {
+        if (CBIN == 1) return koff1[ks];
+        const int tap = CBIN == 2 ? ks : ks >> 1, cb0 = CBIN == 2 ? 0 : 2 * (ks & 1);
+        return (cb0 * K.Wp2 + (tap / 3 - 1) * K.Wp + tap % 3 - 1) * 8;
+    }
+};
+
+// One convolution layer over the `ns` samples of a sub-group, this wavefront's share of the 32-position tiles.
 //   COUT_BLOCKS  channel blocks written: 2 (conv1), 4 (conv2), 8 (conv3)
 //   TO_GLOBAL    conv3: the result goes to the scratch slot X[sample][position][64] instead of an LDS image
 template <int CBIN, int MT, int COUT_BLOCKS, bool TO_GLOBAL, class KP>
-__device__ __forceinline__ void conv_layer(const KP &K, const bf16x8 *wfrag, const float *bias, const __bf16 *in,
-                                           int in_sample_stride, __bf16 *out, int out_sample_stride, __bf16 *xg_tile,
-                                           int s_local0, int ns, int wave, int lane, int mt_base = 0) {
-    constexpr int Q = 9 * CBIN, KS = (Q + 1) / 2;
+__device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W, const __bf16 *in,
+                                           int in_sample_stride, __bf16 *out, int out_sample_stride, GLOBAL_AS __bf16 *xg_tile,
+                                           int s_local0, int ns, int nt_first, int nt_step, int lane, int mt_base = 0) {
+    constexpr int KS = ConvW<CBIN, MT>::KS;
     const int h = lane >> 5, col = lane & 31;
-    // the layer's weight fragments and the per-k-step offsets of this lane half stay in registers for all tiles
-    bf16x8 a[MT][KS];
-    int koff[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt][ks] = wfrag[((mt_base + mt) * KS + ks) * 64 + lane];
-        const int q = 2 * ks + h;
-        const int qq = q < Q ? q : 0;                 // (a padding block: its weights are zero, any in-bounds address will do)
-        const int tap = qq / CBIN, cb = qq % CBIN;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        koff[ks] = (cb * K.Wp2 + dy * K.Wp + dx) * 8;
-    }
     const int n_pos = ns * K.P;
     const int n_tiles = (n_pos + 31) / 32;
-    for (int nt = wave; nt < n_tiles; nt += 4) {
+    for (int nt = nt_first; nt < n_tiles; nt += nt_step) {
         const int n = 32 * nt + col;
         const bool valid = n < n_pos;
         const int nn = valid ? n : 0;
-        const int s = nn / K.P, p = nn - s * K.P;
-        const int y = p / K.R, x = p - y * K.R;
+        const int s = (int)__umulhi((uint32_t)nn, K.magic_P), p = nn - s * K.P;
+        const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.R;
         const int pidx = (y + 1) * K.Wp + (x + 1);
-        const __bf16 *base = in + (size_t)s * in_sample_stride + pidx * 8;
+        const __bf16 *base = in + (size_t)s * in_sample_stride + (pidx + (CBIN > 1 ? h * K.Wp2 : 0)) * 8;
         f32x16 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {   // the bias of this lane's rows (all lanes of a half read the same 16 bytes)
-                const float4 bb = *(const float4 *)(bias + 32 * (mt_base + mt) + 8 * g + 4 * h);
-                acc[mt][4 * g] = bb.x; acc[mt][4 * g + 1] = bb.y; acc[mt][4 * g + 2] = bb.z; acc[mt][4 * g + 3] = bb.w;
+            for (int g = 0; g < 4; ++g) {   // (straight into the accumulator registers; the loads overlap with the LDS reads below)
+                const f32x4 bb = W.bias[8 * mt + g];
+                acc[mt][4 * g] = bb[0]; acc[mt][4 * g + 1] = bb[1]; acc[mt][4 * g + 2] = bb[2]; acc[mt][4 * g + 3] = bb[3];
             }
+        // all of the tile's B fragments are requested before the first MFMA: the LDS latency is paid once per tile, and while this
+        // wavefront's MFMA chain runs the SIMD's other wavefront has the LDS to itself
+        bf16x8 b[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 b = *(const bf16x8 *)(base + koff[ks]);
+        for (int ks = 0; ks < KS; ++ks) b[ks] = *(const bf16x8 *)(base + W.offset(K, ks));
+        __builtin_amdgcn_sched_barrier(0);   // (keep the reads together: left alone, the scheduler re-pairs each with its MFMA)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b, acc[mt], 0, 0, 0);
-        }
-        if (!valid) continue;
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][ks], b[ks], acc[mt], 0, 0, 0);
+        if (!valid || (TO_GLOBAL && (K.debug_skip & 32))) continue;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (4 * mt + g >= COUT_BLOCKS) continue;   // conv1: 16 real output channels = blocks 0, 1
-                const bf16x4 v = relu_pack(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
-                if (TO_GLOBAL) *(bf16x4 *)(xg_tile + ((size_t)(s_local0 + s) * K.P + p) * 64 + 32 * (mt_base + mt) + 8 * g + 4 * h) = v;
-                else *(bf16x4 *)(out + (size_t)s * out_sample_stride + ((4 * (mt_base + mt) + g) * K.Wp2 + pidx) * 8 + 4 * h) = v;
+            for (int j = 0; j < 2; ++j) {   // this lane's channels 32 mt + 16 h + 8 j .. + 7 = channel block 4 mt + 2 h + j
+                const bf16x8 v = relu_pack8(acc[mt], 8 * j);
+                if (TO_GLOBAL) {
+                    // scratch slot X[sample][row tile][position][32]: a wavefront's 32 positions x 32 channels are 2 KB contiguous
+                    *(GLOBAL_AS bf16x8 *)(xg_tile + (((size_t)(s_local0 + s) * 2 + (mt_base + mt)) * K.P + p) * 32 + 16 * h + 8 * j) = v;
+                } else if (4 * (mt_base + mt) + 2 * h + j < COUT_BLOCKS) {   // (conv1: 16 real output channels = blocks 0, 1)
+                    *(bf16x8 *)(out + (size_t)s * out_sample_stride + ((4 * (mt_base + mt) + 2 * h + j) * K.Wp2 + pidx) * 8) = v;
+                }
             }
     }
 }
 
+// FC1 over the tile as an LDS-staged GEMM: M = 256 output features (A = weight fragments), N = 128 samples (B = the scratch slot
+// X[sample][K1]), K in chunks of 32.  Per chunk the workgroup brings 16 KB of weight fragments (a straight, lane-linear copy of
+// the repacked array) and 128 x 64 B of X into one of THREE LDS buffers with LDS-DMA loads (global_load_lds_dwordx4: no
+// registers, 1 KB per wave instruction), two chunks ahead of the one it computes from.  An LDS-DMA writes lane l's 16 bytes at
+// base + 16 l, so the X image cannot be padded; instead the 16-byte pieces of row n sit at position piece ^ ((n >> 2) & 3) -- the
+// swizzle is applied to the SOURCE address of the copy -- which makes the 16-lane groups of the fragment reads conflict-free.
+constexpr int FC1_BUF = 16384 + TILE * 64;                   // bytes per buffer: W chunk + X chunk
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)g, (void __attribute__((address_space(3))) *)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ void fc1_issue(const bf16x8 *w1, int K1, const __bf16 *xg_tile, unsigned char *stage, int c, int wave, int lane) {
+    unsigned char *wb = stage + (size_t)(c % 3) * FC1_BUF, *xb = wb + 16384;
+    const bf16x8 *src = w1 + (size_t)c * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i0 = (wave * 4 + j) * 64;
+        glds16(src + i0 + lane, wb + (size_t)i0 * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i0 = (wave * 2 + j) * 64, i = i0 + lane;
+        const int row = i >> 2, q = (i & 3) ^ ((row >> 2) & 3);
+        glds16(xg_tile + (size_t)row * K1 + 32 * c + 8 * q, xb + (size_t)i0 * 16);
+    }
+}
+
+__device__ __forceinline__ void fc1_compute(const unsigned char *stage, int c, f32x16 (&acc)[4][2], int wave, int lane) {
+    const int h = lane >> 5, col = lane & 31;
+    const int mt0 = 4 * (wave & 1), nt0 = 2 * (wave >> 1);
+    const bf16x8 *wb = (const bf16x8 *)(stage + (size_t)(c % 3) * FC1_BUF);
+    const unsigned char *xb = stage + (size_t)(c % 3) * FC1_BUF + 16384;
+    const int n0 = 32 * nt0 + col, n1 = n0 + 32;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int q = 2 * k2 + h;
+        const bf16x8 x0 = *(const bf16x8 *)(xb + n0 * 64 + 16 * (q ^ ((n0 >> 2) & 3)));
+        const bf16x8 x1 = *(const bf16x8 *)(xb + n1 * 64 + 16 * (q ^ ((n1 >> 2) & 3)));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const bf16x8 w = wb[(k2 * 8 + mt0 + m) * 64 + lane];
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x0, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, acc[m][1], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void fc1_staged(const bf16x8 *w1, int K1, const __bf16 *xg_tile, unsigned char *stage, f32x16 (&acc)[4][2],
+                                           int wave, int lane) {
+    const int n_chunks = K1 / 32;
+    fc1_issue(w1, K1, xg_tile, stage, 0, wave, lane);
+    fc1_issue(w1, K1, xg_tile, stage, 1, wave, lane);
+    for (int c = 0; c < n_chunks; ++c) {
+        // this wavefront's six copies of chunk c have landed when at most the six of chunk c + 1 are still in flight
+        if (c + 1 < n_chunks) __asm__ volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // everybody's copies of chunk c are in LDS, and everybody is done with chunk c - 1's buffer
+        if (c + 2 < n_chunks) fc1_issue(w1, K1, xg_tile, stage, c + 2, wave, lane);
+        fc1_compute(stage, c, acc, wave, lane);
+    }
+    __syncthreads();
+}
+
 // a fully connected layer over the tile: M = 256 output features (8 row tiles), N = 128 samples (4 column tiles).
 // Wavefront w: row tiles 4*(w&1) .. +3, column tiles 2*(w>>1), +1.  B fragments: 16 bytes at bsrc + sample*bstride + 16ks + 8h.
-template <int KSTEPS_KNOWN>
-__device__ __forceinline__ void fc_256(const bf16x8 *wfrag, int ksteps, const __bf16 *bsrc, size_t bstride, f32x16 (&acc)[4][2],
+// (the weight fragments come straight from L2: they are fetched two k-steps ahead of their use)
+template <int KSTEPS>
+__device__ __forceinline__ void fc_256(const bf16x8 *wfrag, const __bf16 *bsrc, size_t bstride, f32x16 (&acc)[4][2],
                                        int wave, int lane) {
     const int h = lane >> 5, col = lane & 31;
     const int mt0 = 4 * (wave & 1), nt0 = 2 * (wave >> 1);
     const __bf16 *b0 = bsrc + (size_t)(32 * nt0 + col) * bstride + 8 * h;
     const __bf16 *b1 = b0 + 32 * bstride;
     const bf16x8 *wa = wfrag + (size_t)mt0 * 64 + lane;
-#pragma unroll 2
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const bf16x8 x0 = *(const bf16x8 *)(b0 + 16 * ks), x1 = *(const bf16x8 *)(b1 + 16 * ks);
-        bf16x8 w[4];
+    bf16x8 w[3][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) w[m] = wa[((size_t)ks * 8 + m) * 64];
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) w[d][m] = wa[((size_t)d * 8 + m) * 64];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int cur = ks % 3, nxt = (ks + 2) % 3;
+        if (ks + 2 < KSTEPS) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) w[nxt][m] = wa[((size_t)(ks + 2) * 8 + m) * 64];
+        }
+        const bf16x8 x0 = *(const bf16x8 *)(b0 + 16 * ks), x1 = *(const bf16x8 *)(b1 + 16 * ks);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m], x0, acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m], x1, acc[m][1], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][m], x0, acc[m][0], 0, 0, 0);
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][m], x1, acc[m][1], 0, 0, 0);
         }
     }
 }
@@ -209,16 +338,14 @@ __device__ __forceinline__ void fc_init(const float *bias, f32x16 (&acc)[4][2], 
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *(const GLOBAL_AS f32x4 *)(bias + 32 * (mt0 + m) + 16 * h + 4 * g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float b = bias[32 * (mt0 + m) + 8 * g + 4 * h + i];
-                acc[m][0][4 * g + i] = b;
-                acc[m][1][4 * g + i] = b;
-            }
+            for (int i = 0; i < 4; ++i) { acc[m][0][4 * g + i] = b[i]; acc[m][1][4 * g + i] = b[i]; }
+        }
 }
 
-// ReLU(acc) -> H[sample][feature] (bf16, LDS)
+// ReLU(acc) -> H[sample][feature] (bf16, LDS): 32 bytes per lane and tile
 __device__ __forceinline__ void fc_store(const f32x16 (&acc)[4][2], __bf16 *H, int wave, int lane) {
     const int h = lane >> 5, col = lane & 31;
     const int mt0 = 4 * (wave & 1), nt0 = 2 * (wave >> 1);
@@ -227,9 +354,8 @@ __device__ __forceinline__ void fc_store(const f32x16 (&acc)[4][2], __bf16 *H, i
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *(bf16x4 *)(H + (size_t)(32 * (nt0 + t) + col) * HSTRIDE + 32 * (mt0 + m) + 8 * g + 4 * h) =
-                    relu_pack(acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]);
+            for (int j = 0; j < 2; ++j)
+                *(bf16x8 *)(H + (size_t)(32 * (nt0 + t) + col) * HSTRIDE + 32 * (mt0 + m) + 16 * h + 8 * j) = relu_pack8(acc[m][t], 8 * j);
 }
 
 __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
@@ -244,151 +370,203 @@ __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, ui
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// KP: the parameter block read in place from the kernarg segment (scalar loads at the use sites) -- by value it would sit in
-// ~100 SGPRs for the whole kernel and spill
-template <bool OBS_F32, class KP>
-__device__ __forceinline__ void policy_main(const KP &K, unsigned char *lds) {
+// The parameter block is read in place from the kernarg segment (scalar loads at the use sites): by value it would sit in ~100
+// SGPRs for the whole kernel.  The three phases of a tile are separate NON-INLINED functions: each gets its own register
+// allocation (inlined into one body, hipcc hoists address arithmetic of every phase to the top of the tile loop and spills
+// hundreds of registers -- scratch reloads then sit between the LDS-DMA loads of FC1 and force vmcnt(0) waits).
+typedef const __attribute__((address_space(4))) PolParams *KPtr;
+
+// ---- phase A: the tile's sample table, then the convolutions, ST samples at a time -> scratch slot X ----
+template <bool OBS_F32>
+__device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile, int n0, int nt_samples, __bf16 *xg_tile) {
+    const auto &K = *Kp;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = (int)K.plan[0];
-    // LDS: [tile table: 128 x {obs row address (8 B), action address (8 B)}] [activation images X, Y | H]
     unsigned long long *tab = (unsigned long long *)lds;
     __bf16 *img = (__bf16 *)(lds + TILE * 16);
     const int x_stride = 4 * K.Wp2 * 8, y_stride = 2 * K.Wp2 * 8;    // elements per sample
-    __bf16 *X = img, *Y = img + (size_t)K.ST * x_stride, *H = img;
-    __bf16 *xg_tile = K.xg + (size_t)blockIdx.x * TILE * K.K1;
+    __bf16 *X = img, *Y = img + (size_t)K.ST * x_stride;
     const int img_elems = K.ST * (x_stride + y_stride);
-
-    for (int tile = (int)blockIdx.x; tile * TILE < N; tile += (int)gridDim.x) {
-        const int n0 = tile * TILE;
-        const int nt_samples = (N - n0) < TILE ? (N - n0) : TILE;
-        __syncthreads();   // the previous tile's readers of H / tab are done
-        // sample -> (handle, env, row): the last env whose prefix sum is <= n
-        if (tid < TILE) {
-            unsigned long long src = 0, dst = 0;
-            if (tid < nt_samples) {
-                const uint32_t n = (uint32_t)(n0 + tid);
-                int lo = 0, hi = K.n_envs - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (K.plan[1 + mid] <= n) lo = mid; else hi = mid - 1;
-                }
-                const int e = lo, row = (int)(n - K.plan[1 + e]);
-                const int k = handle_of(K.env_base, K.n_handles, e);
-                const int b = e - K.env_base[k];
-                src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)(4 * K.P) * (OBS_F32 ? 4 : 8));
-                dst = (unsigned long long)(uintptr_t)(K.actions[k] + (size_t)b * K.S + K.slot0 + row);
-            }
-            tab[2 * tid] = src;
-            tab[2 * tid + 1] = dst;
+    // sample -> (handle, env, row): walk forward from the tile's first env (a tile spans a handful of envs)
+    if (tid < TILE) {
+        unsigned long long src = 0, dst = 0;
+        if (tid < nt_samples) {
+            const uint32_t n = (uint32_t)(n0 + tid);
+            int lo = (int)K.tile_env[tile];
+            while (lo + 1 < K.n_envs && K.plan[2 + lo] <= n) ++lo;
+            const int e = lo, row = (int)(n - K.plan[1 + e]);
+            const int k = handle_of(K.env_base, K.n_handles, e);
+            const int b = e - K.env_base[k];
+            src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)(4 * K.P) * (OBS_F32 ? 4 : 8));
+            dst = (unsigned long long)(uintptr_t)(K.actions[k] + (size_t)b * K.S + K.slot0 + row);
         }
-        // halo rings (and the unused channels of the input image) are zero and stay zero: only interiors are ever written
-        for (int i = tid; i < img_elems / 8; i += 256) ((bf16x8 *)img)[i] = zero8();
-        __syncthreads();
-
-        // ---- A: convolutions, ST samples at a time ----
-        for (int s0 = 0; s0 < nt_samples; s0 += K.ST) {
-            const int ns = (nt_samples - s0) < K.ST ? (nt_samples - s0) : K.ST;
-            for (int idx = tid; idx < ns * K.P; idx += 256) {
-                const int s = idx / K.P, p = idx - s * K.P;
-                const int y = p / K.R, x = p - y * K.R;
-                bf16x8 v = zero8();
+        tab[2 * tid] = src;
+        tab[2 * tid + 1] = dst;
+    }
+    // halo rings (and the unused channels of the input image) are zero and stay zero: only interiors are ever written
+    for (int i = tid; i < img_elems / 8; i += 256) ((bf16x8 *)img)[i] = zero8();
+    __syncthreads();
+    // conv3: wavefronts 0, 1 compute output channels 0-31, wavefronts 2, 3 channels 32-63, each for every other position tile --
+    // so a wavefront needs ONE row tile's weight fragments (72 registers) and keeps them for the whole sample tile.  Those of
+    // conv1 / conv2 (20 / 36 registers) are re-read per sub-group, issued before the observation rows are staged so that their
+    // latency overlaps with that.
+    ConvW<4, 1> w3c;
+    w3c.load(K, K.wc3, K.bc3, lane, wave >> 1);
+    const int dbg = K.debug_skip;
+    // observation values of the NEXT sub-group are requested before conv3 of the current one and written to LDS after it: their
+    // HBM latency hides behind 72 % of the sub-group's matrix work.  A thread stages at most two positions (ST * P <= 512).
+    GLOBAL_AS __bf16 *xg = (GLOBAL_AS __bf16 *)xg_tile;
+    float pre[2][4];
+    auto request = [&](int s0, int ns) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pre[j][c] = 0.0f;
+            if (idx < ns * K.P && !(dbg & 4)) {
+                const int s = (int)__umulhi((uint32_t)idx, K.magic_P), p = idx - s * K.P;
                 if (OBS_F32) {
-                    const float *src = (const float *)(uintptr_t)tab[2 * (s0 + s)];
+                    const GLOBAL_AS float *src = (const GLOBAL_AS float *)(uintptr_t)tab[2 * (s0 + s)];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = (__bf16)src[c * K.P + p];
+                    for (int c = 0; c < 4; ++c) pre[j][c] = src[c * K.P + p];
                 } else {
-                    const double *src = (const double *)(uintptr_t)tab[2 * (s0 + s)];
+                    const GLOBAL_AS double *src = (const GLOBAL_AS double *)(uintptr_t)tab[2 * (s0 + s)];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = (__bf16)(float)src[c * K.P + p];
+                    for (int c = 0; c < 4; ++c) pre[j][c] = (float)src[c * K.P + p];
                 }
+            }
+        }
+    };
+    if (!(dbg & 1)) request(0, nt_samples < K.ST ? nt_samples : K.ST);
+    for (int s0 = 0; s0 < nt_samples && !(dbg & 1); s0 += K.ST) {
+        const int ns = (nt_samples - s0) < K.ST ? (nt_samples - s0) : K.ST;
+        ConvW<1, 1> w1c;
+        ConvW<2, 1> w2c;
+        w1c.load(K, K.wc1, K.bc1, lane);
+        w2c.load(K, K.wc2, K.bc2, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < ns * K.P) {
+                const int s = (int)__umulhi((uint32_t)idx, K.magic_P), p = idx - s * K.P;
+                const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.R;
+                bf16x8 v = zero8();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = (__bf16)pre[j][c];
                 *(bf16x8 *)(X + (size_t)s * x_stride + ((y + 1) * K.Wp + (x + 1)) * 8) = v;
             }
-            __syncthreads();
-            conv_layer<1, 1, 2, false>(K, K.wc1, K.bc1, X, x_stride, Y, y_stride, nullptr, 0, ns, wave, lane);
-            __syncthreads();
-            conv_layer<2, 1, 4, false>(K, K.wc2, K.bc2, Y, y_stride, X, x_stride, nullptr, 0, ns, wave, lane);
-            __syncthreads();
-            // (two passes of 32 output channels each: 72 instead of 144 registers of weight fragments)
-            conv_layer<4, 1, 8, true>(K, K.wc3, K.bc3, X, x_stride, nullptr, 0, xg_tile, s0, ns, wave, lane, 0);
-            conv_layer<4, 1, 8, true>(K, K.wc3, K.bc3, X, x_stride, nullptr, 0, xg_tile, s0, ns, wave, lane, 1);
-            __syncthreads();
         }
-        // rows of the scratch slot behind the last sample of a partial tile hold older data: finite bf16 values whose columns
-        // are never stored.  (The slot is zero-filled at creation, so they are never NaN patterns.)
+        __syncthreads();
+        if (!(dbg & 16)) conv_layer<1, 1, 2, false>(K, w1c, X, x_stride, Y, y_stride, nullptr, 0, ns, wave, 4, lane);
+        __syncthreads();
+        if (!(dbg & 16)) conv_layer<2, 1, 4, false>(K, w2c, Y, y_stride, X, x_stride, nullptr, 0, ns, wave, 4, lane);
+        __syncthreads();
+        if (s0 + K.ST < nt_samples) {
+            const int left = nt_samples - s0 - K.ST;
+            request(s0 + K.ST, left < K.ST ? left : K.ST);
+        }
+        if (!(dbg & 8)) conv_layer<4, 1, 8, true>(K, w3c, X, x_stride, nullptr, 0, xg, s0, ns, wave & 1, 2, lane, wave >> 1);
+        __syncthreads();
+    }
+    // rows of the scratch slot behind the last sample of a partial tile hold older data: finite bf16 values whose columns are
+    // never stored.  (The slot is zero-filled at creation, so they are never NaN patterns.)
+    // This workgroup's stores to its scratch slot are re-read by FC1: drain them, meet, drop stale L1 lines.
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
-        // ---- B: FC1.  This workgroup's stores to its scratch slot have to be re-read: drain them, meet, drop stale L1 lines ----
-        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// ---- phase B: FC1 from the scratch slot, ReLU -> H ----
+__device__ __noinline__ void phase_fc1(KPtr Kp, unsigned char *lds, const __bf16 *xg_tile) {
+    const auto &K = *Kp;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char *overlay = lds + TILE * 16;
+    f32x16 acc[4][2];
+    fc_init(K.b1, acc, wave, lane);
+    if (!(K.debug_skip & 2)) fc1_staged(K.w1, K.K1, xg_tile, overlay, acc, wave, lane);   // (staging buffers overlay the images)
+    __syncthreads();
+    fc_store(acc, (__bf16 *)overlay, wave, lane);      // (so does H)
+    __syncthreads();
+}
+
+// ---- phases C, D: FC2 from H back into H; logits; actions ----
+__device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0, int nt_samples) {
+    const auto &K = *Kp;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long *tab = (const unsigned long long *)lds;
+    __bf16 *H = (__bf16 *)(lds + TILE * 16);
+    {
         f32x16 acc[4][2];
-        fc_init(K.b1, acc, wave, lane);
-        fc_256<0>(K.w1, K.K1 / 16, xg_tile, (size_t)K.K1, acc, wave, lane);
-        fc_store(acc, H, wave, lane);      // (H overlays the activation images: the convolutions of this tile are finished)
-        __syncthreads();
-        // ---- C: FC2 from H, back into H ----
         fc_init(K.b2, acc, wave, lane);
-        fc_256<0>(K.w2, 16, H, (size_t)HSTRIDE, acc, wave, lane);
+        fc_256<16>(K.w2, H, (size_t)HSTRIDE, acc, wave, lane);
         __syncthreads();
         fc_store(acc, H, wave, lane);
         __syncthreads();
-        // ---- D: logits = W3 (actions padded to 32 rows) x H^T, one 32-sample column tile per wavefront ----
-        {
-            const int h = lane >> 5, col = lane & 31;
-            f32x16 lg;
+    }
+    // logits = W3 (actions padded to 32 rows) x H^T, one 32-sample column tile per wavefront
+    const int h = lane >> 5, col = lane & 31;
+    f32x16 lg;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) lg[4 * g + i] = K.b3[8 * g + 4 * h + i];
-            const __bf16 *hb = H + (size_t)(32 * wave + col) * HSTRIDE + 8 * h;
+    for (int r = 0; r < 16; ++r) lg[r] = K.b3[16 * h + r];
+    const __bf16 *hb = H + (size_t)(32 * wave + col) * HSTRIDE + 8 * h;
 #pragma unroll 4
-            for (int ks = 0; ks < 16; ++ks)
-                lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(K.w3[ks * 64 + lane], *(const bf16x8 *)(hb + 16 * ks), lg, 0, 0, 0);
-            // lane (h = 0) of a column holds actions 0-3, 8-11, 16-19, 24-27; its partner lane + 32 holds 4-7, 12-15, ...
-            float mine[16], other[16];
+    for (int ks = 0; ks < 16; ++ks)
+        lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(K.w3[ks * 64 + lane], *(const bf16x8 *)(hb + 16 * ks), lg, 0, 0, 0);
+    // lane (h = 0) of a column holds the logits of actions 0-15, its partner lane + 32 those of actions 16-31
+    float mine[16], other[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { mine[r] = lg[r]; other[r] = __shfl_xor(mine[r], 32, 64); }
-            const int s_local = 32 * wave + col;
-            if (h == 0 && s_local < nt_samples) {
-                float logit[32];
+    for (int r = 0; r < 16; ++r) { mine[r] = lg[r]; other[r] = __shfl_xor(mine[r], 32, 64); }
+    const int s_local = 32 * wave + col;
+    if (h == 0 && s_local < nt_samples) {
+        float logit[32];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+        for (int r = 0; r < 16; ++r) { logit[r] = mine[r]; logit[16 + r] = other[r]; }
+        if (K.logits) {
+            float *lo = K.logits + (size_t)(n0 + s_local) * K.n_actions;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { logit[8 * g + i] = mine[4 * g + i]; logit[8 * g + 4 + i] = other[4 * g + i]; }
-                if (K.logits) {
-                    float *lo = K.logits + (size_t)(n0 + s_local) * K.n_actions;
-#pragma unroll
-                    for (int a = 0; a < 32; ++a) if (a < K.n_actions) lo[a] = logit[a];
-                }
-                int8_t *dst = (int8_t *)(uintptr_t)tab[2 * s_local + 1];
-                uint32_t rnd[4] = {0, 0, 0, 0};
-                int best = 0;
-                float bestv = -INFINITY;
-#pragma unroll
-                for (int a = 0; a < 32; ++a) {
-                    if (a >= K.n_actions) continue;
-                    float v = logit[a];
-                    if (K.sample) {   // Gumbel-max: argmax(logit - log(-log u)) ~ softmax(logits)
-                        if ((a & 3) == 0) philox((uint32_t)(uintptr_t)dst, (uint32_t)((uintptr_t)dst >> 32), (uint32_t)(a >> 2), 0x504F4C31u,
-                                                 K.seed_lo, K.seed_hi, rnd);
-                        const float u = ((float)(rnd[a & 3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-                        v -= __logf(-__logf(u));
-                    }
-                    if (v > bestv) { bestv = v; best = a; }
-                }
-                *dst = (int8_t)best;
-            }
+            for (int a = 0; a < 32; ++a) if (a < K.n_actions) lo[a] = logit[a];
         }
+        int8_t *dst = (int8_t *)(uintptr_t)tab[2 * s_local + 1];
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        int best = 0;
+        float bestv = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+            if (a >= K.n_actions) continue;
+            float v = logit[a];
+            if (K.sample) {   // Gumbel-max: argmax(logit - log(-log u)) ~ softmax(logits)
+                if ((a & 3) == 0) philox((uint32_t)(uintptr_t)dst, (uint32_t)((uintptr_t)dst >> 32), (uint32_t)(a >> 2), 0x504F4C31u,
+                                         K.seed_lo, K.seed_hi, rnd);
+                const float u = ((float)(rnd[a & 3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                v -= __logf(-__logf(u));
+            }
+            if (v > bestv) { bestv = v; best = a; }
+        }
+        *dst = (int8_t)best;
+    }
+}
+
+template <bool OBS_F32>
+__device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
+    const int N = (int)Kp->plan[0];
+    __bf16 *xg_tile = Kp->xg + (size_t)blockIdx.x * TILE * Kp->K1;
+    for (int tile = (int)blockIdx.x; tile * TILE < N; tile += (int)gridDim.x) {
+        const int n0 = tile * TILE;
+        const int nt_samples = (N - n0) < TILE ? (N - n0) : TILE;
+        __syncthreads();   // the previous tile's readers of H / the table are done
+        phase_conv<OBS_F32>(Kp, lds, tile, n0, nt_samples, xg_tile);
+        phase_fc1(Kp, lds, xg_tile);
+        phase_head(Kp, lds, n0, nt_samples);
     }
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2) ppg_policy_forward_f64(const PolParams K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    policy_main<false>(*(const __attribute__((address_space(4))) PolParams *)__builtin_amdgcn_kernarg_segment_ptr(), lds);
+    policy_main<false>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);
 }
 extern "C" __global__ void __launch_bounds__(256, 2) ppg_policy_forward_f32(const PolParams K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    policy_main<true>(*(const __attribute__((address_space(4))) PolParams *)__builtin_amdgcn_kernarg_segment_ptr(), lds);
+    policy_main<true>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);
 }
 
 }  // namespace ppgpol
@@ -402,10 +580,12 @@ struct ppg_policy {
     ppgpol::PolParams base;
     void *dev_weights;     // one allocation: fragments + biases
     __bf16 *xg;            // scratch slots
-    uint32_t *plan;        // [1 + plan_envs]
+    uint32_t *plan;        // [1 + plan_envs] prefix sums, then [plan_tiles] first env of every tile
     int32_t plan_envs;
     int32_t grid;
     int32_t lds_bytes;
+    hipStream_t side;      // ppg_policy_act with both species: the predators' launch runs beside the prey's (fork / join by events)
+    hipEvent_t fork, join;
     char err[256];
 };
 
@@ -426,6 +606,9 @@ static int ppg_policy_fail(ppg_policy *p, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return ppg_policy_fail(p, PPG_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// MFMA row r of a 32-row tile computes this feature of the tile (see ORIENTATION above)
+static int ppg_row_feature(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }
+
 static uint16_t ppg_bf16_bits(float f) {   // round to nearest even (finite weights)
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -441,7 +624,7 @@ static void ppg_pack_conv(const float *w, int cout, int cin, int cbin, int mt_n,
     for (int mt = 0; mt < mt_n; ++mt)
         for (int ks = 0; ks < KS; ++ks)
             for (int lane = 0; lane < 64; ++lane) {
-                const int r = lane & 31, h = lane >> 5, q = 2 * ks + h, co = 32 * mt + r;
+                const int r = lane & 31, h = lane >> 5, q = 2 * ks + h, co = 32 * mt + ppg_row_feature(r);
                 if (q >= Q || co >= cout) continue;
                 const int tap = q / cbin, cb = q % cbin;
                 for (int j = 0; j < 8; ++j) {
@@ -459,7 +642,7 @@ static void ppg_pack_fc(const float *w, int n_out, int K, int mt_n, KMap kmap, s
     for (int ks = 0; ks < KS; ++ks)
         for (int mt = 0; mt < mt_n; ++mt)
             for (int lane = 0; lane < 64; ++lane) {
-                const int r = lane & 31, h = lane >> 5, o = 32 * mt + r;
+                const int r = lane & 31, h = lane >> 5, o = 32 * mt + ppg_row_feature(r);
                 if (o >= n_out) continue;
                 for (int j = 0; j < 8; ++j)
                     out[(((size_t)ks * mt_n + mt) * 64 + lane) * 8 + j] = ppg_bf16_bits(w[(size_t)o * K + kmap(16 * ks + 8 * h + j)]);
@@ -488,8 +671,8 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
     ppg_pack_conv(w->conv_w[0], 16, 4, 1, 1, f[0]);
     ppg_pack_conv(w->conv_w[1], 32, 16, 2, 1, f[1]);
     ppg_pack_conv(w->conv_w[2], 64, 32, 4, 2, f[2]);
-    // FC1: our K order is position-major (k = p * 64 + c, the layout conv3 writes); PyTorch flattens channel-major (c * P + p)
-    ppg_pack_fc(w->fc_w[0], 256, K1, 8, [P](int k) { return (k % 64) * P + k / 64; }, f[3]);
+    // FC1: our K order is the scratch slot's [row tile of conv3][position][32 channels]; PyTorch flattens channel-major (c * P + p)
+    ppg_pack_fc(w->fc_w[0], 256, K1, 8, [P](int k) { return (32 * (k / (32 * P)) + k % 32) * P + (k % (32 * P)) / 32; }, f[3]);
     ppg_pack_fc(w->fc_w[1], 256, 256, 8, [](int k) { return k; }, f[4]);
     ppg_pack_fc(w->fc_w[2], n_actions, 256, 1, [](int k) { return k; }, f[5]);
     std::vector<float> bias(32 + 32 + 64 + 256 + 256 + 32, 0.0f);
@@ -513,6 +696,9 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
         return ppg_policy_fail(nullptr, PPG_EHIP, "upload of the weights failed");
     }
     ppgpol::PolParams &K = p->base;
+    if (const char *dbg = getenv("PPG_POLICY_SKIP")) K.debug_skip = atoi(dbg);
+    K.magic_P = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
+    K.magic_R = (uint32_t)((0x100000000ull + (uint64_t)R - 1) / (uint64_t)R);
     K.R = R; K.P = P; K.Wp = R + 2; K.Wp2 = (R + 2) * (R + 2); K.K1 = K1; K.n_actions = n_actions;
     const unsigned char *dw = (const unsigned char *)p->dev_weights;
     K.wc1 = (const ppgpol::bf16x8 *)(dw + off[0]); K.wc2 = (const ppgpol::bf16x8 *)(dw + off[1]);
@@ -526,9 +712,12 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
     int st = (78 * 1024 - ppgpol::TILE * 16) / per_sample;
     if (st < 1) st = 1;
     if (st > 16) st = 16;
+    while (st > 1 && st * P > 512) --st;   // the staging of a sub-group gives every thread at most two positions
     K.ST = st;
-    const int img = st * per_sample;
-    p->lds_bytes = ppgpol::TILE * 16 + (img > h_bytes ? img : h_bytes);
+    const int img = st * per_sample, fc1_stage = 3 * ppgpol::FC1_BUF;
+    int overlay = img > h_bytes ? img : h_bytes;
+    if (fc1_stage > overlay) overlay = fc1_stage;
+    p->lds_bytes = ppgpol::TILE * 16 + overlay;
     p->grid = 2 * prop.multiProcessorCount;
     const size_t xg_bytes = (size_t)p->grid * ppgpol::TILE * K1 * 2;
     if (hipMalloc((void **)&p->xg, xg_bytes) != hipSuccess || hipMemset(p->xg, 0, xg_bytes) != hipSuccess) {
@@ -548,6 +737,9 @@ int ppg_policy_destroy(ppg_policy *p) {
     if (p->dev_weights) (void)hipFree(p->dev_weights);
     if (p->xg) (void)hipFree(p->xg);
     if (p->plan) (void)hipFree(p->plan);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->fork) (void)hipEventDestroy(p->fork);
+    if (p->join) (void)hipEventDestroy(p->join);
     delete p;
     return PPG_OK;
 }
@@ -596,12 +788,14 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     if (p->plan_envs < total) {
         if (p->plan) (void)hipFree(p->plan);
         p->plan = nullptr;
-        PPG_POL_TRY(p, hipMalloc((void **)&p->plan, (size_t)(1 + total) * 4));
+        const size_t max_tiles = ((size_t)total * K.cap + ppgpol::TILE - 1) / ppgpol::TILE;
+        PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(1 + total) + max_tiles) * 4));
         p->plan_envs = total;
     }
     K.plan = L.plan = p->plan;
+    K.tile_env = L.tile_env = p->plan + 1 + total;
     K.logits = logits;
-    hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, L);
+    hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
     if (K.obs_f32) hipLaunchKernelGGL(ppgpol::ppg_policy_forward_f32, dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     else hipLaunchKernelGGL(ppgpol::ppg_policy_forward_f64, dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     PPG_POL_TRY(p, hipGetLastError());
@@ -615,13 +809,30 @@ int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handle
     if (!handles || !actions || n < 1 || n > ppgpol::MAX_HANDLES || !handles[0]) return ppg_policy_fail(any, PPG_EINVAL, "bad handle list");
     if (flags & ~PPG_POLICY_SAMPLE) return ppg_policy_fail(any, PPG_EINVAL, "unknown policy flags 0x%x", flags);
     // (a failure is also reported through ppg_policy_last_error(NULL), whichever of the two policies it came from)
-    if (pred) {
-        const int rc = ppg_policy_run(pred, 0, handles, n, actions, flags, seed, logits_pred, stream);
-        if (rc != PPG_OK) { memcpy(g_ppg_policy_error, pred->err, sizeof g_ppg_policy_error); return rc; }
+    // The predators are few (a third of the chip's workgroup slots at 4096 envs): their launch goes to a side stream that is
+    // forked from and joined back into `stream` with events, so that it fills the CUs the prey launch leaves idle.
+    void *pred_stream = stream;
+    if (pred && prey) {
+        if (!pred->side) {
+            PPG_POL_TRY(pred, hipStreamCreateWithFlags(&pred->side, hipStreamNonBlocking));
+            PPG_POL_TRY(pred, hipEventCreateWithFlags(&pred->fork, hipEventDisableTiming));
+            PPG_POL_TRY(pred, hipEventCreateWithFlags(&pred->join, hipEventDisableTiming));
+        }
+        PPG_POL_TRY(pred, hipEventRecord(pred->fork, (hipStream_t)stream));
+        PPG_POL_TRY(pred, hipStreamWaitEvent(pred->side, pred->fork, 0));
+        pred_stream = pred->side;
     }
     if (prey) {
         const int rc = ppg_policy_run(prey, 1, handles, n, actions, flags, seed, logits_prey, stream);
         if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
+    }
+    if (pred) {
+        const int rc = ppg_policy_run(pred, 0, handles, n, actions, flags, seed, logits_pred, pred_stream);
+        if (rc != PPG_OK) { memcpy(g_ppg_policy_error, pred->err, sizeof g_ppg_policy_error); return rc; }
+    }
+    if (pred && prey) {
+        PPG_POL_TRY(pred, hipEventRecord(pred->join, pred->side));
+        PPG_POL_TRY(pred, hipStreamWaitEvent((hipStream_t)stream, pred->join, 0));
     }
     return PPG_OK;
 }
