@@ -320,6 +320,12 @@ int ppg_step_many(ppg_handle *const *handles, int32_t n, const int8_t *const *ac
  * 4 envs per CU. */
 int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight);
 
+/* Walls variant: tell the library that the caller has (re)written wall_bits.  It recomputes, for every cell of every env, the
+ * line-of-sight mask over the observation window (one HIP launch; library-owned [B, G*G, words] in HBM) -- from then on
+ * observations read a few mask words per agent instead of walking one Bresenham line per window cell (WO:492-525, 577-589).
+ * Results are identical with or without it as long as it is called after every change of wall_bits (ppg_import_state does). */
+int ppg_walls_changed(ppg_handle *h, void *stream);
+
 /* Scheduling only, results are unaffected: recompute the order in which the handle's envs are assigned to workgroups --
  * envs with many agent rows (much observation data to write) first, so that the load is spread evenly over the CUs.
  * Stream-ordered like a step; populations drift slowly, calling it every few dozen steps is enough (bench.py: every 32).

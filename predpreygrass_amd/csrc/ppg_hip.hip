@@ -56,6 +56,7 @@ static ppg_kernel_fn pick_kernel_gen2(int nq, int mode, bool fast) {
 }
 
 static ppg_kernel_fn pick_kernel_walls(int nq, int mode) {
+    if (mode == ppg::MODE_VIS) return nq == 1 ? ppg3_vis_q1 : nq == 2 ? ppg3_vis_q2 : ppg3_vis_q4;
     static const ppg_kernel_fn table[3][5] = {
         {ppg3_step_q1, ppg3_reset_q1, ppg3_observe_q1, ppg3_grid_q1, ppg3_step_ord_q1},
         {ppg3_step_q2, ppg3_reset_q2, ppg3_observe_q2, ppg3_grid_q2, ppg3_step_ord_q2},
@@ -105,7 +106,16 @@ static int backend_init(ppg_handle *h, int device) {
     return PPG_OK;
 }
 
+static int backend_alloc(ppg_handle *h, void **out, size_t bytes) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
+    PPG_HIP_TRY(h, hipMalloc(out, bytes));
+    return PPG_OK;
+}
+
 static void backend_release(ppg_handle *h) {
+    if (h->vis_dev) (void)hipFree(h->vis_dev);
+    h->vis_dev = nullptr;
     if (h->lut_dev) (void)hipFree(h->lut_dev);
     h->lut_dev = nullptr;
     if (h->order_dev) (void)hipFree(h->order_dev);
@@ -177,7 +187,8 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
     const bool fast = P.nch_p <= 2 && P.nch_q <= 3;
-    if (h->gen2 && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for second-generation handles", mode);
+    if (h->gen2 && mode > ppg::MODE_STEP_ORDERED && !(mode == ppg::MODE_VIS && h->cfg2.walls))
+        return ppg_fail(h, PPG_EINVAL, "mode %d is not available for second-generation handles", mode);
     if (h->drive && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for the drive-conditioned variant", mode);
     ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
                        : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);

@@ -23,6 +23,7 @@ struct ppg_handle {
     int32_t drive;  // drive-conditioned variant of the base family (cfg.n_drive)
     int32_t envs_in_flight;  // scheduling hint (ppg_set_envs_in_flight); 0 = the handle's own batch
     int32_t *order_dev;      // library-owned [batch]: env order of ppg_rebalance (NULL until first used)
+    uint32_t *vis_dev;       // library-owned [batch, G*G, vis_words]: line-of-sight masks of the walls variant (ppg_walls_changed)
     ppg_config cfg;
     ppg_config_gen2 cfg2;
     int32_t gen2;  // created by ppg_create_gen2
@@ -254,6 +255,14 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
     P.los_move = (g.walls && g.respect_los_for_movement) ? 1 : 0;
     P.mask_obs = (g.walls && g.mask_observation_with_visibility) ? 1 : 0;
     P.wall_bits = h->bufs.wall_bits; P.row_info = h->bufs.row_info;
+    if (g.walls) {
+        // window offsets that any observation can ask about: -off .. R-1-off per species (an even R reaches one cell further up)
+        const int offp = (P.Rp - 1) / 2, offq = (P.Rq - 1) / 2;
+        const int neg = offp > offq ? offp : offq;
+        const int posp = P.Rp - 1 - offp, posq = P.Rq - 1 - offq;
+        const int pos = posp > posq ? posp : posq;
+        P.vis_neg = neg; P.vis_w = neg + pos + 1; P.vis_words = (P.vis_w * P.vis_w + 31) / 32;
+    }
     return PPG_OK;
 }
 
@@ -279,6 +288,7 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
 static int backend_rebalance(ppg_handle *h, int weight_pred, int weight_prey, void *stream);
 // snapshot plumbing: a copy between host memory and a caller-owned device tensor, enqueued on `stream`; and the wait
 static int backend_copy(ppg_handle *h, void *dst, const void *src, size_t bytes, bool to_device, void *stream);
+static int backend_alloc(ppg_handle *h, void **out, size_t bytes);   // device memory owned by the handle
 static int backend_sync(ppg_handle *h, void *stream);
 // the two launches of ppg_pack (ppg_pack.h)
 static int backend_pack(ppg_handle *h, const ppg::PackParams &K, void *stream);
@@ -317,6 +327,7 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     h->lut_dev = nullptr; h->backend = nullptr; h->prof_dev = nullptr; h->err[0] = 0;
     h->envs_in_flight = 0;
     h->order_dev = nullptr;
+    h->vis_dev = nullptr;
     h->drive = (cfg && (cfg->n_drive[0] > 0 || cfg->n_drive[1] > 0)) ? 1 : 0;
     int rc = cfg2 ? ppg_validate_and_layout_gen2(h) : ppg_validate_and_layout(h);
     if (rc == PPG_OK) rc = backend_init(h, device);
@@ -427,6 +438,21 @@ int ppg_rebalance(ppg_handle *h, void *stream) {
     return rc;
 }
 
+int ppg_walls_changed(ppg_handle *h, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!(h->gen2 && h->cfg2.walls)) return ppg_fail(h, PPG_EINVAL, "ppg_walls_changed needs a walls handle (ppg_config_gen2.walls)");
+    const ppg::KParams &B = h->base;
+    if (!h->vis_dev) {
+        const int rc = backend_alloc(h, (void **)&h->vis_dev, (size_t)h->batch * B.G * B.G * B.vis_words * sizeof(uint32_t));
+        if (rc != PPG_OK) return rc;
+    }
+    ppg::KParams P = h->base;
+    P.mode = ppg::MODE_VIS; P.vis_masks = h->vis_dev;
+    const int rc = backend_launch(h, ppg::MODE_VIS, P, stream);
+    if (rc == PPG_OK) h->base.vis_masks = h->vis_dev;   // every later launch reads the masks instead of walking the lines
+    return rc;
+}
+
 int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight) {
     if (!h) return PPG_EINVAL;
     if (envs_in_flight < 0) return ppg_fail(h, PPG_EINVAL, "envs_in_flight < 0");
@@ -504,7 +530,12 @@ int ppg_import_state(ppg_handle *h, int32_t env, const void *blob, uint64_t size
         if (rc != PPG_OK) return rc;
         src += (f[i].bytes + 7) / 8 * 8;
     }
-    return backend_sync(h, stream);   // the blob may be freed by the caller as soon as this returns
+    {
+        const int rc = backend_sync(h, stream);   // the blob may be freed by the caller as soon as this returns
+        if (rc != PPG_OK) return rc;
+    }
+    if (h->gen2 && h->cfg2.walls && h->base.vis_masks) return ppg_walls_changed(h, stream);   // the image carried a wall bitmap
+    return PPG_OK;
 }
 
 static int ppg_pack_geometry(const ppg_handle *h, uint32_t flags, int &blk_p, int &blk_q, int &src_elem, int &dst_elem) {

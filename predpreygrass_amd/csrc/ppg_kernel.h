@@ -43,7 +43,8 @@
 namespace ppg {
 
 enum { MODE_STEP = 0, MODE_RESET = 1, MODE_OBSERVE = 2, MODE_EXPORT_GRID = 3, MODE_STEP_ORDERED = 4, MODE_ROLLOUT = 5,
-       MODE_STEP_KICK = 6, MODE_STEP_ORDERED_KICK = 7, N_MODES = 8 };
+       MODE_STEP_KICK = 6, MODE_STEP_ORDERED_KICK = 7, N_MODES = 8,
+       MODE_VIS = 8 };   // walls variant only: (re)compute the per-cell line-of-sight masks (ppg_walls_changed)
 
 // event bits of a row during one call (bits 8-15: kickback counters).  Second generation: EV_REPRO = a child was
 // actually created (EV_PARENT alone = reward without a free id, RQ:715-725); EV_TURN = the prey had its own engagement
@@ -92,6 +93,11 @@ struct KParams {
     int32_t mask_obs;             // mask_observation_with_visibility (WO:111)
     int32_t n_wall_words;         // 32-bit words of the per-env wall bitmap: ceil(G*G / 32)
     int32_t off_wall;             // LDS offset of the wall bitmap
+    // per-cell line-of-sight masks, precomputed from the (static) walls by ppg_walls_changed: bit (dx + vis_neg) * vis_w + (dy + vis_neg)
+    // of cell (x, y)'s vis_words words = "(x + dx, y + dy) is in the grid and no wall lies strictly between" (WO:492-525, 577-589)
+    int32_t vis_neg, vis_w, vis_words;
+    int32_t pad4_;
+    uint32_t *vis_masks;          // library-owned [B, G*G, vis_words]; NULL = not computed: observations walk the lines themselves
     // drive-conditioned variant of the base family (drive_conditioned_environment/predpreygrass_rllib_env.py, "DRV")
     int32_t n_drive[2];           // extra constant-filled observation channels per species (DRV:70-75), <= 4
     int32_t drive_kind[2][4];     // 0 hunger_pressure, 1 reproductive_readiness, 2 prey_opportunity, 3 predator_danger_pressure,
@@ -1176,7 +1182,14 @@ struct Env {
         const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;   // (areas are strided by the larger window: waves work on both species)
         float *visb = (float *)((unsigned char *)map + C.off_win - P.off_map) + wave_idx * rmax * rmax;
         const bool want_vis = WALLS && (C.mask_obs || C.vis_channel);
-        if (want_vis) {
+        const bool have_masks = WALLS && C.vis_masks != nullptr;
+        const uint32_t *visw = (const uint32_t *)visb;
+        if (want_vis && have_masks) {
+            // walls are static: the mask of this agent's cell was computed when they were set (ppg_walls_changed) -- a few words
+            // instead of one Bresenham walk per window cell
+            if (ln < C.vis_words) ((uint32_t *)visb)[ln] = C.vis_masks[((size_t)b * P.G * P.G + s_cell) * C.vis_words + ln];
+            wv::sync();
+        } else if (want_vis) {
             for (int i = ln; i < R * R; i += 64) {
                 const int ci = i / R, cj = i - ci * R;
                 const int gx = x - off + ci, gy = y - off + cj;
@@ -1218,8 +1231,14 @@ struct Env {
                         // for the last row / column of an even R, which the window copy (WO:543) leaves untouched
                         const bool in_grid = (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
                         const bool need_vis = vis_elem ? in_grid : (inb && C.mask_obs && (w & 0x3000000u) != 0u);
-                        const int vcell = ((int)((w >> 16) & 15u) - 8 + off) * R + ((int)((w >> 20) & 15u) - 8 + off);
-                        const float vis = need_vis ? visb[vcell] : 0.0f;
+                        const int vdx = (int)((w >> 16) & 15u) - 8, vdy = (int)((w >> 20) & 15u) - 8;
+                        float vis = 0.0f;
+                        if (need_vis && have_masks) {
+                            const int bi = (vdx + C.vis_neg) * C.vis_w + (vdy + C.vis_neg);
+                            vis = ((visw[bi >> 5] >> (bi & 31)) & 1u) ? 1.0f : 0.0f;
+                        } else if (need_vis) {
+                            vis = visb[(vdx + off) * R + (vdy + off)];
+                        }
                         if (vis_elem) t = (double)vis;
                         else if ((w & 0x3000000u) == 0u) t = (inb && wall_at(gx, gy)) ? 1.0 : 0.0;
                         else if (C.mask_obs) t = (double)((float)t * vis);
@@ -2053,6 +2072,26 @@ struct Env {
         obs_all_alive();
     }
 
+    // MODE_VIS: the line-of-sight masks of every cell of this env from its wall bitmap (one word = 32 window offsets per item)
+    PPG_MEMBER void run_vis() {
+        for (int i = ln; i < C.n_wall_words; i += 64) wallw[i] = C.wall_bits[(size_t)b * C.n_wall_words + i];
+        wv::sync();
+        const int n = P.G * P.G, nw = C.vis_words, wm = C.vis_w, neg = C.vis_neg;
+        for (int it = ln; it < n * nw; it += 64) {
+            const int cell = it / nw, w = it - cell * nw;
+            const int x = (int)wv::mulhi((uint32_t)cell, C.g_magic), y = cell - x * P.G;
+            uint32_t word = 0;
+            for (int k = 0; k < 32; ++k) {
+                const int bi = 32 * w + k;
+                if (bi >= wm * wm) break;
+                const int ci = bi / wm, cj = bi - ci * wm;
+                const int gx = x - neg + ci, gy = y - neg + cj;
+                if ((unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G && los_clear(x, y, gx, gy)) word |= 1u << k;
+            }
+            C.vis_masks[((size_t)b * n + cell) * nw + w] = word;
+        }
+    }
+
     PPG_MEMBER void run_export_grid() {
         Pre pre;
         prefetch(pre, true, false);
@@ -2115,6 +2154,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();
     else if (MODE == MODE_OBSERVE) env.run_observe();
+    else if (MODE == MODE_VIS) env.run_vis();
     else env.run_export_grid();
 }
 

@@ -40,7 +40,8 @@
     PPG_K3(ppg3_reset_q##NQ, NQ, ppg::MODE_RESET)                     \
     PPG_K3(ppg3_observe_q##NQ, NQ, ppg::MODE_OBSERVE)                 \
     PPG_K3(ppg3_grid_q##NQ, NQ, ppg::MODE_EXPORT_GRID)                \
-    PPG_K3(ppg3_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED)
+    PPG_K3(ppg3_step_ord_q##NQ, NQ, ppg::MODE_STEP_ORDERED)          \
+    PPG_K3(ppg3_vis_q##NQ, NQ, ppg::MODE_VIS)
 
 // drive-conditioned variant of the base family: generic observation geometry only (ppg4_<mode>_q<NQ>)
 #define PPG_DEFINE_KERNELS4(NQ)                                       \

@@ -230,7 +230,7 @@ class BatchedRedQueen(BatchedPredPreyGrass):
         self.observe()
         return self
 
-    def set_walls(self, wall_xy, per_env=False):
+    def set_walls(self, wall_xy, per_env=False, precompute_visibility=True):
         """Wall cells (walls variant): a list of (x, y) shared by all envs, or with per_env=True one such list per env.
         They stay in place across device resets until replaced; call before `set_placement` / `reset`."""
         if not self.walls:
@@ -251,6 +251,8 @@ class BatchedRedQueen(BatchedPredPreyGrass):
                 raise ValueError(f"env {b}: {n_free} cells are free of walls but {self.P0 + self.Q0 + self.n_grass} "
                                  "entities have to be placed")
         self.wall_bits.copy_(torch.from_numpy(bits.view(np.int32)))
+        if precompute_visibility:   # the per-cell line-of-sight masks the observations read from now on (ppg_walls_changed)
+            self._check(self._lib.ppg_walls_changed(self._handle, self._stream()), "ppg_walls_changed")
         return self
 
     def step(self, actions=None, random_actions=False, auto_reset=False, act_rank=None, uniforms=None, stream=None):

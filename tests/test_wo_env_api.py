@@ -117,3 +117,24 @@ def test_snapshot_restore_roundtrip_with_walls():
     """ppg_export_state / ppg_import_state carry the wall bitmap and the move infos of the walls variant."""
     from tests.test_rq_env_api import check_rq_snapshot_against_golden
     check_rq_snapshot_against_golden(lambda cfg, **kw: PredPreyGrass(cfg, _library=library(), **kw), "wo_los_two_types_seed5", walls=True)
+
+
+def test_precomputed_visibility_masks_equal_the_walked_lines():
+    """ppg_walls_changed: observations that read the per-cell line-of-sight masks == observations that walk one Bresenham line per
+    window cell (the fallback when the caller never announced its walls), on a random rollout with resets, even and odd windows."""
+    import torch
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+    case = RQGoldenCase("wo_los_two_types_seed5")
+    for extra in ({}, {"predator_obs_range": 6, "prey_obs_range": 8}):
+        cfg = {**case.config, **extra}
+        envs = []
+        for pre in (True, False):
+            e = BatchedRedQueen(cfg, batch_size=6, walls=True, _library=library(), seed=3)
+            e.set_walls(case.wall_xy, precompute_visibility=pre)
+            e.reset()
+            envs.append(e)
+        for _ in range(40):
+            for e in envs:
+                e.step(random_actions=True, auto_reset=True)
+            for n in ("obs_pred", "obs_prey", "row_xy", "row_energy", "row_info", "env_state"):
+                assert torch.equal(getattr(envs[0], n), getattr(envs[1], n)), n

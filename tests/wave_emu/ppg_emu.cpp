@@ -78,6 +78,7 @@ static void run_mode3(const ppg::KParams &P, int mode) {
         case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET, false, true, true>(P, lds); break;
         case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, false, true, true>(P, lds); break;
         case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, false, true, true>(P, lds); break;
+        case ppg::MODE_VIS: ppg::env_main<NQ, ppg::MODE_VIS, false, true, true>(P, lds); break;
         default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, false, true, true>(P, lds); break;
     }
 }
@@ -134,7 +135,13 @@ static int backend_init(ppg_handle *h, int) {
     memcpy(h->lut_dev, h->lut_host.data(), h->lut_host.size() * sizeof(uint32_t));
     return PPG_OK;
 }
+static int backend_alloc(ppg_handle *, void **out, size_t bytes) {
+    *out = malloc(bytes);
+    return *out ? PPG_OK : PPG_ENOMEM;
+}
 static void backend_release(ppg_handle *h) {
+    free(h->vis_dev);
+    h->vis_dev = nullptr;
     free(h->lut_dev);
     h->lut_dev = nullptr;
     free(h->order_dev);
