@@ -125,6 +125,13 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.S = c.pred_capacity + c.prey_capacity;
     P.obs_f32 = c.obs_dtype;
     P.g_magic = (uint32_t)((0x100000000ull + (uint64_t)c.grid_size - 1) / (uint64_t)c.grid_size);
+    P.rp_magic = (uint32_t)((0x100000000ull + (uint64_t)c.predator_obs_range - 1) / (uint64_t)c.predator_obs_range);
+    P.rq_magic = (uint32_t)((0x100000000ull + (uint64_t)c.prey_obs_range - 1) / (uint64_t)c.prey_obs_range);
+    {
+        const uint64_t np = (uint64_t)c.predator_obs_range * c.predator_obs_range, nq = (uint64_t)c.prey_obs_range * c.prey_obs_range;
+        P.np_magic = (uint32_t)((0x100000000ull + np - 1) / np);
+        P.nq_magic = (uint32_t)((0x100000000ull + nq - 1) / nq);
+    }
     P.r_catch = c.reward_predator_catch_prey; P.r_eat = c.reward_prey_eat_grass;
     P.r_pstep = c.reward_predator_step; P.r_qstep = c.reward_prey_step; P.r_caught = c.penalty_prey_caught;
     P.r_repro_p = c.reproduction_reward_predator; P.r_repro_q = c.reproduction_reward_prey;
@@ -170,7 +177,7 @@ static int ppg_validate_and_layout(ppg_handle *h) {
         P.norm_grass_opp = c.grass_opportunity_normalizer;
         const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;
         off = (off + 15) / 16 * 16;
-        P.off_win = off; off += 4 * rmax * rmax * 8;   // one area per wave of a multi-wave workgroup
+        P.off_win = off; off += 4 * 4 * rmax * rmax * 8;   // four channel planes per wave of a multi-wave workgroup
     }
     if (h->gen2 && h->cfg2.walls) {  // wall bitmap
         P.n_wall_words = (n + 31) / 32;

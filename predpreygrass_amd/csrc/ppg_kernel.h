@@ -97,6 +97,8 @@ struct KParams {
     // of cell (x, y)'s vis_words words = "(x + dx, y + dy) is in the grid and no wall lies strictly between" (WO:492-525, 577-589)
     int32_t vis_neg, vis_w, vis_words;
     int32_t pad4_;
+    uint32_t rp_magic, rq_magic;  // ceil(2^32 / Rp), ceil(2^32 / Rq): cell / R == mulhi(cell, magic) for cell < R*R
+    uint32_t np_magic, nq_magic;  // ceil(2^32 / Rp^2), ceil(2^32 / Rq^2): element / R^2 for element < 8 R^2
     uint32_t *vis_masks;          // library-owned [B, G*G, vis_words]; NULL = not computed: observations walk the lines themselves
     // drive-conditioned variant of the base family (drive_conditioned_environment/predpreygrass_rllib_env.py, "DRV")
     int32_t n_drive[2];           // extra constant-filled observation channels per species (DRV:70-75), <= 4
@@ -1111,7 +1113,7 @@ struct Env {
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;
         const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;   // one staging area per wave of a multi-wave workgroup
-        double *win = (double *)((unsigned char *)map + C.off_win - P.off_map) + wave_idx * rmax * rmax;
+        double *win = (double *)((unsigned char *)map + C.off_win - P.off_map) + wave_idx * 4 * rmax * rmax;
         const uint32_t *L = lut + (type ? P.nch_p * 128 : 0);
         const bool strided = (((4 + (type ? C.n_drive[1] : C.n_drive[0])) * n) & 1) != 0;   // see obs_row / ppg_build_lut
         wv::sync();
@@ -1160,11 +1162,170 @@ struct Env {
         }
     }
 
+    // _get_observation of the walls env (WO:527-601), one window CELL per lane (64 cells per pass): in-grid test, wall bit,
+    // line-of-sight bit and the three channel lookups are done once per cell and feed all 4 / 5 channels -- the per-element
+    // formulation below does that work once per channel.  Channel 0 = walls inside the window (0 outside the grid); channels
+    // 1-3 optionally multiplied, in float32 like the reference, by the mask; optional last channel = the mask itself, which is
+    // computed for every cell of the R x R array that maps into the grid (also the last row / column of an even R, which the
+    // window copy WO:543 leaves untouched).  Consecutive lanes write consecutive elements of a channel plane.
+    PPG_MEMBER void obs_row_walls(int type, int j, uint32_t s_xy) {
+        wv::sync();  // LDS writes of the sequential phases -> visible
+        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);   // (arithmetic, not a select of fields: see window_sum)
+        const uint32_t rmagic = C.rp_magic + (type ? C.rq_magic - C.rp_magic : 0u);
+        const int n = R * R, off = (R - 1) / 2, Wc = 2 * off + 1;
+        const int nchan = C.vis_channel ? 5 : 4;
+        const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
+        const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;   // (areas are strided by the larger window: waves work on both species)
+        float *visb = (float *)((unsigned char *)map + C.off_win - P.off_map) + wave_idx * rmax * rmax;
+        const uint32_t *visw = (const uint32_t *)visb;
+        const bool want_vis = C.mask_obs || C.vis_channel;
+        const bool have_masks = C.vis_masks != nullptr;
+        if (want_vis && have_masks) {
+            // walls are static: the mask of this agent's cell was computed when they were set (ppg_walls_changed) -- a few words
+            // instead of one Bresenham walk per window cell
+            if (ln < C.vis_words) ((uint32_t *)visb)[ln] = C.vis_masks[((size_t)b * P.G * P.G + x * P.G + y) * C.vis_words + ln];
+            wv::sync();
+        } else if (want_vis) {
+            for (int i = ln; i < n; i += 64) {
+                const int ci = (int)wv::mulhi((uint32_t)i, rmagic), cj = i - ci * R;
+                const int gx = x - off + ci, gy = y - off + cj;
+                const bool in_grid = (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+                visb[i] = (in_grid && los_clear(x, y, gx, gy)) ? 1.0f : 0.0f;
+            }
+            wv::sync();
+        }
+        const size_t obase = ((size_t)b * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)(nchan * n);
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int cell = c0 + ln;
+            const bool valid = cell < n;
+            const int ci = (int)wv::mulhi((uint32_t)cell, rmagic), cj = cell - ci * R;
+            const int gx = x - off + ci, gy = y - off + cj;
+            const bool in_grid = valid && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+            const bool inb = in_grid && ci < Wc && cj < Wc;
+            const int a = inb ? gx * P.G + gy : 0;
+            double v[5];
+            v[0] = (inb && ((wallw[a >> 5] >> (a & 31)) & 1u)) ? 1.0 : 0.0;
+            float vis = 0.0f;
+            if (want_vis && in_grid) {
+                if (have_masks) {
+                    const int bi = (ci - off + C.vis_neg) * C.vis_w + (cj - off + C.vis_neg);
+                    vis = ((visw[bi >> 5] >> (bi & 31)) & 1u) ? 1.0f : 0.0f;
+                } else {
+                    vis = visb[cell];
+                }
+            }
+#pragma unroll
+            for (int ch = 1; ch < 4; ++ch) {
+                double t = val[chmap(ch)[a]];
+                if (!inb) t = 0.0;
+                if (C.mask_obs) t = (double)((float)t * (inb ? vis : 0.0f));
+                v[ch] = t;
+            }
+            v[4] = (double)vis;
+            if (valid) {
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) {
+                    if (ch >= nchan) continue;
+                    const size_t o = obase + (size_t)ch * n + cell;
+                    if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred))[o] = (float)v[ch];
+                    else ((double *)(type ? P.obs_prey : P.obs_pred))[o] = v[ch];
+                }
+            }
+        }
+        wv::sync();  // reads done before the caller touches the maps again
+    }
+
+    // _get_observation of the drive-conditioned env (DRV:551-616), one window CELL per lane: the three world channels of a cell
+    // are looked up once, stored, and staged in LDS for the window sums -- np.sum(observation[c]) in numpy's order: eight
+    // interleaved accumulators r_q = a[q] + a[q+8] + ... (lanes 8g .. 8g+7 of lane group g = channel g+1 run them side by side for
+    // all three channels), combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by three xor-shuffles (IEEE addition commutes, so
+    // every lane of a group ends with the same bits), then the tail elements one by one.  Needs 8 <= R*R <= 128 (numpy switches
+    // to a plain loop below and to recursive halves above); other sizes take the per-element path.
+    // (Tried and slower, 224 vs 201 us per 1365-env launch: staging all four planes and writing the block in element order with
+    // 16-byte stores -- the second pass over LDS costs more than the wider stores save.)
+    PPG_MEMBER void obs_row_drive(int type, int j, uint32_t s_xy, double s_e) {
+        wv::sync();
+        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
+        const uint32_t rmagic = C.rp_magic + (type ? C.rq_magic - C.rp_magic : 0u);
+        const int n = R * R, off = (R - 1) / 2, Wc = 2 * off + 1;
+        const int nd = type ? C.n_drive[1] : C.n_drive[0];
+        const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
+        const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq, rmax2 = rmax * rmax;
+        double *win = (double *)((unsigned char *)map + C.off_win - P.off_map) + wave_idx * 4 * rmax2;
+        const size_t obase = ((size_t)b * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)((4 + nd) * n);
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int cell = c0 + ln;
+            const bool valid = cell < n;
+            const int ci = (int)wv::mulhi((uint32_t)cell, rmagic), cj = cell - ci * R;
+            const int gx = x - off + ci, gy = y - off + cj;
+            const bool inb = valid && ci < Wc && cj < Wc && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+            const int a = inb ? gx * P.G + gy : 0;
+            double v[4];
+            v[0] = inb ? 0.0 : 1.0;                      // DRV:561-562: 1 everywhere except the in-grid part of the window
+#pragma unroll
+            for (int ch = 1; ch < 4; ++ch) {
+                const double t = val[chmap(ch)[a]];
+                v[ch] = inb ? t : 0.0;
+            }
+            if (valid) {
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const size_t o = obase + (size_t)ch * n + cell;
+                    if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred))[o] = (float)v[ch];
+                    else ((double *)(type ? P.obs_prey : P.obs_pred))[o] = v[ch];
+                    if (ch) win[(ch - 1) * rmax2 + cell] = v[ch];
+                }
+            }
+        }
+        wv::sync();
+        // the three window sums, side by side
+        const int grp = ln >> 3, q = ln & 7, n8 = n & ~7;
+        const double *wc = win + (grp < 3 ? grp : 0) * rmax2;
+        double acc = wc[q];
+        for (int i = 8 + q; i < n8; i += 8) acc += wc[i];
+        acc = acc + wv::shfl_xor_f64(acc, 1);
+        acc = acc + wv::shfl_xor_f64(acc, 2);
+        acc = acc + wv::shfl_xor_f64(acc, 4);
+        for (int i = n8; i < n; ++i) acc += wc[i];
+        const double sum1 = readlane_f64(acc, 0), sum2 = readlane_f64(acc, 8), sum3 = readlane_f64(acc, 16);
+        double dv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= nd) continue;
+            const int kind = type ? C.drive_kind[1][k] : C.drive_kind[0][k];
+            double t;
+            if (kind == 0) t = 1.0 - s_e / (type ? C.hunger_safe[1] : C.hunger_safe[0]);
+            else if (kind == 1) t = s_e / (type ? C.thr_q : C.thr_p);
+            else if (kind == 2) t = sum2 / C.norm_prey_opp;
+            else if (kind == 3) t = sum1 / C.norm_pred_danger;
+            else t = sum3 / C.norm_grass_opp;
+            dv[k] = safe_clip01(t);
+        }
+        for (int c0 = 0; c0 < n; c0 += 64) {   // the drive planes: one scalar per plane (DRV:566-569)
+            const int cell = c0 + ln;
+            if (cell < n) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= nd) continue;
+                    const size_t o = obase + (size_t)(4 + k) * n + cell;
+                    if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred))[o] = (float)dv[k];
+                    else ((double *)(type ? P.obs_prey : P.obs_pred))[o] = dv[k];
+                }
+            }
+        }
+        wv::sync();
+    }
+
     PPG_MEMBER void obs_row(int type, int j, uint32_t s_xy, double s_e = 0.0) {
         if (FASTOBS) {
             if (type) obs_row_fast<1>(j, s_xy);
             else obs_row_fast<0>(j, s_xy);
             return;
+        }
+        if (WALLS) { obs_row_walls(type, j, s_xy); return; }
+        if (DRIVE) {
+            const int Rn = P.Rp + (type ? P.Rq - P.Rp : 0);
+            if (Rn * Rn >= 8 && Rn * Rn <= 128) { obs_row_drive(type, j, s_xy, s_e); return; }
         }
         wv::sync();  // LDS writes of the sequential phases -> visible
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0);   // (arithmetic, not a select of fields: see window_sum)

@@ -57,6 +57,13 @@ PPG_DEVICE uint32_t prefix(uint64_t mask) {
 // value held by lane-1 (lane 0 gets its own).
 PPG_DEVICE uint32_t shfl_up1(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1, 64); }
 
+// value held by lane ^ mask, for a float64 (two 32-bit exchanges)
+PPG_DEVICE double shfl_xor_f64(double v, int mask) {
+    long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, mask, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)b >> 32), mask, 64);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
 // LDS ordering point between lanes of the wave.  A workgroup is ONE wavefront and the LDS unit
 // executes a wave's DS instructions in issue order, so no s_barrier and no counter drain is
 // needed -- only the compiler must not move LDS accesses across this point.  (__syncthreads()

@@ -189,6 +189,15 @@ inline uint32_t shfl_up1(uint32_t v) {
     int l = lane();
     return (uint32_t)s[l ? l - 1 : 0];
 }
+inline double shfl_xor_f64(double v, int mask) {
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const uint64_t *s = exchange(bits);
+    const uint64_t o = s[lane() ^ mask];
+    double r;
+    memcpy(&r, &o, 8);
+    return r;
+}
 inline int wave_index() { return emu().cur / W; }
 // workgroup barrier: the fiber parks until every fiber of the workgroup that has not finished is parked too (a wave that
 // has ended no longer takes part, as on hardware)

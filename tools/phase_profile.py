@@ -20,12 +20,21 @@ lib = _abi.bind(ctypes.CDLL(LIB))
 _abi._lib = lib  # this process only
 lib.ppg_debug_set_profile_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 RQ = "--rq" in sys.argv   # second-generation env on its reference config ("engage_pred" = type-1 classes, "engage_prey" = type-2)
+WALLS = "--walls" in sys.argv   # walls variant, zigzag layout with every line-of-sight option (bench.py --workload walls)
+DRIVE = "--drive" in sys.argv   # drive-conditioned variant of the default config
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if len(args) > 0 else 4096
 warm = int(args[1]) if len(args) > 1 else 400
-if RQ:
+if WALLS:
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+    from predpreygrass_amd.walls_occlusion import config_env_zigzag_walls
+    env = BatchedRedQueen(config_env_zigzag_walls, batch_size=B, device="cuda:0", walls=True, obs_dtype=torch.float32)
+    env.set_walls(config_env_zigzag_walls["manual_wall_positions"])
+elif RQ:
     from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
-    env = BatchedRedQueen(config_env_base, batch_size=B, device="cuda:0")
+    env = BatchedRedQueen(config_env_base, batch_size=B, device="cuda:0", obs_dtype=torch.float32)
+elif DRIVE:
+    env = BatchedPredPreyGrass({**config_env, "enable_drive_channels": True}, batch_size=B, device="cuda:0")
 else:
     env = BatchedPredPreyGrass(config_env, batch_size=B, device="cuda:0")
 env.reset()
