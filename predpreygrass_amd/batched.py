@@ -137,6 +137,8 @@ class BatchedPredPreyGrass:
     def _alloc_buffers(self, prey_capacity):
         self.pred_capacity = PRED_CAPACITY
         self.prey_capacity = int(prey_capacity)
+        if self.n_grass > 255 and self.prey_capacity < 256:
+            self.prey_capacity = 256   # up to 128 prey rows the kernels use 8-bit cell maps: at most 255 grass patches
         self.S = self.pred_capacity + self.prey_capacity
         self.grass_capacity = max(64, (self.n_grass + 63) // 64 * 64)
         B, S, NG, dev = self.batch_size, self.S, self.grass_capacity, self.device

@@ -213,6 +213,16 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
         const bool eight = force8 ? atoi(force8) != 0 : in_flight <= 512;   // even emptier GPU: 8 waves per env
         fn = w[eight ? 1 : 0][h->gen2 ? 1 : 0][fast ? 1 : 0][h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
         block = eight ? 512 : 256;
+        // a full GPU whose LDS admits 5-8 envs per CU (64x64 grids with 8-bit cell maps): TWO waves per env fill the 16 wave slots
+        // of a CU with 8 envs; four waves per env would leave half of the LDS-resident envs without slots
+        const int lds_envs = h->base.lds_bytes > 0 ? (160 * 1024) / h->base.lds_bytes : 16;
+        const char *forcep = getenv("PPG_MULTIWAVE_PAIR");
+        const bool pair = forcep ? atoi(forcep) != 0 : (!force8 && !h->gen2 && in_flight > 3072 && lds_envs >= 5 && lds_envs <= 8);
+        if (pair && !h->gen2) {
+            static const ppg_kernel_fn wp[2][3] = {{ppgwp_step_q1g, ppgwp_step_q2g, ppgwp_step_q4g}, {ppgwp_step_q1, ppgwp_step_q2, ppgwp_step_q4}};
+            fn = wp[fast ? 1 : 0][h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
+            block = 128;
+        }
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(block), (size_t)P.lds_bytes, (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());

@@ -83,7 +83,8 @@ static void ppg_build_lut(int R, int G, int map_n, uint32_t *out, int channels =
             const int moff = cm * map_n + (i - off) * G + (j - off);
             d = ((uint32_t)moff & 0xFFFFu) | ((uint32_t)(i - off + 8) << 16) | ((uint32_t)(j - off + 8) << 20) |
                 ((uint32_t)cm << 24) | 0x4000000u | ((i < W && j < W) ? 0x8000000u : 0u) |
-                ((c >= 4 && !drive) ? 0x10000000u : 0u);
+                ((c >= 4 && !drive) ? 0x10000000u : 0u) |
+                ((uint32_t)(cm >= 2 ? cm - 1 : 0) << 30);   // bits 30-31: value-table section of the channel (8-bit maps, Env::map_base)
             if (c >= 4 && drive) d = 0x4000000u | 0x20000000u | ((uint32_t)(c - 4) << 24);
         }
         out[slot] = d;
@@ -150,9 +151,13 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     const int n = c.grid_size * c.grid_size;
     P.map_n = (n + 7) / 8 * 8;
     int off = 0;
-    P.off_map = off; off += 4 * P.map_n * 2;
+    // cell maps: 8-bit channel-local indices for up to 128 prey rows (Env::MAP8), else 16-bit indices into the value table
+    const int map_elem = h->nq <= 2 ? 1 : 2;
+    if (map_elem == 1 && c.n_grass > 255)
+        return ppg_fail(h, PPG_EINVAL, "more than 255 grass patches need prey_capacity 256 (16-bit cell maps)");
+    P.off_map = off; off += 4 * P.map_n * map_elem;
     off = (off + 15) / 16 * 16;
-    P.off_val = off; off += (1 + P.S + P.cap_grass) * 8;
+    P.off_val = off; off += (map_elem == 1 ? 514 : 1 + P.S + P.cap_grass) * 8;   // (8-bit maps: three sections of 129 + room for 255 patches)
     off = (off + 15) / 16 * 16;
     P.off_scr = off; off += (P.S * 8 > 1024 ? P.S * 8 : 1024);
     const bool drive = !h->gen2 && (c.n_drive[0] > 0 || c.n_drive[1] > 0);
@@ -284,7 +289,7 @@ static bool ppg_use_multiwave(const ppg_handle *h, bool compute_bound = false) {
     if (compute_bound) return true;
     const int lds_envs = h->base.lds_bytes > 0 ? (160 * 1024) / h->base.lds_bytes : 16;
     const int in_flight = h->envs_in_flight > 0 ? h->envs_in_flight : h->batch;
-    return in_flight <= 3072 || lds_envs <= 4;
+    return in_flight <= 3072 || lds_envs <= 8;   // (5-8 envs per CU: the backend takes the two-wave kernel)
 }
 
 static int backend_init(ppg_handle *h, int device);

@@ -234,9 +234,16 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // whole transition and all NW waves of the workgroup write the final observations (the phase that dominates a wave's
 // run time) -- for launches that cannot fill the GPU with one wave per env (small batches; large grids whose LDS
 // footprint allows only a few envs per CU).
+// MAP8 (= NQ <= 2, chosen by env_main): the cell maps hold 8-bit indices LOCAL to their channel (predator row + 1, prey row + 1,
+// grass patch + 1; 0 = empty) instead of 16-bit indices into the whole value table -- half the LDS, which is what decides how many
+// envs of a 64x64 grid fit on a CU (BASELINE config 4).  Needs <= 128 prey rows and <= 255 grass patches (ppg_create checks).
 template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, int NW, class KP, class KC>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
+    static constexpr bool MAP8 = NQ <= 2;
+    template <bool B8, class Dummy = void> struct MapElem { typedef uint16_t type; };
+    template <class Dummy> struct MapElem<true, Dummy> { typedef uint8_t type; };
+    typedef typename MapElem<MAP8>::type map_t;
 
     KP &P;   // hot parameters: by-value kernel argument, resident in SGPRs
     KC &C;   // cold parameters (rewards, thresholds, table pointers ...): the same struct read in place from the
@@ -245,7 +252,7 @@ struct Env {
     const int ln;
     int wave_idx = 0;  // index of this wavefront in its workgroup (multi-wave kernels; 0 otherwise)
 
-    uint16_t *map;   // LDS
+    map_t *map;      // LDS
     double *val;     // LDS
     uint64_t *scr;   // LDS
     uint32_t *lut;   // LDS
@@ -278,17 +285,25 @@ struct Env {
 
     PPG_MEMBER Env(KP &p, KC &c, int b_, unsigned char *lds, int lane)
         : P(p), C(c), b(b_), ln(lane),
-          map((uint16_t *)(lds + p.off_map)), val((double *)(lds + p.off_val)),
+          map((map_t *)(lds + p.off_map)), val((double *)(lds + p.off_val)),
           scr((uint64_t *)(lds + p.off_scr)), lut((uint32_t *)(lds + p.off_lut)), wallw((uint32_t *)(lds + c.off_wall)) {}
 
     // ---- index helpers -------------------------------------------------------------
     static PPG_MEMBER int type_of(int r) { return r ? 1 : 0; }
     static PPG_MEMBER int row_of(int r, int k) { return r ? (r - 1) * 64 + k : k; }  // row within its type
     PPG_MEMBER int slot_of(int r, int k) const { return r ? P.cap_pred + (r - 1) * 64 + k : k; }  // row in [0,S)
-    PPG_MEMBER int validx(int r, int k) const { return 1 + slot_of(r, k); }
-    PPG_MEMBER int grass_validx(int p) const { return 1 + P.S + p; }
+    // Index of an entity's energy in the LDS value table.  16-bit maps: [0] = 0.0, then all row slots, then the grass patches.
+    // MAP8: one section per channel, each led by a zero entry so that "map entry + section base" needs no test for an empty cell:
+    // [0] = 0.0 | predators 1..64 || [129] = 0.0 | prey 130..257 || [258] = 0.0 | grass 259..513  (section base = 129 * (channel - 1)).
+    PPG_MEMBER int validx(int r, int k) const { return MAP8 ? (r ? 130 + row_of(r, k) : 1 + k) : 1 + slot_of(r, k); }
+    PPG_MEMBER int validx_row(int type, int row) const { return MAP8 ? (type ? 130 + row : 1 + row) : 1 + (type ? P.cap_pred + row : row); }
+    PPG_MEMBER int grass_validx(int p) const { return MAP8 ? 259 + p : 1 + P.S + p; }
     PPG_MEMBER int cell_of(uint32_t s_xy) const { return (int)(s_xy >> 8) * P.G + (int)(s_xy & 255u); }
-    PPG_MEMBER uint16_t *chmap(int ch) const { return map + ch * P.map_n; }
+    PPG_MEMBER map_t *chmap(int ch) const { return map + ch * P.map_n; }
+    // what a map entry of channel ch means as an index into the value table, and back (MAP8: channel-local 8-bit indices)
+    PPG_MEMBER int map_base(int ch) const { return MAP8 ? (ch >= 2 ? 129 * (ch - 1) : 0) : 0; }
+    PPG_MEMBER map_t to_map(int ch, int vidx) const { return (map_t)(vidx - map_base(ch)); }
+    PPG_MEMBER int from_map(int ch, uint32_t m) const { return (int)m + map_base(ch); }   // (an empty cell lands on the section's zero entry)
 
     // ---- walls (WO) ----------------------------------------------------------------------
     PPG_MEMBER bool wall_at(int x, int y) const {
@@ -361,7 +376,7 @@ struct Env {
 #pragma unroll
         for (int q = 0; q < T; ++q) owns[q] |= (q == r) ? bit64(k) : 0ull;
         if (touch_lds && ln == 0) {
-            chmap(1 + type)[cell_of(s_xy)] = (uint16_t)validx(r, k);
+            chmap(1 + type)[cell_of(s_xy)] = to_map(1 + type, validx(r, k));
             val[validx(r, k)] = s_e;
         }
     }
@@ -474,7 +489,7 @@ struct Env {
     // maps -> all zero, observation descriptors -> LDS
     PPG_MEMBER void init_lds(const Pre &p) {
         uint32_t *m32 = (uint32_t *)map;
-        const int n32 = 4 * P.map_n / 2;
+        const int n32 = 4 * P.map_n * (int)sizeof(map_t) / 4;
         for (int i = ln; i < n32; i += 64) m32[i] = 0u;
         if (FASTOBS) {
 #pragma unroll
@@ -483,6 +498,7 @@ struct Env {
             for (int i = ln; i < (P.nch_p + P.nch_q) * 128; i += 64) lut[i] = C.obs_lut[i];
         }
         if (ln == 0) val[0] = 0.0;
+        if (MAP8 && ln < 2) val[129 * (ln + 1)] = 0.0;   // the zero entries leading the prey and grass sections
         gxyr[0] = p.gxy[0];
         gxyr[1] = p.gxy[1];
         if (WALLS)
@@ -505,7 +521,7 @@ struct Env {
                     g = (C.cap_g < v) ? C.cap_g : v;  // Python min(v, cap)
                 }
                 val[grass_validx(pp)] = g;
-                chmap(3)[cell_of(gxyr[q])] = (uint16_t)grass_validx(pp);
+                chmap(3)[cell_of(gxyr[q])] = to_map(3, grass_validx(pp));
             }
         }
         for (int pp = 128 + ln; pp < C.n_grass; pp += 64) {
@@ -515,7 +531,7 @@ struct Env {
                 g = (C.cap_g < v) ? C.cap_g : v;
             }
             val[grass_validx(pp)] = g;
-            chmap(3)[cell_of(C.grass_xy[gb + pp])] = (uint16_t)grass_validx(pp);
+            chmap(3)[cell_of(C.grass_xy[gb + pp])] = to_map(3, grass_validx(pp));
         }
     }
 
@@ -633,11 +649,11 @@ struct Env {
         bool mism[T];
 #pragma unroll
         for (int r = 0; r < T; ++r)
-            if ((alive[r] >> ln) & 1ull) chmap(1 + type_of(r))[cell_of(xy[r])] = (uint16_t)validx(r, ln);
+            if ((alive[r] >> ln) & 1ull) chmap(1 + type_of(r))[cell_of(xy[r])] = to_map(1 + type_of(r), validx(r, ln));
         wv::sync();
 #pragma unroll
         for (int r = 0; r < T; ++r)
-            mism[r] = ((alive[r] >> ln) & 1ull) && chmap(1 + type_of(r))[cell_of(xy[r])] != (uint16_t)validx(r, ln);
+            mism[r] = ((alive[r] >> ln) & 1ull) && chmap(1 + type_of(r))[cell_of(xy[r])] != to_map(1 + type_of(r), validx(r, ln));
         uint64_t mm[2] = {0, 0};
 #pragma unroll
         for (int r = 0; r < T; ++r) mm[type_of(r)] |= wv::ballot(mism[r]);
@@ -779,7 +795,7 @@ struct Env {
 #pragma unroll
             for (int r = 0; r < T; ++r) todo[r] = (type_of(r) == type) ? acted[r] : 0ull;
             if (!cooc[type]) {
-                uint16_t *A = chmap(1 + type), *F = chmap(0);
+                map_t *A = chmap(1 + type), *F = chmap(0);
                 const int G1 = P.G - 1;
                 uint32_t t_xy[T], rd[T], verdict[T];
                 bool mover[T];
@@ -799,7 +815,7 @@ struct Env {
                     }
                     mover[r] = ((acted[r] >> ln) & 1ull) && t_xy[r] != xy[r];
                     rd[r] = 0;
-                    if ((alive[r] >> ln) & 1ull) A[cell_of(xy[r])] = (uint16_t)validx(r, ln);  // sitters
+                    if ((alive[r] >> ln) & 1ull) A[cell_of(xy[r])] = to_map(1 + type, validx(r, ln));  // sitters
                 }
                 wv::sync();
 #pragma unroll
@@ -814,13 +830,13 @@ struct Env {
 #pragma unroll
                 for (int r = 0; r < T; ++r) {
                     if (type_of(r) != type) continue;
-                    if (mover[r] && rd[r] == 0u) A[cell_of(t_xy[r])] = (uint16_t)validx(r, ln);  // claim
+                    if (mover[r] && rd[r] == 0u) A[cell_of(t_xy[r])] = to_map(1 + type, validx(r, ln));  // claim
                 }
                 wv::sync();
 #pragma unroll
                 for (int r = 0; r < T; ++r) {
                     if (type_of(r) != type) continue;
-                    if (mover[r] && rd[r] == 0u && A[cell_of(t_xy[r])] != (uint16_t)validx(r, ln))
+                    if (mover[r] && rd[r] == 0u && A[cell_of(t_xy[r])] != to_map(1 + type, validx(r, ln)))
                         F[cell_of(t_xy[r])] = 1;  // contested target
                 }
                 wv::sync();
@@ -999,7 +1015,7 @@ struct Env {
         for (int r = 0; r < T; ++r) {
             if ((alive[r] >> ln) & 1ull) {
                 val[validx(r, ln)] = shown(r);
-                if ((owns[r] >> ln) & 1ull) chmap(1 + type_of(r))[cell_of(xy[r])] = (uint16_t)validx(r, ln);
+                if ((owns[r] >> ln) & 1ull) chmap(1 + type_of(r))[cell_of(xy[r])] = to_map(1 + type_of(r), validx(r, ln));
             }
         }
         wv::sync();
@@ -1038,7 +1054,7 @@ struct Env {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const uint32_t w = lutr[BASE + 2 * c + h];
-                    idx[c][h] = map[(int)(int16_t)(w & 0xFFFFu) + s_cell];
+                    idx[c][h] = (uint32_t)map[(int)(int16_t)(w & 0xFFFFu) + s_cell] + (MAP8 ? (w >> 30) * 129u : 0u);  // bits 30-31: section
                     one[c][h] = false;
                 }
         } else {
@@ -1049,7 +1065,7 @@ struct Env {
                     const uint32_t w = lutr[BASE + 2 * c + h];
                     const int gx = x + (int)((w >> 16) & 15u) - 8, gy = y + (int)((w >> 20) & 15u) - 8;
                     const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
-                    idx[c][h] = map[inb ? (int)(int16_t)(w & 0xFFFFu) + s_cell : 0];
+                    idx[c][h] = (uint32_t)map[inb ? (int)(int16_t)(w & 0xFFFFu) + s_cell : 0] + ((MAP8 && inb) ? (w >> 30) * 129u : 0u);
                     one[c][h] = !inb && (w & 0x3000000u) == 0u;  // channel 0 outside the grid (BASE:522-523)
                 }
         }
@@ -1122,7 +1138,7 @@ struct Env {
             const uint32_t w = L[strided ? (el & ~127) + (w7 & 63) * 2 + (w7 >> 6) : el];
             const int gx = x + (int)((w >> 16) & 15u) - 8, gy = y + (int)((w >> 20) & 15u) - 8;
             const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
-            win[i] = val[map[inb ? (int)(int16_t)(w & 0xFFFFu) + s_cell : 0]];
+            win[i] = val[from_map(ch, map[inb ? (int)(int16_t)(w & 0xFFFFu) + s_cell : 0])];
         }
         wv::sync();
         double res;
@@ -1216,7 +1232,7 @@ struct Env {
             }
 #pragma unroll
             for (int ch = 1; ch < 4; ++ch) {
-                double t = val[chmap(ch)[a]];
+                double t = val[from_map(ch, chmap(ch)[a])];
                 if (!inb) t = 0.0;
                 if (C.mask_obs) t = (double)((float)t * (inb ? vis : 0.0f));
                 v[ch] = t;
@@ -1264,7 +1280,7 @@ struct Env {
             v[0] = inb ? 0.0 : 1.0;                      // DRV:561-562: 1 everywhere except the in-grid part of the window
 #pragma unroll
             for (int ch = 1; ch < 4; ++ch) {
-                const double t = val[chmap(ch)[a]];
+                const double t = val[from_map(ch, chmap(ch)[a])];
                 v[ch] = inb ? t : 0.0;
             }
             if (valid) {
@@ -1368,7 +1384,7 @@ struct Env {
                 for (int h = 0; h < 2; ++h) {
                     const uint32_t w = h ? d.y : d.x;
                     const int a = (int)(int16_t)(w & 0xFFFFu) + s_cell;
-                    v[h] = val[map[a]];  // a non-existent element has moff 0: reads the observer's own cell, unused
+                    v[h] = val[from_map((int)((w >> 24) & 3u), map[a])];  // a non-existent element has moff 0: reads the observer's own cell in the all-zero map, unused
                 }
             } else {
 #pragma unroll
@@ -1377,7 +1393,8 @@ struct Env {
                     const int gx = x + (int)((w >> 16) & 15u) - 8, gy = y + (int)((w >> 20) & 15u) - 8;
                     const bool inb = (w & 0x8000000u) && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
                     const int a = (int)(int16_t)(w & 0xFFFFu) + s_cell;
-                    double t = val[map[inb ? a : 0]];        // map[0] (channel 0, cell 0) is always 0 -> val[0] = 0.0
+                    double t = val[from_map((int)((w >> 24) & 3u), map[inb ? a : 0])];   // map[0] (channel 0, cell 0) is always 0 -> val[0] = 0.0
+                                                                                          // (a drive element carries its plane index there: its map entry is 0 anyway)
                     if (DRIVE && (w & 0x20000000u)) {       // a drive channel: the whole (R,R) plane holds one scalar (DRV:566-569)
                         const uint32_t k = (w >> 24) & 3u;
                         t = k == 0 ? dv[0] : k == 1 ? dv[1] : k == 2 ? dv[2] : dv[3];
@@ -1441,7 +1458,7 @@ struct Env {
             const uint32_t en = wv::first(lst[1 + i]);
             const int ty = (int)(en >> 31), row = (int)((en >> 16) & 0x7FFFu);
             // (drive variant: the agent's energy is its entry of the LDS value table -- row energies are kept current there)
-            const double s_e = DRIVE ? first_f64(val[1 + (ty ? P.cap_pred + row : row)]) : 0.0;
+            const double s_e = DRIVE ? first_f64(val[validx_row(ty, row)]) : 0.0;
             obs_row(ty, row, en & 0xFFFFu, s_e);
         }
     }
@@ -1565,7 +1582,8 @@ struct Env {
 #pragma unroll
         for (int r = 1; r < T; ++r) {
             const uint64_t mine = alive[r] & (sel == 0 ? ~0ull : (sel == 2 ? t2m[r] : ~t2m[r]));
-            pidx[r] = ((mine >> ln) & 1ull) ? chmap(3)[cell_of(xy[r])] : 0u;
+            const uint32_t gm = ((mine >> ln) & 1ull) ? (uint32_t)chmap(3)[cell_of(xy[r])] : 0u;
+            pidx[r] = gm ? (uint32_t)from_map(3, gm) : 0u;   // 0 = not standing on a patch
             ong[r] = wv::ballot(pidx[r] != 0u) & mine;
             stv[r] = wv::ballot(e[r] <= 0.0) & mine;
             anystv |= stv[r];
@@ -1580,7 +1598,7 @@ struct Env {
                     if (GEN2) keep[r] &= ~(uint32_t)PPG_ROW_GRID_E0;
                     val[pidx[r]] = 0.0;
                     val[validx(r, ln)] = e[r];
-                    chmap(2)[cell_of(xy[r])] = (uint16_t)validx(r, ln);
+                    chmap(2)[cell_of(xy[r])] = to_map(2, validx(r, ln));
                     ev[r] |= EV_ATE;
                 }
                 owns[r] |= ong[r];
@@ -1612,7 +1630,7 @@ struct Env {
     PPG_MEMBER bool fallback_spawn(int type, int cid, uint32_t &child_xy) {
         // BASE:759-764.  The reference draws from the unseeded global np.random; the build's
         // contract (oracle/ppg_oracle.c:find_spawn) is the k-th free cell in x-major order.
-        uint16_t *occ = chmap(0);
+        map_t *occ = chmap(0);
         wv::sync();
 #pragma unroll
         for (int r = 0; r < T; ++r)
@@ -2016,7 +2034,8 @@ struct Env {
         episode = new_episode;
         const int n = P.G * P.G;
         const int K = C.n_init_pred + C.n_init_prey + C.n_grass;
-        uint16_t *perm = chmap(1), *ent = chmap(2);
+        // two arrays of G*G 16-bit cell indices over the map area (MAP8: the four 8-bit maps together are exactly that large)
+        uint16_t *perm = MAP8 ? (uint16_t *)map : (uint16_t *)chmap(1), *ent = MAP8 ? (uint16_t *)map + P.map_n : (uint16_t *)chmap(2);
         uint32_t *rnd = (uint32_t *)scr;  // 256 words per round
         wv::sync();
         int n_free = n;
@@ -2097,7 +2116,7 @@ struct Env {
         for (int p = ln; p < C.n_grass; p += 64) {
             // re-read what this lane just wrote (same lane, same address)
             val[grass_validx(p)] = C.e0_g;
-            chmap(3)[cell_of(C.grass_xy[gb + p])] = (uint16_t)grass_validx(p);
+            chmap(3)[cell_of(C.grass_xy[gb + p])] = to_map(3, grass_validx(p));
         }
         n_rows[0] = P0; n_rows[1] = Q0;
         next_id[0] = P0; next_id[1] = Q0;            // BASE:153-154
@@ -2266,7 +2285,7 @@ struct Env {
         double *out = C.grid_out + (size_t)b * 4 * n;
         for (int i = ln; i < 4 * n; i += 64) {
             const int ch = i / n, c = i - ch * n;
-            out[i] = ch ? val[chmap(ch)[c]] : ((WALLS && ((wallw[c >> 5] >> (c & 31)) & 1u)) ? 1.0 : 0.0);  // WO:271-273
+            out[i] = ch ? val[from_map(ch, chmap(ch)[c])] : ((WALLS && ((wallw[c >> 5] >> (c & 31)) & 1u)) ? 1.0 : 0.0);  // WO:271-273
         }
     }
 };

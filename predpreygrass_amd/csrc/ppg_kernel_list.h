@@ -20,12 +20,14 @@
     PPG_K(ppg_step_kick_q##NQ##g, NQ, ppg::MODE_STEP_KICK, false)     \
     PPG_K(ppg_step_ord_kick_q##NQ##g, NQ, ppg::MODE_STEP_ORDERED_KICK, false)
 
-// multi-wave step kernels of the base family (4 or 8 wavefronts per env; see Env's NW): ppgw_step_q<NQ>[g], ppgw8_step_*
+// multi-wave step kernels of the base family (4, 8 or 2 wavefronts per env; see Env's NW): ppgw_step_q<NQ>[g], ppgw8_step_*, ppgwp_step_* (a pair)
 #define PPG_DEFINE_KERNELSW(NQ)                                       \
     PPG_KW(ppgw_step_q##NQ, NQ, true, 4)                              \
     PPG_KW(ppgw_step_q##NQ##g, NQ, false, 4)                          \
     PPG_KW(ppgw8_step_q##NQ, NQ, true, 8)                             \
-    PPG_KW(ppgw8_step_q##NQ##g, NQ, false, 8)
+    PPG_KW(ppgw8_step_q##NQ##g, NQ, false, 8)                         \
+    PPG_KW(ppgwp_step_q##NQ, NQ, true, 2)                             \
+    PPG_KW(ppgwp_step_q##NQ##g, NQ, false, 2)
 
 #define PPG_DEFINE_KERNELSW2(NQ)                                      \
     PPG_KW2(ppgw2_step_q##NQ, NQ, true, 4)                            \

@@ -31,6 +31,8 @@ def make_gen2(cfg, B, **kw):
     ("4", ["default_seed0"], 150),              # descriptors in registers (7x7 / 9x9 windows)
     ("8", ["default_seed1"], 150),
     ("4", ["c4_seed0"], 100),                   # 64x64 grid
+    ("2", ["c4_seed0"], 100),                   # the pair kernel (what the library picks for 64x64 grids: 8-bit maps, 7 envs per CU)
+    ("2", ["dense_seed3"], None),               # ghost cells / co-occupancy through the pair kernel
     ("8", ["even_obs_seed0"], None),            # even windows, ends with the truncation call
     ("4", ["kickback_fast_seed5"], 120),        # reward kick-backs to grandparents
     ("4", ["drive_default_seed2"], 100),        # drive variant: four-wave kernel with per-wave window staging
@@ -43,7 +45,7 @@ def test_base_family_golden_cases_multiwave(waves, names, max_calls, monkeypatch
 
 def test_wave_count_takes_effect(monkeypatch):
     lib = emu_backend.library()
-    for waves, drive, expect in (("1", False, 1), ("4", False, 4), ("8", False, 8), ("8", True, 4)):
+    for waves, drive, expect in (("1", False, 1), ("2", False, 2), ("4", False, 4), ("8", False, 8), ("8", True, 4), ("2", True, 4)):
         monkeypatch.setenv("PPG_EMU_WAVES", waves)
         env = make_base({**config_env, "enable_drive_channels": drive}, 1)
         env.reset(seed=1)
@@ -62,7 +64,7 @@ def test_second_generation_golden_cases_multiwave(waves, name, monkeypatch):
     replay_golden_case(make_gen2, name, max_calls=100)
 
 
-@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("waves", ["2", "4", "8"])
 def test_multiwave_random_rollout_matches_oracle_and_single_wave(waves, monkeypatch):
     """Device reset + Philox actions + auto-reset on a config with the generic (LDS descriptor) observation path and
     more prey than one register holds; every call against the oracle, and the final state against the single-wave run."""

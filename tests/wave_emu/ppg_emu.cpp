@@ -97,6 +97,7 @@ static void run_mode4(const ppg::KParams &P, int mode) {
 
 template <bool FAST>
 static void run_nq(const EmuLaunch *L) {
+    if (L->nw == 2) { run_step_nq<FAST, 2>(L); return; }
     if (L->nw == 4) { run_step_nq<FAST, 4>(L); return; }
     if (L->nw == 8) { run_step_nq<FAST, 8>(L); return; }
     if (L->gen2 == 3) {  // drive-conditioned variant of the base family: generic observation geometry only
@@ -168,9 +169,9 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     if (mode == ppg::MODE_STEP) {
         const char *w = getenv("PPG_EMU_WAVES");
         const int nw = w ? atoi(w) : 1;
-        if (nw == 4 || (nw == 8 && L.gen2 < 2)) L.nw = nw;
-        else if (nw == 8) L.nw = 4;
-        else if (nw != 1 && nw != 0) return ppg_fail(h, PPG_EINVAL, "PPG_EMU_WAVES=%d (1, 4 or 8)", nw);
+        if (nw == 4 || (nw == 8 && L.gen2 < 2) || (nw == 2 && L.gen2 == 0)) L.nw = nw;
+        else if (nw == 8 || nw == 2) L.nw = 4;
+        else if (nw != 1 && nw != 0) return ppg_fail(h, PPG_EINVAL, "PPG_EMU_WAVES=%d (1, 2, 4 or 8)", nw);
     }
     for (int b = 0; b < h->batch; ++b) wv::run_block(lane_entry, &L, b, (size_t)P.lds_bytes, L.nw);
     return PPG_OK;

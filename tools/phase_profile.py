@@ -33,6 +33,9 @@ if WALLS:
 elif RQ:
     from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
     env = BatchedRedQueen(config_env_base, batch_size=B, device="cuda:0", obs_dtype=torch.float32)
+elif "--c4" in sys.argv:   # BASELINE.json configs[3]: 64x64 grid, 16 predators / 32 prey, 7x7 windows
+    env = BatchedPredPreyGrass({**config_env, "grid_size": 64, "n_initial_active_predator": 16, "n_initial_active_prey": 32,
+                                "predator_obs_range": 7, "prey_obs_range": 7}, batch_size=B, device="cuda:0")
 elif DRIVE:
     env = BatchedPredPreyGrass({**config_env, "enable_drive_channels": True}, batch_size=B, device="cuda:0")
 else:
