@@ -494,9 +494,12 @@ def main(argv=None, backend=None):
     survey_bytes = env_steps_rank * 2 * 3 * G * G * 8 + obs_bytes + 64 * (n_obs_pred + n_obs_prey)
     # which step kernel the library picked (predpreygrass_amd/csrc/ppg_host.h: ppg_use_multiwave): four waves per env while the
     # GPU is not full (<= 3072 envs in flight) or when LDS admits at most 4 envs per CU
-    multiwave = (B <= 3072) or (160 * 1024 // max(env.lds_bytes, 1) <= 4) or args.workload in ("drive", "walls")
+    lds_envs = 160 * 1024 // max(env.lds_bytes, 1)
+    multiwave = (B <= 3072) or (lds_envs <= 8) or args.workload in ("drive", "walls")
     if os.environ.get("PPG_MULTIWAVE") is not None:
         multiwave = os.environ["PPG_MULTIWAVE"] != "0"
+    # a full GPU whose LDS admits 5-8 envs per CU (64x64 grids): the two-waves-per-env kernel
+    pair = multiwave and not rq and args.workload != "drive" and B > 3072 and 5 <= lds_envs <= 8 and os.environ.get("PPG_MULTIWAVE_PAIR", "1") != "0"
     kernel_s = dev_ms / 1e3 / args.steps          # per launch; n_sub launches are in flight concurrently
     achieved = run_bytes / args.steps / kernel_s / 1e9   # all n_sub concurrent launches together
     value = n_gpus * env_steps_rank / wall
@@ -535,7 +538,7 @@ def main(argv=None, backend=None):
             "kernel": {"walls": "ppgw3_step_q2" if multiwave else "ppg3_step_q2",
                        "drive": "ppgw4_step_q2" if multiwave else "ppg4_step_q2",
                        "red_queen": "ppgw2_step_q2" if multiwave else "ppg2_step_q2"}.get(
-                           args.workload, "ppgw_step_q2" if multiwave else "ppg_step_q2"),
+                           args.workload, "ppgwp_step_q2" if pair else "ppgw_step_q2" if multiwave else "ppg_step_q2"),
             "kernel_ms": round(kernel_s * 1e3, 5),
             "concurrent_launches": n_sub,
             "counted_bytes_per_launch": int(run_bytes / args.steps / n_sub),
