@@ -328,8 +328,8 @@ int ppg_walls_changed(ppg_handle *h, void *stream);
 
 /* Scheduling only, results are unaffected: recompute the order in which the handle's envs are assigned to workgroups --
  * envs with many agent rows (much observation data to write) first, so that the load is spread evenly over the CUs.
- * Stream-ordered like a step; populations drift slowly, calling it every few dozen steps is enough (bench.py: every 32).
- * The order is used by every later launch of the handle. */
+ * Stream-ordered like a step (one small launch: a counting sort in LDS, any batch size); populations drift slowly, calling it
+ * every few dozen steps is enough (bench.py: every 64).  The order is used by every later launch of the handle. */
 int ppg_rebalance(ppg_handle *h, void *stream);
 
 /* grid_world_state (BASE:124): dense float64 [B,4,G,G] rebuilt from the rows. */

@@ -122,31 +122,43 @@ static void backend_release(ppg_handle *h) {
     h->order_dev = nullptr;
 }
 
-// order[rank(i)] = i, rank by descending key (rows weighted by observation size), ties by index: a counting sort that
-// needs no scratch.  Every workgroup stages all keys in LDS (4 bytes per env) and each thread ranks one env.
-extern "C" __global__ void __launch_bounds__(256) ppg_rank_envs(const int32_t *env_state, int batch, int wp, int wq, int32_t *order) {
-    extern __shared__ int32_t keys[];
-    for (int j = (int)threadIdx.x; j < batch; j += (int)blockDim.x)
-        keys[j] = env_state[(size_t)j * PPG_ENV_WORDS + PPG_ENV_N_PRED_ROWS] * wp + env_state[(size_t)j * PPG_ENV_WORDS + PPG_ENV_N_PREY_ROWS] * wq;
+// order[] = the envs sorted by descending key (rows weighted by observation size): a counting sort in ONE workgroup, O(B) for any
+// batch size.  Keys are small (<= 64 * 8 + 256 * 8), so the histogram lives in LDS; envs with equal keys land in arbitrary order
+// (atomics) -- the order only decides which workgroup steps which env, never a result.
+#define PPG_RANK_BINS 2568
+extern "C" __global__ void __launch_bounds__(1024) ppg_rank_envs(const int32_t *env_state, int batch, int wp, int wq, int32_t *order) {
+    __shared__ int32_t hist[PPG_RANK_BINS];
+    const int t = (int)threadIdx.x;
+    for (int k = t; k < PPG_RANK_BINS; k += 1024) hist[k] = 0;
     __syncthreads();
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= batch) return;
-    const int ki = keys[i];
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < batch; ++j) {
-        const int kj = keys[j];
-        rank += (kj > ki) || (kj == ki && j < i);
+    for (int i = t; i < batch; i += 1024) {
+        int key = env_state[(size_t)i * PPG_ENV_WORDS + PPG_ENV_N_PRED_ROWS] * wp + env_state[(size_t)i * PPG_ENV_WORDS + PPG_ENV_N_PREY_ROWS] * wq;
+        key = key < 0 ? 0 : (key >= PPG_RANK_BINS ? PPG_RANK_BINS - 1 : key);
+        atomicAdd(&hist[key], 1);
     }
-    order[rank] = i;
+    __syncthreads();
+    if (t < 64) {   // exclusive prefix over the bins in DESCENDING key order: one wavefront, 41 bins per lane
+        const int per = (PPG_RANK_BINS + 63) / 64;
+        const int hi = PPG_RANK_BINS - 1 - t * per;          // this lane's bins: hi, hi-1, ..., hi-per+1
+        int sum = 0;
+        for (int q = 0; q < per; ++q) if (hi - q >= 0) sum += hist[hi - q];
+        int before = 0;
+        for (int l = 0; l < 64; ++l) { const int v = __shfl(sum, l, 64); if (l < t) before += v; }
+        for (int q = 0; q < per; ++q) if (hi - q >= 0) { const int c = hist[hi - q]; hist[hi - q] = before; before += c; }
+    }
+    __syncthreads();
+    for (int i = t; i < batch; i += 1024) {
+        int key = env_state[(size_t)i * PPG_ENV_WORDS + PPG_ENV_N_PRED_ROWS] * wp + env_state[(size_t)i * PPG_ENV_WORDS + PPG_ENV_N_PREY_ROWS] * wq;
+        key = key < 0 ? 0 : (key >= PPG_RANK_BINS ? PPG_RANK_BINS - 1 : key);
+        order[atomicAdd(&hist[key], 1)] = i;
+    }
 }
 
 static int backend_rebalance(ppg_handle *h, int weight_pred, int weight_prey, void *stream) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
     if (!h->order_dev) PPG_HIP_TRY(h, hipMalloc((void **)&h->order_dev, (size_t)h->batch * sizeof(int32_t)));
-    if (h->batch > 16000) return ppg_fail(h, PPG_EINVAL, "ppg_rebalance supports up to 16000 envs per handle (use sub-batches)");
-    hipLaunchKernelGGL(ppg_rank_envs, dim3((unsigned)((h->batch + 255) / 256)), dim3(256), (size_t)h->batch * sizeof(int32_t), (hipStream_t)stream,
+    hipLaunchKernelGGL(ppg_rank_envs, dim3(1), dim3(1024), 0, (hipStream_t)stream,
                        (const int32_t *)h->bufs.env_state, (int)h->batch, weight_pred, weight_prey, h->order_dev);
     PPG_HIP_TRY(h, hipGetLastError());
     return PPG_OK;

@@ -1,0 +1,30 @@
+#!/bin/bash
+# On the GPU box: the end-of-round evidence run.  usage: tools/gpu_round_report.sh <tag>
+set -u
+tag=${1:-r02c}
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${tag}_pytest.log
+bash tools/gpu_profile_driver_cmd.sh ${tag} > gpurun_out/${tag}_profile.log 2>&1
+for w in c4 red_queen drive walls; do
+  python3 bench.py --workload $w --steps 1000 --warmup 100 > gpurun_out/${tag}_bench_$w.json 2>> gpurun_out/${tag}_bench.err
+done
+python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --cpu-seconds 8 > gpurun_out/${tag}_bench_policy_rollout.json 2>> gpurun_out/${tag}_bench.err
+python3 bench.py --envs 256 --steps 2000 --warmup 100 --no-cpu-baseline > gpurun_out/${tag}_bench_c2_256envs.json 2>> gpurun_out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_ptrace -o t -- python3 bench.py --workload policy_rollout --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_policy_under_trace.json 2> gpurun_out/${tag}_ptrace.err
+find gpurun_out/${tag}_ptrace -name '*kernel_stats.csv' -exec cp {} gpurun_out/${tag}_kernel_stats_policy.csv \;
+rm -rf gpurun_out/${tag}_ptrace
+cat gpurun_out/${tag}_pytest.log
+for f in gpurun_out/${tag}_bench_*.json gpurun_out/${tag}_bench.json; do python3 - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print(sys.argv[1].split("/")[-1], d["value"], d["ms_per_step"], r.get("kernel"), r["kernel_ms"], r["frac"], d["config"].get("mean_agents_per_env"))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+done
+tail -c 600 gpurun_out/${tag}_summary.log
+head -5 gpurun_out/${tag}_kernel_stats_policy.csv | cut -c1-200
