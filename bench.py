@@ -263,12 +263,14 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
                                  "kernel_ms = both species' forward launches + their plan launches per step (HIP events on the stream)"},
         }
         if not args.no_cpu_baseline and n_gpus == 1:
-            torch.set_num_threads(os.cpu_count() or 1)
-            x = [torch.rand(256, 4, env.Rp, env.Rp), torch.rand(1024, 4, env.Rq, env.Rq)]
+            n_threads = min(os.cpu_count() or 1, 32)   # (more threads than that make these small convolutions slower, not faster)
+            torch.set_num_threads(n_threads)
+            x = [torch.rand(2048, 4, env.Rp, env.Rp), torch.rand(2048, 4, env.Rq, env.Rq)]
             cost = []   # seconds per observation on the host, per species (bounded: --cpu-seconds in total)
             with torch.no_grad():
                 for net, xx in zip(nets, x):
                     net = net.to("cpu")
+                    net(xx)
                     net(xx)
                     tc, reps = time.perf_counter(), 0
                     while time.perf_counter() - tc < args.cpu_seconds / 2:
@@ -277,8 +279,8 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
                     cost.append((time.perf_counter() - tc) / reps / xx.shape[0])
             tp, tq = cost
             mp, mq = n_pred / (B * args.steps), n_prey / (B * args.steps)
-            out["cpu_baseline"] = {"value": round(1.0 / (mp * tp + mq * tq), 1), "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": f"the same two networks as float32 PyTorch modules on the host ({os.cpu_count()} threads): "
+            out["cpu_baseline"] = {"value": round(1.0 / (mp * tp + mq * tq), 1), "unit": "env-steps/s", "cores": n_threads, "kind": "port",
+                                   "sample": f"the same two networks as float32 PyTorch modules on the host ({n_threads} threads, batches of 2048): "
                                              f"{tp * 1e6:.1f} us per predator observation, {tq * 1e6:.1f} us per prey observation, x {mp:.1f} / {mq:.1f} "
                                              "observations per env-step; the env transition itself (0.5 M env-steps/s on these cores) is not included"}
         print(json.dumps(out), flush=True)
