@@ -68,8 +68,8 @@ struct PolParams {
     int8_t *actions[MAX_HANDLES];
     int32_t S, cap, slot0;        // rows per env of the action tensor; row capacity of this species; its first slot
     // scratch
-    const uint32_t *plan;         // [0] = total rows of this species, [1 + e] = exclusive prefix sum of env e
-    const uint32_t *tile_env;     // [tile] = env of sample tile * 128
+    const uint32_t *plan;         // [0] = total rows of this species, [1] = samples per tile (64 / 96 / 128), [2 + e] = exclusive prefix sum of env e
+    const uint32_t *tile_env;     // [tile] = env of the tile's first sample
     uint32_t magic_P, magic_R;    // ceil(2^32 / P), ceil(2^32 / R): n / P == mulhi(n, magic_P) for the small n used here
     __bf16 *xg;                   // [gridDim.x][TILE][K1]
     float *logits;                // optional [rows][n_actions]
@@ -77,6 +77,8 @@ struct PolParams {
 
 struct PlanParams {
     int32_t n_handles, n_envs, word;   // word: PPG_ENV_N_PRED_ROWS / PPG_ENV_N_PREY_ROWS
+    int32_t slots;                     // workgroups the forward launch keeps resident (its grid)
+    int32_t force_ts;                  // experiments (env PPG_POLICY_TILE): 64 / 96 / 128 instead of the choice below; 0 = choose
     int32_t env_base[MAX_HANDLES + 1];
     const int32_t *env_state[MAX_HANDLES];
     uint32_t *plan;
@@ -116,19 +118,27 @@ extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan(const PlanPar
     const uint32_t all = part[1023];
     for (int e = lo; e < hi; ++e) {
         const int k = handle_of(K.env_base, K.n_handles, e);
-        K.plan[1 + e] = before;
+        K.plan[2 + e] = before;
         before += (uint32_t)K.env_state[k][(size_t)(e - K.env_base[k]) * PPG_ENV_WORDS + K.word];
     }
-    if (t == 0) K.plan[0] = all;
+    // Samples per workgroup tile: 128 (the FC1 weights are re-read once per tile) unless that leaves resident workgroup slots empty:
+    // then the largest of 96 / 64 that fills them, else 64.  (Measured at 134 k prey + 22 k predator rows: prey 128 / predators 64
+    // 1.60 ms; 128 / 128 1.67; prey 96 1.67-1.89; prey 64 1.95-2.04 -- two workgroups share a CU, so a thinly filled last round
+    // of large tiles runs faster than its share, and smaller tiles only pay where workgroups would otherwise be missing.)
+    uint32_t ts = 64;
+    for (uint32_t cand = (uint32_t)TILE; cand >= 64; cand -= 32)
+        if ((all + cand - 1) / cand >= (uint32_t)K.slots) { ts = cand; break; }
+    if (K.force_ts) ts = (uint32_t)K.force_ts;
+    if (t == 0) { K.plan[0] = all; K.plan[1] = ts; }
     __threadfence_block();
     __syncthreads();   // (the prefix sums are re-read below by other threads of this workgroup: same CU, written through L1)
-    const int n_tiles = (int)((all + TILE - 1) / TILE);
+    const int n_tiles = (int)((all + ts - 1) / ts);
     for (int tile = t; tile < n_tiles; tile += 1024) {
-        const uint32_t n = (uint32_t)tile * TILE;
+        const uint32_t n = (uint32_t)tile * ts;
         int a = 0, b = K.n_envs - 1;
         while (a < b) {   // the last env whose prefix sum is <= n
             const int mid = (a + b + 1) >> 1;
-            if (__builtin_nontemporal_load(&K.plan[1 + mid]) <= n) a = mid; else b = mid - 1;
+            if (__builtin_nontemporal_load(&K.plan[2 + mid]) <= n) a = mid; else b = mid - 1;
         }
         K.tile_env[tile] = (uint32_t)a;
     }
@@ -265,27 +275,33 @@ __device__ __forceinline__ void fc1_issue(const bf16x8 *w1, int K1, const __bf16
     }
 }
 
-__device__ __forceinline__ void fc1_compute(const unsigned char *stage, int c, f32x16 (&acc)[4][2], int wave, int lane) {
+// FC layers over a tile of NT x 32 samples: wavefront w owns the feature row tiles 2w, 2w + 1 and ALL column tiles (2 x NT
+// accumulators), so the same code serves tiles of 64, 96 and 128 samples.
+template <int NT>
+__device__ __forceinline__ void fc1_compute(const unsigned char *stage, int c, f32x16 (&acc)[2][NT], int wave, int lane) {
     const int h = lane >> 5, col = lane & 31;
-    const int mt0 = 4 * (wave & 1), nt0 = 2 * (wave >> 1);
     const bf16x8 *wb = (const bf16x8 *)(stage + (size_t)(c % 3) * FC1_BUF);
     const unsigned char *xb = stage + (size_t)(c % 3) * FC1_BUF + 16384;
-    const int n0 = 32 * nt0 + col, n1 = n0 + 32;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
         const int q = 2 * k2 + h;
-        const bf16x8 x0 = *(const bf16x8 *)(xb + n0 * 64 + 16 * (q ^ ((n0 >> 2) & 3)));
-        const bf16x8 x1 = *(const bf16x8 *)(xb + n1 * 64 + 16 * (q ^ ((n1 >> 2) & 3)));
+        bf16x8 x[NT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const bf16x8 w = wb[(k2 * 8 + mt0 + m) * 64 + lane];
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x0, acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, acc[m][1], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) {
+            const int n = 32 * t + col;
+            x[t] = *(const bf16x8 *)(xb + n * 64 + 16 * (q ^ ((n >> 2) & 3)));
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const bf16x8 w = wb[(k2 * 8 + 2 * wave + m) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x[t], acc[m][t], 0, 0, 0);
         }
     }
 }
 
-__device__ __forceinline__ void fc1_staged(const bf16x8 *w1, int K1, const __bf16 *xg_tile, unsigned char *stage, f32x16 (&acc)[4][2],
+template <int NT>
+__device__ __forceinline__ void fc1_staged(const bf16x8 *w1, int K1, const __bf16 *xg_tile, unsigned char *stage, f32x16 (&acc)[2][NT],
                                            int wave, int lane) {
     const int n_chunks = K1 / 32;
     fc1_issue(w1, K1, xg_tile, stage, 0, wave, lane);
@@ -296,66 +312,66 @@ __device__ __forceinline__ void fc1_staged(const bf16x8 *w1, int K1, const __bf1
         else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // everybody's copies of chunk c are in LDS, and everybody is done with chunk c - 1's buffer
         if (c + 2 < n_chunks) fc1_issue(w1, K1, xg_tile, stage, c + 2, wave, lane);
-        fc1_compute(stage, c, acc, wave, lane);
+        fc1_compute<NT>(stage, c, acc, wave, lane);
     }
     __syncthreads();
 }
 
-// a fully connected layer over the tile: M = 256 output features (8 row tiles), N = 128 samples (4 column tiles).
-// Wavefront w: row tiles 4*(w&1) .. +3, column tiles 2*(w>>1), +1.  B fragments: 16 bytes at bsrc + sample*bstride + 16ks + 8h.
-// (the weight fragments come straight from L2: they are fetched two k-steps ahead of their use)
-template <int KSTEPS>
-__device__ __forceinline__ void fc_256(const bf16x8 *wfrag, const __bf16 *bsrc, size_t bstride, f32x16 (&acc)[4][2],
-                                       int wave, int lane) {
+// M = 256 output features from K = 16 * KSTEPS inputs held in LDS as bsrc[sample][...] (B fragments: 16 bytes at
+// bsrc + sample * bstride + 16 ks + 8 h); the weight fragments come straight from L2, fetched two k-steps ahead of their use.
+template <int KSTEPS, int NT>
+__device__ __forceinline__ void fc_256(const bf16x8 *wfrag, const __bf16 *bsrc, size_t bstride, f32x16 (&acc)[2][NT], int wave, int lane) {
     const int h = lane >> 5, col = lane & 31;
-    const int mt0 = 4 * (wave & 1), nt0 = 2 * (wave >> 1);
-    const __bf16 *b0 = bsrc + (size_t)(32 * nt0 + col) * bstride + 8 * h;
-    const __bf16 *b1 = b0 + 32 * bstride;
-    const bf16x8 *wa = wfrag + (size_t)mt0 * 64 + lane;
-    bf16x8 w[3][4];
+    const __bf16 *b0 = bsrc + (size_t)col * bstride + 8 * h;
+    const bf16x8 *wa = wfrag + (size_t)(2 * wave) * 64 + lane;
+    bf16x8 w[3][2];
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) w[d][m] = wa[((size_t)d * 8 + m) * 64];
+        for (int m = 0; m < 2; ++m) w[d][m] = wa[((size_t)d * 8 + m) * 64];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
         const int cur = ks % 3, nxt = (ks + 2) % 3;
         if (ks + 2 < KSTEPS) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) w[nxt][m] = wa[((size_t)(ks + 2) * 8 + m) * 64];
+            for (int m = 0; m < 2; ++m) w[nxt][m] = wa[((size_t)(ks + 2) * 8 + m) * 64];
         }
-        const bf16x8 x0 = *(const bf16x8 *)(b0 + 16 * ks), x1 = *(const bf16x8 *)(b1 + 16 * ks);
+        bf16x8 x[NT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][m], x0, acc[m][0], 0, 0, 0);
-            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][m], x1, acc[m][1], 0, 0, 0);
-        }
+        for (int t = 0; t < NT; ++t) x[t] = *(const bf16x8 *)(b0 + (size_t)(32 * t) * bstride + 16 * ks);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cur][m], x[t], acc[m][t], 0, 0, 0);
     }
 }
 
-__device__ __forceinline__ void fc_init(const float *bias, f32x16 (&acc)[4][2], int wave, int lane) {
-    const int h = lane >> 5, mt0 = 4 * (wave & 1);
+template <int NT>
+__device__ __forceinline__ void fc_init(const float *bias, f32x16 (&acc)[2][NT], int wave, int lane) {
+    const int h = lane >> 5;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *(const GLOBAL_AS f32x4 *)(bias + 32 * (mt0 + m) + 16 * h + 4 * g);
+            const f32x4 b = *(const GLOBAL_AS f32x4 *)(bias + 32 * (2 * wave + m) + 16 * h + 4 * g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { acc[m][0][4 * g + i] = b[i]; acc[m][1][4 * g + i] = b[i]; }
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[m][t][4 * g + i] = b[i];
         }
 }
 
 // ReLU(acc) -> H[sample][feature] (bf16, LDS): 32 bytes per lane and tile
-__device__ __forceinline__ void fc_store(const f32x16 (&acc)[4][2], __bf16 *H, int wave, int lane) {
+template <int NT>
+__device__ __forceinline__ void fc_store(const f32x16 (&acc)[2][NT], __bf16 *H, int wave, int lane) {
     const int h = lane >> 5, col = lane & 31;
-    const int mt0 = 4 * (wave & 1), nt0 = 2 * (wave >> 1);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                *(bf16x8 *)(H + (size_t)(32 * (nt0 + t) + col) * HSTRIDE + 32 * (mt0 + m) + 16 * h + 8 * j) = relu_pack8(acc[m][t], 8 * j);
+                *(bf16x8 *)(H + (size_t)(32 * t + col) * HSTRIDE + 32 * (2 * wave + m) + 16 * h + 8 * j) = relu_pack8(acc[m][t], 8 * j);
 }
 
 __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
@@ -392,8 +408,8 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile, i
         if (tid < nt_samples) {
             const uint32_t n = (uint32_t)(n0 + tid);
             int lo = (int)K.tile_env[tile];
-            while (lo + 1 < K.n_envs && K.plan[2 + lo] <= n) ++lo;
-            const int e = lo, row = (int)(n - K.plan[1 + e]);
+            while (lo + 1 < K.n_envs && K.plan[3 + lo] <= n) ++lo;
+            const int e = lo, row = (int)(n - K.plan[2 + e]);
             const int k = handle_of(K.env_base, K.n_handles, e);
             const int b = e - K.env_base[k];
             src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)(4 * K.P) * (OBS_F32 ? 4 : 8));
@@ -477,32 +493,35 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile, i
 }
 
 // ---- phase B: FC1 from the scratch slot, ReLU -> H ----
+template <int NT>
 __device__ __noinline__ void phase_fc1(KPtr Kp, unsigned char *lds, const __bf16 *xg_tile) {
     const auto &K = *Kp;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char *overlay = lds + TILE * 16;
-    f32x16 acc[4][2];
-    fc_init(K.b1, acc, wave, lane);
-    if (!(K.debug_skip & 2)) fc1_staged(K.w1, K.K1, xg_tile, overlay, acc, wave, lane);   // (staging buffers overlay the images)
+    f32x16 acc[2][NT];
+    fc_init<NT>(K.b1, acc, wave, lane);
+    if (!(K.debug_skip & 2)) fc1_staged<NT>(K.w1, K.K1, xg_tile, overlay, acc, wave, lane);   // (staging buffers overlay the images)
     __syncthreads();
-    fc_store(acc, (__bf16 *)overlay, wave, lane);      // (so does H)
+    fc_store<NT>(acc, (__bf16 *)overlay, wave, lane);      // (so does H)
     __syncthreads();
 }
 
 // ---- phases C, D: FC2 from H back into H; logits; actions ----
+template <int NT>
 __device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0, int nt_samples) {
     const auto &K = *Kp;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long *tab = (const unsigned long long *)lds;
     __bf16 *H = (__bf16 *)(lds + TILE * 16);
     {
-        f32x16 acc[4][2];
-        fc_init(K.b2, acc, wave, lane);
-        fc_256<16>(K.w2, H, (size_t)HSTRIDE, acc, wave, lane);
+        f32x16 acc[2][NT];
+        fc_init<NT>(K.b2, acc, wave, lane);
+        fc_256<16, NT>(K.w2, H, (size_t)HSTRIDE, acc, wave, lane);
         __syncthreads();
-        fc_store(acc, H, wave, lane);
+        fc_store<NT>(acc, H, wave, lane);
         __syncthreads();
     }
+    if (wave >= NT) return;   // (one 32-sample column tile per wavefront)
     // logits = W3 (actions padded to 32 rows) x H^T, one 32-sample column tile per wavefront
     const int h = lane >> 5, col = lane & 31;
     f32x16 lg;
@@ -548,15 +567,16 @@ __device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0, int
 
 template <bool OBS_F32>
 __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
-    const int N = (int)Kp->plan[0];
+    const int N = (int)Kp->plan[0], ts = (int)Kp->plan[1];
     __bf16 *xg_tile = Kp->xg + (size_t)blockIdx.x * TILE * Kp->K1;
-    for (int tile = (int)blockIdx.x; tile * TILE < N; tile += (int)gridDim.x) {
-        const int n0 = tile * TILE;
-        const int nt_samples = (N - n0) < TILE ? (N - n0) : TILE;
+    for (int tile = (int)blockIdx.x; tile * ts < N; tile += (int)gridDim.x) {
+        const int n0 = tile * ts;
+        const int nt_samples = (N - n0) < ts ? (N - n0) : ts;
         __syncthreads();   // the previous tile's readers of H / the table are done
         phase_conv<OBS_F32>(Kp, lds, tile, n0, nt_samples, xg_tile);
-        phase_fc1(Kp, lds, xg_tile);
-        phase_head(Kp, lds, n0, nt_samples);
+        if (ts <= 64) { phase_fc1<2>(Kp, lds, xg_tile); phase_head<2>(Kp, lds, n0, nt_samples); }
+        else if (ts <= 96) { phase_fc1<3>(Kp, lds, xg_tile); phase_head<3>(Kp, lds, n0, nt_samples); }
+        else { phase_fc1<4>(Kp, lds, xg_tile); phase_head<4>(Kp, lds, n0, nt_samples); }
     }
 }
 
@@ -788,12 +808,17 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     if (p->plan_envs < total) {
         if (p->plan) (void)hipFree(p->plan);
         p->plan = nullptr;
-        const size_t max_tiles = ((size_t)total * K.cap + ppgpol::TILE - 1) / ppgpol::TILE;
-        PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(1 + total) + max_tiles) * 4));
+        const size_t max_tiles = ((size_t)total * K.cap + 63) / 64;   // (tiles of 64 samples are the smallest the plan picks)
+        PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(2 + total) + max_tiles) * 4));
         p->plan_envs = total;
     }
     K.plan = L.plan = p->plan;
-    K.tile_env = L.tile_env = p->plan + 1 + total;
+    K.tile_env = L.tile_env = p->plan + 2 + total;
+    L.slots = p->grid;
+    if (const char *f = getenv(species ? "PPG_POLICY_TILE_PREY" : "PPG_POLICY_TILE_PRED")) {
+        const int v = atoi(f);
+        if (v == 64 || v == 96 || v == 128) L.force_ts = v;
+    }
     K.logits = logits;
     hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
     if (K.obs_f32) hipLaunchKernelGGL(ppgpol::ppg_policy_forward_f32, dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
