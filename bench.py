@@ -494,14 +494,7 @@ def main(argv=None, backend=None):
     # SURVEY.md section 8(d)'s model of the REFERENCE's data structures: 2*(3*G^2*8) + sum_obs(4*R^2*osz) + 64*L per env-step
     # (its first term is a dense-grid read+write this design never performs) -- kept for comparison only
     survey_bytes = env_steps_rank * 2 * 3 * G * G * 8 + obs_bytes + 64 * (n_obs_pred + n_obs_prey)
-    # which step kernel the library picked (predpreygrass_amd/csrc/ppg_host.h: ppg_use_multiwave): four waves per env while the
-    # GPU is not full (<= 3072 envs in flight) or when LDS admits at most 4 envs per CU
-    lds_envs = 160 * 1024 // max(env.lds_bytes, 1)
-    multiwave = (B <= 3072) or (lds_envs <= 8) or args.workload in ("drive", "walls")
-    if os.environ.get("PPG_MULTIWAVE") is not None:
-        multiwave = os.environ["PPG_MULTIWAVE"] != "0"
-    # a full GPU whose LDS admits 5-8 envs per CU (64x64 grids): the two-waves-per-env kernel
-    pair = multiwave and not rq and args.workload != "drive" and B > 3072 and 5 <= lds_envs <= 8 and os.environ.get("PPG_MULTIWAVE_PAIR", "1") != "0"
+    kernel_name = env._lib.ppg_step_kernel_name(env._handle).decode()   # what ppg_step launches for these handles (csrc/ppg_host.h: ppg_wave_plan)
     kernel_s = dev_ms / 1e3 / args.steps          # per launch; n_sub launches are in flight concurrently
     achieved = run_bytes / args.steps / kernel_s / 1e9   # all n_sub concurrent launches together
     value = n_gpus * env_steps_rank / wall
@@ -537,10 +530,7 @@ def main(argv=None, backend=None):
             "traffic_source": traffic_src,
             "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
                                      "launch = 4.85 TB/s (profiles/r01/c_store_pattern_ceiling.txt); linear fill 6.5 TB/s",
-            "kernel": {"walls": "ppgw3_step_q2" if multiwave else "ppg3_step_q2",
-                       "drive": "ppgw4_step_q2" if multiwave else "ppg4_step_q2",
-                       "red_queen": "ppgw2_step_q2" if multiwave else "ppg2_step_q2"}.get(
-                           args.workload, "ppgwp_step_q2" if pair else "ppgw_step_q2" if multiwave else "ppg_step_q2"),
+            "kernel": kernel_name,
             "kernel_ms": round(kernel_s * 1e3, 5),
             "concurrent_launches": n_sub,
             "counted_bytes_per_launch": int(run_bytes / args.steps / n_sub),

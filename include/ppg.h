@@ -426,6 +426,10 @@ const char *ppg_policy_last_error(const ppg_policy *p);
 /* Sort key of the decimal string of `id` (digits d: sum (d+1)*11^(5-pos)); host helper. */
 uint32_t ppg_lexkey(uint32_t id);
 
+/* Name of the kernel ppg_step launches for this handle right now (it depends on the variant, the row capacity and -- through
+ * ppg_set_envs_in_flight -- on how full the GPU is: one, two, four or eight wavefronts per env).  Diagnostic: profiles name it. */
+const char *ppg_step_kernel_name(ppg_handle *h);
+
 /* Dynamic LDS bytes per wavefront the step kernel uses for this handle (diagnostic). */
 int32_t ppg_lds_bytes(const ppg_handle *h);
 

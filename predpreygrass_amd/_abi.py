@@ -130,7 +130,7 @@ EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
     "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_rebalance",
     "ppg_export_grid", "ppg_walls_changed", "ppg_state_bytes", "ppg_export_state", "ppg_import_state", "ppg_pack_bytes", "ppg_pack",
-    "ppg_lexkey", "ppg_lds_bytes", "ppg_last_error",
+    "ppg_lexkey", "ppg_lds_bytes", "ppg_step_kernel_name", "ppg_last_error",
 ] + POLICY_SYMBOLS
 
 
@@ -189,6 +189,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
         lib.ppg_policy_last_error.argtypes = [C.c_void_p]
     lib.ppg_lexkey.restype = C.c_uint32
     lib.ppg_lexkey.argtypes = [C.c_uint32]
+    lib.ppg_step_kernel_name.restype = C.c_char_p
+    lib.ppg_step_kernel_name.argtypes = [C.c_void_p]
     lib.ppg_lds_bytes.restype = C.c_int32
     lib.ppg_lds_bytes.argtypes = [C.c_void_p]
     lib.ppg_last_error.restype = C.c_char_p

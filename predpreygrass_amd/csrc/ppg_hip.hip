@@ -205,36 +205,27 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
                        : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);
     unsigned block = 64;
-    if (mode == ppg::MODE_STEP && h->drive && ppg_use_multiwave(h, true)) {
-        static const ppg_kernel_fn w4[3] = {ppgw4_step_q1, ppgw4_step_q2, ppgw4_step_q4};
-        fn = w4[h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
-        block = 256;
-    } else if (mode == ppg::MODE_STEP && h->gen2 && h->cfg2.walls && ppg_use_multiwave(h, true)) {
-        static const ppg_kernel_fn w3[3] = {ppgw3_step_q1, ppgw3_step_q2, ppgw3_step_q4};
-        fn = w3[h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
-        block = 256;
-    } else if (mode == ppg::MODE_STEP && !h->drive && !(h->gen2 && h->cfg2.walls) && ppg_use_multiwave(h)) {
-        // one wave per env cannot fill the GPU: 4 waves per env, wave 0 steps, all 4 write the final observations
-        static const ppg_kernel_fn w[2][2][2][3] = {
-            {{{ppgw_step_q1g, ppgw_step_q2g, ppgw_step_q4g}, {ppgw_step_q1, ppgw_step_q2, ppgw_step_q4}},
-             {{ppgw2_step_q1g, ppgw2_step_q2g, ppgw2_step_q4g}, {ppgw2_step_q1, ppgw2_step_q2, ppgw2_step_q4}}},
-            {{{ppgw8_step_q1g, ppgw8_step_q2g, ppgw8_step_q4g}, {ppgw8_step_q1, ppgw8_step_q2, ppgw8_step_q4}},
-             {{ppgw28_step_q1g, ppgw28_step_q2g, ppgw28_step_q4g}, {ppgw28_step_q1, ppgw28_step_q2, ppgw28_step_q4}}}};
-        const int in_flight = h->envs_in_flight > 0 ? h->envs_in_flight : h->batch;
-        const char *force8 = getenv("PPG_MULTIWAVE8");
-        const bool eight = force8 ? atoi(force8) != 0 : in_flight <= 512;   // even emptier GPU: 8 waves per env
-        fn = w[eight ? 1 : 0][h->gen2 ? 1 : 0][fast ? 1 : 0][h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
-        block = eight ? 512 : 256;
-        // a full GPU whose LDS admits 5-8 envs per CU (64x64 grids with 8-bit cell maps): TWO waves per env fill the 16 wave slots
-        // of a CU with 8 envs; four waves per env would leave half of the LDS-resident envs without slots
-        const int lds_envs = h->base.lds_bytes > 0 ? (160 * 1024) / h->base.lds_bytes : 16;
-        const char *forcep = getenv("PPG_MULTIWAVE_PAIR");
-        const bool pair = forcep ? atoi(forcep) != 0 : (!force8 && !h->gen2 && in_flight > 3072 && lds_envs >= 5 && lds_envs <= 8);
-        if (pair && !h->gen2) {
-            static const ppg_kernel_fn wp[2][3] = {{ppgwp_step_q1g, ppgwp_step_q2g, ppgwp_step_q4g}, {ppgwp_step_q1, ppgwp_step_q2, ppgwp_step_q4}};
-            fn = wp[fast ? 1 : 0][h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2];
-            block = 128;
+    const ppg_wave_plan_t wp = ppg_wave_plan(h);
+    if (mode == ppg::MODE_STEP && wp.nw > 1) {   // several waves per env: wave 0 steps, all of them write the final observations
+        const int qi = h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2;
+        if (h->drive) {
+            static const ppg_kernel_fn w4[3] = {ppgw4_step_q1, ppgw4_step_q2, ppgw4_step_q4};
+            fn = w4[qi];
+        } else if (h->gen2 && h->cfg2.walls) {
+            static const ppg_kernel_fn w3[3] = {ppgw3_step_q1, ppgw3_step_q2, ppgw3_step_q4};
+            fn = w3[qi];
+        } else if (wp.nw == 2) {
+            static const ppg_kernel_fn wpair[2][3] = {{ppgwp_step_q1g, ppgwp_step_q2g, ppgwp_step_q4g}, {ppgwp_step_q1, ppgwp_step_q2, ppgwp_step_q4}};
+            fn = wpair[fast ? 1 : 0][qi];
+        } else {
+            static const ppg_kernel_fn w[2][2][2][3] = {
+                {{{ppgw_step_q1g, ppgw_step_q2g, ppgw_step_q4g}, {ppgw_step_q1, ppgw_step_q2, ppgw_step_q4}},
+                 {{ppgw2_step_q1g, ppgw2_step_q2g, ppgw2_step_q4g}, {ppgw2_step_q1, ppgw2_step_q2, ppgw2_step_q4}}},
+                {{{ppgw8_step_q1g, ppgw8_step_q2g, ppgw8_step_q4g}, {ppgw8_step_q1, ppgw8_step_q2, ppgw8_step_q4}},
+                 {{ppgw28_step_q1g, ppgw28_step_q2g, ppgw28_step_q4g}, {ppgw28_step_q1, ppgw28_step_q2, ppgw28_step_q4}}}};
+            fn = w[wp.nw == 8 ? 1 : 0][h->gen2 ? 1 : 0][fast ? 1 : 0][qi];
         }
+        block = 64u * (unsigned)wp.nw;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(block), (size_t)P.lds_bytes, (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());

@@ -36,6 +36,7 @@ struct ppg_handle {
     uint32_t *lut_dev;
     void *backend;
     unsigned long long *prof_dev;  // diagnostic build only
+    char kernel_name[48];          // ppg_step_kernel_name
     char err[256];
 };
 
@@ -278,18 +279,47 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
     return PPG_OK;
 }
 
-// Multi-wave step kernels pay off while single-wave workgroups leave wave slots of the CUs empty (256 CUs x 16 slots):
-// measured on MI355X, 4 waves per env win up to about 3072 envs in flight (256 envs: 1.8x, 1024: 1.7x, 2048: 1.3x,
-// 3072: 1.02x, 4096: 0.93x), and whenever the LDS footprint admits at most 4 envs per CU (64x64 grids: 1.4x).
-// PPG_MULTIWAVE=0/1 forces (experiments).
-// compute_bound: the walls and drive variants (Bresenham walks / window sums per observation) are never limited by HBM:
-// four waves per env pay off at every batch size (4096 envs: 1.7-1.9x).
-static bool ppg_use_multiwave(const ppg_handle *h, bool compute_bound = false) {
-    if (const char *f = getenv("PPG_MULTIWAVE")) return atoi(f) != 0;
-    if (compute_bound) return true;
+// How many wavefronts step one env (wave 0 runs the transition; all of them write the final observations), and from how many
+// agent rows on the helper wavefronts of an env stay (lighter envs are left to wave 0: Env::helpers).  Measured on MI355X:
+//  - up to 512 envs in flight the GPU is nearly empty: 8 waves per env; up to ~3072: 4 waves (256 envs 1.8x, 1024 1.7x, 2048 1.3x);
+//  - walls / drive variants are bound by per-row work: 4 waves at every batch size (4096 envs: 1.7-1.9x); on a full GPU the walls
+//    helpers only stay for envs with >= 56 rows (+6 %);
+//  - a FULL GPU (> 3072 envs in flight) runs as fast as the slowest env of a launch lets it, and that is always a heavy one.  Base
+//    family: a PAIR of waves per env (+4 % at 25x25, interleaved A/B; 64x64 grids: 8-bit maps admit 7 envs per CU and a pair fills
+//    the 16 wave slots, +27 %); second generation (float32 observations: no longer store-bound): four waves, helpers only for envs
+//    with >= 72 rows -- the stragglers -- +25 % (48.0 -> 60.2 M env-steps/s), where helpers for every env cost 6 %.
+// PPG_MULTIWAVE=0 forces one wave; PPG_MULTIWAVE=1 forces several (PPG_MULTIWAVE8=1: eight, PPG_MULTIWAVE_PAIR=1: two, else four);
+// PPG_HELPER_MIN_ROWS overrides the threshold (experiments, tests).
+struct ppg_wave_plan_t { int nw; int min_rows; };
+static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
     const int lds_envs = h->base.lds_bytes > 0 ? (160 * 1024) / h->base.lds_bytes : 16;
     const int in_flight = h->envs_in_flight > 0 ? h->envs_in_flight : h->batch;
-    return in_flight <= 3072 || lds_envs <= 8;   // (5-8 envs per CU: the backend takes the two-wave kernel)
+    const bool walls = h->gen2 && h->cfg2.walls;
+    const bool pair_ok = !h->gen2 && !h->drive;           // the two-wave kernels exist for the base family
+    ppg_wave_plan_t p = {1, 0};
+    const char *force = getenv("PPG_MULTIWAVE");
+    if (force) {
+        if (atoi(force) == 0) return p;
+        const char *f8 = getenv("PPG_MULTIWAVE8"), *fp = getenv("PPG_MULTIWAVE_PAIR");
+        const bool eight = f8 ? atoi(f8) != 0 : in_flight <= 512;
+        p.nw = (walls || h->drive) ? 4 : eight ? 8 : (fp && atoi(fp) != 0 && pair_ok) ? 2 : 4;
+    } else if (h->drive) {
+        p.nw = 4;
+    } else if (walls) {
+        p.nw = 4;
+        p.min_rows = in_flight > 3072 ? 56 : 0;
+    } else if (in_flight <= 512) {
+        p.nw = 8;
+    } else if (in_flight <= 3072) {
+        p.nw = 4;
+    } else if (h->gen2) {
+        p.nw = 4;
+        p.min_rows = 72;
+    } else {
+        p.nw = lds_envs <= 4 ? 4 : 2;
+    }
+    if (const char *hm = getenv("PPG_HELPER_MIN_ROWS")) p.min_rows = atoi(hm);
+    return p;
 }
 
 static int backend_init(ppg_handle *h, int device);
@@ -390,6 +420,7 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
     ppg::KParams P = h->base;
     const int mode = h->cfg.kickback ? ppg::MODE_STEP_KICK : ppg::MODE_STEP;
     P.mode = mode; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
+    P.helper_min_rows = ppg_wave_plan(h).min_rows;
     return backend_launch(h, mode, P, stream);
 }
 
@@ -481,6 +512,22 @@ int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream) {
 }
 
 int32_t ppg_lds_bytes(const ppg_handle *h) { return h ? h->base.lds_bytes : 0; }
+
+const char *ppg_step_kernel_name(ppg_handle *h) {
+    if (!h) return "";
+    ppg_wave_plan_t wp = ppg_wave_plan(h);
+    if (h->cfg.kickback) wp.nw = 1;   // (the kickback variant has single-wave kernels only)
+    const bool walls = h->gen2 && h->cfg2.walls, fast = h->base.nch_p <= 2 && h->base.nch_q <= 3 && !walls && !h->drive;
+    const char *family = h->drive ? "4" : walls ? "3" : h->gen2 ? "2" : "";
+    // ppg[w|w8|wp]<family>_step... the names of ppg_kernel_list.h: ppgw_step / ppgw8_step / ppgwp_step, ppgw2_step / ppgw28_step, ppgw3_step, ppgw4_step
+    const char *waves = wp.nw == 1 ? "" : wp.nw == 2 ? "wp" : wp.nw == 8 ? "w8" : "w";
+    char fam[8];
+    if (wp.nw == 8 && h->gen2 && !walls) snprintf(fam, sizeof fam, "w28");
+    else snprintf(fam, sizeof fam, "%s%s", wp.nw == 8 ? "w8" : waves, family);
+    snprintf(h->kernel_name, sizeof h->kernel_name, "ppg%s_step_%sq%d%s", fam, h->cfg.kickback && wp.nw == 1 ? "kick_" : "", h->nq,
+             (fast || walls || h->drive) ? "" : "g");
+    return h->kernel_name;
+}
 
 uint64_t ppg_state_bytes(const ppg_handle *h) {
     if (!h) return 0;

@@ -145,7 +145,8 @@ struct KParams {
     uint32_t flags;
     uint32_t reset_episode;
     int32_t n_steps;   // transitions per launch (ppg_step: 1; ppg_rollout: n)
-    int32_t pad1_;
+    int32_t helper_min_rows;   // multi-wave kernels: helper wavefronts only stay for envs with at least this many agent rows at the
+                               // start of the call (0 = always); for lighter envs they exit at once and wave 0 writes all rows
     int32_t mode;
     int32_t batch;
 };
@@ -251,6 +252,7 @@ struct Env {
     const int b;
     const int ln;
     int wave_idx = 0;  // index of this wavefront in its workgroup (multi-wave kernels; 0 otherwise)
+    bool helpers = true;  // multi-wave kernels: the helper wavefronts of this env take part (see KParams::helper_min_rows)
 
     map_t *map;      // LDS
     double *val;     // LDS
@@ -1476,7 +1478,7 @@ struct Env {
     }
 
     PPG_MEMBER void obs_all_alive() {
-        if (NW > 1) {  // publish (type, row, cell) of every live row, then all waves of the workgroup share the rows
+        if (NW > 1 && helpers) {  // publish (type, row, cell) of every live row, then all waves of the workgroup share the rows
             uint32_t *lst = (uint32_t *)scr;
             int n = 0;
             wv::sync();
@@ -2329,7 +2331,16 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     if (NW > 1) {
         const int w = wv::wave_index();
         env.wave_idx = w;
-        if (w != 0) { env.run_helper(w); return; }
+        {   // light envs are left to wave 0 alone: the launch is as slow as its slowest env, and that is a HEAVY one
+            const PPG_CONSTANT_AS KParams *Pk = PPG_KERNARG_PTR(KParams, P);
+            const int32_t *es = Pk->env_state + (size_t)b * PPG_ENV_WORDS;
+            const int rows0 = (int)wv::first((uint32_t)(es[PPG_ENV_N_PRED_ROWS] + es[PPG_ENV_N_PREY_ROWS]));
+            env.helpers = rows0 >= Pk->helper_min_rows;
+        }
+        if (w != 0) {
+            if (env.helpers) env.run_helper(w);
+            return;
+        }
     }
     if (MODE == MODE_STEP || MODE == MODE_STEP_ORDERED || MODE == MODE_STEP_KICK || MODE == MODE_STEP_ORDERED_KICK) env.run_step();
     else if (MODE == MODE_RESET) env.run_reset();

@@ -11,6 +11,8 @@
 //  6 quadchunk 4 waves per env, the 4 waves split EVERY row (adjacent 1 KB chunks at the same time)
 //  7 sc1       base with sc1 (write-through) stores
 //  8 linear    the same number of bytes as one linear fill (reference point)
+//  9 rowwave   ONE SHORT-LIVED WAVE PER ROW, launched in address order (env-major): each writes its 2592-byte row and exits
+// 10 rowwave2  one short-lived wave per PAIR of rows
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +31,24 @@ __global__ void __launch_bounds__(256) pattern(double *obs, const int *rows, int
         return;
     }
     const int nch = (blk + 127) / 128;
+    if (variant == 9 || variant == 10) {   // rows[] holds the exclusive prefix sums here: block -> (env, row) by bisection
+        const int per = variant == 9 ? 1 : 2;
+        const int first = blockIdx.x * per;
+        int lo = 0, hi = B - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rows[mid] <= first) lo = mid; else hi = mid - 1; }
+        int b = lo, r = first - rows[b];
+        for (int k = 0; k < per; ++k) {
+            while (b + 1 < B && first + k >= rows[b + 1]) { ++b; }
+            r = first + k - rows[b];
+            if (first + k >= rows[B]) return;
+            double *base = obs + ((size_t)b * cap + r) * stride;
+            for (int c = 0; c < nch; ++c) {
+                const int e = c * 128 + 2 * ln;
+                if (e < blk) st16(base + e, (double)r, (double)c, 0);
+            }
+        }
+        return;
+    }
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int n = rows[b];
         double *base = variant == 2 ? obs + (size_t)b * stride : obs + (size_t)b * cap * stride;
@@ -54,21 +74,26 @@ int main(int argc, char **argv) {
     double *obs; int *rows;
     hipMalloc(&obs, (size_t)B * cap * 336 * 8);
     hipMalloc(&rows, B * sizeof(int));
-    const char *names[] = {"base", "aligned", "rowmajor", "half", "third", "quad", "quadchunk", "nontemporal", "linear"};
+    const char *names[] = {"base", "aligned", "rowmajor", "half", "third", "quad", "quadchunk", "nontemporal", "linear", "rowwave", "rowwave2"};
+    int *prefix; hipMalloc(&prefix, (B + 1) * sizeof(int));
     for (int mode = 0; mode < 2; ++mode) {
         std::vector<int> h(B);
         unsigned s = 12345; size_t tot = 0;
         for (int i = 0; i < B; ++i) { s = s * 1664525u + 1013904223u; h[i] = mode ? 10 + (s >> 8) % (2 * mean - 19) : mean; tot += h[i]; }
         hipMemcpy(rows, h.data(), B * sizeof(int), hipMemcpyHostToDevice);
-        for (int variant = 0; variant < 9; ++variant) {
+        std::vector<int> pf(B + 1, 0);
+        for (int i = 0; i < B; ++i) pf[i + 1] = pf[i] + h[i];
+        hipMemcpy(prefix, pf.data(), (B + 1) * sizeof(int), hipMemcpyHostToDevice);
+        for (int variant = 0; variant < 11; ++variant) {
             const int stride = variant == 1 ? 336 : blk;
-            const int grid = variant == 3 ? B / 2 : variant == 4 ? (B + 2) / 3 : variant == 8 ? 256 * 8 : B;
+            const int grid = variant == 3 ? B / 2 : variant == 4 ? (B + 2) / 3 : variant == 8 ? 256 * 8 : variant == 9 ? (int)tot : variant == 10 ? (int)(tot + 1) / 2 : B;
             const int block = (variant == 5 || variant == 6 || variant == 8) ? 256 : 64;
             const size_t total16 = tot * blk / 2;
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(pattern, dim3(grid), dim3(block), 0, 0, obs, rows, cap, blk, stride, variant, B, total16);
+            const int *rp = variant >= 9 ? prefix : rows;
+            for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(pattern, dim3(grid), dim3(block), 0, 0, obs, rp, cap, blk, stride, variant, B, total16);
             hipEventRecord(e0);
-            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(pattern, dim3(grid), dim3(block), 0, 0, obs, rows, cap, blk, stride, variant, B, total16);
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(pattern, dim3(grid), dim3(block), 0, 0, obs, rp, cap, blk, stride, variant, B, total16);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double bytes = (double)tot * blk * 8;
