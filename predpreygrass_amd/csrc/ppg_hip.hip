@@ -214,6 +214,9 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
         } else if (h->gen2 && h->cfg2.walls) {
             static const ppg_kernel_fn w3[3] = {ppgw3_step_q1, ppgw3_step_q2, ppgw3_step_q4};
             fn = w3[qi];
+        } else if (wp.nw == 16) {
+            static const ppg_kernel_fn w16[3] = {ppgw16_step_q1, ppgw16_step_q2, ppgw16_step_q4};
+            fn = w16[qi];
         } else if (wp.nw == 2) {
             static const ppg_kernel_fn wpair[2][3] = {{ppgwp_step_q1g, ppgwp_step_q2g, ppgwp_step_q4g}, {ppgwp_step_q1, ppgwp_step_q2, ppgwp_step_q4}};
             fn = wpair[fast ? 1 : 0][qi];

@@ -281,7 +281,8 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
 
 // How many wavefronts step one env (wave 0 runs the transition; all of them write the final observations), and from how many
 // agent rows on the helper wavefronts of an env stay (lighter envs are left to wave 0: Env::helpers).  Measured on MI355X:
-//  - up to 512 envs in flight the GPU is nearly empty: 8 waves per env; up to ~3072: 4 waves (256 envs 1.8x, 1024 1.7x, 2048 1.3x);
+//  - up to 512 envs in flight the GPU is nearly empty: 8 waves per env (16 up to 256 envs); up to ~3072: 4 waves (256 envs 1.8x,
+//    1024 1.7x, 2048 1.3x);
 //  - walls / drive variants are bound by per-row work: 4 waves at every batch size (4096 envs: 1.7-1.9x); on a full GPU the walls
 //    helpers only stay for envs with >= 56 rows (+6 %);
 //  - a FULL GPU (> 3072 envs in flight) runs as fast as the slowest env of a launch lets it, and that is always a heavy one.  Base
@@ -310,6 +311,9 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         p.min_rows = in_flight > 3072 ? 56 : 0;
     } else if (in_flight <= 512) {
         p.nw = 8;
+        // up to 256 envs one workgroup per CU is all there is: sixteen waves (base family, register-descriptor observation path):
+        // 256 envs 11.3 -> 12.1 M env-steps/s; at 512 envs eight are faster (20.5 vs 17.8 M)
+        if (in_flight <= 256 && !h->gen2 && h->base.nch_p <= 2 && h->base.nch_q <= 3) p.nw = 16;
     } else if (in_flight <= 3072) {
         p.nw = 4;
     } else if (h->gen2) {
@@ -520,7 +524,7 @@ const char *ppg_step_kernel_name(ppg_handle *h) {
     const bool walls = h->gen2 && h->cfg2.walls, fast = h->base.nch_p <= 2 && h->base.nch_q <= 3 && !walls && !h->drive;
     const char *family = h->drive ? "4" : walls ? "3" : h->gen2 ? "2" : "";
     // ppg[w|w8|wp]<family>_step... the names of ppg_kernel_list.h: ppgw_step / ppgw8_step / ppgwp_step, ppgw2_step / ppgw28_step, ppgw3_step, ppgw4_step
-    const char *waves = wp.nw == 1 ? "" : wp.nw == 2 ? "wp" : wp.nw == 8 ? "w8" : "w";
+    const char *waves = wp.nw == 1 ? "" : wp.nw == 2 ? "wp" : wp.nw == 8 ? "w8" : wp.nw == 16 ? "w16" : "w";
     char fam[8];
     if (wp.nw == 8 && h->gen2 && !walls) snprintf(fam, sizeof fam, "w28");
     else snprintf(fam, sizeof fam, "%s%s", wp.nw == 8 ? "w8" : waves, family);

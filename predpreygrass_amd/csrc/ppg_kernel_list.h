@@ -27,7 +27,8 @@
     PPG_KW(ppgw8_step_q##NQ, NQ, true, 8)                             \
     PPG_KW(ppgw8_step_q##NQ##g, NQ, false, 8)                         \
     PPG_KW(ppgwp_step_q##NQ, NQ, true, 2)                             \
-    PPG_KW(ppgwp_step_q##NQ##g, NQ, false, 2)
+    PPG_KW(ppgwp_step_q##NQ##g, NQ, false, 2)                         \
+    PPG_KW(ppgw16_step_q##NQ, NQ, true, 16)
 
 #define PPG_DEFINE_KERNELSW2(NQ)                                      \
     PPG_KW2(ppgw2_step_q##NQ, NQ, true, 4)                            \

@@ -271,6 +271,40 @@ def test_multiwave_step_kernels_give_identical_results(cls_name, monkeypatch):
             assert torch.equal(a, b), n
 
 
+def test_default_wave_plans_give_identical_results(monkeypatch):
+    """What the library picks by itself -- sixteen waves per env at 200 envs, a pair of waves with 8-bit maps for a full GPU of 64x64
+    grids, helper waves only for heavy envs in the second generation -- against the one-wave kernels, bit for bit."""
+    from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
+    c4 = {**config_env, **C4}
+    cases = [(lambda: make_env(dict(config_env), 200), b"ppgw16_step_q2", 120),
+             (lambda: make_env(c4, 4096), b"ppgwp_step_q2", 40),
+             (lambda: BatchedRedQueen(config_env_base, batch_size=4096, device="cuda:0"), b"ppgw2_step_q2", 120)]
+    names = ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state", "grass_energy", "obs_pred", "obs_prey")
+    for mk, kernel, calls in cases:
+        results = []
+        for force in (None, "0"):
+            if force is None:
+                monkeypatch.delenv("PPG_MULTIWAVE", raising=False)
+            else:
+                monkeypatch.setenv("PPG_MULTIWAVE", force)
+            env = mk()
+            if force is None:
+                assert env._lib.ppg_step_kernel_name(env._handle) == kernel
+            env.reset(seed=21)
+            for _ in range(calls):
+                env.step(random_actions=True, auto_reset=True)
+            torch.cuda.synchronize()
+            results.append({n: getattr(env, n).clone() for n in names})
+            del env
+        for n in names:
+            a, b = results[0][n], results[1][n]
+            if n == "env_state":
+                a, b = a[:, : _abi.ENV_CALLS], b[:, : _abi.ENV_CALLS]
+            assert torch.equal(a, b), (kernel, n)
+        del results
+        torch.cuda.empty_cache()
+
+
 def test_bench_rccl_gather_legs_with_one_rank():
     """bench.py under torch.distributed.run with a world of ONE rank and --force-dist: process-group init on RCCL,
     barrier / max-over-ranks timing, the synchronous and the overlapped single-collective observation-gather legs on the
