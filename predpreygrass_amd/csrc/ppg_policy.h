@@ -162,23 +162,26 @@ __device__ __forceinline__ bf16x8 relu_pack8(const f32x16 &a, int r0) {
 // The weight fragments of one convolution layer and, per k-step, the offset of this lane half's K block: in registers.
 //   CBIN   channel blocks (of 8) of the input image: 1 (4 real channels), 2, 4        K = 9 taps x CBIN blocks
 //   MT     32-row tiles of output channels: 1 (16 real for conv1 / 32 for conv2), 2 (conv3)
+// The bias rides in the GEMM: K block Q (the first one behind the 9 taps x CBIN channel blocks) holds the bias, split into a bf16
+// head and a bf16 remainder, against a constant B fragment {1, 1, 0, ...} -- no bias loads per position tile and no registers to
+// keep it in.  For CBIN = 1 that block is the second half of the last tap's k-step (free); for CBIN = 2 / 4 it costs one more MFMA
+// per tile (10 instead of 9 / 19 instead of 18).
 template <int CBIN, int MT>
 struct ConvW {
-    static constexpr int Q = 9 * CBIN, KS = (Q + 1) / 2;
+    static constexpr int Q = 9 * CBIN, KS = (Q + 2) / 2;       // k-steps incl. the bias block
+    static constexpr int KS_BIAS = Q / 2, H_BIAS = Q & 1;      // the bias block is block Q = 2 * KS_BIAS + H_BIAS
     bf16x8 a[MT][KS];
-    const GLOBAL_AS f32x4 *bias;    // of this lane half's 16 consecutive channels: bias[8 * mt + g], g < 4 (read per position tile)
     int koff1[CBIN == 1 ? KS : 1];   // CBIN == 1 only: the tap of a k-step depends on the lane half -> per-lane offsets
     template <class KP>
-    __device__ __forceinline__ void load(const KP &K, const bf16x8 *wfrag, const float *b, int lane, int mt_base = 0) {
+    __device__ __forceinline__ void load(const KP &K, const bf16x8 *wfrag, int lane, int mt_base = 0) {
         const int h = lane >> 5;
-        bias = (const GLOBAL_AS f32x4 *)(b + 32 * mt_base + 16 * h);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt][ks] = wfrag[((mt_base + mt) * KS + ks) * 64 + lane];
             if (CBIN == 1) {
                 const int q = 2 * ks + h;
-                const int tap = q < Q ? q : 0;        // (a padding block: its weights are zero, any in-bounds address will do)
+                const int tap = q < Q ? q : 0;        // (the bias block: its B fragment is a constant, any in-bounds address will do)
                 koff1[ks] = ((tap / 3 - 1) * K.Wp + tap % 3 - 1) * 8;
             }
         }
@@ -217,15 +220,21 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {   // (straight into the accumulator registers; the loads overlap with the LDS reads below)
-                const f32x4 bb = W.bias[8 * mt + g];
-                acc[mt][4 * g] = bb[0]; acc[mt][4 * g + 1] = bb[1]; acc[mt][4 * g + 2] = bb[2]; acc[mt][4 * g + 3] = bb[3];
-            }
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
         // all of the tile's B fragments are requested before the first MFMA: the LDS latency is paid once per tile, and while this
         // wavefront's MFMA chain runs the SIMD's other wavefront has the LDS to itself
         bf16x8 b[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) b[ks] = *(const bf16x8 *)(base + W.offset(K, ks));
+        for (int ks = 0; ks < KS; ++ks) {
+            constexpr int KSB = ConvW<CBIN, MT>::KS_BIAS, HB = ConvW<CBIN, MT>::H_BIAS;
+            if (ks == KSB && CBIN > 1) {       // the bias block's k-step: {1, 1, 0 ...} in the lane half that holds it, zeros in the other
+                b[ks] = zero8();
+                if (h == HB) { b[ks][0] = (__bf16)1.0f; b[ks][1] = (__bf16)1.0f; }
+            } else {
+                b[ks] = *(const bf16x8 *)(base + W.offset(K, ks));
+                if (ks == KSB && h == HB) { b[ks] = zero8(); b[ks][0] = (__bf16)1.0f; b[ks][1] = (__bf16)1.0f; }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);   // (keep the reads together: left alone, the scheduler re-pairs each with its MFMA)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -282,22 +291,26 @@ __device__ __forceinline__ void fc1_compute(const unsigned char *stage, int c, f
     const int h = lane >> 5, col = lane & 31;
     const bf16x8 *wb = (const bf16x8 *)(stage + (size_t)(c % 3) * FC1_BUF);
     const unsigned char *xb = stage + (size_t)(c % 3) * FC1_BUF + 16384;
+    // all 2 x (NT + 2) fragments of the chunk are requested before its first MFMA (the LDS latency is paid once per chunk)
+    bf16x8 x[2][NT], w[2][2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
         const int q = 2 * k2 + h;
-        bf16x8 x[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = 32 * t + col;
-            x[t] = *(const bf16x8 *)(xb + n * 64 + 16 * (q ^ ((n >> 2) & 3)));
+            x[k2][t] = *(const bf16x8 *)(xb + n * 64 + 16 * (q ^ ((n >> 2) & 3)));
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const bf16x8 w = wb[(k2 * 8 + 2 * wave + m) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x[t], acc[m][t], 0, 0, 0);
-        }
+        for (int m = 0; m < 2; ++m) w[k2][m] = wb[(k2 * 8 + 2 * wave + m) * 64 + lane];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[k2][m], x[k2][t], acc[m][t], 0, 0, 0);
 }
 
 template <int NT>
@@ -426,7 +439,7 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile, i
     // conv1 / conv2 (20 / 36 registers) are re-read per sub-group, issued before the observation rows are staged so that their
     // latency overlaps with that.
     ConvW<4, 1> w3c;
-    w3c.load(K, K.wc3, K.bc3, lane, wave >> 1);
+    w3c.load(K, K.wc3, lane, wave >> 1);
     const int dbg = K.debug_skip;
     // observation values of the NEXT sub-group are requested before conv3 of the current one and written to LDS after it: their
     // HBM latency hides behind 72 % of the sub-group's matrix work.  A thread stages at most two positions (ST * P <= 512).
@@ -457,8 +470,8 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile, i
         const int ns = (nt_samples - s0) < K.ST ? (nt_samples - s0) : K.ST;
         ConvW<1, 1> w1c;
         ConvW<2, 1> w2c;
-        w1c.load(K, K.wc1, K.bc1, lane);
-        w2c.load(K, K.wc2, K.bc2, lane);
+        w1c.load(K, K.wc1, lane);
+        w2c.load(K, K.wc2, lane);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + 256 * j;
@@ -638,18 +651,28 @@ static uint16_t ppg_bf16_bits(float f) {   // round to nearest even (finite weig
 
 // conv weights [cout][cin][3][3] -> fragments [mt][ks][lane][8]: lane (r = lane & 31, h = lane >> 5) holds, for K block
 // q = 2 ks + h = tap * CBIN + cb, the eight input channels 8 cb .. 8 cb + 7 of output channel 32 mt + r at tap (ky, kx)
-static void ppg_pack_conv(const float *w, int cout, int cin, int cbin, int mt_n, std::vector<uint16_t> &out) {
-    const int Q = 9 * cbin, KS = (Q + 1) / 2;
+static void ppg_pack_conv(const float *w, const float *bias, int cout, int cin, int cbin, int mt_n, std::vector<uint16_t> &out) {
+    const int Q = 9 * cbin, KS = (Q + 2) / 2;   // (block Q = the bias, ConvW)
     out.assign((size_t)mt_n * KS * 64 * 8, 0);
     for (int mt = 0; mt < mt_n; ++mt)
         for (int ks = 0; ks < KS; ++ks)
             for (int lane = 0; lane < 64; ++lane) {
                 const int r = lane & 31, h = lane >> 5, q = 2 * ks + h, co = 32 * mt + ppg_row_feature(r);
-                if (q >= Q || co >= cout) continue;
+                if (q > Q || co >= cout) continue;
+                uint16_t *dst = &out[(((size_t)mt * KS + ks) * 64 + lane) * 8];
+                if (q == Q) {   // bias = bf16 head + bf16 remainder
+                    const uint16_t hi = ppg_bf16_bits(bias[co]);
+                    uint32_t hb = (uint32_t)hi << 16;
+                    float hf;
+                    memcpy(&hf, &hb, 4);
+                    dst[0] = hi;
+                    dst[1] = ppg_bf16_bits(bias[co] - hf);
+                    continue;
+                }
                 const int tap = q / cbin, cb = q % cbin;
                 for (int j = 0; j < 8; ++j) {
                     const int ci = 8 * cb + j;
-                    if (ci < cin) out[(((size_t)mt * KS + ks) * 64 + lane) * 8 + j] = ppg_bf16_bits(w[((size_t)co * cin + ci) * 9 + tap]);
+                    if (ci < cin) dst[j] = ppg_bf16_bits(w[((size_t)co * cin + ci) * 9 + tap]);
                 }
             }
 }
@@ -688,9 +711,9 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
     p->device = device; p->R = obs_range; p->n_actions = n_actions;
     const int R = obs_range, P = R * R, K1 = 64 * P;
     std::vector<uint16_t> f[6];
-    ppg_pack_conv(w->conv_w[0], 16, 4, 1, 1, f[0]);
-    ppg_pack_conv(w->conv_w[1], 32, 16, 2, 1, f[1]);
-    ppg_pack_conv(w->conv_w[2], 64, 32, 4, 2, f[2]);
+    ppg_pack_conv(w->conv_w[0], w->conv_b[0], 16, 4, 1, 1, f[0]);
+    ppg_pack_conv(w->conv_w[1], w->conv_b[1], 32, 16, 2, 1, f[1]);
+    ppg_pack_conv(w->conv_w[2], w->conv_b[2], 64, 32, 4, 2, f[2]);
     // FC1: our K order is the scratch slot's [row tile of conv3][position][32 channels]; PyTorch flattens channel-major (c * P + p)
     ppg_pack_fc(w->fc_w[0], 256, K1, 8, [P](int k) { return (32 * (k / (32 * P)) + k % 32) * P + (k % (32 * P)) / 32; }, f[3]);
     ppg_pack_fc(w->fc_w[1], 256, 256, 8, [](int k) { return k; }, f[4]);
