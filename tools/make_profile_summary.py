@@ -7,7 +7,7 @@ steps, 3 sub-batches), taken on the GPU box by tools/gpu_profile_driver_cmd.sh:
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/<tag>_f -o f -- python3 bench.py <args>
   python3 bench.py <args without --no-cpu-baseline> > gpurun_out/<tag>_bench.json        (unprofiled, same box)
 The timed region of each run = its last steps x streams dispatches of the step kernel.
-usage: make_profile_summary.py <tag> <kernel name> <out.json> [steps=20] [streams=3]"""
+usage: make_profile_summary.py <tag> <kernel name | auto = roofline.kernel of the bench line> <out.json> [steps=20] [streams=3]"""
 import csv
 import glob
 import json
@@ -17,6 +17,8 @@ tag, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 streams = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 last = steps * streams
+if kernel == "auto":
+    kernel = json.loads(open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1])["roofline"]["kernel"]
 
 
 def one(pattern):
