@@ -283,8 +283,8 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
 // agent rows on the helper wavefronts of an env stay (lighter envs are left to wave 0: Env::helpers).  Measured on MI355X:
 //  - up to 512 envs in flight the GPU is nearly empty: 8 waves per env (16 up to 256 envs); up to ~3072: 4 waves (256 envs 1.8x,
 //    1024 1.7x, 2048 1.3x);
-//  - walls / drive variants are bound by per-row work: 4 waves at every batch size (4096 envs: 1.7-1.9x); on a full GPU the walls
-//    helpers only stay for envs with >= 56 rows (+6 %);
+//  - walls / drive variants are bound by per-row work: 4 waves at every batch size (4096 envs: 1.7-1.9x), always all of
+//    them: a second, wave-0-only copy of their large observation code in the same kernel cost 10-15 % (Env::ADAPTIVE_HELPERS);
 //  - a FULL GPU (> 3072 envs in flight) runs as fast as the slowest env of a launch lets it, and that is always a heavy one.  Base
 //    family: a PAIR of waves per env (+4 % at 25x25, interleaved A/B; 64x64 grids: 8-bit maps admit 7 envs per CU and a pair fills
 //    the 16 wave slots, +27 %); second generation (float32 observations: no longer store-bound): four waves, helpers only for envs
@@ -308,7 +308,6 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         p.nw = 4;
     } else if (walls) {
         p.nw = 4;
-        p.min_rows = in_flight > 3072 ? 56 : 0;
     } else if (in_flight <= 512) {
         p.nw = 8;
         // up to 256 envs one workgroup per CU is all there is: sixteen waves (base family, register-descriptor observation path):
@@ -323,6 +322,7 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         p.nw = lds_envs <= 4 ? 4 : 2;
     }
     if (const char *hm = getenv("PPG_HELPER_MIN_ROWS")) p.min_rows = atoi(hm);
+    if (walls || h->drive) p.min_rows = 0;   // (their kernels carry no wave-0-only observation path: Env::ADAPTIVE_HELPERS)
     return p;
 }
 

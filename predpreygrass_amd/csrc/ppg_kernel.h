@@ -242,6 +242,10 @@ template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, 
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
     static constexpr bool MAP8 = NQ <= 2;
+    // Helper wavefronts that leave light envs to wave 0 (KParams::helper_min_rows) need BOTH observation paths in one kernel.  The
+    // walls and drive variants' observation code is large: with two copies of it their kernels ran 10-15 % slower, so their helpers
+    // always stay.
+    static constexpr bool ADAPTIVE_HELPERS = NW > 1 && !WALLS && !DRIVE;
     template <bool B8, class Dummy = void> struct MapElem { typedef uint16_t type; };
     template <class Dummy> struct MapElem<true, Dummy> { typedef uint8_t type; };
     typedef typename MapElem<MAP8>::type map_t;
@@ -1478,7 +1482,7 @@ struct Env {
     }
 
     PPG_MEMBER void obs_all_alive() {
-        if (NW > 1 && helpers) {  // publish (type, row, cell) of every live row, then all waves of the workgroup share the rows
+        if (NW > 1 && (!ADAPTIVE_HELPERS || helpers)) {  // publish (type, row, cell) of every live row, then all waves of the workgroup share the rows
             uint32_t *lst = (uint32_t *)scr;
             int n = 0;
             wv::sync();
@@ -2331,7 +2335,7 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     if (NW > 1) {
         const int w = wv::wave_index();
         env.wave_idx = w;
-        {   // light envs are left to wave 0 alone: the launch is as slow as its slowest env, and that is a HEAVY one
+        if (decltype(env)::ADAPTIVE_HELPERS) {   // light envs are left to wave 0 alone: the launch is as slow as its slowest env, and that is a HEAVY one
             const PPG_CONSTANT_AS KParams *Pk = PPG_KERNARG_PTR(KParams, P);
             const int32_t *es = Pk->env_state + (size_t)b * PPG_ENV_WORDS;
             const int rows0 = (int)wv::first((uint32_t)(es[PPG_ENV_N_PRED_ROWS] + es[PPG_ENV_N_PREY_ROWS]));

@@ -90,7 +90,7 @@ def test_multiwave_second_generation_rollout_matches_oracle(monkeypatch):
     assert stats["births"] > 3
 
 
-@pytest.mark.parametrize("waves,family", [("4", "base"), ("2", "base"), ("4", "gen2"), ("4", "walls")])
+@pytest.mark.parametrize("waves,family", [("4", "base"), ("2", "base"), ("4", "gen2")])
 def test_helper_waves_only_for_heavy_envs(waves, family, monkeypatch):
     """KParams::helper_min_rows: the helper wavefronts of envs with fewer agent rows exit at once and wave 0 writes every row; envs
     cross the threshold in both directions during the rollout (population 14 .. 60+).  Every call against the oracle."""
@@ -101,19 +101,10 @@ def test_helper_waves_only_for_heavy_envs(waves, family, monkeypatch):
         rollout_vs_oracle(env, lambda: OracleEnv(dict(config_env)), seed0=17, n_calls=90, check_grid=True)
         rows = env.env_state[:, _abi.ENV_N_PRED_ROWS] + env.env_state[:, _abi.ENV_N_PREY_ROWS]
         assert int(rows.max()) >= 16 > int(rows.min())   # (both sides of the threshold were exercised; the rollout starts at 14 rows)
-    elif family == "gen2":
+    else:
         cfg = RQGoldenCase("rq_mixed_types_seed7").config
         env = make_gen2(cfg, 2)
         rq_rollout_vs_oracle(env, lambda: RQOracleEnv(cfg), seed0=43, n_calls=80, check_every=1, check_grid=True)
-    else:
-        case = RQGoldenCase("wo_los_two_types_seed5")
-        def oracle():
-            o = RQOracleEnv(case.config, walls=True)
-            o.set_walls(case.wall_xy)
-            return o
-        env = make_gen2(case.config, 2, walls=True)
-        env.set_walls(case.wall_xy)
-        rq_rollout_vs_oracle(env, oracle, seed0=31, n_calls=80, check_every=1, check_grid=True)
 
 
 def test_unknown_wave_count_is_rejected(monkeypatch):
