@@ -256,26 +256,28 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
     }
 }
 
-// FC1 over the tile as an LDS-staged GEMM: M = 256 output features (A = weight fragments), N = 128 samples (B = the scratch slot
-// X[sample][K1]), K in chunks of 32.  Per chunk the workgroup brings 16 KB of weight fragments (a straight, lane-linear copy of
-// the repacked array) and 128 x 64 B of X into one of THREE LDS buffers with LDS-DMA loads (global_load_lds_dwordx4: no
-// registers, 1 KB per wave instruction), two chunks ahead of the one it computes from.  An LDS-DMA writes lane l's 16 bytes at
-// base + 16 l, so the X image cannot be padded; instead the 16-byte pieces of row n sit at position piece ^ ((n >> 2) & 3) -- the
-// swizzle is applied to the SOURCE address of the copy -- which makes the 16-lane groups of the fragment reads conflict-free.
-constexpr int FC1_BUF = 16384 + TILE * 64;                   // bytes per buffer: W chunk + X chunk
+// FC1 over the tile: M = 256 output features (A = weight fragments), N = up to 128 samples (B = the scratch slot X[sample][K1]),
+// K in chunks of 32.  Wavefront w owns the feature row tiles 2w, 2w + 1 and ALL column tiles (2 x NT accumulators), so the same
+// code serves tiles of 64, 96 and 128 samples.
+//  - X: every wavefront needs every column, so the chunk (128 x 64 B) goes through LDS, brought by LDS-DMA loads
+//    (global_load_lds_dwordx4: no registers, 1 KB per wave instruction) into one of THREE buffers, two chunks ahead of the one
+//    being computed.  An LDS-DMA writes lane l's 16 bytes at base + 16 l, so the image cannot be padded; instead the 16-byte pieces
+//    of row n sit at position piece ^ ((n >> 2) & 3) -- the swizzle is applied to the SOURCE address of the copy -- which makes the
+//    16-lane groups of the fragment reads conflict-free.
+//  - W: a wavefront's four fragments of a chunk are its own (nobody else reads them), so they go from L2 straight into registers,
+//    one chunk ahead (two register sets, the chunk loop is unrolled by two; K1 / 32 = 2 R^2 is even).  Through LDS they cost a
+//    third of the LDS bandwidth of the phase, which was its bound: with two workgroups per CU the fragment reads + DMA writes of a
+//    chunk took longer than its 16 MFMAs per wavefront.
+// Loads complete in order, so "chunk c is here" is a count: a step requests W(c + 1) [4 loads] and then X(c + 2) [2 loads]; at the
+// top of step c everything but the two X(c + 1) loads must have landed: s_waitcnt vmcnt(2).
+constexpr int FC1_BUF = TILE * 64;                   // bytes per X buffer
 
 __device__ __forceinline__ void glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)g, (void __attribute__((address_space(3))) *)l, 16, 0, 0);
 }
 
-__device__ __forceinline__ void fc1_issue(const bf16x8 *w1, int K1, const __bf16 *xg_tile, unsigned char *stage, int c, int wave, int lane) {
-    unsigned char *wb = stage + (size_t)(c % 3) * FC1_BUF, *xb = wb + 16384;
-    const bf16x8 *src = w1 + (size_t)c * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i0 = (wave * 4 + j) * 64;
-        glds16(src + i0 + lane, wb + (size_t)i0 * 16);
-    }
+__device__ __forceinline__ void fc1_issue_x(int K1, const __bf16 *xg_tile, unsigned char *stage, int c, int buf, int wave, int lane) {
+    unsigned char *xb = stage + (size_t)buf * FC1_BUF;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i0 = (wave * 2 + j) * 64, i = i0 + lane;
@@ -284,15 +286,28 @@ __device__ __forceinline__ void fc1_issue(const bf16x8 *w1, int K1, const __bf16
     }
 }
 
-// FC layers over a tile of NT x 32 samples: wavefront w owns the feature row tiles 2w, 2w + 1 and ALL column tiles (2 x NT
-// accumulators), so the same code serves tiles of 64, 96 and 128 samples.
+// The weight loads are written as inline assembly ON PURPOSE: hipcc's wait-count bookkeeping cannot follow loads whose results
+// are consumed one loop iteration later in a rotating register set -- it puts s_waitcnt vmcnt(0) in front of the first MFMA of
+// every chunk, i.e. it waits for the loads it has just issued.  Loads it does not know about it does not wait for; the explicit
+// s_waitcnt vmcnt(2) at the top of each step is what guarantees their arrival, and fc1_landed() (an empty asm that "redefines" the
+// registers behind that wait) keeps every use of them below it.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fc1_issue_w(const GLOBAL_AS bf16x8 *wlane, int c, u32x4 (&w)[2][2]) {
+    const GLOBAL_AS bf16x8 *p0 = wlane + (size_t)c * 1024, *p1 = p0 + 512;   // k2 = 0 / 1: 8 KB apart; m = 1: + 1 KB
+    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[0][0]) : "v"(p0) : "memory");
+    __asm__ volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(w[0][1]) : "v"(p0) : "memory");
+    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[1][0]) : "v"(p1) : "memory");
+    __asm__ volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(w[1][1]) : "v"(p1) : "memory");
+}
+__device__ __forceinline__ void fc1_landed(u32x4 (&w)[2][2]) {
+    __asm__ volatile("" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+}
+
 template <int NT>
-__device__ __forceinline__ void fc1_compute(const unsigned char *stage, int c, f32x16 (&acc)[2][NT], int wave, int lane) {
+__device__ __forceinline__ void fc1_compute(const unsigned char *xb, const u32x4 (&w)[2][2], f32x16 (&acc)[2][NT], int lane) {
     const int h = lane >> 5, col = lane & 31;
-    const bf16x8 *wb = (const bf16x8 *)(stage + (size_t)(c % 3) * FC1_BUF);
-    const unsigned char *xb = stage + (size_t)(c % 3) * FC1_BUF + 16384;
-    // all 2 x (NT + 2) fragments of the chunk are requested before its first MFMA (the LDS latency is paid once per chunk)
-    bf16x8 x[2][NT], w[2][2];
+    // all 2 x NT fragments of the chunk are requested before its first MFMA (the LDS latency is paid once per chunk)
+    bf16x8 x[2][NT];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
         const int q = 2 * k2 + h;
@@ -301,8 +316,6 @@ __device__ __forceinline__ void fc1_compute(const unsigned char *stage, int c, f
             const int n = 32 * t + col;
             x[k2][t] = *(const bf16x8 *)(xb + n * 64 + 16 * (q ^ ((n >> 2) & 3)));
         }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) w[k2][m] = wb[(k2 * 8 + 2 * wave + m) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -310,23 +323,44 @@ __device__ __forceinline__ void fc1_compute(const unsigned char *stage, int c, f
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[k2][m], x[k2][t], acc[m][t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[k2][m]), x[k2][t], acc[m][t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);   // (or the next step's wait + barrier are scheduled in front of these MFMAs: nothing hidden)
+}
+
+// one chunk: wait for it, meet, request W(c + 1) and X(c + 2) (compile-time switches: with a run-time condition around the loads
+// the compiler's own wait-count bookkeeping gives up at the join and drains ALL loads before the MFMAs), compute.
+template <int NT, bool ISSUE_W, bool ISSUE_X>
+__device__ __forceinline__ void fc1_step(const GLOBAL_AS bf16x8 *wlane, int K1, const __bf16 *xg_tile, unsigned char *stage, int c, int buf,
+                                         u32x4 (&w_cur)[2][2], u32x4 (&w_next)[2][2], f32x16 (&acc)[2][NT], int wave, int lane) {
+    if (ISSUE_W) __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fc1_landed(w_cur);
+    __builtin_amdgcn_s_barrier();   // everybody's X copies of chunk c are in LDS, and everybody is done with chunk c - 1's buffer
+    if (ISSUE_W) fc1_issue_w(wlane, c + 1, w_next);
+    if (ISSUE_X) fc1_issue_x(K1, xg_tile, stage, c + 2, buf >= 1 ? buf - 1 : 2, wave, lane);
+    fc1_compute<NT>(stage + (size_t)buf * FC1_BUF, w_cur, acc, lane);
 }
 
 template <int NT>
 __device__ __forceinline__ void fc1_staged(const bf16x8 *w1, int K1, const __bf16 *xg_tile, unsigned char *stage, f32x16 (&acc)[2][NT],
                                            int wave, int lane) {
-    const int n_chunks = K1 / 32;
-    fc1_issue(w1, K1, xg_tile, stage, 0, wave, lane);
-    fc1_issue(w1, K1, xg_tile, stage, 1, wave, lane);
-    for (int c = 0; c < n_chunks; ++c) {
-        // this wavefront's six copies of chunk c have landed when at most the six of chunk c + 1 are still in flight
-        if (c + 1 < n_chunks) __asm__ volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // everybody's copies of chunk c are in LDS, and everybody is done with chunk c - 1's buffer
-        if (c + 2 < n_chunks) fc1_issue(w1, K1, xg_tile, stage, c + 2, wave, lane);
-        fc1_compute<NT>(stage, c, acc, wave, lane);
+    const int n_chunks = K1 / 32;    // = 2 R^2: even, >= 18
+    const GLOBAL_AS bf16x8 *wlane = (const GLOBAL_AS bf16x8 *)w1 + (2 * wave) * 64 + lane;
+    u32x4 w[2][2][2];
+    fc1_issue_x(K1, xg_tile, stage, 0, 0, wave, lane);
+    fc1_issue_w(wlane, 0, w[0]);
+    fc1_issue_x(K1, xg_tile, stage, 1, 1, wave, lane);
+    int buf = 0;
+    for (int c = 0; c + 2 < n_chunks; c += 2) {   // (chunk c uses LDS buffer c % 3 and register set c % 2)
+        fc1_step<NT, true, true>(wlane, K1, xg_tile, stage, c, buf, w[0], w[1], acc, wave, lane);
+        buf = buf == 2 ? 0 : buf + 1;
+        fc1_step<NT, true, true>(wlane, K1, xg_tile, stage, c + 1, buf, w[1], w[0], acc, wave, lane);
+        buf = buf == 2 ? 0 : buf + 1;
     }
+    fc1_step<NT, true, false>(wlane, K1, xg_tile, stage, n_chunks - 2, buf, w[0], w[1], acc, wave, lane);
+    buf = buf == 2 ? 0 : buf + 1;
+    fc1_step<NT, false, false>(wlane, K1, xg_tile, stage, n_chunks - 1, buf, w[1], w[0], acc, wave, lane);
     __syncthreads();
 }
 
@@ -404,11 +438,25 @@ __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, ui
 // allocation (inlined into one body, hipcc hoists address arithmetic of every phase to the top of the tile loop and spills
 // hundreds of registers -- scratch reloads then sit between the LDS-DMA loads of FC1 and force vmcnt(0) waits).
 typedef const __attribute__((address_space(4))) PolParams *KPtr;
+// Arguments of a non-inlined device function arrive in VECTOR registers: the compiler has to treat them (and everything loaded
+// through them) as possibly different per lane -- vector loads of the parameters, loop bounds in VGPRs, exec-masked "divergent"
+// loops, conservative s_waitcnt vmcnt(0) at every join.  So the phases make their arguments uniform again with v_readfirstlane,
+// the kernarg pointer included (__builtin_amdgcn_kernarg_segment_ptr() is a null pointer inside a callee).
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uintptr_t uniform(uintptr_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uintptr_t)hi << 32) | lo;
+}
+template <class T>
+__device__ __forceinline__ T *uniform(T *p) { return (T *)uniform((uintptr_t)p); }
+__device__ __forceinline__ KPtr uniform(KPtr p) { return (KPtr)uniform((uintptr_t)p); }
 
 // ---- phase A: the tile's sample table, then the convolutions, ST samples at a time -> scratch slot X ----
 template <bool OBS_F32>
-__device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile, int n0, int nt_samples, __bf16 *xg_tile) {
-    const auto &K = *Kp;
+__device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, int n0_, int nt_samples_, __bf16 *xg_tile_) {
+    const auto &K = *uniform(Kp);
+    const int tile = uniform(tile_), n0 = uniform(n0_), nt_samples = uniform(nt_samples_);
+    __bf16 *xg_tile = uniform(xg_tile_);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long *tab = (unsigned long long *)lds;
     __bf16 *img = (__bf16 *)(lds + TILE * 16);
@@ -507,8 +555,9 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile, i
 
 // ---- phase B: FC1 from the scratch slot, ReLU -> H ----
 template <int NT>
-__device__ __noinline__ void phase_fc1(KPtr Kp, unsigned char *lds, const __bf16 *xg_tile) {
-    const auto &K = *Kp;
+__device__ __noinline__ void phase_fc1(KPtr Kp, unsigned char *lds, const __bf16 *xg_tile_) {
+    const auto &K = *uniform(Kp);
+    const __bf16 *xg_tile = uniform(xg_tile_);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char *overlay = lds + TILE * 16;
     f32x16 acc[2][NT];
@@ -521,8 +570,9 @@ __device__ __noinline__ void phase_fc1(KPtr Kp, unsigned char *lds, const __bf16
 
 // ---- phases C, D: FC2 from H back into H; logits; actions ----
 template <int NT>
-__device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0, int nt_samples) {
-    const auto &K = *Kp;
+__device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0_, int nt_samples_) {
+    const auto &K = *uniform(Kp);
+    const int n0 = uniform(n0_), nt_samples = uniform(nt_samples_);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long *tab = (const unsigned long long *)lds;
     __bf16 *H = (__bf16 *)(lds + TILE * 16);

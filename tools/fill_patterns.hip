@@ -11,7 +11,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // v4: one-shot single-wave blocks writing `chunk` bytes contiguous, 16 B per lane per instruction
 // v5: 4096 persistent waves, each streams its own contiguous region (total / 4096), 1 KB per instruction (the env pattern)
 // v6: like v5 but 32 B per lane (2 KB per instruction pair)
-// v7: like v5, but every wave covers its region in 4 interleaved passes?? (not used)
+// v7: like v5 (every wave streams `per` contiguous bytes), but the waves' regions lie `chunk16` x 16 B apart: a SPARSE footprint, like
+//     the capacity-strided observation slabs of which only the rows in use are written
 __global__ void __launch_bounds__(256) fill(double *p, size_t n16, int v, int chunk16) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
     d2 val; val.x = 1.0; val.y = 2.0;
@@ -29,12 +30,15 @@ __global__ void __launch_bounds__(256) fill(double *p, size_t n16, int v, int ch
     } else if (v == 6) {
         const size_t per = n16 / gridDim.x, base = (size_t)blockIdx.x * per;
         for (size_t i = threadIdx.x; 2 * i + 1 < per; i += 64) { q[base + 2 * i] = val; q[base + 2 * i + 1] = val; }
+    } else if (v == 7) {
+        const size_t per = n16 / gridDim.x, base = (size_t)blockIdx.x * chunk16;
+        for (size_t i = threadIdx.x; i < per; i += 64) q[base + i] = val;
     }
 }
 int main(int argc, char **argv) {
     const size_t mib = argc > 1 ? atoi(argv[1]) : 384; const int iters = argc > 2 ? atoi(argv[2]) : 50;
     const size_t bytes = mib << 20, n16 = bytes / 16;
-    double *p; hipMalloc(&p, bytes);
+    double *p; hipMalloc(&p, bytes * 6);   // (v7 spreads its writes over up to 6x the bytes written)
     struct { const char *name; int v; int block; size_t grid; int chunk16; } cases[] = {
         {"grid-stride 16B/lane, 2048x256", 0, 256, 2048, 0},
         {"grid-stride 16B/lane, 1024x256", 0, 256, 1024, 0},
@@ -48,6 +52,11 @@ int main(int argc, char **argv) {
         {"4096 persistent waves, own region, 1 KB/instr", 5, 64, 4096, 0},
         {"4096 persistent waves, own region, 32B/lane", 6, 64, 4096, 0},
         {"1024 persistent waves, own region, 1 KB/instr", 5, 64, 1024, 0},
+        {"4096 persistent waves, regions 1.0x apart (dense)", 7, 64, 4096, (int)(n16 / 4096)},
+        {"4096 persistent waves, regions 1.5x apart", 7, 64, 4096, (int)(n16 / 4096 * 3 / 2)},
+        {"4096 persistent waves, regions 2x apart", 7, 64, 4096, (int)(n16 / 4096 * 2)},
+        {"4096 persistent waves, regions 4.5x apart", 7, 64, 4096, (int)(n16 / 4096 * 9 / 2)},
+        {"4096 persistent waves, regions 6x apart", 7, 64, 4096, (int)(n16 / 4096 * 6)},
     };
     for (auto &c : cases) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
