@@ -1323,15 +1323,30 @@ struct Env {
             else t = sum3 / C.norm_grass_opp;
             dv[k] = safe_clip01(t);
         }
-        for (int c0 = 0; c0 < n; c0 += 64) {   // the drive planes: one scalar per plane (DRV:566-569)
-            const int cell = c0 + ln;
-            if (cell < n) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k >= nd) continue;
-                    const size_t o = obase + (size_t)(4 + k) * n + cell;
-                    if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred))[o] = (float)dv[k];
-                    else ((double *)(type ? P.obs_prey : P.obs_pred))[o] = dv[k];
+        // the drive planes: one scalar per plane (DRV:566-569).  The nd planes are ONE contiguous run of nd * n elements: written as
+        // element pairs (16-byte stores for float64), behind one leading single element when the run starts on an odd element
+        {
+            const size_t start = obase + (size_t)4 * n;
+            const int len = nd * n, sh = (int)(start & 1);
+            auto plane_value = [&](int e) { return e < n ? dv[0] : e < 2 * n ? dv[1] : e < 3 * n ? dv[2] : dv[3]; };
+            if (sh && ln == 0) {
+                if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred))[start] = (float)dv[0];
+                else ((double *)(type ? P.obs_prey : P.obs_pred))[start] = dv[0];
+            }
+            for (int e = sh + 2 * ln; e < len; e += 128) {
+                const double v0 = plane_value(e), v1 = plane_value(e + 1);
+                if (e + 1 < len) {
+                    if (P.obs_f32) {
+                        float2 f; f.x = (float)v0; f.y = (float)v1;
+                        *(float2 *)((float *)(type ? P.obs_prey : P.obs_pred) + start + e) = f;
+                    } else {
+                        double2 g; g.x = v0; g.y = v1;
+                        *(double2 *)((double *)(type ? P.obs_prey : P.obs_pred) + start + e) = g;
+                    }
+                } else if (P.obs_f32) {
+                    ((float *)(type ? P.obs_prey : P.obs_pred))[start + e] = (float)v0;
+                } else {
+                    ((double *)(type ? P.obs_prey : P.obs_pred))[start + e] = v0;
                 }
             }
         }
