@@ -1263,8 +1263,11 @@ struct Env {
     // all three channels), combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by three xor-shuffles (IEEE addition commutes, so
     // every lane of a group ends with the same bits), then the tail elements one by one.  Needs 8 <= R*R <= 128 (numpy switches
     // to a plain loop below and to recursive halves above); other sizes take the per-element path.
-    // (Tried and slower, 224 vs 201 us per 1365-env launch: staging all four planes and writing the block in element order with
-    // 16-byte stores -- the second pass over LDS costs more than the wider stores save.)
+    // Tried and slower (per 1365-env launch, against this version = 1.00): staging all four planes and writing the block in
+    // element order with 16-byte stores 1.11 (the second pass over LDS costs more than the wider stores save); two adjacent cells
+    // per lane with aligned pair stores 1.07 (shuffles for the odd planes, 41 of 64 lanes busy); element order through the
+    // descriptor table with the staging folded into the same pass 1.11 (one lookup per ELEMENT instead of per cell, also for
+    // plane 0).  The per-cell lookups are what this path is bound by, not the width of its stores.
     PPG_MEMBER void obs_row_drive(int type, int j, uint32_t s_xy, double s_e) {
         wv::sync();
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
