@@ -1,6 +1,6 @@
 // Calibration kernel (not product code): variants of the observation WRITE PATTERN of ppg_step, no compute, footprint beyond the
 // 256 MB Infinity Cache.  Which space/time arrangement of the same bytes does HBM take fastest?
-//   ./a.out B mean iters
+//   ./a.out B mean iters [cap=128] [variants: all | base]
 // variants:
 //  0 base      one wave per env, rows of 324 doubles at stride 324 (the API layout [env][row]), 1 KB per store instruction
 //  1 aligned   the same with rows padded to 336 doubles (128-byte aligned rows)
@@ -70,9 +70,9 @@ __global__ void __launch_bounds__(256) pattern(double *obs, const int *rows, int
 }
 int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4096, mean = argc > 2 ? atoi(argv[2]) : 36, iters = argc > 3 ? atoi(argv[3]) : 100;
-    const int cap = 128, blk = 324;
+    const int cap = argc > 4 ? atoi(argv[4]) : 128, blk = 324;   // cap: rows per env slab (the slab stride = cap * row bytes)
     double *obs; int *rows;
-    hipMalloc(&obs, (size_t)B * cap * 336 * 8);
+    hipMalloc(&obs, (size_t)B * cap * 336 * 8 + 4096);
     hipMalloc(&rows, B * sizeof(int));
     const char *names[] = {"base", "aligned", "rowmajor", "half", "third", "quad", "quadchunk", "nontemporal", "linear", "rowwave", "rowwave2"};
     int *prefix; hipMalloc(&prefix, (B + 1) * sizeof(int));
@@ -84,7 +84,9 @@ int main(int argc, char **argv) {
         std::vector<int> pf(B + 1, 0);
         for (int i = 0; i < B; ++i) pf[i + 1] = pf[i] + h[i];
         hipMemcpy(prefix, pf.data(), (B + 1) * sizeof(int), hipMemcpyHostToDevice);
+        const bool only_base = argc > 5;
         for (int variant = 0; variant < 11; ++variant) {
+            if (only_base && variant != 0 && variant != 5) continue;
             const int stride = variant == 1 ? 336 : blk;
             const int grid = variant == 3 ? B / 2 : variant == 4 ? (B + 2) / 3 : variant == 8 ? 256 * 8 : variant == 9 ? (int)tot : variant == 10 ? (int)(tot + 1) / 2 : B;
             const int block = (variant == 5 || variant == 6 || variant == 8) ? 256 : 64;
@@ -97,7 +99,7 @@ int main(int argc, char **argv) {
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double bytes = (double)tot * blk * 8;
-            printf("%-12s B=%d rows %s (mean %.1f): %.1f us per launch, %.2f TB/s\n", names[variant], B, mode ? "spread " : "uniform", (double)tot / B,
+            printf("%-12s B=%d cap=%d rows %s (mean %.1f): %.1f us per launch, %.2f TB/s\n", names[variant], B, cap, mode ? "spread " : "uniform", (double)tot / B,
                    ms / iters * 1e3, bytes * iters / (ms * 1e-3) / 1e12);
         }
     }
