@@ -27,108 +27,27 @@ struct EmuLaunch {
     int nw;  // wavefronts per workgroup: 1, or 4 / 8 for the multi-wave step kernels (MODE_STEP only)
 };
 
-// the multi-wave step kernels (ppgw*_step_*): family 0 base, 1 second generation, 2 walls, 3 drive
-template <int NQ, bool FAST, int NW>
-static void run_step_nw(const ppg::KParams &P, int family) {
-    PPG_DYNAMIC_LDS(lds);
-    if (family == 3) ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, NW>(P, lds);
-    else if (family == 2) ppg::env_main<NQ, ppg::MODE_STEP, false, true, true, false, NW>(P, lds);
-    else if (family == 1) ppg::env_main<NQ, ppg::MODE_STEP, FAST, true, false, false, NW>(P, lds);
-    else ppg::env_main<NQ, ppg::MODE_STEP, FAST, false, false, false, NW>(P, lds);
-}
-template <bool FAST, int NW>
-static void run_step_nq(const EmuLaunch *L) {
-    if (L->nq == 1) run_step_nw<1, FAST, NW>(*L->P, L->gen2);
-    else if (L->nq == 2) run_step_nw<2, FAST, NW>(*L->P, L->gen2);
-    else run_step_nw<4, FAST, NW>(*L->P, L->gen2);
-}
+// The kernel instantiations live in twelve separately compiled units (ppg_emu_part.cpp: family x prey registers), built in
+// parallel by tests/emu_backend.py; family 0 base, 1 second generation, 2 walls, 3 drive.
+#define PPG_EMU_PART_DECL(F, NQ) void ppg_emu_run_f##F##_q##NQ(const ppg::KParams &P, int mode, int nw, bool fast);
+PPG_EMU_PART_DECL(0, 1) PPG_EMU_PART_DECL(0, 2) PPG_EMU_PART_DECL(0, 4)
+PPG_EMU_PART_DECL(1, 1) PPG_EMU_PART_DECL(1, 2) PPG_EMU_PART_DECL(1, 4)
+PPG_EMU_PART_DECL(2, 1) PPG_EMU_PART_DECL(2, 2) PPG_EMU_PART_DECL(2, 4)
+PPG_EMU_PART_DECL(3, 1) PPG_EMU_PART_DECL(3, 2) PPG_EMU_PART_DECL(3, 4)
 
-template <int NQ, bool FAST>
-static void run_mode(const ppg::KParams &P, int mode) {
-    PPG_DYNAMIC_LDS(lds);
-    switch (mode) {
-        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP, FAST>(P, lds); break;
-        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET, FAST>(P, lds); break;
-        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, FAST>(P, lds); break;
-        case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, FAST>(P, lds); break;
-        case ppg::MODE_ROLLOUT: ppg::env_main<NQ, ppg::MODE_ROLLOUT, FAST>(P, lds); break;
-        case ppg::MODE_STEP_KICK: ppg::env_main<NQ, ppg::MODE_STEP_KICK, FAST>(P, lds); break;
-        case ppg::MODE_STEP_ORDERED_KICK: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED_KICK, FAST>(P, lds); break;
-        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, FAST>(P, lds); break;
-    }
-}
-
-template <int NQ, bool FAST>
-static void run_mode2(const ppg::KParams &P, int mode) {
-    PPG_DYNAMIC_LDS(lds);
-    switch (mode) {
-        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP, FAST, true>(P, lds); break;
-        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET, FAST, true>(P, lds); break;
-        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, FAST, true>(P, lds); break;
-        case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, FAST, true>(P, lds); break;
-        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, FAST, true>(P, lds); break;
-    }
-}
-
-template <int NQ>
-static void run_mode3(const ppg::KParams &P, int mode) {
-    PPG_DYNAMIC_LDS(lds);
-    switch (mode) {
-        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP, false, true, true>(P, lds); break;
-        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET, false, true, true>(P, lds); break;
-        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, false, true, true>(P, lds); break;
-        case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, false, true, true>(P, lds); break;
-        case ppg::MODE_VIS: ppg::env_main<NQ, ppg::MODE_VIS, false, true, true>(P, lds); break;
-        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, false, true, true>(P, lds); break;
-    }
-}
-
-template <int NQ>
-static void run_mode4(const ppg::KParams &P, int mode) {
-    PPG_DYNAMIC_LDS(lds);
-    switch (mode) {
-        case ppg::MODE_STEP: ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true>(P, lds); break;
-        case ppg::MODE_RESET: ppg::env_main<NQ, ppg::MODE_RESET, false, false, false, true>(P, lds); break;
-        case ppg::MODE_OBSERVE: ppg::env_main<NQ, ppg::MODE_OBSERVE, false, false, false, true>(P, lds); break;
-        case ppg::MODE_STEP_ORDERED: ppg::env_main<NQ, ppg::MODE_STEP_ORDERED, false, false, false, true>(P, lds); break;
-        default: ppg::env_main<NQ, ppg::MODE_EXPORT_GRID, false, false, false, true>(P, lds); break;
-    }
-}
-
-template <bool FAST>
-static void run_nq(const EmuLaunch *L) {
-    if (L->nw == 2) { run_step_nq<FAST, 2>(L); return; }
-    if (L->nw == 4) { run_step_nq<FAST, 4>(L); return; }
-    if (L->nw == 8) { run_step_nq<FAST, 8>(L); return; }
-    if (L->gen2 == 3) {  // drive-conditioned variant of the base family: generic observation geometry only
-        if (L->nq == 1) run_mode4<1>(*L->P, L->mode);
-        else if (L->nq == 2) run_mode4<2>(*L->P, L->mode);
-        else run_mode4<4>(*L->P, L->mode);
-        return;
-    }
-    if (L->gen2 == 2) {  // walls variant: generic observation geometry only
-        if (L->nq == 1) run_mode3<1>(*L->P, L->mode);
-        else if (L->nq == 2) run_mode3<2>(*L->P, L->mode);
-        else run_mode3<4>(*L->P, L->mode);
-        return;
-    }
-    if (L->gen2) {
-        if (L->nq == 1) run_mode2<1, FAST>(*L->P, L->mode);
-        else if (L->nq == 2) run_mode2<2, FAST>(*L->P, L->mode);
-        else run_mode2<4, FAST>(*L->P, L->mode);
-        return;
-    }
-    if (L->nq == 1) run_mode<1, FAST>(*L->P, L->mode);
-    else if (L->nq == 2) run_mode<2, FAST>(*L->P, L->mode);
-    else run_mode<4, FAST>(*L->P, L->mode);
+static void run_part(const EmuLaunch *L, bool fast) {
+    typedef void (*part_fn)(const ppg::KParams &, int, int, bool);
+    static const part_fn table[4][3] = {
+        {ppg_emu_run_f0_q1, ppg_emu_run_f0_q2, ppg_emu_run_f0_q4}, {ppg_emu_run_f1_q1, ppg_emu_run_f1_q2, ppg_emu_run_f1_q4},
+        {ppg_emu_run_f2_q1, ppg_emu_run_f2_q2, ppg_emu_run_f2_q4}, {ppg_emu_run_f3_q1, ppg_emu_run_f3_q2, ppg_emu_run_f3_q4}};
+    table[L->gen2][L->nq == 1 ? 0 : L->nq == 2 ? 1 : 2](*L->P, L->mode, L->nw, fast);
 }
 
 static void lane_entry(void *arg) {
     const EmuLaunch *L = (const EmuLaunch *)arg;
     // same selection rule as the HIP backend; PPG_EMU_FORCE_GENERIC_OBS=1 exercises the LDS-descriptor path
     static const bool force_generic = getenv("PPG_EMU_FORCE_GENERIC_OBS") != nullptr;
-    if (L->P->nch_p <= 2 && L->P->nch_q <= 3 && !force_generic && L->gen2 < 2) run_nq<true>(L);
-    else run_nq<false>(L);
+    run_part(L, L->P->nch_p <= 2 && L->P->nch_q <= 3 && !force_generic && L->gen2 < 2);
 }
 
 static int backend_init(ppg_handle *h, int) {
