@@ -262,6 +262,9 @@ int ppg_abi_version(void);
 /* Validates cfg and binds the buffers.  Replaces PredPreyGrass.__init__ (BASE:18-127). */
 int ppg_create(const ppg_config *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out);
 int ppg_destroy(ppg_handle *h);
+/* The buffers the handle was created with (borrowed device pointers; the caller keeps owning them): what a binding that did
+ * not allocate them itself needs to find observations, row tables and the status words. */
+int ppg_get_buffers(const ppg_handle *h, ppg_buffers *out);
 
 /* Second generation: replaces PredPreyGrass.__init__ of the red_queen env (RQ:15-86).  bufs->row_lastrep is required.
  * The handle works with ppg_reset / ppg_observe / ppg_step / ppg_step_ordered / ppg_step_many / ppg_export_grid

@@ -127,7 +127,7 @@ POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_destroy", "ppg_policy_act", "
 
 
 EXPORTED_SYMBOLS = [
-    "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
+    "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_get_buffers", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
     "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_rebalance",
     "ppg_export_grid", "ppg_walls_changed", "ppg_state_bytes", "ppg_export_state", "ppg_import_state", "ppg_pack_bytes", "ppg_pack",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_step_kernel_name", "ppg_last_error",
@@ -159,6 +159,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_step_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p]
     lib.ppg_rebalance.restype = C.c_int
     lib.ppg_rebalance.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ppg_get_buffers.restype = C.c_int
+    lib.ppg_get_buffers.argtypes = [C.c_void_p, C.c_void_p]
     lib.ppg_set_envs_in_flight.restype = C.c_int
     lib.ppg_set_envs_in_flight.argtypes = [C.c_void_p, C.c_int32]
     lib.ppg_export_grid.restype = C.c_int

@@ -500,6 +500,12 @@ int ppg_walls_changed(ppg_handle *h, void *stream) {
     return rc;
 }
 
+int ppg_get_buffers(const ppg_handle *h, ppg_buffers *out) {
+    if (!h || !out) return PPG_EINVAL;
+    *out = h->bufs;
+    return PPG_OK;
+}
+
 int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight) {
     if (!h) return PPG_EINVAL;
     if (envs_in_flight < 0) return ppg_fail(h, PPG_EINVAL, "envs_in_flight < 0");

@@ -351,3 +351,15 @@ def test_pettingzoo_parallel_wraps_the_other_env_classes():
             assert set(obs) == set(rew) == set(term) == set(trunc) == set(infos)
         if cls is walls_occlusion.PredPreyGrass:
             assert any("los_rejected" in v for v in infos.values())
+
+
+def test_get_buffers_returns_the_bound_pointers():
+    """ppg_get_buffers: a binding that did not allocate the tensors itself finds them through the handle."""
+    import ctypes
+    from predpreygrass_amd import _abi
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    env = BatchedPredPreyGrass(dict(config_env), batch_size=2, _library=library())
+    out = _abi.PpgBuffers()
+    assert env._lib.ppg_get_buffers(env._handle, ctypes.byref(out)) == 0
+    assert out.obs_prey == env.obs_prey.data_ptr() and out.env_state == env.env_state.data_ptr() and out.row_xy == env.row_xy.data_ptr()
+    assert env._lib.ppg_get_buffers(env._handle, None) != 0
