@@ -44,6 +44,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TILE = 128;         // samples per workgroup tile
 constexpr int HSTRIDE = 264;      // H[sample][256 + 8] bf16: rows 528 B apart -> conflict-free 16-byte fragment reads
 constexpr int MAX_HANDLES = PPG_PACK_MAX_HANDLES;
+constexpr int PLAN_HDR = 3;       // words in front of the prefix sums of PolParams::plan
 
 struct PolParams {
     // geometry
@@ -68,7 +69,9 @@ struct PolParams {
     int8_t *actions[MAX_HANDLES];
     int32_t S, cap, slot0;        // rows per env of the action tensor; row capacity of this species; its first slot
     // scratch
-    const uint32_t *plan;         // [0] = total rows of this species, [1] = samples per tile (64 / 96 / 128), [2 + e] = exclusive prefix sum of env e
+    const uint32_t *plan;         // [0] = total rows of this species, [1] = number of FULL tiles (128 samples, whole rounds of the
+                                  // resident workgroups), [2] = samples per tile of the last round (32 / 64 / 96 / 128),
+                                  // [PLAN_HDR + e] = exclusive prefix sum of env e
     const uint32_t *tile_env;     // [tile] = env of the tile's first sample
     uint32_t magic_P, magic_R;    // ceil(2^32 / P), ceil(2^32 / R): n / P == mulhi(n, magic_P) for the small n used here
     __bf16 *xg;                   // [gridDim.x][TILE][K1]
@@ -78,7 +81,7 @@ struct PolParams {
 struct PlanParams {
     int32_t n_handles, n_envs, word;   // word: PPG_ENV_N_PRED_ROWS / PPG_ENV_N_PREY_ROWS
     int32_t slots;                     // workgroups the forward launch keeps resident (its grid)
-    int32_t force_ts;                  // experiments (env PPG_POLICY_TILE): 64 / 96 / 128 instead of the choice below; 0 = choose
+    int32_t force_ts;                  // experiments (env PPG_POLICY_TILE_PREY / _PRED): every tile 32 / 64 / 96 / 128 samples; 0 = choose
     int32_t env_base[MAX_HANDLES + 1];
     const int32_t *env_state[MAX_HANDLES];
     uint32_t *plan;
@@ -118,27 +121,31 @@ extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan(const PlanPar
     const uint32_t all = part[1023];
     for (int e = lo; e < hi; ++e) {
         const int k = handle_of(K.env_base, K.n_handles, e);
-        K.plan[2 + e] = before;
+        K.plan[PLAN_HDR + e] = before;
         before += (uint32_t)K.env_state[k][(size_t)(e - K.env_base[k]) * PPG_ENV_WORDS + K.word];
     }
-    // Samples per workgroup tile: 128 (the FC1 weights are re-read once per tile) unless that leaves resident workgroup slots empty:
-    // then the largest of 96 / 64 that fills them, else 64.  (Measured at 134 k prey + 22 k predator rows: prey 128 / predators 64
-    // 1.60 ms; 128 / 128 1.67; prey 96 1.67-1.89; prey 64 1.95-2.04 -- two workgroups share a CU, so a thinly filled last round
-    // of large tiles runs faster than its share, and smaller tiles only pay where workgroups would otherwise be missing.)
-    uint32_t ts = 64;
-    for (uint32_t cand = (uint32_t)TILE; cand >= 64; cand -= 32)
-        if ((all + cand - 1) / cand >= (uint32_t)K.slots) { ts = cand; break; }
-    if (K.force_ts) ts = (uint32_t)K.force_ts;
-    if (t == 0) { K.plan[0] = all; K.plan[1] = ts; }
+    // Tiles: as many whole ROUNDS of 128-sample tiles as the resident workgroups (slots) can be given (the FC1 weights are re-read
+    // once per tile, so tiles are as large as the accumulators allow), then ONE last round in which the remaining samples are
+    // spread over the slots in tiles of 32 / 64 / 96 / 128.  A last round of a few full tiles would take as long as any other
+    // round while most of the chip idles: at the benchmark's 134 k prey rows, 1047 tiles of 128 on 512 slots are 2.04 rounds and
+    // cost three; 1024 + 92 tiles of 32 cost two and a short one.
+    const uint32_t per_round = (uint32_t)TILE * (uint32_t)K.slots;
+    uint32_t n_full = (all / per_round) * (uint32_t)K.slots;
+    const uint32_t rest = all - n_full * (uint32_t)TILE;
+    uint32_t ts = 32u * ((rest + 32u * (uint32_t)K.slots - 1u) / (32u * (uint32_t)K.slots));   // 32 * ceil(rest / (32 * slots))
+    if (ts < 32u) ts = 32u;
+    if (K.force_ts) { ts = (uint32_t)K.force_ts; n_full = 0; }
+    if (t == 0) { K.plan[0] = all; K.plan[1] = n_full; K.plan[2] = ts; }
     __threadfence_block();
     __syncthreads();   // (the prefix sums are re-read below by other threads of this workgroup: same CU, written through L1)
-    const int n_tiles = (int)((all + ts - 1) / ts);
+    const uint32_t tail = all - n_full * (uint32_t)TILE;
+    const int n_tiles = (int)(n_full + (tail + ts - 1) / ts);
     for (int tile = t; tile < n_tiles; tile += 1024) {
-        const uint32_t n = (uint32_t)tile * ts;
+        const uint32_t n = (uint32_t)tile < n_full ? (uint32_t)tile * (uint32_t)TILE : n_full * (uint32_t)TILE + ((uint32_t)tile - n_full) * ts;
         int a = 0, b = K.n_envs - 1;
         while (a < b) {   // the last env whose prefix sum is <= n
             const int mid = (a + b + 1) >> 1;
-            if (__builtin_nontemporal_load(&K.plan[2 + mid]) <= n) a = mid; else b = mid - 1;
+            if (__builtin_nontemporal_load(&K.plan[PLAN_HDR + mid]) <= n) a = mid; else b = mid - 1;
         }
         K.tile_env[tile] = (uint32_t)a;
     }
@@ -272,6 +279,8 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
 // top of step c everything but the two X(c + 1) loads must have landed: s_waitcnt vmcnt(2).
 constexpr int FC1_BUF = TILE * 64;                   // bytes per X buffer
 
+// (Cache hints were tried for the scratch slot -- nt stores in conv3, nt on these loads, nt on the observation reads, so that the
+// streaming data would not push FC1's weights out of L2: every combination was 5-10 % SLOWER.)
 __device__ __forceinline__ void glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)g, (void __attribute__((address_space(3))) *)l, 16, 0, 0);
 }
@@ -469,8 +478,8 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
         if (tid < nt_samples) {
             const uint32_t n = (uint32_t)(n0 + tid);
             int lo = (int)K.tile_env[tile];
-            while (lo + 1 < K.n_envs && K.plan[3 + lo] <= n) ++lo;
-            const int e = lo, row = (int)(n - K.plan[2 + e]);
+            while (lo + 1 < K.n_envs && K.plan[PLAN_HDR + 1 + lo] <= n) ++lo;
+            const int e = lo, row = (int)(n - K.plan[PLAN_HDR + e]);
             const int k = handle_of(K.env_base, K.n_handles, e);
             const int b = e - K.env_base[k];
             src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)(4 * K.P) * (OBS_F32 ? 4 : 8));
@@ -630,15 +639,18 @@ __device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0_, in
 
 template <bool OBS_F32>
 __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
-    const int N = (int)Kp->plan[0], ts = (int)Kp->plan[1];
+    const int N = (int)Kp->plan[0], n_full = (int)Kp->plan[1], ts = (int)Kp->plan[2];
+    const int n_tiles = n_full + (N - n_full * TILE + ts - 1) / ts;
     __bf16 *xg_tile = Kp->xg + (size_t)blockIdx.x * TILE * Kp->K1;
-    for (int tile = (int)blockIdx.x; tile * ts < N; tile += (int)gridDim.x) {
-        const int n0 = tile * ts;
-        const int nt_samples = (N - n0) < ts ? (N - n0) : ts;
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int size = tile < n_full ? TILE : ts;
+        const int n0 = tile < n_full ? tile * TILE : n_full * TILE + (tile - n_full) * ts;
+        const int nt_samples = (N - n0) < size ? (N - n0) : size;
         __syncthreads();   // the previous tile's readers of H / the table are done
         phase_conv<OBS_F32>(Kp, lds, tile, n0, nt_samples, xg_tile);
-        if (ts <= 64) { phase_fc1<2>(Kp, lds, xg_tile); phase_head<2>(Kp, lds, n0, nt_samples); }
-        else if (ts <= 96) { phase_fc1<3>(Kp, lds, xg_tile); phase_head<3>(Kp, lds, n0, nt_samples); }
+        if (size <= 32) { phase_fc1<1>(Kp, lds, xg_tile); phase_head<1>(Kp, lds, n0, nt_samples); }
+        else if (size <= 64) { phase_fc1<2>(Kp, lds, xg_tile); phase_head<2>(Kp, lds, n0, nt_samples); }
+        else if (size <= 96) { phase_fc1<3>(Kp, lds, xg_tile); phase_head<3>(Kp, lds, n0, nt_samples); }
         else { phase_fc1<4>(Kp, lds, xg_tile); phase_head<4>(Kp, lds, n0, nt_samples); }
     }
 }
@@ -663,7 +675,7 @@ struct ppg_policy {
     ppgpol::PolParams base;
     void *dev_weights;     // one allocation: fragments + biases
     __bf16 *xg;            // scratch slots
-    uint32_t *plan;        // [1 + plan_envs] prefix sums, then [plan_tiles] first env of every tile
+    uint32_t *plan;        // [PLAN_HDR + plan_envs] header + prefix sums, then the first env of every tile
     int32_t plan_envs;
     int32_t grid;
     int32_t lds_bytes;
@@ -881,16 +893,16 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     if (p->plan_envs < total) {
         if (p->plan) (void)hipFree(p->plan);
         p->plan = nullptr;
-        const size_t max_tiles = ((size_t)total * K.cap + 63) / 64;   // (tiles of 64 samples are the smallest the plan picks)
-        PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(2 + total) + max_tiles) * 4));
+        const size_t max_tiles = ((size_t)total * K.cap + 31) / 32 + 1;   // (tiles of 32 samples are the smallest the plan picks)
+        PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(ppgpol::PLAN_HDR + total) + max_tiles) * 4));
         p->plan_envs = total;
     }
     K.plan = L.plan = p->plan;
-    K.tile_env = L.tile_env = p->plan + 2 + total;
+    K.tile_env = L.tile_env = p->plan + ppgpol::PLAN_HDR + total;
     L.slots = p->grid;
     if (const char *f = getenv(species ? "PPG_POLICY_TILE_PREY" : "PPG_POLICY_TILE_PRED")) {
         const int v = atoi(f);
-        if (v == 64 || v == 96 || v == 128) L.force_ts = v;
+        if (v == 32 || v == 64 || v == 96 || v == 128) L.force_ts = v;
     }
     K.logits = logits;
     hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
