@@ -173,7 +173,11 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     const int channels = (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
     const int ch_p = drive ? 4 + c.n_drive[0] : channels, ch_q = drive ? 4 + c.n_drive[1] : channels;
     P.nch_p = ppg_obs_chunks_c(P.Rp, ch_p); P.nch_q = ppg_obs_chunks_c(P.Rq, ch_q);
-    P.off_lut = off; off += (P.nch_p + P.nch_q) * 128 * 4;
+    // the descriptor table lives in LDS only for the kernels that read it from there: the FASTOBS kernels (base family / second
+    // generation with <= 2 predator and <= 3 prey chunks: the same rule as the backends' kernel selection) keep it in registers.
+    // (64x64 grid, 7x7 windows: 24080 -> 22032 bytes per env = 7 instead of 6 envs per CU.)
+    const bool lut_in_registers = P.nch_p <= 2 && P.nch_q <= 3 && !drive && !(h->gen2 && h->cfg2.walls) && !getenv("PPG_EMU_FORCE_GENERIC_OBS");
+    P.off_lut = off; off += lut_in_registers ? 0 : (P.nch_p + P.nch_q) * 128 * 4;
     if (drive) {  // staging area for the window sums of the drive features
         for (int t = 0; t < 2; ++t) {
             P.n_drive[t] = c.n_drive[t]; P.hunger_safe[t] = c.hunger_safe_energy[t];
