@@ -158,9 +158,15 @@ static int ppg_validate_and_layout(ppg_handle *h) {
         return ppg_fail(h, PPG_EINVAL, "more than 255 grass patches need prey_capacity 256 (16-bit cell maps)");
     P.off_map = off; off += 4 * P.map_n * map_elem;
     off = (off + 15) / 16 * 16;
-    P.off_val = off; off += (map_elem == 1 ? 514 : 1 + P.S + P.cap_grass) * 8;   // (8-bit maps: three sections of 129 + room for 255 patches)
+    // value table; 8-bit maps: three zero-led sections at 0 / 129 / 258, the last one as long as there are patches (Env::grass_validx)
+    P.off_val = off; off += (map_elem == 1 ? 259 + c.n_grass : 1 + P.S + P.cap_grass) * 8;
     off = (off + 15) / 16 * 16;
-    P.off_scr = off; off += (P.S * 8 > 1024 ? P.S * 8 : 1024);
+    // scratch: 8 bytes per row of ONE species at a time (compaction), int32 per slot (parents), a list of 1 + S words (rows to
+    // observe), 256 random words (reset).  (64x64 grid, 7x7 windows: with the shorter value table 20280 bytes per env = 8 per CU.)
+    const int cap_max = P.cap_pred > P.cap_prey ? P.cap_pred : P.cap_prey;
+    int scr_bytes = cap_max * 8 > (1 + P.S) * 4 ? cap_max * 8 : (1 + P.S) * 4;
+    if (scr_bytes < 1024) scr_bytes = 1024;
+    P.off_scr = off; off += scr_bytes;
     const bool drive = !h->gen2 && (c.n_drive[0] > 0 || c.n_drive[1] > 0);
     if (!h->gen2) {
         for (int t = 0; t < 2; ++t) {

@@ -958,7 +958,7 @@ struct Env {
                 }
             }
             // scatter through LDS, one 8-byte field at a time
-            const int sbase = type ? 64 : 0;
+            const int sbase = 0;   // (one species at a time)
             int n_new = 0;
 #pragma unroll
             for (int r = 0; r < T; ++r)

@@ -89,13 +89,15 @@ inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_by
     Emu &e = emu();
     if (nwaves < 1 || nwaves > MAXW) { fprintf(stderr, "wave_emu: %d waves per workgroup\n", nwaves); abort(); }
     if (!e.stacks) e.stacks = (unsigned char *)aligned_alloc(64, STACK_BYTES * NF);  // (untouched pages stay virtual)
-    if (e.lds_bytes < lds_bytes + 64) {
+    constexpr size_t REDZONE = 4096;   // behind the workgroup's LDS: a write there is a kernel writing past its allocation
+    if (e.lds_bytes < lds_bytes + REDZONE) {
         free(e.lds);
-        e.lds = (unsigned char *)aligned_alloc(64, (lds_bytes + 127) / 64 * 64);
-        e.lds_bytes = lds_bytes + 64;
+        e.lds = (unsigned char *)aligned_alloc(64, (lds_bytes + REDZONE + 63) / 64 * 64);
+        e.lds_bytes = lds_bytes + REDZONE;
     }
     // LDS content is undefined at launch on hardware: poison it.
     memset(e.lds, 0xA5, lds_bytes);
+    memset(e.lds + lds_bytes, 0x5C, REDZONE);
     e.entry = entry;
     e.arg = arg;
     e.block = block;
@@ -151,6 +153,11 @@ inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_by
         }
         e.n_collectives++;
     }
+    for (size_t i = 0; i < REDZONE; ++i)
+        if (e.lds[lds_bytes + i] != 0x5C) {
+            fprintf(stderr, "wave_emu: block %d wrote %zu bytes past its %zu bytes of LDS\n", block, i + 1, lds_bytes);
+            abort();
+        }
 }
 
 // ---- the primitives of wave.h ----
