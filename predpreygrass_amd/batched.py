@@ -323,6 +323,26 @@ class BatchedPredPreyGrass:
             self._check(self._lib.ppg_step(self._handle, ptr, flags, self._stream(stream)), "ppg_step")
         return self
 
+    # SURVEY.md section 8(b)'s spelling of the tensor API: the same calls, returning views of the buffers the kernel wrote
+    def reset_batch(self, seeds=None, episode=0):
+        """reset() of every env (env b seeded `seeds + b`, or one seed per env); returns (obs_pred, obs_prey)."""
+        self.reset(seed=seeds, episode=episode)
+        return self.obs_pred, self.obs_prey
+
+    def step_batch(self, actions=None, **kw):
+        """step() of every env; returns (obs_pred[B,Sp,C,Rp,Rp], obs_prey[B,Sq,C,Rq,Rq], reward[B,S], terminated[B,S],
+        truncated[B,S], live_mask[B,S], agent_id[B,S]).  Row s of env b is in use iff live_mask[b,s]; a row that terminated in
+        this call is still in use (it carries its last observation and reward) and is dropped by the next call, like the
+        reference keeps a dead agent in `agents` until the next step (predpreygrass_rllib_env.py:222-225,459-461)."""
+        self.step(actions, **kw)
+        n_pred = self.env_state[:, _abi.ENV_N_PRED_ROWS:_abi.ENV_N_PRED_ROWS + 1]
+        n_prey = self.env_state[:, _abi.ENV_N_PREY_ROWS:_abi.ENV_N_PREY_ROWS + 1]
+        slot = torch.arange(self.S, device=self.device, dtype=torch.int32).unsqueeze(0)
+        live = torch.where(slot < self.pred_capacity, slot < n_pred, slot - self.pred_capacity < n_prey)
+        flags = self.row_flags
+        return (self.obs_pred, self.obs_prey, self.row_reward, ((flags & _abi.ROW_DIED) != 0) & live,
+                ((flags & _abi.ROW_TRUNC) != 0) & live, live, self.row_id)
+
     def rollout(self, n_steps, actions=None, random_actions=False, auto_reset=False, stream=None):
         """`n_steps` transitions in ONE kernel launch (state stays on chip between steps): the same result
         as `n_steps` calls of step().  Actions come from the device-side uniform random policy

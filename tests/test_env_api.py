@@ -363,3 +363,25 @@ def test_get_buffers_returns_the_bound_pointers():
     assert env._lib.ppg_get_buffers(env._handle, ctypes.byref(out)) == 0
     assert out.obs_prey == env.obs_prey.data_ptr() and out.env_state == env.env_state.data_ptr() and out.row_xy == env.row_xy.data_ptr()
     assert env._lib.ppg_get_buffers(env._handle, None) != 0
+
+
+def test_reset_batch_step_batch_views_agree_with_the_records():
+    """SURVEY 8(b)'s reset_batch / step_batch: masks and tensors describe the same rows as records() (the dict assembly)."""
+    import torch
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    env = BatchedPredPreyGrass(dict(config_env), batch_size=3, _library=library())
+    obs_pred, obs_prey = env.reset_batch(seeds=11)
+    assert obs_pred.shape[:2] == (3, env.pred_capacity) and obs_prey.shape[:2] == (3, env.prey_capacity)
+    seen_dead = 0
+    for _ in range(40):
+        op, oq, rew, term, trunc, live, ids = env.step_batch(random_actions=True)
+        tables = env.host_tables()
+        for b in range(3):
+            recs = env.records(b, tables)
+            assert int(live[b].sum()) == len(recs)
+            assert int(term[b].sum()) == sum(1 for r in recs if r[4])
+            assert int(trunc[b].sum()) == sum(1 for r in recs if r[5])
+            assert not bool((term[b] & ~live[b]).any())
+            seen_dead += int(term[b].sum())
+            assert abs(float(rew[b][live[b]].sum()) - sum(r[3] for r in recs)) < 1e-9
+    assert seen_dead > 0
