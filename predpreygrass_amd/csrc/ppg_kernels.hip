@@ -9,22 +9,36 @@
 #error "define PPG_TU_GEN and PPG_TU_NQ"
 #endif
 
+// Waves per SIMD the compiler is asked to make room for (the register cap): 4 = 128 VGPRs.  The walls kernels are bound by
+// latency, not by registers: at 8 (64 VGPRs, a few spilled) the four-wave step kernel is 12 % faster than at 4 (84 VGPRs = 5).
+#ifndef PPG_WPE
+#define PPG_WPE 4
+#endif
+#ifndef PPG_WPE_WALLS
+#define PPG_WPE_WALLS 8
+#endif
+#ifndef PPG_WPE_GEN2
+#define PPG_WPE_GEN2 PPG_WPE
+#endif
+#ifndef PPG_WPE_DRIVE
+#define PPG_WPE_DRIVE PPG_WPE
+#endif
 #define PPG_K(name, NQ, MODE, FAST)                                                         \
-    PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, FAST>(P, lds); }
+    PPG_KERNEL(name, (NQ <= 2 ? PPG_WPE : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, FAST>(P, lds); }
 #define PPG_K2(name, NQ, MODE, FAST)                                                        \
-    PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, FAST, true>(P, lds); }
+    PPG_KERNEL(name, (NQ <= 2 ? PPG_WPE_GEN2 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, FAST, true>(P, lds); }
 #define PPG_K3(name, NQ, MODE)                                                               \
-    PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, false, true, true>(P, lds); }
+    PPG_KERNEL(name, (NQ <= 2 ? PPG_WPE_WALLS : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, false, true, true>(P, lds); }
 #define PPG_K4(name, NQ, MODE)                                                               \
-    PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, false, false, false, true>(P, lds); }
+    PPG_KERNEL(name, (NQ <= 2 ? PPG_WPE_DRIVE : 2))(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, MODE, false, false, false, true>(P, lds); }
 #define PPG_KW(name, NQ, FAST, NW)                                                           \
-    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, false, false, false, NW>(P, lds); }
+    PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, false, false, false, NW>(P, lds); }
 #define PPG_KW2(name, NQ, FAST, NW)                                                          \
-    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, true, false, false, NW>(P, lds); }
+    PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_GEN2 : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, true, false, false, NW>(P, lds); }
 #define PPG_KW3(name, NQ)                                                                    \
-    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, true, true, false, 4>(P, lds); }
+    PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_WALLS : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, true, true, false, 4>(P, lds); }
 #define PPG_KW4(name, NQ)                                                                    \
-    PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, 4>(P, lds); }
+    PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_DRIVE : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, 4>(P, lds); }
 #include "ppg_kernel_list.h"
 
 #define PPG_APPLY(M, NQ) M(NQ)  // expands PPG_TU_NQ before the list pastes it into the kernel names
