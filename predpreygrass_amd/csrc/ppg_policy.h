@@ -162,7 +162,12 @@ __device__ __forceinline__ bf16x8 zero8() {
 __device__ __forceinline__ bf16x8 relu_pack8(const f32x16 &a, int r0) {
     bf16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float x = a[r0 + j]; v[j] = (__bf16)(x > 0.f ? x : 0.f); }
+    // ReLU on the bits: a float with the sign bit set is a negative INTEGER, so one v_max_i32 with 0 clears it (x > 0 ? x : 0 and
+    // v_med3_f32 both compile to two v_max_f32: canonicalise, then max)
+    for (int j = 0; j < 8; ++j) {
+        const int b = __float_as_int(a[r0 + j]);
+        v[j] = (__bf16)__int_as_float(b > 0 ? b : 0);
+    }
     return v;
 }
 
