@@ -158,6 +158,9 @@ def parse_args(argv):
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=3,
                     help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step)")
+    ap.add_argument("--wave-plan", default=None,
+                    help="A/B experiments: 'waves,helper_min_rows,coop_envs' forced on every sub-batch (ppg_set_wave_plan); the default is "
+                         "the library's own choice, which the JSON line names (roofline.kernel)")
     ap.add_argument("--rebalance-every", type=int, default=64,
                     help="call ppg_rebalance every that many steps (0 = never): heavy envs are assigned to workgroups first")
     ap.add_argument("--preroll-min", type=int, default=3072,
@@ -344,6 +347,10 @@ def main(argv=None, backend=None):
     if args.workload == "walls":
         for e in group.subs:
             e.set_walls(cfg["manual_wall_positions"])
+    if args.wave_plan:
+        wp = [int(v) for v in args.wave_plan.split(",")]
+        for e in group.subs:
+            e.set_wave_plan(*wp)
     group.reset()
     group.synchronize()
     env = group.subs[0]

@@ -323,6 +323,15 @@ int ppg_step_many(ppg_handle *const *handles, int32_t n, const int8_t *const *ac
  * 4 envs per CU. */
 int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight);
 
+/* Scheduling override (tests, A/B tools): which step kernel ppg_step launches for this handle.  waves = wavefronts per workgroup
+ * (0 = back to the automatic choice; 1, 2, 4, 8, 16), helper_min_rows = helper wavefronts only stay for envs with at least that
+ * many agent rows, coop_envs = envs sharing one workgroup (cooperative kernels: every wave of the workgroup runs one env's
+ * transition, then all of them write all the workgroup's observations; 0 = one env per workgroup).  Combinations a variant has
+ * no kernel for fall back to the nearest one it has.  Results never depend on the plan -- the GPU tests compare them bit for
+ * bit.  The plan is fixed here, at ppg_create and at ppg_set_envs_in_flight: ppg_step itself reads no environment variables. */
+int ppg_set_wave_plan(ppg_handle *h, int32_t waves, int32_t helper_min_rows, int32_t coop_envs);
+int ppg_get_wave_plan(const ppg_handle *h, int32_t *waves, int32_t *helper_min_rows, int32_t *coop_envs);
+
 /* Walls variant: tell the library that the caller has (re)written wall_bits.  It recomputes, for every cell of every env, the
  * line-of-sight mask over the observation window (one HIP launch; library-owned [B, G*G, words] in HBM) -- from then on
  * observations read a few mask words per agent instead of walking one Bresenham line per window cell (WO:492-525, 577-589).

@@ -128,7 +128,8 @@ POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_destroy", "ppg_policy_act", "
 
 EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_get_buffers", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
-    "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_rebalance",
+    "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_set_wave_plan",
+    "ppg_get_wave_plan", "ppg_rebalance",
     "ppg_export_grid", "ppg_walls_changed", "ppg_state_bytes", "ppg_export_state", "ppg_import_state", "ppg_pack_bytes", "ppg_pack",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_step_kernel_name", "ppg_last_error",
 ] + POLICY_SYMBOLS
@@ -163,6 +164,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_get_buffers.argtypes = [C.c_void_p, C.c_void_p]
     lib.ppg_set_envs_in_flight.restype = C.c_int
     lib.ppg_set_envs_in_flight.argtypes = [C.c_void_p, C.c_int32]
+    lib.ppg_set_wave_plan.restype = C.c_int
+    lib.ppg_set_wave_plan.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.ppg_get_wave_plan.restype = C.c_int
+    lib.ppg_get_wave_plan.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.ppg_export_grid.restype = C.c_int
     lib.ppg_export_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ppg_walls_changed.restype = C.c_int

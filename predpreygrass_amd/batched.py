@@ -281,6 +281,22 @@ class BatchedPredPreyGrass:
         self.observe()
         return self
 
+    def set_wave_plan(self, waves=0, helper_min_rows=0, coop_envs=0):
+        """Scheduling override (tests, A/B tools; results never depend on it): wavefronts per workgroup of the step kernel
+        (0 = automatic), the row count from which helper wavefronts stay, envs per workgroup of the cooperative kernels
+        (`ppg_set_wave_plan`)."""
+        self._check(self._lib.ppg_set_wave_plan(self._handle, int(waves), int(helper_min_rows), int(coop_envs)), "ppg_set_wave_plan")
+        return self
+
+    def wave_plan(self):
+        """(wavefronts per workgroup, helper_min_rows, envs per workgroup) ppg_step uses right now."""
+        w, m, e = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.ppg_get_wave_plan(self._handle, C.byref(w), C.byref(m), C.byref(e)), "ppg_get_wave_plan")
+        return w.value, m.value, e.value
+
+    def step_kernel_name(self) -> str:
+        return self._lib.ppg_step_kernel_name(self._handle).decode()
+
     def rebalance(self, stream=None):
         """Scheduling only (results are unaffected): let envs with many agents start first so that the observation
         writing is spread evenly over the CUs; call every few dozen steps (`ppg_rebalance`)."""

@@ -20,8 +20,11 @@
 #define PPG_KW4(name, NQ) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
 #define PPG_KW(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KW2(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
+#define PPG_KC(name, NQ, GEN2, NW) PPG_KERNEL_NW(name, 4, NW)(const ppg::KParams P);
 #include "ppg_kernel_list.h"
 
+PPG_DEFINE_KERNELSC(1)
+PPG_DEFINE_KERNELSC(2)
 PPG_DEFINE_KERNELS(1)
 PPG_DEFINE_KERNELS(2)
 PPG_DEFINE_KERNELS(4)
@@ -103,6 +106,10 @@ static int backend_init(ppg_handle *h, int device) {
     PPG_HIP_TRY(h, hipSetDevice(device));
     PPG_HIP_TRY(h, hipMalloc((void **)&h->lut_dev, h->lut_host.size() * sizeof(uint32_t)));
     PPG_HIP_TRY(h, hipMemcpy(h->lut_dev, h->lut_host.data(), h->lut_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (h->coop_ok) {
+        PPG_HIP_TRY(h, hipMalloc((void **)&h->coop_tab_dev, h->coop_tab_host.size() * sizeof(uint32_t)));
+        PPG_HIP_TRY(h, hipMemcpy(h->coop_tab_dev, h->coop_tab_host.data(), h->coop_tab_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     return PPG_OK;
 }
 
@@ -118,6 +125,8 @@ static void backend_release(ppg_handle *h) {
     h->vis_dev = nullptr;
     if (h->lut_dev) (void)hipFree(h->lut_dev);
     h->lut_dev = nullptr;
+    if (h->coop_tab_dev) (void)hipFree(h->coop_tab_dev);
+    h->coop_tab_dev = nullptr;
     if (h->order_dev) (void)hipFree(h->order_dev);
     h->order_dev = nullptr;
 }
@@ -204,9 +213,17 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     if (h->drive && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for the drive-conditioned variant", mode);
     ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
                        : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);
-    unsigned block = 64;
-    const ppg_wave_plan_t wp = ppg_wave_plan(h);
-    if (mode == ppg::MODE_STEP && wp.nw > 1) {   // several waves per env: wave 0 steps, all of them write the final observations
+    unsigned block = 64, grid = (unsigned)h->batch;
+    const ppg_wave_plan_t wp = h->plan;
+    if (mode == ppg::MODE_STEP && P.coop_e > 0) {   // cooperative kernels: coop_e envs per workgroup of wp.nw wavefronts
+        static const ppg_kernel_fn c[4][2] = {{ppgc_step_q1, ppgc_step_q2}, {ppgc8_step_q1, ppgc8_step_q2}, {ppgc16_step_q1, ppgc16_step_q2},
+                                              {ppgc6_step_q1, ppgc6_step_q2}};
+        fn = c[wp.nw == 8 ? 1 : wp.nw == 16 ? 2 : wp.nw == 6 ? 3 : 0][h->nq == 1 ? 0 : 1];
+        block = 64u * (unsigned)wp.nw;
+        grid = (unsigned)((h->batch + P.coop_e - 1) / P.coop_e);
+        if (P.lds_bytes > 64 * 1024)
+            PPG_HIP_TRY(h, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes));
+    } else if (mode == ppg::MODE_STEP && wp.nw > 1) {   // several waves per env: wave 0 steps, all of them write the final observations
         const int qi = h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2;
         if (h->drive) {
             static const ppg_kernel_fn w4[3] = {ppgw4_step_q1, ppgw4_step_q2, ppgw4_step_q4};
@@ -230,7 +247,7 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
         }
         block = 64u * (unsigned)wp.nw;
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)h->batch), dim3(block), (size_t)P.lds_bytes, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(block), (size_t)P.lds_bytes, (hipStream_t)stream, P);
     PPG_HIP_TRY(h, hipGetLastError());
     return PPG_OK;
 }

@@ -19,7 +19,17 @@
 #include "ppg_kernel.h"
 #include "ppg_pack.h"
 
+// How a handle's step is scheduled (never what it computes): wavefronts per workgroup, the row count from which helper wavefronts
+// stay, and -- cooperative kernels -- how many envs share a workgroup (0 = one env per workgroup, the ppg[w]_step kernels).
+struct ppg_wave_plan_t { int nw; int min_rows; int coop_e; };
+
 struct ppg_handle {
+    ppg_wave_plan_t plan;     // what ppg_step launches: decided at ppg_create / ppg_set_envs_in_flight / ppg_set_wave_plan
+    ppg_wave_plan_t forced;   // ppg_set_wave_plan: nw = 0 -> automatic
+    ppg::KParams coop;        // parameter block of the cooperative step kernels (their own LDS layout: padded cell maps)
+    int32_t coop_ok;          // the configuration has cooperative kernels (ppg_coop_layout)
+    std::vector<uint32_t> coop_tab_host;
+    uint32_t *coop_tab_dev;   // library-owned: KParams::coop_tab
     int32_t drive;  // drive-conditioned variant of the base family (cfg.n_drive)
     int32_t envs_in_flight;  // scheduling hint (ppg_set_envs_in_flight); 0 = the handle's own batch
     int32_t *order_dev;      // library-owned [batch]: env order of ppg_rebalance (NULL until first used)
@@ -182,7 +192,11 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     // the descriptor table lives in LDS only for the kernels that read it from there: the FASTOBS kernels (base family / second
     // generation with <= 2 predator and <= 3 prey chunks: the same rule as the backends' kernel selection) keep it in registers.
     // (64x64 grid, 7x7 windows: 24080 -> 22032 bytes per env = 7 instead of 6 envs per CU.)
-    const bool lut_in_registers = P.nch_p <= 2 && P.nch_q <= 3 && !drive && !(h->gen2 && h->cfg2.walls) && !getenv("PPG_EMU_FORCE_GENERIC_OBS");
+    const bool lut_in_registers = P.nch_p <= 2 && P.nch_q <= 3 && !drive && !(h->gen2 && h->cfg2.walls)
+#ifdef PPG_WAVE_EMU   // (tests: exercise the LDS-descriptor observation path on configurations that would keep it in registers)
+                                  && !getenv("PPG_EMU_FORCE_GENERIC_OBS")
+#endif
+        ;
     P.off_lut = off; off += lut_in_registers ? 0 : (P.nch_p + P.nch_q) * 128 * 4;
     if (drive) {  // staging area for the window sums of the drive features
         for (int t = 0; t < 2; ++t) {
@@ -205,7 +219,6 @@ static int ppg_validate_and_layout(ppg_handle *h) {
         P.off_win = off; off += 4 * rmax * rmax * 4;
     }
     P.lds_bytes = off;
-    if (const char *pad = getenv("PPG_DEBUG_LDS_BYTES")) { int v = atoi(pad); if (v > P.lds_bytes) P.lds_bytes = v; }  // occupancy experiments
     if (P.lds_bytes > 64 * 1024) return ppg_fail(h, PPG_EINVAL, "configuration needs %d bytes of LDS per wave (> 64 KiB)", P.lds_bytes);
 
     P.row_xy = b.row_xy; P.row_e = b.row_energy; P.row_id = b.row_id; P.row_key = b.row_key;
@@ -289,6 +302,61 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
     return PPG_OK;
 }
 
+// Cooperative step kernels (Env's COOP): eligibility and LDS layout of one env's region.  The maps are padded by the larger
+// window's reach, so the map offsets of an observation block's elements are position-independent (Env::coop_build_lut).
+static void ppg_coop_layout(ppg_handle *h) {
+    h->coop_ok = 0;
+    const ppg_config &c = h->cfg;
+    const bool walls = h->gen2 && h->cfg2.walls;
+    if (walls || h->drive || c.kickback || h->nq > 2) return;           // (8-bit maps; generic 4-channel observations only)
+    if (!(c.predator_obs_range & 1) || !(c.prey_obs_range & 1)) return;  // even windows keep the element-descriptor kernels
+    ppg::KParams P = h->base;
+    const int offp = (P.Rp - 1) / 2, offq = (P.Rq - 1) / 2;
+    P.pad = offp > offq ? offp : offq;
+    P.Gp = P.G + 2 * P.pad;
+    P.map_n = (P.Gp * P.Gp + 7) / 8 * 8;
+    if (3 * P.map_n + P.pad * P.Gp + P.pad > 32767) return;             // 16-bit map offsets
+    int off = 0;
+    P.off_map = off; off += 4 * P.map_n;
+    off = (off + 15) / 16 * 16;
+    P.off_val = off; off += (196 + c.n_grass) * 8;      // packed sections (Env::SEC_Q, SEC_G)
+    off = (off + 15) / 16 * 16;
+    const int cap_max = P.cap_pred > P.cap_prey ? P.cap_pred : P.cap_prey;
+    int scr_bytes = cap_max * 8 > (64 + P.cap_prey) * 4 ? cap_max * 8 : (64 + P.cap_prey) * 4;   // compaction / the two row lists
+    if (scr_bytes < 1024) scr_bytes = 1024;                                                       // (reset: 256 random words)
+    P.off_scr = off; off += scr_bytes;
+    P.off_lut = off;
+    P.lds_env_bytes = (off + 15) / 16 * 16;
+    P.blk_p = 4 * P.Rp * P.Rp; P.blk_q = 4 * P.Rq * P.Rq;
+    P.bp_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_p - 1) / (uint64_t)P.blk_p);
+    P.bq_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_q - 1) / (uint64_t)P.blk_q);
+    // KParams::coop_tab: the observation descriptors of both species, then the channel-0 map of an empty grid
+    h->coop_tab_host.assign((size_t)(P.blk_p + P.blk_q) + (size_t)P.map_n / 4, 0u);
+    for (int t = 0; t < 2; ++t) {
+        const int R = t ? P.Rq : P.Rp, o = (R - 1) / 2;
+        uint32_t *out = h->coop_tab_host.data() + (t ? P.blk_p : 0);
+        for (int e = 0; e < 4 * R * R; ++e) {
+            const int ch = e / (R * R), i = (e % (R * R)) / R, j = e % R;
+            const int moff = ch * P.map_n + (i - o) * P.Gp + (j - o);
+            const int section = ch == 2 ? 66 : ch == 3 ? 66 + 129 : 0;     // Env::map_base of the cooperative kernels (SEC_Q, SEC_G)
+            out[e] = ((uint32_t)moff & 0xFFFFu) | ((uint32_t)section << 16);
+        }
+    }
+    {
+        unsigned char *m0 = (unsigned char *)(h->coop_tab_host.data() + P.blk_p + P.blk_q);
+        for (int x = 0; x < P.Gp; ++x)
+            for (int y = 0; y < P.Gp; ++y)
+                if (x < P.pad || x >= P.pad + P.G || y < P.pad || y >= P.pad + P.G) m0[x * P.Gp + y] = 65;   // Env::ONE_IDX
+    }
+    h->coop = P;
+    h->coop_ok = 1;
+}
+// dynamic LDS of a cooperative workgroup of `e` envs: env regions, descriptor table, control words
+static int ppg_coop_lds_bytes(const ppg_handle *h, int e) {
+    const ppg::KParams &P = h->coop;
+    return e * P.lds_env_bytes + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16 + 80 * 4;   // (Env::CTL_WORDS)
+}
+
 // How many wavefronts step one env (wave 0 runs the transition; all of them write the final observations), and from how many
 // agent rows on the helper wavefronts of an env stay (lighter envs are left to wave 0: Env::helpers).  Measured on MI355X:
 //  - up to 512 envs in flight the GPU is nearly empty: 8 waves per env (16 up to 256 envs); up to ~3072: 4 waves (256 envs 1.8x,
@@ -296,25 +364,35 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
 //  - walls / drive variants are bound by per-row work: 4 waves at every batch size (4096 envs: 1.7-1.9x), always all of
 //    them: a second, wave-0-only copy of their large observation code in the same kernel cost 10-15 % (Env::ADAPTIVE_HELPERS);
 //  - a FULL GPU (> 3072 envs in flight) runs as fast as the slowest env of a launch lets it, and that is always a heavy one.  Base
-//    family: a PAIR of waves per env (+4 % at 25x25, interleaved A/B; 64x64 grids: 8-bit maps admit 7 envs per CU and a pair fills
-//    the 16 wave slots, +27 %); second generation (float32 observations: no longer store-bound): four waves, helpers only for envs
+//    family: the cooperative kernels (two envs per four-wave workgroup, Env's COOP) where the configuration has them and six
+//    workgroups fit a CU's LDS; else a PAIR of waves per env (64x64 grids: 8-bit maps admit 7-8 envs per CU and a pair fills the 16
+//    wave slots, +27 %); second generation (float32 observations: no longer store-bound): four waves, helpers only for envs
 //    with >= 72 rows -- the stragglers -- +25 % (48.0 -> 60.2 M env-steps/s), where helpers for every env cost 6 %.
-// PPG_MULTIWAVE=0 forces one wave; PPG_MULTIWAVE=1 forces several (PPG_MULTIWAVE8=1: eight, PPG_MULTIWAVE_PAIR=1: two, else four);
-// PPG_HELPER_MIN_ROWS overrides the threshold (experiments, tests).
-struct ppg_wave_plan_t { int nw; int min_rows; };
+// The plan is computed when the handle is created and when ppg_set_envs_in_flight / ppg_set_wave_plan change its inputs -- never
+// per step.  ppg_set_wave_plan overrides it (tests, A/B tools).
 static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
     const int lds_envs = h->base.lds_bytes > 0 ? (160 * 1024) / h->base.lds_bytes : 16;
     const int in_flight = h->envs_in_flight > 0 ? h->envs_in_flight : h->batch;
     const bool walls = h->gen2 && h->cfg2.walls;
-    const bool pair_ok = !h->gen2 && !h->drive;           // the two-wave kernels exist for the base family
-    ppg_wave_plan_t p = {1, 0};
-    const char *force = getenv("PPG_MULTIWAVE");
-    if (force) {
-        if (atoi(force) == 0) return p;
-        const char *f8 = getenv("PPG_MULTIWAVE8"), *fp = getenv("PPG_MULTIWAVE_PAIR");
-        const bool eight = f8 ? atoi(f8) != 0 : in_flight <= 512;
-        p.nw = (walls || h->drive) ? 4 : eight ? 8 : (fp && atoi(fp) != 0 && pair_ok) ? 2 : 4;
-    } else if (h->drive) {
+    ppg_wave_plan_t p = {1, 0, 0};
+    if (h->forced.nw > 0) {
+        p = h->forced;
+        if (walls || h->drive) { p.nw = p.nw > 1 ? 4 : 1; p.min_rows = 0; p.coop_e = 0; }   // (four-wave kernels only, helpers always stay)
+        if (h->cfg.kickback) { p.nw = 1; p.coop_e = 0; }
+        if (p.coop_e > 0 && (!h->coop_ok || h->gen2)) p.coop_e = 0;
+        if (p.coop_e > 0) {
+            if (p.nw != 4 && p.nw != 6 && p.nw != 8 && p.nw != 16) p.nw = 4;
+            if (p.coop_e > p.nw) p.coop_e = p.nw;
+            p.min_rows = 0;
+        } else {
+            if (p.nw != 1 && p.nw != 2 && p.nw != 4 && p.nw != 8 && p.nw != 16) p.nw = 4;
+            if (p.nw == 2 && (h->gen2 || h->drive)) p.nw = 4;                                  // the pair kernels exist for the base family
+            if (p.nw == 16 && (h->gen2 || h->base.nch_p > 2 || h->base.nch_q > 3)) p.nw = 8;  // sixteen waves: base family, register descriptors
+        }
+        return p;
+    }
+    if (h->cfg.kickback) return p;   // (single-wave kernels only)
+    if (h->drive) {
         p.nw = 4;
     } else if (walls) {
         p.nw = 4;
@@ -328,11 +406,16 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
     } else if (h->gen2) {
         p.nw = 4;
         p.min_rows = 72;
+    } else if (h->coop_ok && ppg_coop_lds_bytes(h, 2) * 6 <= 160 * 1024) {
+        // cooperative kernels, TWO envs per four-wave workgroup (six workgroups = 24 waves = 12 envs per CU): two waves run a
+        // transition each, the other two wait at the barrier, then all four write both envs' observations as whole 1 KB pieces.
+        // Interleaved A/B on one box (tools/ab_plans.py, 4096 envs, 2 / 3 sub-batches): 68.3 / 71.2 us per step against 74.0 /
+        // 76.9 for the pair kernel; four envs per workgroup (every wave runs a transition) 72.2 / 75.9, three 70.1 / 74.6.
+        p.nw = 4;
+        p.coop_e = 2;
     } else {
         p.nw = lds_envs <= 4 ? 4 : 2;
     }
-    if (const char *hm = getenv("PPG_HELPER_MIN_ROWS")) p.min_rows = atoi(hm);
-    if (walls || h->drive) p.min_rows = 0;   // (their kernels carry no wave-0-only observation path: Env::ADAPTIVE_HELPERS)
     return p;
 }
 
@@ -381,11 +464,14 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     if (cfg) h->cfg = *cfg; else h->cfg2 = *cfg2;
     h->bufs = *bufs; h->batch = batch; h->device = device;
     h->lut_dev = nullptr; h->backend = nullptr; h->prof_dev = nullptr; h->err[0] = 0;
+    h->coop_ok = 0; h->coop_tab_dev = nullptr;
+    h->forced = {0, 0, 0};
     h->envs_in_flight = 0;
     h->order_dev = nullptr;
     h->vis_dev = nullptr;
     h->drive = (cfg && (cfg->n_drive[0] > 0 || cfg->n_drive[1] > 0)) ? 1 : 0;
     int rc = cfg2 ? ppg_validate_and_layout_gen2(h) : ppg_validate_and_layout(h);
+    if (rc == PPG_OK) ppg_coop_layout(h);
     if (rc == PPG_OK) rc = backend_init(h, device);
     if (rc != PPG_OK) {
         memcpy(g_ppg_create_error, h->err, sizeof g_ppg_create_error);
@@ -394,6 +480,9 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
         return rc;
     }
     h->base.obs_lut = h->lut_dev;
+    h->coop.obs_lut = h->lut_dev;
+    h->coop.coop_tab = h->coop_tab_dev;
+    h->plan = ppg_wave_plan(h);
     *out = h;
     return PPG_OK;
 }
@@ -431,10 +520,18 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
     if (!h) return PPG_EINVAL;
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
-    ppg::KParams P = h->base;
     const int mode = h->cfg.kickback ? ppg::MODE_STEP_KICK : ppg::MODE_STEP;
+    const ppg_wave_plan_t &wp = h->plan;
+    ppg::KParams P = wp.coop_e > 0 ? h->coop : h->base;
+    if (wp.coop_e > 0) {   // cooperative kernels: wp.coop_e env regions, then the workgroup's descriptor table and control words
+        P.coop_e = wp.coop_e;
+        P.off_lut2 = wp.coop_e * P.lds_env_bytes;
+        P.off_ctl = P.off_lut2 + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16;
+        P.lds_bytes = ppg_coop_lds_bytes(h, wp.coop_e);
+        P.env_order = h->base.env_order;
+    }
     P.mode = mode; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
-    P.helper_min_rows = ppg_wave_plan(h).min_rows;
+    P.helper_min_rows = wp.min_rows;
     return backend_launch(h, mode, P, stream);
 }
 
@@ -520,6 +617,23 @@ int ppg_set_envs_in_flight(ppg_handle *h, int32_t envs_in_flight) {
     if (!h) return PPG_EINVAL;
     if (envs_in_flight < 0) return ppg_fail(h, PPG_EINVAL, "envs_in_flight < 0");
     h->envs_in_flight = envs_in_flight;
+    h->plan = ppg_wave_plan(h);
+    return PPG_OK;
+}
+
+int ppg_set_wave_plan(ppg_handle *h, int32_t waves, int32_t helper_min_rows, int32_t coop_envs) {
+    if (!h) return PPG_EINVAL;
+    if (waves < 0 || helper_min_rows < 0 || coop_envs < 0) return ppg_fail(h, PPG_EINVAL, "negative wave plan");
+    h->forced = {waves, helper_min_rows, coop_envs};
+    h->plan = ppg_wave_plan(h);
+    return PPG_OK;
+}
+
+int ppg_get_wave_plan(const ppg_handle *h, int32_t *waves, int32_t *helper_min_rows, int32_t *coop_envs) {
+    if (!h) return PPG_EINVAL;
+    if (waves) *waves = h->plan.nw;
+    if (helper_min_rows) *helper_min_rows = h->plan.min_rows;
+    if (coop_envs) *coop_envs = h->plan.coop_e;
     return PPG_OK;
 }
 
@@ -535,8 +649,11 @@ int32_t ppg_lds_bytes(const ppg_handle *h) { return h ? h->base.lds_bytes : 0; }
 
 const char *ppg_step_kernel_name(ppg_handle *h) {
     if (!h) return "";
-    ppg_wave_plan_t wp = ppg_wave_plan(h);
-    if (h->cfg.kickback) wp.nw = 1;   // (the kickback variant has single-wave kernels only)
+    const ppg_wave_plan_t wp = h->plan;
+    if (wp.coop_e > 0) {   // ppgc_step_q<NQ> (4 waves) / ppgc8_ / ppgc16_
+        snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc%s_step_q%d", wp.nw == 8 ? "8" : wp.nw == 16 ? "16" : wp.nw == 6 ? "6" : "", h->nq);
+        return h->kernel_name;
+    }
     const bool walls = h->gen2 && h->cfg2.walls, fast = h->base.nch_p <= 2 && h->base.nch_q <= 3 && !walls && !h->drive;
     const char *family = h->drive ? "4" : walls ? "3" : h->gen2 ? "2" : "";
     // ppg[w|w8|wp]<family>_step... the names of ppg_kernel_list.h: ppgw_step / ppgw8_step / ppgwp_step, ppgw2_step / ppgw28_step, ppgw3_step, ppgw4_step

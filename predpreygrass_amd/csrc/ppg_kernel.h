@@ -149,6 +149,19 @@ struct KParams {
                                // start of the call (0 = always); for lighter envs they exit at once and wave 0 writes all rows
     int32_t mode;
     int32_t batch;
+    // cooperative step kernels (ppgc_*, Env's COOP): coop_e envs share one workgroup of NW >= coop_e wavefronts.  The cell maps are
+    // padded by `pad` cells on every side (Gp = G + 2 pad), so an observation window never leaves its map.
+    int32_t pad, Gp;
+    int32_t coop_e;            // envs per workgroup
+    int32_t lds_env_bytes;     // LDS region of one env (map / val / scr offsets above are relative to it)
+    int32_t off_lut2;          // from the start of dynamic LDS: the workgroup's copy of obs_lut2
+    int32_t off_ctl;           // from the start of dynamic LDS: control words (Env::CTL_*)
+    int32_t blk_p, blk_q;      // elements per observation block: 4 Rp^2, 4 Rq^2
+    uint32_t bp_magic, bq_magic;  // ceil(2^32 / blk): element / blk == mulhi(element, magic)
+    const uint32_t *coop_tab;  // library-owned: blk_p + blk_q observation descriptors (bits 0-15 the signed map offset of element
+                               // (channel, i, j) of a species' (4,R,R) block relative to the observer's padded cell, channel * map_n
+                               // + (i - off) * Gp + (j - off); bits 16-31 the value-table section of the channel), then map_n / 4
+                               // words: the padded channel-0 map of an empty grid (halo cells = Env::ONE_IDX)
 };
 
 // ---------------------------------------------------------------------------------
@@ -238,14 +251,25 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // MAP8 (= NQ <= 2, chosen by env_main): the cell maps hold 8-bit indices LOCAL to their channel (predator row + 1, prey row + 1,
 // grass patch + 1; 0 = empty) instead of 16-bit indices into the whole value table -- half the LDS, which is what decides how many
 // envs of a 64x64 grid fit on a CU (BASELINE config 4).  Needs <= 128 prey rows and <= 255 grass patches (ppg_create checks).
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, int NW, class KP, class KC>
+// COOP: the cooperative step kernels (ppgc_*).  A workgroup of NW wavefronts steps P.coop_e <= NW envs: wave k < coop_e runs the
+// transition of env k in its own LDS region and publishes the rows to observe; after ONE workgroup barrier all NW waves write the
+// final observations of all the workgroup's envs, cut into whole 1 KB pieces that ignore row boundaries (an env's live rows are a
+// run of elements; piece p of the workgroup goes to wave p mod NW).  Every store instruction writes a full 1 KB, the rows of
+// the workgroup's envs are balanced over its waves at piece grain, every wave runs a transition (no idle helper waves on a full
+// GPU) and the waves of a workgroup write neighbouring addresses at the same time.  Cell maps are padded (KParams::pad), so no
+// window element needs a bounds check: channel 0's halo points at a constant 1.0 (BASE:522-523), the other halos at 0.0.
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, int NW, class KP, class KC, bool COOP = false>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
     static constexpr bool MAP8 = NQ <= 2;
     // Helper wavefronts that leave light envs to wave 0 (KParams::helper_min_rows) need BOTH observation paths in one kernel.  The
     // walls and drive variants' observation code is large: with two copies of it their kernels ran 10-15 % slower, so their helpers
     // always stay.
-    static constexpr bool ADAPTIVE_HELPERS = NW > 1 && !WALLS && !DRIVE;
+    static constexpr bool ADAPTIVE_HELPERS = NW > 1 && !WALLS && !DRIVE && !COOP;
+    // cumulative_rewards rides through the step in registers (fetched with the rows, permuted with them).  The other kernels read
+    // it back from HBM at the row's start-of-step slot when the rewards are assembled, to save two registers per row register --
+    // but that is a second dependent memory round trip per call, and under a saturated memory system a round trip is 5-10 k cycles.
+    static constexpr bool CARRY_CUM = COOP;
     template <bool B8, class Dummy = void> struct MapElem { typedef uint16_t type; };
     template <class Dummy> struct MapElem<true, Dummy> { typedef uint8_t type; };
     typedef typename MapElem<MAP8>::type map_t;
@@ -263,6 +287,12 @@ struct Env {
     uint64_t *scr;   // LDS
     uint32_t *lut;   // LDS
     uint32_t *wallw; // LDS: wall bitmap (WALLS)
+    // COOP: the workgroup's shared LDS area (set by env_main): observation descriptors and control words
+    uint32_t *lut2 = nullptr;
+    uint32_t *ctl = nullptr;
+    // control words: per env slot k of the workgroup CTL_SLOT + 4k: live predator rows, live prey rows, env index (-1 = no env);
+    // per wavefront w CTL_MID + w: the (row, cell) entry of a mid-step observation
+    enum { CTL_SLOT = 0, CTL_MID = 64, CTL_WORDS = 80 };
 
     // per-lane row fields
     uint32_t xy[T];
@@ -276,6 +306,7 @@ struct Env {
     uint32_t gxyr[2];  // grass_xy of patches ln and ln+64 (static within an episode)
     uint32_t lutr[10]; // FASTOBS: this lane's descriptors, predator chunks 0-1 then prey chunks 0-2, two words each
     int32_t lr[T];     // GEN2: agent_last_reproduction of the row
+    double cum[T];     // CARRY_CUM: cumulative_rewards of the row
 
     // wave-uniform state
     uint64_t rows[T], alive[T], owns[T];
@@ -301,13 +332,25 @@ struct Env {
     // Index of an entity's energy in the LDS value table.  16-bit maps: [0] = 0.0, then all row slots, then the grass patches.
     // MAP8: one section per channel, each led by a zero entry so that "map entry + section base" needs no test for an empty cell:
     // [0] = 0.0 | predators 1..64 || [129] = 0.0 | prey 130..257 || [258] = 0.0 | grass 259..513  (section base = 129 * (channel - 1)).
-    PPG_MEMBER int validx(int r, int k) const { return MAP8 ? (r ? 130 + row_of(r, k) : 1 + k) : 1 + slot_of(r, k); }
-    PPG_MEMBER int validx_row(int type, int row) const { return MAP8 ? (type ? 130 + row : 1 + row) : 1 + (type ? P.cap_pred + row : row); }
-    PPG_MEMBER int grass_validx(int p) const { return MAP8 ? 259 + p : 1 + P.S + p; }
-    PPG_MEMBER int cell_of(uint32_t s_xy) const { return (int)(s_xy >> 8) * P.G + (int)(s_xy & 255u); }
+    // The cooperative kernels pack the sections (LDS decides how many envs a CU holds): [0] = 0.0 | predators 1..64 | [65] = 1.0 (the
+    // "outside the grid" value of channel 0's halo) || [66] = 0.0 | prey 67..194 || [195] = 0.0 | grass 196...
+    static constexpr int SEC_Q = COOP ? 66 : 129, SEC_G = SEC_Q + 129;
+    PPG_MEMBER int validx(int r, int k) const { return MAP8 ? (r ? SEC_Q + 1 + row_of(r, k) : 1 + k) : 1 + slot_of(r, k); }
+    PPG_MEMBER int validx_row(int type, int row) const { return MAP8 ? (type ? SEC_Q + 1 + row : 1 + row) : 1 + (type ? P.cap_pred + row : row); }
+    PPG_MEMBER int grass_validx(int p) const { return MAP8 ? SEC_G + 1 + p : 1 + P.S + p; }
+    PPG_MEMBER int cell_of(uint32_t s_xy) const {
+        if (COOP) return ((int)(s_xy >> 8) + P.pad) * P.Gp + (int)(s_xy & 255u) + P.pad;   // padded maps
+        return (int)(s_xy >> 8) * P.G + (int)(s_xy & 255u);
+    }
+    // map index of cell c = x * G + y (0 <= c < G*G)
+    PPG_MEMBER int cell_index(int c) const {
+        if (!COOP) return c;
+        const int x = (int)wv::mulhi((uint32_t)c, C.g_magic);
+        return (x + P.pad) * P.Gp + (c - x * P.G) + P.pad;
+    }
     PPG_MEMBER map_t *chmap(int ch) const { return map + ch * P.map_n; }
     // what a map entry of channel ch means as an index into the value table, and back (MAP8: channel-local 8-bit indices)
-    PPG_MEMBER int map_base(int ch) const { return MAP8 ? (ch >= 2 ? 129 * (ch - 1) : 0) : 0; }
+    PPG_MEMBER int map_base(int ch) const { return MAP8 ? (ch == 2 ? SEC_Q : ch == 3 ? SEC_G : 0) : 0; }
     PPG_MEMBER map_t to_map(int ch, int vidx) const { return (map_t)(vidx - map_base(ch)); }
     PPG_MEMBER int from_map(int ch, uint32_t m) const { return (int)m + map_base(ch); }   // (an empty cell lands on the section's zero entry)
 
@@ -398,6 +441,7 @@ struct Env {
         uint32_t xy[T], key[T], fl[T];
         int32_t id[T], a[T];
         double e[T];
+        double cum[T];
         uint32_t gxy[2];
         double ge[2];
         uint2 lutd[5];
@@ -409,11 +453,12 @@ struct Env {
         p.sd = C.env_seed[b];
 #pragma unroll
         for (int r = 0; r < T; ++r) {
-            p.xy[r] = 0xFFFFu; p.key[r] = 0; p.fl[r] = 0; p.id[r] = 0; p.a[r] = -1; p.e[r] = 0.0;
+            p.xy[r] = 0xFFFFu; p.key[r] = 0; p.fl[r] = 0; p.id[r] = 0; p.a[r] = -1; p.e[r] = 0.0; p.cum[r] = 0.0;
             if (r < 2 && want_rows) {
                 const size_t s = (size_t)b * P.S + slot_of(r, ln);
                 p.xy[r] = C.row_xy[s];
                 p.e[r] = C.row_e[s];
+                if (CARRY_CUM) p.cum[r] = C.row_cum[s];
                 p.id[r] = C.row_id[s];
                 p.key[r] = C.row_key[s];
                 p.fl[r] = C.row_flags[s];
@@ -465,15 +510,17 @@ struct Env {
             const int i = row_of(r, ln);
             const bool valid = i < n_rows[type_of(r)];
             uint32_t fl = 0;
-            xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; act[r] = -1; ev[r] = 0;
+            xy[r] = 0xFFFFu; id[r] = 0; key[r] = 0; e[r] = 0.0; act[r] = -1; ev[r] = 0; cum[r] = 0.0;
             if (valid) {
                 if (r < 2) {
                     xy[r] = p.xy[r]; e[r] = p.e[r]; id[r] = p.id[r]; key[r] = p.key[r];
                     fl = p.fl[r]; act[r] = p.a[r];
+                    if (CARRY_CUM) cum[r] = p.cum[r];
                 } else {  // rows 64.. of the prey table: rarely in use, loaded on demand
                     const size_t s = (size_t)b * P.S + slot_of(r, ln);
                     xy[r] = C.row_xy[s];
                     e[r] = C.row_e[s];
+                    if (CARRY_CUM) cum[r] = C.row_cum[s];
                     id[r] = C.row_id[s];
                     key[r] = C.row_key[s];
                     fl = C.row_flags[s];
@@ -494,21 +541,63 @@ struct Env {
 
     // maps -> all zero, observation descriptors -> LDS
     PPG_MEMBER void init_lds(const Pre &p) {
-        uint32_t *m32 = (uint32_t *)map;
-        const int n32 = 4 * P.map_n * (int)sizeof(map_t) / 4;
-        for (int i = ln; i < n32; i += 64) m32[i] = 0u;
-        if (FASTOBS) {
+        if (COOP) {   // (maps: coop_tab_store)
+            if (ln == 0) val[ONE_IDX] = 1.0;
+        } else {
+            init_maps();
+        }
+        if (COOP) {
+        } else if (FASTOBS) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) { lutr[2 * c] = p.lutd[c].x; lutr[2 * c + 1] = p.lutd[c].y; }
         } else {
             for (int i = ln; i < (P.nch_p + P.nch_q) * 128; i += 64) lut[i] = C.obs_lut[i];
         }
         if (ln == 0) val[0] = 0.0;
-        if (MAP8 && ln < 2) val[129 * (ln + 1)] = 0.0;   // the zero entries leading the prey and grass sections
+        if (MAP8 && ln < 2) val[ln ? SEC_G : SEC_Q] = 0.0;   // the zero entries leading the prey and grass sections
         gxyr[0] = p.gxy[0];
         gxyr[1] = p.gxy[1];
         if (WALLS)
             for (int i = ln; i < C.n_wall_words; i += 64) wallw[i] = C.wall_bits[(size_t)b * C.n_wall_words + i];
+    }
+
+    // all four cell maps empty.  COOP: plus the halo of channel 0 -> the constant 1.0 of the value table ("outside the grid",
+    // BASE:520-523); the halos of channels 1-3 stay 0 -> the zero entry of their section.
+    static constexpr int ONE_IDX = 65;   // a free entry of the predator section (rows use 1..64)
+    PPG_MEMBER void init_maps() {
+        uint32_t *m32 = (uint32_t *)map;
+        const int n32 = 4 * P.map_n * (int)sizeof(map_t) / 4;
+        if (COOP) {   // (channel 0 from the template behind the descriptors in C.coop_tab; the start of a step has it prefetched: TabPre)
+            const uint32_t *tmpl = C.coop_tab + C.blk_p + C.blk_q;
+            const int n0 = P.map_n / 4;
+            for (int i = ln; i < n32; i += 64) m32[i] = i < n0 ? tmpl[i] : 0u;
+        } else {
+            for (int i = ln; i < n32; i += 64) m32[i] = 0u;
+        }
+    }
+    // COOP: the workgroup's descriptor table and this env's channel-0 map come from C.coop_tab.  Their loads are issued in front
+    // of everything else and held in registers (up to LUT_REGS / TMPL_REGS words per lane, enough for 7x7 / 9x9 windows on a
+    // 25x25 grid; larger geometries finish with plain copy loops), so the tables cost no memory round trip of their own.
+    static constexpr int LUT_REGS = 9, TMPL_REGS = 5;
+    struct TabPre { uint32_t l[LUT_REGS], m[TMPL_REGS]; };
+    PPG_MEMBER void coop_tab_issue(TabPre &t) const {
+        const int nl = C.blk_p + C.blk_q, nm = P.map_n / 4;
+#pragma unroll
+        for (int u = 0; u < LUT_REGS; ++u) { t.l[u] = 0; if (u * 64 + ln < nl) t.l[u] = C.coop_tab[u * 64 + ln]; }
+#pragma unroll
+        for (int u = 0; u < TMPL_REGS; ++u) { t.m[u] = 0; if (u * 64 + ln < nm) t.m[u] = C.coop_tab[nl + u * 64 + ln]; }
+    }
+    PPG_MEMBER void coop_tab_store(const TabPre &t) {
+        const int nl = C.blk_p + C.blk_q, nm = P.map_n / 4;
+        uint32_t *m32 = (uint32_t *)map;
+        const int n32 = P.map_n;   // (four 8-bit maps of map_n entries)
+        for (int i = nm + ln; i < n32; i += 64) m32[i] = 0u;   // channels 1-3: empty
+#pragma unroll
+        for (int u = 0; u < LUT_REGS; ++u) if (u * 64 + ln < nl) lut2[u * 64 + ln] = t.l[u];
+#pragma unroll
+        for (int u = 0; u < TMPL_REGS; ++u) if (u * 64 + ln < nm) m32[u * 64 + ln] = t.m[u];
+        for (int i = LUT_REGS * 64 + ln; i < nl; i += 64) lut2[i] = C.coop_tab[i];
+        for (int i = TMPL_REGS * 64 + ln; i < nm; i += 64) m32[i] = C.coop_tab[nl + i];
     }
 
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
@@ -965,13 +1054,14 @@ struct Env {
                 if (type_of(r) == type) n_new += wv::popc(alive[r]);
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                if (f == 1) continue;  // (slot 1 was the cumulative reward: no longer carried in registers)
+                if (f == 1 && !CARRY_CUM) continue;  // (the cumulative reward: only the cooperative kernels carry it in registers)
 #pragma unroll
                 for (int r = 0; r < T; ++r) {
                     if (type_of(r) != type) continue;
                     if ((alive[r] >> ln) & 1ull) {
                         uint64_t v;
                         if (f == 0) v = (uint64_t)__double_as_longlong(e[r]);
+                        else if (f == 1) v = (uint64_t)__double_as_longlong(cum[r]);
                         else if (f == 2) v = ((uint64_t)key[r] << 32) | (uint32_t)id[r];
                         else v = (uint64_t)xy[r] | ((uint64_t)((owns[r] >> ln) & 1ull) << 16) | ((uint64_t)keep[r] << 20);
                         scr[sbase + rk[r]] = v;
@@ -985,6 +1075,7 @@ struct Env {
                     if (i < n_new) {
                         uint64_t v = scr[sbase + i];
                         if (f == 0) e[r] = __longlong_as_double((long long)v);
+                        else if (f == 1) cum[r] = __longlong_as_double((long long)v);
                         else if (f == 2) { key[r] = (uint32_t)(v >> 32); id[r] = (int32_t)(uint32_t)v; }
                         else { xy[r] = (uint32_t)(v & 0xFFFFu); ev[r] = (uint32_t)((v >> 16) & 1u); keep[r] = (uint32_t)(v >> 20) & 0x3FFFFu; }
                     } else if (f == 3) {
@@ -1356,7 +1447,102 @@ struct Env {
         wv::sync();
     }
 
+    // ---- COOP: observations as whole 1 KB pieces of an env's run of live rows ---------------------------------
+    // The live rows of `type` of the env whose LDS region is `region` are listed in `list` (n_live words: row << 16 | padded
+    // cell of the agent); concatenated they are a run of n_live * blk elements.  Piece p is elements 128 p .. 128 p + 127 of
+    // the run: lane l produces elements 128 p + 2l and + 1 (blk is even: a pair never straddles two rows) -- BASE:511-526 per
+    // element: value = val[map[cell + offset of the element] + section of its channel]; the padded maps make the window
+    // clipping of _obs_clip (BASE:528-539) implicit.  This wavefront writes pieces first, first + stride, ...
+    PPG_MEMBER void coop_pieces(int type, const unsigned char *region, const uint32_t *list, int n_live, int eb, int first, int stride) {
+        const map_t *m = (const map_t *)(region + P.off_map);
+        const double *vt = (const double *)(region + P.off_val);
+        const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);   // (arithmetic, not a select of fields: see window_sum)
+        const uint32_t magic = C.bp_magic + (type ? C.bq_magic - C.bp_magic : 0u);
+        const uint32_t *L = lut2 + (type ? C.blk_p : 0);
+        const int total = n_live * blk;
+        const size_t obase = (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;
+        constexpr int U = 2;   // pieces in flight per wavefront: the three dependent LDS lookups of one hide behind the other's
+        for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
+            uint32_t o[U], i0[U], i1[U];
+            bool on[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s0 = (p0 + u * stride) * 128 + 2 * ln;
+                on[u] = s0 < total;
+                const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
+                const uint32_t i = wv::mulhi(sc, magic), w = sc - i * (uint32_t)blk;
+                const uint32_t ent = on[u] ? list[i] : 0u;
+                const uint2 d = *(const uint2 *)(L + w);
+                const int pc = (int)(ent & 0xFFFFu);
+                i0[u] = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)] + (d.x >> 16);
+                i1[u] = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)] + (d.y >> 16);
+                o[u] = (ent >> 16) * (uint32_t)blk + w;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double v0 = vt[i0[u]], v1 = vt[i1[u]];
+                if (!on[u]) continue;
+                if (P.obs_f32) {
+                    float2 f; f.x = (float)v0; f.y = (float)v1;
+                    *(float2 *)((float *)(type ? P.obs_prey : P.obs_pred) + obase + o[u]) = f;
+                } else {
+                    double2 g; g.x = v0; g.y = v1;
+                    *(double2 *)((double *)(type ? P.obs_prey : P.obs_pred) + obase + o[u]) = g;
+                }
+            }
+        }
+    }
+    // a mid-step observation (an agent that starves or is caught, BASE:287,327): its block alone, at this point of the sequence
+    PPG_MEMBER void obs_row_coop(int type, int j, uint32_t s_xy) {
+        wv::sync();   // LDS writes of the sequential phases -> visible
+        uint32_t *mid = ctl + CTL_MID + wave_idx;
+        if (ln == 0) mid[0] = ((uint32_t)j << 16) | (uint32_t)cell_of(s_xy);
+        wv::sync();
+        coop_pieces(type, (const unsigned char *)map - P.off_map, mid, 1, b, 0, 1);
+        wv::sync();   // reads done before the caller touches the maps again
+    }
+    // the rows to observe at the end of the call, per species, in the env's scratch: [0] predators, [64] prey
+    PPG_MEMBER void coop_publish() {
+        uint32_t *lst = (uint32_t *)scr;
+        int n[2] = {0, 0};
+        wv::sync();
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int type = type_of(r);
+            if ((alive[r] >> ln) & 1ull)
+                lst[(type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])] = ((uint32_t)row_of(r, ln) << 16) | (uint32_t)cell_of(xy[r]);
+            n[type] += wv::popc(alive[r]);
+        }
+        if (ln == 0) {
+            uint32_t *slot = ctl + CTL_SLOT + 4 * wave_idx;
+            slot[0] = (uint32_t)n[0]; slot[1] = (uint32_t)n[1]; slot[2] = (uint32_t)b;
+        }
+        wv::sync();
+    }
+    // after the workgroup barrier: all the workgroup's envs, piece p of the workgroup to wavefront p mod NW
+    PPG_MEMBER void coop_write_all(const unsigned char *wg_lds) {
+        int at = 0;   // pieces handed out so far, mod NW
+        for (int k = 0; k < C.coop_e; ++k) {
+            const uint32_t *slot = ctl + CTL_SLOT + 4 * k;
+            const int eb = (int)wv::first(slot[2]);
+            if (eb < 0) continue;
+            const unsigned char *region = wg_lds + (size_t)k * C.lds_env_bytes;
+            const uint32_t *lst = (const uint32_t *)(region + P.off_scr);
+#pragma unroll
+            for (int type = 0; type < 2; ++type) {
+                const int n_live = (int)wv::first(slot[type]);
+                const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);
+                const int pieces = (n_live * blk + 127) >> 7;
+                int first = wave_idx - at;
+                if (first < 0) first += NW;
+                coop_pieces(type, region, lst + (type ? 64 : 0), n_live, eb, first, NW);
+                at = (at + pieces) % NW;
+            }
+        }
+    }
+
     PPG_MEMBER void obs_row(int type, int j, uint32_t s_xy, double s_e = 0.0) {
+        if (COOP) { obs_row_coop(type, j, s_xy); return; }
         if (FASTOBS) {
             if (type) obs_row_fast<1>(j, s_xy);
             else obs_row_fast<0>(j, s_xy);
@@ -1500,6 +1686,7 @@ struct Env {
     }
 
     PPG_MEMBER void obs_all_alive() {
+        if (COOP) { coop_publish(); return; }   // written by the whole workgroup after its barrier (env_main)
         if (NW > 1 && (!ADAPTIVE_HELPERS || helpers)) {  // publish (type, row, cell) of every live row, then all waves of the workgroup share the rows
             uint32_t *lst = (uint32_t *)scr;
             int n = 0;
@@ -1664,7 +1851,7 @@ struct Env {
         int nfree = 0;
         for (int base = 0; base < n; base += 64) {
             const int c = base + ln;
-            nfree += wv::popc(wv::ballot(c < n && occ[c] == 0));
+            nfree += wv::popc(wv::ballot(c < n && occ[cell_index(c < n ? c : 0)] == 0));
         }
         bool ok = false;
         if (nfree > 0) {
@@ -1674,7 +1861,7 @@ struct Env {
             int kth = (int)wv::mulhi(wv::first(w[0]), (uint32_t)nfree);
             for (int base = 0; base < n; base += 64) {
                 const int c = base + ln;
-                uint64_t fm = wv::ballot(c < n && occ[c] == 0);
+                uint64_t fm = wv::ballot(c < n && occ[cell_index(c < n ? c : 0)] == 0);
                 const int cnt = wv::popc(fm);
                 if (kth < cnt) {
                     for (int s = 0; s < kth; ++s) fm &= fm - 1;
@@ -1921,7 +2108,7 @@ struct Env {
             if (i < n_rows[type_of(r)]) {
                 // cumulative_rewards of a surviving agent still sits in HBM at the row's start-of-step slot
                 // (keep[] bits 8..): read it here instead of carrying two registers per row through the step
-                if (transition && !(v & EV_BORN)) c = C.row_cum[(size_t)b * P.S + (keep[r] >> 8)];
+                if (transition && !(v & EV_BORN)) c = CARRY_CUM ? cum[r] : C.row_cum[(size_t)b * P.S + (keep[r] >> 8)];
                 if (!transition) {
                     rew = 0.0;  // reset returns observations only; cumulative_rewards = 0 (BASE:150)
                 } else if (v & EV_BORN) {
@@ -2000,7 +2187,9 @@ struct Env {
                 else par_[r] = C.row_parent[(size_t)b * P.S + (keep[r] >> 8)];
             }
         }
-        if (transition) wv::drain_loads();  // every lane has its start-of-step values before any row is overwritten
+        // every lane has its start-of-step values before any row is overwritten (CARRY_CUM: nothing was read here unless the dense
+        // reward modes looked up the start-of-step energies)
+        if (transition && (!CARRY_CUM || dense || GEN2)) wv::drain_loads();
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);
@@ -2135,7 +2324,8 @@ struct Env {
             if (p == ln + 64) gxyr[1] = gxy;
         }
         wv::sync();
-        for (int i = ln; i < n; i += 64) { perm[i] = 0; ent[i] = 0; }
+        if (COOP) init_maps();   // (the arrays lay across the padded maps and their halos)
+        else for (int i = ln; i < n; i += 64) { perm[i] = 0; ent[i] = 0; }
         wv::sync();
         for (int p = ln; p < C.n_grass; p += 64) {
             // re-read what this lane just wrote (same lane, same address)
@@ -2242,9 +2432,12 @@ struct Env {
     PPG_MEMBER void run_step(int it = 0) {
         PPG_STAMP(0);
         Pre pre;
+        TabPre tab;
+        if (COOP) coop_tab_issue(tab);
         prefetch(pre, true, C.actions != nullptr && !(C.flags & PPG_STEP_RANDOM_ACTIONS));
-        load_env_words(pre);
+        if (COOP) coop_tab_store(tab);   // (waits for the table words only: the row loads behind them stay in flight)
         init_lds(pre);
+        load_env_words(pre);
         step_body(pre, it);
     }
 
@@ -2369,6 +2562,37 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
     else if (MODE == MODE_OBSERVE) env.run_observe();
     else if (MODE == MODE_VIS) env.run_vis();
     else env.run_export_grid();
+}
+
+// The cooperative step kernels (ppgc_*): see Env's COOP.  Workgroup g steps envs g * coop_e ... g * coop_e + coop_e - 1.
+template <int NQ, bool GEN2, int NW>
+PPG_DEVICE void coop_main(const KParams &P, unsigned char *lds) {
+    const PPG_CONSTANT_AS KParams *Pc = PPG_KERNARG_PTR(KParams, P);
+    typedef Env<NQ, false, false, false, false, GEN2, false, false, NW, const KParams, const PPG_CONSTANT_AS KParams, true> CoopEnv;
+    const int w = wv::wave_index(), ln = wv::lane();
+    const int ne = Pc->coop_e;
+    uint32_t *lut2 = (uint32_t *)(lds + Pc->off_lut2), *ctl = (uint32_t *)(lds + Pc->off_ctl);
+    int b = PPG_BLOCK_INDEX() * ne + w;
+    const bool has_env = w < ne && b < P.batch;
+    if (has_env && Pc->env_order) b = (int)wv::first((uint32_t)Pc->env_order[b]);   // scheduling only (ppg_rebalance)
+    CoopEnv env(P, *Pc, has_env ? b : 0, lds + (size_t)(w < ne ? w : 0) * (size_t)Pc->lds_env_bytes, ln);
+    env.wave_idx = w;
+    env.lut2 = lut2;
+    env.ctl = ctl;
+    // (every wavefront that steps an env writes the whole descriptor table, identical words: it may need it for a mid-step
+    // observation long before the workgroup's barrier; a workgroup always has at least one env)
+    if (has_env) env.run_step();
+    else if (w < ne && ln == 0) ctl[CoopEnv::CTL_SLOT + 4 * w + 2] = 0xFFFFFFFFu;   // an env slot beyond the batch
+#ifdef PPG_PROFILE_PHASES
+#define PPG_COOP_STAMP(i) do { if (Pc->prof && has_env) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); if (ln == 0) Pc->prof[(size_t)b * 16 + (i)] = t_; } } while (0)
+#else
+#define PPG_COOP_STAMP(i) do { } while (0)
+#endif
+    wv::wg_barrier_lds();   // (LDS only: the table stores of this wave need not have reached memory)
+    PPG_COOP_STAMP(13);
+    env.coop_write_all(lds);
+    PPG_COOP_STAMP(14);
 }
 
 }  // namespace ppg

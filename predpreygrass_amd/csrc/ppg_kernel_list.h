@@ -30,6 +30,13 @@
     PPG_KW(ppgwp_step_q##NQ##g, NQ, false, 2)                         \
     PPG_KW(ppgw16_step_q##NQ, NQ, true, 16)
 
+// cooperative step kernels of the base family (Env's COOP): coop_e envs per workgroup of 4 / 8 / 16 wavefronts
+#define PPG_DEFINE_KERNELSC(NQ)                                       \
+    PPG_KC(ppgc_step_q##NQ, NQ, false, 4)                             \
+    PPG_KC(ppgc6_step_q##NQ, NQ, false, 6)                            \
+    PPG_KC(ppgc8_step_q##NQ, NQ, false, 8)                            \
+    PPG_KC(ppgc16_step_q##NQ, NQ, false, 16)
+
 #define PPG_DEFINE_KERNELSW2(NQ)                                      \
     PPG_KW2(ppgw2_step_q##NQ, NQ, true, 4)                            \
     PPG_KW2(ppgw2_step_q##NQ##g, NQ, false, 4)                        \

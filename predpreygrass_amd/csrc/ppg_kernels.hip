@@ -1,6 +1,7 @@
 // ppg_kernels.hip -- one group of gfx950 kernels of libppg_hip.so per compilation:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -c -DPPG_TU_GEN=<1|2|3> -DPPG_TU_NQ=<1|2|4> ppg_kernels.hip
-// (1 = base family, 2 = second generation, 3 = second generation with walls, 4 = base family with drive channels; NQ = prey row registers).  Host code: ppg_hip.hip.
+// (1 = base family, 2 = second generation, 3 = second generation with walls, 4 = base family with drive channels, 5 = cooperative
+// step kernels of the base family; NQ = prey row registers).  Host code: ppg_hip.hip.
 #include <hip/hip_runtime.h>
 
 #include "ppg_kernel.h"
@@ -39,6 +40,8 @@
     PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_WALLS : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, true, true, false, 4>(P, lds); }
 #define PPG_KW4(name, NQ)                                                                    \
     PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_DRIVE : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, 4>(P, lds); }
+#define PPG_KC(name, NQ, GEN2, NW)                                                           \
+    PPG_KERNEL_NW(name, PPG_WPE, NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_main<NQ, GEN2, NW>(P, lds); }
 #include "ppg_kernel_list.h"
 
 #define PPG_APPLY(M, NQ) M(NQ)  // expands PPG_TU_NQ before the list pastes it into the kernel names
@@ -50,6 +53,8 @@ PPG_APPLY(PPG_DEFINE_KERNELS2, PPG_TU_NQ)
 PPG_APPLY(PPG_DEFINE_KERNELSW2, PPG_TU_NQ)
 #elif PPG_TU_GEN == 3
 PPG_APPLY(PPG_DEFINE_KERNELS3, PPG_TU_NQ)
+#elif PPG_TU_GEN == 5
+PPG_APPLY(PPG_DEFINE_KERNELSC, PPG_TU_NQ)
 #else
 PPG_APPLY(PPG_DEFINE_KERNELS4, PPG_TU_NQ)
 #endif

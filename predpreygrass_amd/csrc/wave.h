@@ -35,6 +35,9 @@ PPG_DEVICE int lane() { return (int)(threadIdx.x & 63u); }
 PPG_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 // workgroup barrier of the multi-wave variants (LDS writes of every wave visible afterwards)
 PPG_DEVICE void wg_barrier() { __syncthreads(); }
+// the same without waiting for this wave's outstanding global stores / loads (__syncthreads drains vmcnt too): only LDS traffic is
+// ordered across the barrier -- for hand-overs that go through LDS alone
+PPG_DEVICE void wg_barrier_lds() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // 64-bit mask of lanes whose predicate is true (s_* result: lives in SGPRs).
 PPG_DEVICE uint64_t ballot(bool p) { return __ballot(p); }

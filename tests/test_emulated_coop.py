@@ -1,0 +1,79 @@
+"""The COOPERATIVE step kernels (ppgc*_step_*: several envs per workgroup, every wavefront runs one env's transition, then all
+of them write all the workgroup's observations as whole 1 KB pieces through padded cell maps) under the CPU wave emulator.
+Same golden vectors and oracle as the other emulator tests; the GPU tests compare the real kernels
+(test_hip_parity.py::test_cooperative_step_kernels_give_identical_results)."""
+import pytest
+import torch
+
+from oracle.ppg_oracle import OracleEnv
+from predpreygrass_amd import _abi
+from predpreygrass_amd.batched import BatchedPredPreyGrass
+from predpreygrass_amd.config import config_env
+from tests import emu_backend
+from tests.parity_utils import replay_golden_cases, rollout_vs_oracle
+
+
+def maker(waves, coop, **kw):
+    def make(cfg, B, **kw2):
+        env = BatchedPredPreyGrass(cfg, batch_size=B, _library=emu_backend.library(), **kw, **kw2)
+        env.set_wave_plan(waves, 0, coop)
+        assert env.wave_plan() == (waves, 0, coop), env.wave_plan()
+        return env
+    return make
+
+
+@pytest.mark.parametrize("waves,coop,names,max_calls", [
+    (4, 4, ["default_seed0", "default_seed1"], 150),   # two envs in a workgroup with room for four: two empty env slots
+    (4, 1, ["default_seed0"], 120),                     # one env, three pure helper waves
+    (8, 2, ["c4_seed0"], 100),                          # 64x64 grid
+    (4, 4, ["dense_seed0", "dense_seed3"], None),       # ghost cells / co-occupancy, many mid-step observations
+    (16, 1, ["c1_seed0"], None),                        # sixteen waves on one env (small batches)
+    (4, 2, ["pool_seed3"], None),                       # id pools run dry
+    (4, 4, ["rewards_seed3"], None),
+    (4, 4, ["seasonal_short_seed0"], 150),
+    (4, 4, ["dense_rewards_seed0"], 100),               # dense reward mode reads the start-of-step energies back
+])
+def test_base_family_golden_cases_cooperative(waves, coop, names, max_calls):
+    replay_golden_cases(maker(waves, coop), names, config_env, max_calls=max_calls)
+
+
+def test_cooperative_launch_shape():
+    lib = emu_backend.library()
+    env = maker(4, 4)(dict(config_env), 6)
+    env.reset(seed=1)
+    env.step(random_actions=True)
+    assert lib.ppg_emu_last_waves() == 4
+    assert env.step_kernel_name() == "ppgc_step_q2"
+
+
+@pytest.mark.parametrize("waves,coop,batch", [(4, 4, 6), (4, 3, 5), (8, 8, 9)])
+def test_cooperative_random_rollout_matches_oracle_and_single_wave(waves, coop, batch):
+    """Device reset + Philox actions + auto-reset (the reset runs inside the cooperative kernel too), a batch that does not fill
+    the last workgroup; every call against the oracle, and the final state against the one-wave kernels."""
+    cfg = {**config_env, "grid_size": 12, "n_initial_active_predator": 7, "n_initial_active_prey": 20, "initial_num_grass": 40,
+           "max_steps": 40, "energy_gain_per_step_grass": 0.3}
+    states = []
+    for w, c in ((1, 0), (waves, coop)):
+        env = maker(w, c, prey_capacity=128)(cfg, batch)
+        rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=31, n_calls=60, check_grid=True)
+        states.append({n: getattr(env, n).clone() for n in
+                       ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey")})
+        states[-1]["env_state"] = env.env_state[:, : _abi.ENV_CALLS].clone()
+    for n, t in states[0].items():
+        assert torch.equal(t, states[1][n]), n
+
+
+def test_cooperative_big_windows_and_float32():
+    """13x13 / 15x15 windows on a 9x9 grid (every window leaves the grid on all sides), float32 observations."""
+    cfg = {**config_env, "grid_size": 9, "n_initial_active_predator": 5, "n_initial_active_prey": 12, "initial_num_grass": 20,
+           "predator_obs_range": 13, "prey_obs_range": 15, "max_steps": 30}
+    env = maker(4, 4, obs_dtype=torch.float32)(cfg, 4)
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=5, n_calls=45, check_grid=True)
+
+
+def test_configurations_without_cooperative_kernels_fall_back():
+    """Even windows, drive channels and the kickback variant keep their element-descriptor kernels: the plan drops coop_envs."""
+    for extra in ({"predator_obs_range": 6}, {"enable_drive_channels": True}, {"kickback_reward_predator": 1.0}):
+        env = BatchedPredPreyGrass({**config_env, **extra}, batch_size=2, _library=emu_backend.library())
+        env.set_wave_plan(4, 0, 4)
+        assert env.wave_plan()[2] == 0, extra

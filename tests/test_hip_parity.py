@@ -228,36 +228,37 @@ def test_drive_conditioned_variant_on_gpu():
 
 
 @pytest.mark.parametrize("cap,G,prey0,grass0", [(64, 14, 8, 30), (128, 14, 80, 100), (256, 18, 170, 140)])
-@pytest.mark.parametrize("multi", ["0", "1"])
-def test_drive_variant_every_register_count_on_gpu(cap, G, prey0, grass0, multi, monkeypatch):
+@pytest.mark.parametrize("multi", [1, 4])
+def test_drive_variant_every_register_count_on_gpu(cap, G, prey0, grass0, multi):
     """ppg4_step_q{1,2,4} and ppgw4_step_q{1,2,4}: 64 / 128 / 256 prey rows per env (1, 2, 4 prey registers; the configs
     start with 8 / 80 / 170 prey so that the upper registers are in use), one and four waves per env; every fourth call
     against the oracle."""
-    monkeypatch.setenv("PPG_MULTIWAVE", multi)
     cfg = {**config_env, "enable_drive_channels": True, "grid_size": G, "initial_num_grass": grass0,
            "n_initial_active_predator": 6, "n_initial_active_prey": prey0, "max_steps": 80,
            "predator_creation_energy_threshold": 30.0, "prey_creation_energy_threshold": 12.0}
     if cap == 64:
         cfg.update(energy_gain_per_step_grass=0.4, predator_creation_energy_threshold=12.0, prey_creation_energy_threshold=8.0)
     env = make_env(cfg, 16, prey_capacity=cap)
+    env.set_wave_plan(multi)
+    assert env.wave_plan()[0] == multi
     rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=1234 + cap, n_calls=100, check_every=4)
     assert not (env.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_PREY_OVERFLOW).any()
 
 
 @pytest.mark.parametrize("cls_name", ["base", "red_queen"])
-def test_multiwave_step_kernels_give_identical_results(cls_name, monkeypatch):
-    """One, four and eight wavefronts per env (ppg_step / ppgw_step / ppgw8_step; the library picks by batch size, the
-    environment variables force a choice) must produce the same tables and observations, bit for bit."""
+def test_multiwave_step_kernels_give_identical_results(cls_name):
+    """One, four and eight wavefronts per env (ppg_step / ppgw_step / ppgw8_step; the library picks by batch size,
+    ppg_set_wave_plan forces a choice) must produce the same tables and observations, bit for bit."""
     if cls_name == "base":
         mk = lambda: make_env(dict(config_env), 300)
     else:
         from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
         mk = lambda: BatchedRedQueen(config_env_base, batch_size=300, device="cuda:0")
     results = []
-    for multi, eight in (("0", "0"), ("1", "0"), ("1", "1")):
-        monkeypatch.setenv("PPG_MULTIWAVE", multi)
-        monkeypatch.setenv("PPG_MULTIWAVE8", eight)
+    for waves in (1, 4, 8):
         env = mk()
+        env.set_wave_plan(waves)
+        assert env.wave_plan()[0] == waves
         env.reset(seed=11)
         for _ in range(150):
             env.step(random_actions=True, auto_reset=True)
@@ -271,25 +272,75 @@ def test_multiwave_step_kernels_give_identical_results(cls_name, monkeypatch):
             assert torch.equal(a, b), n
 
 
-def test_default_wave_plans_give_identical_results(monkeypatch):
-    """What the library picks by itself -- sixteen waves per env at 200 envs, a pair of waves with 8-bit maps for a full GPU of 64x64
-    grids, helper waves only for heavy envs in the second generation -- against the one-wave kernels, bit for bit."""
+def make_coop(waves, coop, **kw):
+    def make(cfg, B, **kw2):
+        env = make_env(cfg, B, **kw, **kw2)
+        env.set_wave_plan(waves, 0, coop)
+        assert env.wave_plan() == (waves, 0, coop)
+        return env
+    return make
+
+
+@pytest.mark.parametrize("waves,coop,names", [
+    (4, 4, ["default_seed0", "default_seed1"]), (4, 4, ["dense_seed0", "dense_seed3"]), (8, 2, ["c4_seed0"]), (16, 1, ["c1_seed0"]),
+    (4, 3, ["pool_seed3"]), (8, 8, ["rewards_seed3"]), (4, 4, ["seasonal_default_seed1"]), (4, 4, ["dense_additive_seed4"]),
+])
+def test_golden_cases_through_the_cooperative_kernels(waves, coop, names):
+    """The reference's golden episodes through ppgc*_step (several envs per workgroup, padded maps, 1 KB observation pieces)."""
+    replay_golden_cases(make_coop(waves, coop), names, config_env)
+
+
+@pytest.mark.parametrize("over,B,calls,cap,waves,coop", [
+    ({}, 256, 300, 128, 4, 4), (C4, 30, 120, 128, 8, 2), (DENSE, 61, 250, 128, 4, 4), (TINY, 64, 250, 128, 8, 8), ({}, 37, 200, 64, 16, 1),
+])
+def test_cooperative_random_rollout_matches_oracle_on_gpu(over, B, calls, cap, waves, coop):
+    cfg = {**config_env, **over}
+    env = make_coop(waves, coop, prey_capacity=cap)(cfg, B)
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=778, n_calls=calls, check_every=5, check_grid=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_cooperative_step_kernels_give_identical_results(dtype):
+    """ppgc_step (4 envs x 4 waves), ppgc8_step, ppgc16_step and odd env counts per workgroup against the one-wave kernel on 1000
+    envs x 200 calls with auto-reset: tables and observations bit for bit."""
+    names = ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state", "grass_energy", "obs_pred", "obs_prey")
+    results = []
+    for waves, coop in ((1, 0), (4, 4), (8, 8), (16, 5), (4, 1)):
+        env = make_env(dict(config_env), 1000, obs_dtype=dtype)
+        env.set_wave_plan(waves, 0, coop)
+        assert env.wave_plan() == (waves, 0, coop)
+        env.reset(seed=12)
+        for _ in range(200):
+            env.step(random_actions=True, auto_reset=True)
+        torch.cuda.synchronize()
+        results.append({n: getattr(env, n).clone() for n in names})
+        del env
+    for other in results[1:]:
+        for n, t in results[0].items():
+            a, b = (t[:, : _abi.ENV_CALLS], other[n][:, : _abi.ENV_CALLS]) if n == "env_state" else (t, other[n])
+            assert torch.equal(a, b), n
+
+
+def test_default_wave_plans_give_identical_results():
+    """What the library picks by itself -- sixteen waves per env at 200 envs, the cooperative kernel (two envs per four-wave
+    workgroup) for a full GPU of 25x25 grids, a pair of waves with 8-bit maps for a full GPU of 64x64 grids, helper waves only for
+    heavy envs in the second generation -- against the one-wave kernels, bit for bit."""
     from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
     c4 = {**config_env, **C4}
     cases = [(lambda: make_env(dict(config_env), 200), b"ppgw16_step_q2", 120),
+             (lambda: make_env(dict(config_env), 4096), b"ppgc_step_q2", 60),
              (lambda: make_env(c4, 4096), b"ppgwp_step_q2", 40),
              (lambda: BatchedRedQueen(config_env_base, batch_size=4096, device="cuda:0"), b"ppgw2_step_q2", 120)]
     names = ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state", "grass_energy", "obs_pred", "obs_prey")
     for mk, kernel, calls in cases:
         results = []
-        for force in (None, "0"):
-            if force is None:
-                monkeypatch.delenv("PPG_MULTIWAVE", raising=False)
-            else:
-                monkeypatch.setenv("PPG_MULTIWAVE", force)
+        for force in (None, 1):
             env = mk()
             if force is None:
                 assert env._lib.ppg_step_kernel_name(env._handle) == kernel
+            else:
+                env.set_wave_plan(force)
+                assert env.wave_plan() == (1, 0, 0)
             env.reset(seed=21)
             for _ in range(calls):
                 env.step(random_actions=True, auto_reset=True)

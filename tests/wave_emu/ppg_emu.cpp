@@ -53,6 +53,10 @@ static void lane_entry(void *arg) {
 static int backend_init(ppg_handle *h, int) {
     h->lut_dev = (uint32_t *)malloc(h->lut_host.size() * sizeof(uint32_t));
     memcpy(h->lut_dev, h->lut_host.data(), h->lut_host.size() * sizeof(uint32_t));
+    if (h->coop_ok) {
+        h->coop_tab_dev = (uint32_t *)malloc(h->coop_tab_host.size() * sizeof(uint32_t));
+        memcpy(h->coop_tab_dev, h->coop_tab_host.data(), h->coop_tab_host.size() * sizeof(uint32_t));
+    }
     return PPG_OK;
 }
 static int backend_alloc(ppg_handle *, void **out, size_t bytes) {
@@ -64,6 +68,8 @@ static void backend_release(ppg_handle *h) {
     h->vis_dev = nullptr;
     free(h->lut_dev);
     h->lut_dev = nullptr;
+    free(h->coop_tab_dev);
+    h->coop_tab_dev = nullptr;
     free(h->order_dev);
     h->order_dev = nullptr;
 }
@@ -85,6 +91,12 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     EmuLaunch L{&P, h->nq, mode, h->drive ? 3 : h->gen2 ? (h->cfg2.walls ? 2 : 1) : 0, 1};
     // The HIP backend picks the multi-wave step kernels from the batch size (ppg_use_multiwave); here the tests ask for
     // them explicitly: PPG_EMU_WAVES=4|8 (walls / drive have a four-wave kernel only, as in the library).
+    if (mode == ppg::MODE_STEP && P.coop_e > 0) {   // cooperative kernels (ppg_set_wave_plan): coop_e envs per workgroup of plan.nw waves
+        L.nw = h->plan.nw;
+        const int groups = (h->batch + P.coop_e - 1) / P.coop_e;
+        for (int g = 0; g < groups; ++g) wv::run_block(lane_entry, &L, g, (size_t)P.lds_bytes, L.nw);
+        return PPG_OK;
+    }
     if (mode == ppg::MODE_STEP) {
         const char *w = getenv("PPG_EMU_WAVES");
         const int nw = w ? atoi(w) : 1;

@@ -25,8 +25,22 @@ void run_nw(const ppg::KParams &P) {
     ppg::env_main<NQ, ppg::MODE_STEP, FAST, GEN2, WALLS, DRIVE, NW>(P, lds);
 }
 
+#if PPG_EMU_FAMILY == 0 && PPG_EMU_NQ <= 2
+template <int NW>
+void run_coop(const ppg::KParams &P) {
+    PPG_DYNAMIC_LDS(lds);
+    ppg::coop_main<NQ, false, NW>(P, lds);
+}
+#endif
+
 template <bool FAST>
 void run(const ppg::KParams &P, int mode, int nw) {
+#if PPG_EMU_FAMILY == 0 && PPG_EMU_NQ <= 2
+    if (P.coop_e > 0) {   // cooperative kernels (Env's COOP)
+        if (nw == 16) run_coop<16>(P); else if (nw == 8) run_coop<8>(P); else if (nw == 6) run_coop<6>(P); else run_coop<4>(P);
+        return;
+    }
+#endif
     if (nw == 4) { run_nw<FAST, 4>(P); return; }
 #if PPG_EMU_FAMILY == 0
     if (nw == 2) { run_nw<FAST, 2>(P); return; }

@@ -34,7 +34,7 @@
 namespace wv {
 
 constexpr int W = 64;
-constexpr int MAXW = 8;           // wavefronts per workgroup
+constexpr int MAXW = 16;          // wavefronts per workgroup
 constexpr int NF = W * MAXW;      // fibers
 
 extern "C" void ppg_emu_ctx_switch(void **save_sp, void *load_sp);
@@ -215,6 +215,7 @@ inline void wg_barrier() {
     ppg_emu_ctx_switch(&e.fiber_sp[me], e.main_sp);
     e.cur = me;
 }
+inline void wg_barrier_lds() { wg_barrier(); }
 inline void sync() { (void)exchange(0); }
 inline void drain_loads() { (void)exchange(0); }  // lanes run one after another here: a collective orders reads before writes
 inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }

@@ -40,6 +40,10 @@ elif DRIVE:
     env = BatchedPredPreyGrass({**config_env, "enable_drive_channels": True}, batch_size=B, device="cuda:0")
 else:
     env = BatchedPredPreyGrass(config_env, batch_size=B, device="cuda:0")
+PLAN = [a for a in sys.argv if a.startswith("--plan=")]
+if PLAN:   # e.g. --plan=4,0,2: force a wave plan (ppg_set_wave_plan)
+    env.set_wave_plan(*[int(v) for v in PLAN[0][7:].split(",")])
+print("kernel:", env.step_kernel_name(), env.wave_plan())
 env.reset()
 prof = torch.zeros((B, 16), dtype=torch.int64, device="cuda:0")
 for _ in range(warm):
@@ -47,7 +51,11 @@ for _ in range(warm):
 lib.ppg_debug_set_profile_buffer(env._handle, ctypes.c_void_p(prof.data_ptr()))
 names = ["load_env+rows", "actions", "decay", "grass", "move", "sort", "build_maps", "engage_pred", "engage_prey",
          "reproduce", "obs", "store"]
-acc = np.zeros((12,)); accmax = np.zeros((12,)); tot = []; rows = []
+COOP = env.wave_plan()[2] > 0   # cooperative kernels: "obs" = publishing the row lists; then the workgroup barrier and the shared write phase
+if COOP:
+    names += ["wait_barrier", "coop_write"]
+NS = len(names)
+acc = np.zeros((NS,)); accmax = np.zeros((NS,)); tot = []; rows = []
 N = 20
 for it in range(N):
     prof.zero_()
@@ -56,15 +64,15 @@ for it in range(N):
     p = prof.cpu().numpy().astype(np.float64)
     es = env.env_state.cpu().numpy()
     ok = (p[:, 12] > 0) & (p[:, 1] > 0)   # envs that took the normal path (not reset / truncation)
-    d = np.diff(p[ok][:, :13], axis=1)
+    d = np.diff(p[ok][:, :NS + 1], axis=1)
     acc += d.mean(axis=0)
-    whole = p[ok][:, 12] - p[ok][:, 0]
+    whole = p[ok][:, NS] - p[ok][:, 0]
     slow = np.argsort(whole)[-max(1, len(whole) // 100):]
     accmax += d[slow].mean(axis=0)
     tot.append((whole.mean(), whole.max(), np.percentile(whole, 99)))
     n = (es[ok][:, 0] + es[ok][:, 1])
     rows.append((n.mean(), n.max(), np.corrcoef(n, whole)[0, 1]))
-    span = p[ok][:, 12].max() - p[ok][:, 0].min()
+    span = p[ok][:, NS].max() - p[ok][:, 0].min()
 print("phase               mean cyc   share | slowest-1%% cyc  share")
 for k, n in enumerate(names):
     print(f"{n:18s} {acc[k]/N:9.0f}  {acc[k]/acc.sum():6.1%} | {accmax[k]/N:9.0f}  {accmax[k]/accmax.sum():6.1%}")
