@@ -20,7 +20,7 @@ N GPUs = N independent shards of 4096 envs (weak scaling, no data-path collectiv
 interact).  `python bench.py --gpus N` without a torch.distributed launcher starts the N ranks itself.
 For N>1 two extra legs measure the step followed by the ONE RCCL all-gather of the packed observation
 image that north_star specifies ("obs_gather", "obs_gather_overlapped"; bandwidth-bound on xGMI, see
-DESIGN.md).  Within one GPU the 4096 envs are stepped as --streams (default 3) independent sub-batches on
+DESIGN.md).  Within one GPU the 4096 envs are stepped as --streams (default 2) independent sub-batches on
 separate HIP streams.
 
 Prints ONE JSON line (rank 0).
@@ -38,7 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_driver_summary.json")
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r03", "bench_driver_summary.json")
 
 
 def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
@@ -156,8 +156,12 @@ def parse_args(argv):
                          "(SURVEY 8(f) N4; no observation leaves the GPU, roofline = bf16 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--streams", type=int, default=3,
-                    help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step); interleaved A/B on one "
+                         "box with the cooperative kernels: 2 sub-batches 68.3 us per 4096-env step, 3 sub-batches 71.2 (tools/ab_plans.py)")
+    ap.add_argument("--sustained-steps", type=int, default=2000,
+                    help="after the timed region: a second leg of this many steps timed with HIP events on the launch streams "
+                         "(roofline.kernel_ms_sustained); 0 = skip")
     ap.add_argument("--wave-plan", default=None,
                     help="A/B experiments: 'waves,helper_min_rows,coop_envs' forced on every sub-batch (ppg_set_wave_plan); the default is "
                          "the library's own choice, which the JSON line names (roofline.kernel)")
@@ -429,6 +433,27 @@ def main(argv=None, backend=None):
     calls0 = np.concatenate([c.cpu().numpy() for c in calls0])
     assert ((es[:, _abi.ENV_CALLS] - calls0) == args.steps).all()
 
+    # ---- second leg: the same loop for --sustained-steps more steps, HIP events on the launch streams -------------------------
+    # (the driver's 20-step window is 1.4 ms long: first-kernel latency and the drain of the last launches are 6-7 % of it; this leg
+    # says what the same kernel does back to back.  Not `value`: the driver asked for exactly --steps steps.)
+    sustained = None
+    if args.sustained_steps > 0 and not dry:
+        s0 = [backend.event() for _ in group.streams]
+        s1 = [backend.event() for _ in group.streams]
+        backend.synchronize(device)
+        ts = time.perf_counter()
+        for st, e in zip(group.streams, s0):
+            e.record(st)
+        for _ in range(args.sustained_steps):
+            one_step()
+        for st, e in zip(group.streams, s1):
+            e.record(st)
+        backend.synchronize(device)
+        ts = time.perf_counter() - ts
+        sustained = {"steps": args.sustained_steps,
+                     "kernel_ms": sum(a.elapsed_time(b) for a, b in zip(s0, s1)) / len(s0) / args.sustained_steps,
+                     "ms_per_step": ts / args.sustained_steps * 1e3}
+
     # ---- optional legs: the ONE RCCL all-gather per step north_star specifies (N > 1 only) -------------------------
     gather_info = gather_overlapped = None
     if distributed and args.gather_steps > 0:
@@ -487,7 +512,11 @@ def main(argv=None, backend=None):
                 gather_info = res
 
     # ---- accounting ------------------------------------------------------------------
-    status = int((es[:, _abi.ENV_STATUS]).max())
+    status = int(np.bitwise_or.reduce(es[:, _abi.ENV_STATUS]))
+    # envs that have gone through the reference's own non-deterministic branch (BASE:759-764: all four neighbour cells taken, the
+    # child lands on a free cell chosen by an unseeded global RNG) at least once since their last ppg_reset: there the build's
+    # Philox choice is its own contract, everything else is the reference's arithmetic
+    fallback_envs = int(((es[:, _abi.ENV_STATUS] & _abi.STATUS_FALLBACK_SPAWN) != 0).sum())
     n_obs_pred = int(es[:, _abi.ENV_OBS_PRED].sum())
     n_obs_prey = int(es[:, _abi.ENV_OBS_PREY].sum())
     G, Rp, Rq = env.grid_size, env.Rp, env.Rq
@@ -515,7 +544,7 @@ def main(argv=None, backend=None):
         if same:
             scale = (run_bytes / args.steps / n_sub) / prof["counted_bytes_per_launch"]
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"] * scale)
-            traffic_src = (f"profiles/r02/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+            traffic_src = (f"profiles/r03/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            f"{prof['hbm_traffic_per_launch_bytes']['total_corrected']} B per launch at "
                            f"{prof['mean_agents_per_env']} agents/env, scaled x{scale:.4f} by this run's counted bytes")
     except Exception:
@@ -535,17 +564,22 @@ def main(argv=None, backend=None):
             "frac_survey_formula": round(survey_bytes / args.steps / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "write_pattern_ceiling": "the same observation write pattern with no compute: 79.6 us per 4096-env "
-                                     "launch = 4.85 TB/s (profiles/r01/c_store_pattern_ceiling.txt); linear fill 6.5 TB/s",
+            "write_pattern_ceiling": "the same write pattern and launch structure with no compute (tools/store_patterns4.hip, "
+                                     "profiles/r03): 61-70 us per 4096-env step depending on the box and its state; linear fill 6.5 TB/s",
             "kernel": kernel_name,
             "kernel_ms": round(kernel_s * 1e3, 5),
+            "kernel_ms_sustained": None if sustained is None else round(sustained["kernel_ms"], 5),
+            "frac_sustained": None if sustained is None else round(run_bytes / args.steps / (sustained["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "sustained_steps": None if sustained is None else sustained["steps"],
+            "value_sustained": None if sustained is None else round(n_gpus * B / (sustained["ms_per_step"] * 1e-3), 1),
             "concurrent_launches": n_sub,
             "counted_bytes_per_launch": int(run_bytes / args.steps / n_sub),
             "survey_formula_bytes_per_launch": int(survey_bytes / args.steps / n_sub),
             "note": "kernel_ms = mean launch-to-launch time of the step kernel on its stream (HIP events on that "
                     "stream); concurrent_launches such kernels (one per sub-batch of envs_per_gpu/concurrent_"
                     "launches envs) overlap in time, so achieved = concurrent_launches x counted_bytes_per_"
-                    "launch / kernel_ms.",
+                    "launch / kernel_ms.  kernel_ms_sustained / frac_sustained: the same over a second leg of sustained_steps "
+                    "steps run right after the timed region (same envs, same loop).",
         }
         if not dry and achieved > HBM_PEAK_GBS:
             raise SystemExit(f"bench.py: achieved {achieved:.0f} GB/s exceeds the HBM peak -- the timing or the byte count is broken")
@@ -583,6 +617,9 @@ def main(argv=None, backend=None):
                 "preroll_mean_agents_per_env_by_64_step_window": [round(v, 2) for v in trace[-8:]],
                 "mean_agents_per_env": round((n_obs_pred + n_obs_prey) / env_steps_rank, 2),
                 "status_bits": status,
+                "fallback_spawn_envs": fallback_envs,
+                "step_kernel": kernel_name,
+                "wave_plan": list(env.wave_plan()),
             },
             "roofline": roof,
         }
@@ -590,7 +627,7 @@ def main(argv=None, backend=None):
             out["obs_gather"] = gather_info
         if gather_overlapped is not None:
             out["obs_gather_overlapped"] = gather_overlapped
-        if not args.no_cpu_baseline and n_gpus == 1 and not dry:
+        if not args.no_cpu_baseline and not dry:   # rank 0's host cores, also next to the N > 1 curve (north_star)
             out["cpu_baseline"] = cpu_baseline(cfg, args.seed, seconds=args.cpu_seconds, workload=args.workload)
         print(json.dumps(out), flush=True)
     if distributed:

@@ -387,7 +387,7 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         } else {
             if (p.nw != 1 && p.nw != 2 && p.nw != 4 && p.nw != 8 && p.nw != 16) p.nw = 4;
             if (p.nw == 2 && (h->gen2 || h->drive)) p.nw = 4;                                  // the pair kernels exist for the base family
-            if (p.nw == 16 && (h->gen2 || h->base.nch_p > 2 || h->base.nch_q > 3)) p.nw = 8;  // sixteen waves: base family, register descriptors
+            if (p.nw == 16 && (h->gen2 || h->base.nch_p > 2 || h->base.nch_q > 3 || h->nq > 2)) p.nw = 8;  // sixteen waves: base family, register descriptors, <= 128 prey rows
         }
         return p;
     }
@@ -400,7 +400,8 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         p.nw = 8;
         // up to 256 envs one workgroup per CU is all there is: sixteen waves (base family, register-descriptor observation path):
         // 256 envs 11.3 -> 12.1 M env-steps/s; at 512 envs eight are faster (20.5 vs 17.8 M)
-        if (in_flight <= 256 && !h->gen2 && h->base.nch_p <= 2 && h->base.nch_q <= 3) p.nw = 16;
+        // (not with 256 prey rows: a 1024-thread workgroup caps the registers at 128 and four prey row registers spill there)
+        if (in_flight <= 256 && !h->gen2 && h->base.nch_p <= 2 && h->base.nch_q <= 3 && h->nq <= 2) p.nw = 16;
     } else if (in_flight <= 3072) {
         p.nw = 4;
     } else if (h->gen2) {

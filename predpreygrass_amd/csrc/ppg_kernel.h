@@ -1660,11 +1660,27 @@ struct Env {
         wv::sync();  // reads done before the caller touches the maps again
     }
 
-    // multi-wave variants: rows of the published list, every NW-th one starting at `w`
-    PPG_MEMBER void obs_shared(int w) {
+    // multi-wave variants: rows of the published list, every stride-th one starting at `w`
+    PPG_MEMBER void obs_shared(int w, int stride = NW) {
         const uint32_t *lst = (const uint32_t *)scr;
-        const int n = (int)wv::first(lst[0]);
-        for (int i = w; i < n; i += NW) {
+        const uint32_t head = wv::first(lst[0]);   // rows in the list | predators among them (they come first) << 16
+        const int n = (int)(head & 0xFFFFu);
+        if (FASTOBS) {
+            // predators come first in the list: two loops with a compile-time species each (one loop with a run-time species keeps
+            // both species' unrolled observation code and all ten descriptor registers live together: +20 registers)
+            const int n_pred = (int)(head >> 16);
+            int i = w;
+            for (; i < n_pred; i += stride) {
+                const uint32_t en = wv::first(lst[1 + i]);
+                obs_row_fast<0>((int)((en >> 16) & 0x7FFFu), en & 0xFFFFu);
+            }
+            for (; i < n; i += stride) {
+                const uint32_t en = wv::first(lst[1 + i]);
+                obs_row_fast<1>((int)((en >> 16) & 0x7FFFu), en & 0xFFFFu);
+            }
+            return;
+        }
+        for (int i = w; i < n; i += stride) {
             const uint32_t en = wv::first(lst[1 + i]);
             const int ty = (int)(en >> 31), row = (int)((en >> 16) & 0x7FFFu);
             // (drive variant: the agent's energy is its entry of the LDS value table -- row energies are kept current there)
@@ -1685,9 +1701,21 @@ struct Env {
         obs_shared(w);
     }
 
-    PPG_MEMBER void obs_all_alive() {
+    // Multi-wave kernels: the shared writing of the published rows.  It comes AFTER rewards_and_store: the row registers are dead by
+    // then, which is what keeps these kernels inside 128 registers (with the stores behind the observation loops they spilled).
+    static constexpr bool DEFER_OBS = NW > 1 && !COOP;
+    PPG_MEMBER void obs_finish() {
+        if (!DEFER_OBS) return;
+        if (!ADAPTIVE_HELPERS || helpers) { wv::wg_barrier(); obs_shared(0); }
+        else { wv::sync(); obs_shared(0, 1); }
+    }
+
+    // write_now = false (step paths of the multi-wave kernels): publish only, obs_finish() follows the table stores
+    PPG_MEMBER void obs_all_alive(bool write_now = true) {
         if (COOP) { coop_publish(); return; }   // written by the whole workgroup after its barrier (env_main)
-        if (NW > 1 && (!ADAPTIVE_HELPERS || helpers)) {  // publish (type, row, cell) of every live row, then all waves of the workgroup share the rows
+        if (NW > 1) {  // publish (type, row, cell) of every live row, then all waves of the workgroup share the rows
+            // (an env whose helper waves have left -- ADAPTIVE_HELPERS -- goes through the same list with stride 1: a second, register-
+            // indexed copy of the observation code in one kernel is what pushed the multi-wave kernels over 128 registers)
             uint32_t *lst = (uint32_t *)scr;
             int n = 0;
             wv::sync();
@@ -1697,9 +1725,8 @@ struct Env {
                     lst[1 + n + (int)wv::prefix(alive[r])] = ((uint32_t)type_of(r) << 31) | ((uint32_t)row_of(r, ln) << 16) | xy[r];
                 n += wv::popc(alive[r]);
             }
-            if (ln == 0) lst[0] = (uint32_t)n;
-            wv::wg_barrier();
-            obs_shared(0);
+            if (ln == 0) lst[0] = (uint32_t)n | ((uint32_t)wv::popc(alive[0]) << 16);
+            if (write_now) obs_finish();
             return;
         }
 #pragma unroll
@@ -2345,8 +2372,9 @@ struct Env {
         fb_count = 0;
         envflags = PPG_ENVF_WAS_RESET | PPG_ENVF_LIST_IS_ROW_ORDER;
         build_maps();
-        obs_all_alive();                             // BASE:215
+        obs_all_alive(false);                        // BASE:215
         rewards_and_store(false, false);
+        obs_finish();
     }
 
     // ---- the transition ----------------------------------------------------------------
@@ -2372,11 +2400,12 @@ struct Env {
             compact_and_sort(!list_is_row_order);
             if (GEN2) after_compact();
             build_maps();
-            obs_all_alive();
+            obs_all_alive(false);
 #pragma unroll
             for (int r = 0; r < T; ++r) ev[r] = ((alive[r] >> ln) & 1ull) ? EV_TRUNC : 0u;
             envflags = (envflags & PPG_ENVF_LIST_IS_ROW_ORDER) | PPG_ENVF_TRUNC_ALL | PPG_ENVF_DONE;
             rewards_and_store(false);  // (agents_just_ate is untouched by a truncation call: keep[] rides along in the flags)
+            obs_finish();
             return;
         }
 
@@ -2420,13 +2449,14 @@ struct Env {
         if (GEN2) reproduce2(list_is_row_order);   // RQ:248-254
         else reproduce();                          // BASE:389-448
         PPG_STAMP(10);
-        obs_all_alive();                           // BASE:451-453
+        obs_all_alive(false);                      // BASE:451-453
         PPG_STAMP(11);
         step += 1;                                 // BASE:471
         envflags = 0;
         if (n_alive[0] <= 0 || n_alive[1] <= 0) envflags |= PPG_ENVF_TERM_ALL | PPG_ENVF_DONE;  // BASE:466
         rewards_and_store(true);
         PPG_STAMP(12);
+        obs_finish();
     }
 
     PPG_MEMBER void run_step(int it = 0) {
@@ -2551,6 +2581,9 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
             const int32_t *es = Pk->env_state + (size_t)b * PPG_ENV_WORDS;
             const int rows0 = (int)wv::first((uint32_t)(es[PPG_ENV_N_PRED_ROWS] + es[PPG_ENV_N_PREY_ROWS]));
             env.helpers = rows0 >= Pk->helper_min_rows;
+            // every wave has read the two words before wave 0 can get to overwrite them at the end of its step: all waves of the
+            // workgroup are still here, so this barrier costs nothing, and all of them take the same decision
+            wv::wg_barrier();
         }
         if (w != 0) {
             if (env.helpers) env.run_helper(w);
