@@ -409,11 +409,20 @@ int ppg_pack(ppg_handle *const *handles, int32_t n, void *out, uint64_t capacity
  * (ray.rllib DefaultPPOTorchRLModule) is not importable here: parity is pinned against a float32 PyTorch module of the
  * architecture above on the same weights, within the tolerance the tests state. */
 typedef struct ppg_policy_weights {   /* HOST pointers, float32, PyTorch layouts */
-    const float *conv_w[3];  /* Conv2d.weight [cout][cin][3][3]: cin = 4 / 16 / 32, cout = 16 / 32 / 64 */
+    const float *conv_w[3];  /* Conv2d.weight [cout][cin][3][3]: cin = C / 16 / 32, cout = 16 / 32 / 64 */
     const float *conv_b[3];  /* Conv2d.bias [cout] */
-    const float *fc_w[3];    /* Linear.weight [out][in]: [256][64*R*R] (input flattened channel-major), [256][256], [n_actions][256] */
+    const float *fc_w[3];    /* Linear.weight [out][in]: [256][64*P] (input flattened channel-major), [256][256], [n_actions][256] */
     const float *fc_b[3];    /* Linear.bias [out] */
 } ppg_policy_weights;
+
+/* How the network reads the (4,R,R) observation as an image with C channels and P positions:
+ *   PPG_POLICY_LAYOUT_CHW  channel-first: an R x R image with C = 4 channels (P = R*R) -- conv1 weight [16][4][3][3];
+ *   PPG_POLICY_LAYOUT_HWC  channels-last: a 4 x R image with C = R channels (P = 4*R) -- conv1 weight [16][R][3][3].  This is how
+ *                          RLlib's CNN encoder reads a 3-D Box (its observation spaces are [H, W, C]), i.e. what a module trained by
+ *                          tune_ppo_base_environment.py:106-141 on Box(0, 100, (4,R,R)) holds.
+ * The conv1 weight shape of a checkpoint tells the two apart (predpreygrass_amd.policy.load_rllib_state_dict). */
+#define PPG_POLICY_LAYOUT_CHW 0
+#define PPG_POLICY_LAYOUT_HWC 1
 
 typedef struct ppg_policy ppg_policy;
 
@@ -423,6 +432,9 @@ typedef struct ppg_policy ppg_policy;
 /* obs_range: the R of the species' (4,R,R) observations; n_actions <= 32.  The weights are repacked into MFMA fragment
  * order (bf16) on the device; the host arrays may be freed afterwards. */
 int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, const ppg_policy_weights *w, ppg_policy **out);
+/* the same with the image layout stated (ppg_policy_create = PPG_POLICY_LAYOUT_CHW) */
+int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_actions, int32_t layout, const ppg_policy_weights *w,
+                             ppg_policy **out);
 int ppg_policy_destroy(ppg_policy *p);
 /* One forward pass of `pred` over the predator rows in use and of `prey` over the prey rows in use of all n handles (either
  * may be NULL: that species keeps whatever actions[] holds).  actions[k]: device int8 [B_k, S] of handle k.

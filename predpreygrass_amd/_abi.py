@@ -122,7 +122,8 @@ class PpgPolicyWeights(C.Structure):
 
 
 POLICY_ARGMAX, POLICY_SAMPLE = 0x0, 0x1
-POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_destroy", "ppg_policy_act", "ppg_policy_macs_per_observation",
+POLICY_LAYOUT_CHW, POLICY_LAYOUT_HWC = 0, 1
+POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_destroy", "ppg_policy_act", "ppg_policy_macs_per_observation",
                   "ppg_policy_last_error"]
 
 
@@ -185,6 +186,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     if hasattr(lib, "ppg_policy_create"):   # (the MFMA kernels exist in the HIP library only, not in the CPU test build)
         lib.ppg_policy_create.restype = C.c_int
         lib.ppg_policy_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(PpgPolicyWeights), C.POINTER(C.c_void_p)]
+        lib.ppg_policy_create_layout.restype = C.c_int
+        lib.ppg_policy_create_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PpgPolicyWeights), C.POINTER(C.c_void_p)]
         lib.ppg_policy_destroy.restype = C.c_int
         lib.ppg_policy_destroy.argtypes = [C.c_void_p]
         lib.ppg_policy_act.restype = C.c_int

@@ -1,8 +1,11 @@
 // ppg_policy.h -- policy inference next to the env (include/ppg.h: ppg_policy_*).
 //
 // The network the reference trains for each species (base_environment/tune_ppo_base_environment.py:106-141):
-//     (4,R,R) observation -> conv3x3(4->16) ReLU -> conv3x3(16->32) ReLU -> conv3x3(32->64) ReLU   ("same" padding, stride 1)
-//                         -> flatten -> Linear(64 R^2 -> 256) ReLU -> Linear(256 -> 256) ReLU -> Linear(256 -> n_actions)
+//     (4,R,R) observation -> conv3x3(C->16) ReLU -> conv3x3(16->32) ReLU -> conv3x3(32->64) ReLU   ("same" padding, stride 1)
+//                         -> flatten -> Linear(64 P -> 256) ReLU -> Linear(256 -> 256) ReLU -> Linear(256 -> n_actions)
+// in either of the two ways a (4,R,R) Box can be read as an image (include/ppg.h: PPG_POLICY_LAYOUT_*): channel-first -- an R x R
+// image with C = 4 channels, P = R^2 positions -- or channels-last, which is how RLlib's CNN encoder reads a 3-D Box ([H, W, C]:
+// a 4 x R image with C = R channels, P = 4 R positions).  The kernels work on an IH x IW image with CIN channels;
 // evaluated for every agent row in use, reading the observation rows where ppg_step wrote them and writing one int8 action per
 // row.  gfx950 only: every layer is a GEMM on the matrix cores, v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate).
 //
@@ -48,14 +51,17 @@ constexpr int PLAN_HDR = 3;       // words in front of the prefix sums of PolPar
 
 struct PolParams {
     // geometry
-    int32_t R, P, Wp, Wp2;        // window side, R*R, R+2, (R+2)^2
+    int32_t R, P, Wp, Wp2;        // window side of the observation; image positions IH*IW; padded row pitch IW+2; (IH+2)*(IW+2)
+    int32_t IH, IW, cin;          // the image the convolutions run on and its real input channels
+    int32_t c_stride, p_stride;   // observation element of (channel c, position p) = c * c_stride + p * p_stride
+    int32_t obs_elems;            // elements per observation row: 4 R^2
     int32_t K1;                   // 64 * P
     int32_t ST;                   // samples per convolution sub-group
     int32_t n_actions;
     int32_t species;              // 0 predators, 1 prey
     int32_t obs_f32;
     int32_t sample;               // PPG_POLICY_SAMPLE
-    int32_t debug_skip;           // timing experiments only (env PPG_POLICY_SKIP, results are then meaningless): 1 no convolutions,
+    int32_t debug_skip;           // ablation builds only (-DPPG_EXPERIMENTS + env PPG_POLICY_SKIP; always 0 in the product): 1 no convolutions,
                                   // 2 no FC1, 4 no observation staging, 8 no conv3, 16 no conv1/conv2, 32 no conv3 stores
     uint32_t seed_lo, seed_hi;
     // weights in fragment order (device, bf16) and biases (float)
@@ -73,7 +79,7 @@ struct PolParams {
                                   // resident workgroups), [2] = samples per tile of the last round (32 / 64 / 96 / 128),
                                   // [PLAN_HDR + e] = exclusive prefix sum of env e
     const uint32_t *tile_env;     // [tile] = env of the tile's first sample
-    uint32_t magic_P, magic_R;    // ceil(2^32 / P), ceil(2^32 / R): n / P == mulhi(n, magic_P) for the small n used here
+    uint32_t magic_P, magic_R;    // ceil(2^32 / P), ceil(2^32 / IW): n / P == mulhi(n, magic_P) for the small n used here
     __bf16 *xg;                   // [gridDim.x][TILE][K1]
     float *logits;                // optional [rows][n_actions]
 };
@@ -225,7 +231,7 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
         const bool valid = n < n_pos;
         const int nn = valid ? n : 0;
         const int s = (int)__umulhi((uint32_t)nn, K.magic_P), p = nn - s * K.P;
-        const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.R;
+        const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.IW;
         const int pidx = (y + 1) * K.Wp + (x + 1);
         const __bf16 *base = in + (size_t)s * in_sample_stride + (pidx + (CBIN > 1 ? h * K.Wp2 : 0)) * 8;
         f32x16 acc[MT];
@@ -469,8 +475,11 @@ __device__ __forceinline__ T *uniform(T *p) { return (T *)uniform((uintptr_t)p);
 __device__ __forceinline__ KPtr uniform(KPtr p) { return (KPtr)uniform((uintptr_t)p); }
 
 // ---- phase A: the tile's sample table, then the convolutions, ST samples at a time -> scratch slot X ----
-template <bool OBS_F32>
+// NCH = input channel slots a thread stages per position: 4 (channel-first: the four observation channels), 8 or 16 (channels-last:
+// R <= 8 / R <= 15 channels); conv1 reads CB1 = 1 or 2 channel blocks of 8.
+template <bool OBS_F32, int NCH>
 __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, int n0_, int nt_samples_, __bf16 *xg_tile_) {
+    constexpr int CB1 = NCH > 8 ? 2 : 1;
     const auto &K = *uniform(Kp);
     const int tile = uniform(tile_), n0 = uniform(n0_), nt_samples = uniform(nt_samples_);
     __bf16 *xg_tile = uniform(xg_tile_);
@@ -490,7 +499,7 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
             const int e = lo, row = (int)(n - K.plan[PLAN_HDR + e]);
             const int k = handle_of(K.env_base, K.n_handles, e);
             const int b = e - K.env_base[k];
-            src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)(4 * K.P) * (OBS_F32 ? 4 : 8));
+            src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS_F32 ? 4 : 8));
             dst = (unsigned long long)(uintptr_t)(K.actions[k] + (size_t)b * K.S + K.slot0 + row);
         }
         tab[2 * tid] = src;
@@ -509,23 +518,23 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
     // observation values of the NEXT sub-group are requested before conv3 of the current one and written to LDS after it: their
     // HBM latency hides behind 72 % of the sub-group's matrix work.  A thread stages at most two positions (ST * P <= 512).
     GLOBAL_AS __bf16 *xg = (GLOBAL_AS __bf16 *)xg_tile;
-    float pre[2][4];
+    float pre[2][NCH];
     auto request = [&](int s0, int ns) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + 256 * j;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) pre[j][c] = 0.0f;
+            for (int c = 0; c < NCH; ++c) pre[j][c] = 0.0f;
             if (idx < ns * K.P && !(dbg & 4)) {
                 const int s = (int)__umulhi((uint32_t)idx, K.magic_P), p = idx - s * K.P;
                 if (OBS_F32) {
-                    const GLOBAL_AS float *src = (const GLOBAL_AS float *)(uintptr_t)tab[2 * (s0 + s)];
+                    const GLOBAL_AS float *src = (const GLOBAL_AS float *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) pre[j][c] = src[c * K.P + p];
+                    for (int c = 0; c < NCH; ++c) if (NCH == 4 || c < K.cin) pre[j][c] = src[c * K.c_stride];
                 } else {
-                    const GLOBAL_AS double *src = (const GLOBAL_AS double *)(uintptr_t)tab[2 * (s0 + s)];
+                    const GLOBAL_AS double *src = (const GLOBAL_AS double *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) pre[j][c] = (float)src[c * K.P + p];
+                    for (int c = 0; c < NCH; ++c) if (NCH == 4 || c < K.cin) pre[j][c] = (float)src[c * K.c_stride];
                 }
             }
         }
@@ -533,7 +542,7 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
     if (!(dbg & 1)) request(0, nt_samples < K.ST ? nt_samples : K.ST);
     for (int s0 = 0; s0 < nt_samples && !(dbg & 1); s0 += K.ST) {
         const int ns = (nt_samples - s0) < K.ST ? (nt_samples - s0) : K.ST;
-        ConvW<1, 1> w1c;
+        ConvW<CB1, 1> w1c;
         ConvW<2, 1> w2c;
         w1c.load(K, K.wc1, lane);
         w2c.load(K, K.wc2, lane);
@@ -542,15 +551,18 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
             const int idx = tid + 256 * j;
             if (idx < ns * K.P) {
                 const int s = (int)__umulhi((uint32_t)idx, K.magic_P), p = idx - s * K.P;
-                const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.R;
-                bf16x8 v = zero8();
+                const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.IW;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = (__bf16)pre[j][c];
-                *(bf16x8 *)(X + (size_t)s * x_stride + ((y + 1) * K.Wp + (x + 1)) * 8) = v;
+                for (int cb = 0; cb < CB1; ++cb) {
+                    bf16x8 v = zero8();
+#pragma unroll
+                    for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = (__bf16)pre[j][8 * cb + c];
+                    *(bf16x8 *)(X + (size_t)s * x_stride + (cb * K.Wp2 + (y + 1) * K.Wp + (x + 1)) * 8) = v;
+                }
             }
         }
         __syncthreads();
-        if (!(dbg & 16)) conv_layer<1, 1, 2, false>(K, w1c, X, x_stride, Y, y_stride, nullptr, 0, ns, wave, 4, lane);
+        if (!(dbg & 16)) conv_layer<CB1, 1, 2, false>(K, w1c, X, x_stride, Y, y_stride, nullptr, 0, ns, wave, 4, lane);
         __syncthreads();
         if (!(dbg & 16)) conv_layer<2, 1, 4, false>(K, w2c, Y, y_stride, X, x_stride, nullptr, 0, ns, wave, 4, lane);
         __syncthreads();
@@ -626,6 +638,20 @@ __device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0_, in
             for (int a = 0; a < 32; ++a) if (a < K.n_actions) lo[a] = logit[a];
         }
         int8_t *dst = (int8_t *)(uintptr_t)tab[2 * s_local + 1];
+        // Philox counter of this agent = (global env index, row slot): recovered from where its action goes.  (Never the address
+        // itself: the same seed must give the same actions whatever tensor they are written to.)
+        uint32_t c_env = 0, c_slot = 0;
+        if (K.sample) {
+            int k = 0;
+#pragma unroll
+            for (int q = 1; q < MAX_HANDLES; ++q)
+                if (q < K.n_handles && (uintptr_t)dst >= (uintptr_t)K.actions[q] &&
+                    (uintptr_t)dst < (uintptr_t)K.actions[q] + (size_t)(K.env_base[q + 1] - K.env_base[q]) * (size_t)K.S) k = q;
+            const uint32_t off = (uint32_t)((uintptr_t)dst - (uintptr_t)K.actions[k]);
+            const uint32_t b = off / (uint32_t)K.S;
+            c_env = (uint32_t)K.env_base[k] + b;
+            c_slot = off - b * (uint32_t)K.S;
+        }
         uint32_t rnd[4] = {0, 0, 0, 0};
         int best = 0;
         float bestv = -INFINITY;
@@ -634,9 +660,8 @@ __device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0_, in
             if (a >= K.n_actions) continue;
             float v = logit[a];
             if (K.sample) {   // Gumbel-max: argmax(logit - log(-log u)) ~ softmax(logits)
-                if ((a & 3) == 0) philox((uint32_t)(uintptr_t)dst, (uint32_t)((uintptr_t)dst >> 32), (uint32_t)(a >> 2), 0x504F4C31u,
-                                         K.seed_lo, K.seed_hi, rnd);
-                const float u = ((float)(rnd[a & 3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                if ((a & 3) == 0) philox(c_env, c_slot, (uint32_t)(a >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
+                const float u = (float)(rnd[a & 3] >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
                 v -= __logf(-__logf(u));
             }
             if (v > bestv) { bestv = v; best = a; }
@@ -645,7 +670,7 @@ __device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0_, in
     }
 }
 
-template <bool OBS_F32>
+template <bool OBS_F32, int NCH>
 __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
     const int N = (int)Kp->plan[0], n_full = (int)Kp->plan[1], ts = (int)Kp->plan[2];
     const int n_tiles = n_full + (N - n_full * TILE + ts - 1) / ts;
@@ -655,7 +680,7 @@ __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
         const int n0 = tile < n_full ? tile * TILE : n_full * TILE + (tile - n_full) * ts;
         const int nt_samples = (N - n0) < size ? (N - n0) : size;
         __syncthreads();   // the previous tile's readers of H / the table are done
-        phase_conv<OBS_F32>(Kp, lds, tile, n0, nt_samples, xg_tile);
+        phase_conv<OBS_F32, NCH>(Kp, lds, tile, n0, nt_samples, xg_tile);
         if (size <= 32) { phase_fc1<1>(Kp, lds, xg_tile); phase_head<1>(Kp, lds, n0, nt_samples); }
         else if (size <= 64) { phase_fc1<2>(Kp, lds, xg_tile); phase_head<2>(Kp, lds, n0, nt_samples); }
         else if (size <= 96) { phase_fc1<3>(Kp, lds, xg_tile); phase_head<3>(Kp, lds, n0, nt_samples); }
@@ -663,14 +688,17 @@ __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
     }
 }
 
-extern "C" __global__ void __launch_bounds__(256, 2) ppg_policy_forward_f64(const PolParams K) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    policy_main<false>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);
-}
-extern "C" __global__ void __launch_bounds__(256, 2) ppg_policy_forward_f32(const PolParams K) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    policy_main<true>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);
-}
+#define PPG_POLICY_KERNEL(name, F32, NCH)                                                        \
+    extern "C" __global__ void __launch_bounds__(256, 2) name(const PolParams K) {               \
+        extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                      \
+        policy_main<F32, NCH>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);                \
+    }
+PPG_POLICY_KERNEL(ppg_policy_forward_f64, false, 4)          // channel-first: R x R image, 4 channels
+PPG_POLICY_KERNEL(ppg_policy_forward_f32, true, 4)
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc8_f64, false, 8)     // channels-last: 4 x R image, R <= 8 channels
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc8_f32, true, 8)
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_f64, false, 16)   // channels-last, 9 <= R <= 15 channels (two channel blocks into conv1)
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_f32, true, 16)
 
 }  // namespace ppgpol
 
@@ -679,7 +707,7 @@ extern "C" __global__ void __launch_bounds__(256, 2) ppg_policy_forward_f32(cons
 // ---------------------------------------------------------------------------------------------------------------------------
 
 struct ppg_policy {
-    int32_t device, R, n_actions;
+    int32_t device, R, n_actions, layout, cin;
     ppgpol::PolParams base;
     void *dev_weights;     // one allocation: fragments + biases
     __bf16 *xg;            // scratch slots
@@ -764,8 +792,17 @@ static void ppg_pack_fc(const float *w, int n_out, int K, int mt_n, KMap kmap, s
 
 extern "C" {
 
+int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_actions, int32_t layout, const ppg_policy_weights *w,
+                             ppg_policy **out);
+
 int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, const ppg_policy_weights *w, ppg_policy **out) {
+    return ppg_policy_create_layout(device, obs_range, n_actions, PPG_POLICY_LAYOUT_CHW, w, out);
+}
+
+int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_actions, int32_t layout, const ppg_policy_weights *w,
+                             ppg_policy **out) {
     if (!w || !out) return ppg_policy_fail(nullptr, PPG_EINVAL, "null argument");
+    if (layout != PPG_POLICY_LAYOUT_CHW && layout != PPG_POLICY_LAYOUT_HWC) return ppg_policy_fail(nullptr, PPG_EINVAL, "unknown layout %d", layout);
     if (obs_range < 1 || obs_range > 15) return ppg_policy_fail(nullptr, PPG_EINVAL, "obs_range %d outside 1..15", obs_range);
     if (n_actions < 1 || n_actions > 32) return ppg_policy_fail(nullptr, PPG_EINVAL, "n_actions %d outside 1..32", n_actions);
     for (int l = 0; l < 3; ++l)
@@ -778,10 +815,14 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
     ppg_policy *p = new (std::nothrow) ppg_policy();
     if (!p) return ppg_policy_fail(nullptr, PPG_ENOMEM, "out of host memory");
     memset(p, 0, sizeof *p);
-    p->device = device; p->R = obs_range; p->n_actions = n_actions;
-    const int R = obs_range, P = R * R, K1 = 64 * P;
+    p->device = device; p->R = obs_range; p->n_actions = n_actions; p->layout = layout;
+    // the image the convolutions run on: R x R with 4 channels, or (channels-last) 4 x R with R channels
+    const int R = obs_range, hwc = layout == PPG_POLICY_LAYOUT_HWC;
+    const int IH = hwc ? 4 : R, IW = R, CIN = hwc ? R : 4, CB1 = CIN > 8 ? 2 : 1;
+    const int P = IH * IW, K1 = 64 * P;
+    p->cin = CIN;
     std::vector<uint16_t> f[6];
-    ppg_pack_conv(w->conv_w[0], w->conv_b[0], 16, 4, 1, 1, f[0]);
+    ppg_pack_conv(w->conv_w[0], w->conv_b[0], 16, CIN, CB1, 1, f[0]);
     ppg_pack_conv(w->conv_w[1], w->conv_b[1], 32, 16, 2, 1, f[1]);
     ppg_pack_conv(w->conv_w[2], w->conv_b[2], 64, 32, 4, 2, f[2]);
     // FC1: our K order is the scratch slot's [row tile of conv3][position][32 channels]; PyTorch flattens channel-major (c * P + p)
@@ -809,10 +850,16 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
         return ppg_policy_fail(nullptr, PPG_EHIP, "upload of the weights failed");
     }
     ppgpol::PolParams &K = p->base;
+#ifdef PPG_EXPERIMENTS   // ablation builds only (hipcc -DPPG_EXPERIMENTS): skip phases -- the results are then meaningless
     if (const char *dbg = getenv("PPG_POLICY_SKIP")) K.debug_skip = atoi(dbg);
+#endif
     K.magic_P = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
-    K.magic_R = (uint32_t)((0x100000000ull + (uint64_t)R - 1) / (uint64_t)R);
-    K.R = R; K.P = P; K.Wp = R + 2; K.Wp2 = (R + 2) * (R + 2); K.K1 = K1; K.n_actions = n_actions;
+    K.magic_R = (uint32_t)((0x100000000ull + (uint64_t)IW - 1) / (uint64_t)IW);
+    K.R = R; K.P = P; K.Wp = IW + 2; K.Wp2 = (IH + 2) * (IW + 2); K.K1 = K1; K.n_actions = n_actions;
+    K.IH = IH; K.IW = IW; K.cin = CIN; K.obs_elems = 4 * R * R;
+    // observation element [a][b][c] of the (4,R,R) row: channel-first = (channel a, position b * R + c); channels-last = (position
+    // a * R + b, channel c)
+    K.c_stride = hwc ? 1 : R * R; K.p_stride = hwc ? R : 1;
     const unsigned char *dw = (const unsigned char *)p->dev_weights;
     K.wc1 = (const ppgpol::bf16x8 *)(dw + off[0]); K.wc2 = (const ppgpol::bf16x8 *)(dw + off[1]);
     K.wc3 = (const ppgpol::bf16x8 *)(dw + off[2]); K.w1 = (const ppgpol::bf16x8 *)(dw + off[3]);
@@ -832,7 +879,9 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
     if (fc1_stage > overlay) overlay = fc1_stage;
     p->lds_bytes = ppgpol::TILE * 16 + overlay;
     p->grid = 2 * prop.multiProcessorCount;
-    if (const char *g = getenv("PPG_POLICY_GRID")) p->grid = atoi(g) > 0 ? atoi(g) : p->grid;   // experiments: resident workgroups
+#ifdef PPG_EXPERIMENTS
+    if (const char *g = getenv("PPG_POLICY_GRID")) p->grid = atoi(g) > 0 ? atoi(g) : p->grid;   // resident workgroups
+#endif
     const size_t xg_bytes = (size_t)p->grid * ppgpol::TILE * K1 * 2;
     if (hipMalloc((void **)&p->xg, xg_bytes) != hipSuccess || hipMemset(p->xg, 0, xg_bytes) != hipSuccess) {
         (void)hipFree(p->dev_weights);
@@ -840,8 +889,10 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
         return ppg_policy_fail(nullptr, PPG_EHIP, "hipMalloc of %zu bytes of scratch failed", xg_bytes);
     }
     K.xg = p->xg;
-    (void)hipFuncSetAttribute((const void *)ppgpol::ppg_policy_forward_f64, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
-    (void)hipFuncSetAttribute((const void *)ppgpol::ppg_policy_forward_f32, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+    for (const void *fn : {(const void *)ppgpol::ppg_policy_forward_f64, (const void *)ppgpol::ppg_policy_forward_f32,
+                           (const void *)ppgpol::ppg_policy_forward_hwc8_f64, (const void *)ppgpol::ppg_policy_forward_hwc8_f32,
+                           (const void *)ppgpol::ppg_policy_forward_hwc16_f64, (const void *)ppgpol::ppg_policy_forward_hwc16_f32})
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
     *out = p;
     return PPG_OK;
 }
@@ -860,8 +911,8 @@ int ppg_policy_destroy(ppg_policy *p) {
 
 uint64_t ppg_policy_macs_per_observation(const ppg_policy *p) {
     if (!p) return 0;
-    const uint64_t P = (uint64_t)p->R * p->R;
-    return P * (16 * 36 + 32 * 144 + 64 * 288) + 64 * P * 256 + 256 * 256 + 256 * (uint64_t)p->n_actions;
+    const uint64_t P = p->layout == PPG_POLICY_LAYOUT_HWC ? 4 * (uint64_t)p->R : (uint64_t)p->R * p->R;
+    return P * (16 * 9 * (uint64_t)p->cin + 32 * 144 + 64 * 288) + 64 * P * 256 + 256 * 256 + 256 * (uint64_t)p->n_actions;
 }
 
 const char *ppg_policy_last_error(const ppg_policy *p) { return p ? p->err : g_ppg_policy_error; }
@@ -884,6 +935,7 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     int total = 0;
     for (int k = 0; k < n; ++k) {
         const ppg_handle *h = handles[k];
+        if (!h) return ppg_policy_fail(p, PPG_EINVAL, "handle %d is NULL", k);
         if (h->drive || (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel))
             return ppg_policy_fail(p, PPG_EINVAL, "ppg_policy_act expects 4-channel observations");
         if ((species ? h->base.Rq : h->base.Rp) != R || h->base.S != K.S || h->base.obs_f32 != K.obs_f32 || h->device != p->device)
@@ -909,14 +961,20 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     K.plan = L.plan = p->plan;
     K.tile_env = L.tile_env = p->plan + ppgpol::PLAN_HDR + total;
     L.slots = p->grid;
+#ifdef PPG_EXPERIMENTS
     if (const char *f = getenv(species ? "PPG_POLICY_TILE_PREY" : "PPG_POLICY_TILE_PRED")) {
         const int v = atoi(f);
         if (v == 32 || v == 64 || v == 96 || v == 128) L.force_ts = v;
     }
+#endif
     K.logits = logits;
     hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
-    if (K.obs_f32) hipLaunchKernelGGL(ppgpol::ppg_policy_forward_f32, dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
-    else hipLaunchKernelGGL(ppgpol::ppg_policy_forward_f64, dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
+    typedef void (*fwd_fn)(const ppgpol::PolParams);
+    const fwd_fn fwd[3][2] = {{ppgpol::ppg_policy_forward_f64, ppgpol::ppg_policy_forward_f32},
+                              {ppgpol::ppg_policy_forward_hwc8_f64, ppgpol::ppg_policy_forward_hwc8_f32},
+                              {ppgpol::ppg_policy_forward_hwc16_f64, ppgpol::ppg_policy_forward_hwc16_f32}};
+    const int variant = p->layout == PPG_POLICY_LAYOUT_HWC ? (p->cin > 8 ? 2 : 1) : 0;
+    hipLaunchKernelGGL(fwd[variant][K.obs_f32 ? 1 : 0], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     PPG_POL_TRY(p, hipGetLastError());
     return PPG_OK;
 }

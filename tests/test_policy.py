@@ -16,10 +16,10 @@ from predpreygrass_amd.policy import PolicyNet
 REL_TOL = 0.02
 
 
-def make_nets(Rp=7, Rq=9, scale=3.0, seed=0):
+def make_nets(Rp=7, Rq=9, scale=3.0, seed=0, layout="chw"):
     """Default-initialised networks with the weights scaled up so that the logits are O(1) and distinct."""
     torch.manual_seed(seed)
-    nets = [PolicyNet(Rp), PolicyNet(Rq)]
+    nets = [PolicyNet(Rp, layout=layout), PolicyNet(Rq, layout=layout)]
     with torch.no_grad():
         for net in nets:
             for m in list(net.conv) + list(net.fc):
@@ -35,6 +35,67 @@ def test_policy_net_is_the_reference_architecture():
     assert [tuple(f.weight.shape) for f in net.fc] == [(256, 64 * 81), (256, 256), (9, 256)]
     out = net(torch.zeros(5, 4, 9, 9, dtype=torch.float64))
     assert out.shape == (5, 9) and out.dtype == torch.float32
+
+
+def rllib_style_state_dict(net, shared_encoder=False, numpy_values=False):
+    """The parameter names an RLlib PPO RLModule gives such a network (actor / critic encoder or one shared encoder: a TorchCNN is
+    ZeroPad2d, Conv2d, activation per layer, so the convolutions sit at cnn.1 / cnn.4 / cnn.7; heads are TorchMLPs), with a critic
+    next to the actor."""
+    enc = "encoder.encoder" if shared_encoder else "encoder.actor_encoder"
+    sd = {}
+    for l in range(3):
+        sd[f"{enc}.net.0.cnn.{1 + 3 * l}.weight"] = net.conv[l].weight.detach().clone()
+        sd[f"{enc}.net.0.cnn.{1 + 3 * l}.bias"] = net.conv[l].bias.detach().clone()
+        if not shared_encoder:
+            sd[f"encoder.critic_encoder.net.0.cnn.{1 + 3 * l}.weight"] = torch.randn_like(net.conv[l].weight)
+            sd[f"encoder.critic_encoder.net.0.cnn.{1 + 3 * l}.bias"] = torch.randn_like(net.conv[l].bias)
+        sd[f"pi.net.mlp.{2 * l}.weight"] = net.fc[l].weight.detach().clone()
+        sd[f"pi.net.mlp.{2 * l}.bias"] = net.fc[l].bias.detach().clone()
+    flat = net.fc[0].weight.shape[1]
+    for l, shape in enumerate([(256, flat), (256, 256), (1, 256)]):
+        sd[f"vf.net.mlp.{2 * l}.weight"] = torch.randn(shape)
+        sd[f"vf.net.mlp.{2 * l}.bias"] = torch.randn(shape[0])
+    if numpy_values:
+        sd = {k: v.numpy() for k, v in sd.items()}
+    return sd
+
+
+@pytest.mark.parametrize("layout,R", [("chw", 7), ("chw", 9), ("hwc", 7), ("hwc", 9), ("hwc", 5)])
+@pytest.mark.parametrize("shared,as_numpy", [(False, False), (True, True)])
+def test_load_rllib_state_dict_recovers_the_network_in_either_layout(layout, R, shared, as_numpy):
+    """conv1 [16,4,3,3] = channel-first, [16,R,3,3] = RLlib's channels-last reading of the (4,R,R) Box; the loaded network gives the
+    same logits as the one the state dict was taken from, the critic's parameters are ignored."""
+    from predpreygrass_amd.policy import load_rllib_state_dict
+    torch.manual_seed(R)
+    src = PolicyNet(R, 9, layout)
+    net = load_rllib_state_dict(rllib_style_state_dict(src, shared, as_numpy))
+    assert (net.layout, net.obs_range, net.n_actions) == (layout, R, 9)
+    assert tuple(net.conv[0].weight.shape) == ((16, 4, 3, 3) if layout == "chw" else (16, R, 3, 3))
+    assert net.fc[0].weight.shape[1] == (64 * R * R if layout == "chw" else 64 * 4 * R)
+    x = torch.rand(6, 4, R, R, dtype=torch.float64)
+    assert torch.equal(net(x), src(x))
+    # the channels-last network really convolves over the (4, R) plane with the last axis as channels
+    if layout == "hwc":
+        y = torch.relu(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), net.conv[0].weight, net.conv[0].bias, padding=1))
+        assert y.shape == (6, 16, 4, R)
+
+
+def test_load_rllib_state_dict_fails_loudly():
+    from predpreygrass_amd.policy import load_rllib_state_dict
+    good = rllib_style_state_dict(PolicyNet(7, 9, "hwc"))
+    for mutate, what in [
+        (lambda d: d.pop("pi.net.mlp.4.weight"), "3 linear"),                                            # a head layer missing
+        (lambda d: d.pop("encoder.actor_encoder.net.0.cnn.4.bias"), "no bias"),
+        (lambda d: d.update({"encoder.actor_encoder.net.0.cnn.4.weight": torch.zeros(32, 16, 5, 5)}), "not 3x3"),   # another filter size
+        (lambda d: d.update({"pi.net.mlp.0.weight": torch.zeros(256, 64 * 4 * 7 + 64), "pi.net.mlp.0.bias": torch.zeros(256)}), "neither"),
+        (lambda d: d.update({"pi.net.mlp.2.weight": torch.zeros(128, 256), "pi.net.mlp.2.bias": torch.zeros(128)}), "policy head"),
+    ]:
+        d = dict(good)
+        mutate(d)
+        with pytest.raises(ValueError, match=what):
+            load_rllib_state_dict(d)
+    with pytest.raises(ValueError, match="obs_range 9"):
+        load_rllib_state_dict(good, obs_range=9)     # a 7-window network for 9-window observations
 
 
 def test_fused_policy_fails_loudly_without_a_gpu():
@@ -134,6 +195,53 @@ def test_policy_over_sub_batches_partial_tiles_and_other_window_sizes():
     check_against_fp32([env], nets2, fused2, dense_obs=True, seed=4)
     with pytest.raises(ValueError):
         fused.act(env)            # 7x7 / 9x9 networks on 5x5 / 11x11 observations
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Rp,Rq", [(7, 9), (5, 11), (9, 15)])
+def test_channels_last_networks_match_fp32_reference(Rp, Rq):
+    """RLlib's reading of the (4,R,R) Box -- a 4 x R image with R channels (PPG_POLICY_LAYOUT_HWC): one and two channel blocks into
+    conv1 (R <= 8 / R >= 9), loaded from an RLlib-style state dict, float64 and float32 observations, sparse and dense windows."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy, load_rllib_state_dict
+    src = make_nets(Rp, Rq, seed=11, layout="hwc")
+    nets = [load_rllib_state_dict(rllib_style_state_dict(n)) for n in src]
+    assert [n.layout for n in nets] == ["hwc", "hwc"]
+    fused = FusedPolicy(nets[0], nets[1])
+    cfg = {**config_env, "predator_obs_range": Rp, "prey_obs_range": Rq}
+    for dt in (torch.float64, torch.float32):
+        env = BatchedPredPreyGrass(cfg, batch_size=41, device="cuda:0", obs_dtype=dt, seed=6)
+        env.reset()
+        for _ in range(50):
+            env.step(random_actions=True, auto_reset=True)
+        w1, a1 = check_against_fp32([env], nets, fused)
+        w2, a2 = check_against_fp32([env], nets, fused, dense_obs=True, seed=2)
+        print(f"hwc {Rp}/{Rq} {dt}: max relative logit error {max(w1, w2):.2e}; greedy agreement {a1:.4f} / {a2:.4f}")
+        assert a1 > 0.97 and a2 > 0.97
+
+
+@pytest.mark.gpu
+def test_sampled_actions_do_not_depend_on_where_they_are_written():
+    """PPG_POLICY_SAMPLE is keyed by (seed, env, row): the same seed gives the same actions in another tensor, in another
+    process, on another rank; split into sub-batches the envs keep their draws."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy
+    nets = make_nets(seed=5)
+    fused = FusedPolicy(nets[0], nets[1])
+    env = BatchedPredPreyGrass(dict(config_env), batch_size=64, device="cuda:0", seed=8)
+    env.reset()
+    for _ in range(20):
+        env.step(random_actions=True, auto_reset=True)
+    fused.act(env, sample=True, seed=77)
+    own = env.actions.clone()
+    pad = torch.empty((1 << 20,), dtype=torch.int8, device="cuda:0")     # (moves the next allocation somewhere else)
+    other = torch.full_like(env.actions, -1)
+    fused.act(env, actions=[other], sample=True, seed=77)
+    assert other.data_ptr() != env.actions.data_ptr()
+    assert torch.equal(own, other)
+    fused.act(env, actions=[other], sample=True, seed=78)
+    assert not torch.equal(own, other)
+    del pad
 
 
 @pytest.mark.gpu

@@ -1,83 +1,68 @@
-"""The seasonal grass-regrowth variant (base_environment_seasonal in the reference: a square wave on
-energy_gain_per_step_grass, predpreygrass_rllib_env.py:224-234,268-271 of that directory).
+"""Known answers for the seasonal grass-regrowth variant (a square wave on energy_gain_per_step_grass keyed on current_step:
+base_environment_seasonal/predpreygrass_rllib_env.py:224-234,268-271 of the reference), run on the emulated kernel.
 
-The three tests below mirror the reference's own
-base_environment_seasonal/tests/test_seasonal_grass_regrowth.py (same scenarios, same expected numbers),
-run against predpreygrass_amd.PredPreyGrass on the emulated kernel; bit-exact parity with that variant's
-step() is covered by the seasonal_* golden cases."""
-import copy
-
+Table-driven: every row states a season configuration and what the square wave must do.  Bit-exact parity with that variant's
+step() is the job of the seasonal_* golden cases (tests/test_oracle_golden.py, tests/test_emulated_kernel.py); these rows pin the
+arithmetic of the wave itself and of the regrowth it scales, with numbers derived here from the definition -- gain(step) =
+base_gain * (high if (step // length) is even else low), capped at initial_energy_grass."""
 import pytest
 
 from predpreygrass_amd.config import config_env as base_config
 from predpreygrass_amd.env import PredPreyGrass
 from tests.emu_backend import library
 
-# base_environment_seasonal/config_env.py:35-40
-config_env = {**base_config, "season_length_steps": 40, "season_high_multiplier": 1.5, "season_low_multiplier": 0.5}
+GAIN = base_config["energy_gain_per_step_grass"]
+CAP = base_config["initial_energy_grass"]
+
+# (season_length_steps, high, low, {step: expected multiplier})
+WAVE = [
+    (5, 1.5, 0.5, {0: 1.5, 4: 1.5, 5: 0.5, 9: 0.5, 10: 1.5, 14: 1.5, 15: 0.5, 999: 0.5}),
+    (1, 2.0, 0.25, {0: 2.0, 1: 0.25, 2: 2.0, 7: 0.25}),
+    (40, 1.5, 0.5, {39: 1.5, 40: 0.5, 79: 0.5, 80: 1.5}),        # the variant's own config (its config_env.py:35-40)
+    (3, 1.0, 1.0, {s: 1.0 for s in range(12)}),                    # both multipliers 1: the base environment
+    (0, 7.0, 9.0, {s: 1.0 for s in (0, 1, 45, 1000)}),             # no cycle configured: the base environment
+]
 
 
-def _make_env(**overrides):
-    config = copy.deepcopy(config_env)
-    config.update(overrides)
-    return PredPreyGrass(config, _library=library())
+def make(**season):
+    return PredPreyGrass({**base_config, **season}, _library=library())
 
 
-def test_season_multiplier_phase_boundaries():
-    env = _make_env(season_length_steps=5, season_high_multiplier=1.5, season_low_multiplier=0.5)
-    for step in (0, 1, 4):
+@pytest.mark.parametrize("length,high,low,expect", WAVE)
+def test_square_wave(length, high, low, expect):
+    env = make(season_length_steps=length, season_high_multiplier=high, season_low_multiplier=low)
+    for step, want in expect.items():
         env.current_step = step
-        assert env._current_season_multiplier() == 1.5
-    for step in (5, 6, 9):
-        env.current_step = step
-        assert env._current_season_multiplier() == 0.5
-    env.current_step = 10
-    assert env._current_season_multiplier() == 1.5
-    env.current_step = 14
-    assert env._current_season_multiplier() == 1.5
+        assert env._current_season_multiplier() == want, (length, step)
 
 
-def test_season_disabled_reproduces_flat_baseline():
-    env = _make_env(season_length_steps=3, season_high_multiplier=1.0, season_low_multiplier=1.0)
-    for step in range(0, 20):
+def test_base_config_is_flat():
+    env = PredPreyGrass(base_config, _library=library())
+    for step in (0, 3, 45, 400):
         env.current_step = step
         assert env._current_season_multiplier() == 1.0
 
 
-def _stay_actions(env, live):
-    return {agent: 4 for agent in live}  # action 4 == (0, 0), i.e. stay in place
+# (season length, high, low, calls, start energy of the tracked patch)
+REGROWTH = [
+    (3, 1.5, 0.5, 9, 0.0),       # three phases: high, low, high
+    (2, 2.0, 0.0, 6, 0.3),       # a low phase in which nothing grows
+    (4, 10.0, 10.0, 8, 1.0),     # runs into the cap (initial_energy_grass) during the first phase and stays there
+]
 
 
-def test_grass_regrows_faster_in_abundant_phase_than_scarce_phase():
-    season_length_steps = 3
-    high_multiplier = 1.5
-    low_multiplier = 0.5
-    base_gain = config_env["energy_gain_per_step_grass"]
-    env = _make_env(season_length_steps=season_length_steps, season_high_multiplier=high_multiplier,
-                    season_low_multiplier=low_multiplier)
-    obs, _ = env.reset(seed=0)
-    live = list(obs)
-    tracked_grass = next(iter(env.grass_positions))
-    # a patch no prey stands on (the reference test relies on that implicitly with its seed-0 placement)
-    occupied = set(env.agent_positions.values())
-    tracked_grass = next(g for g, p in env.grass_positions.items() if p not in occupied)
-    env.set_grass_energy(tracked_grass, 0.0)
-
-    for _ in range(season_length_steps):  # steps 0, 1, 2: abundant phase
-        o, r, te, tr, _ = env.step(_stay_actions(env, live))
-        live = [a for a in o if not te[a]]
-    energy_after_abundant_phase = env.grass_energies[tracked_grass]
-    for _ in range(season_length_steps):  # steps 3, 4, 5: scarce phase
-        o, r, te, tr, _ = env.step(_stay_actions(env, live))
-        live = [a for a in o if not te[a]]
-    growth_in_scarce_phase = env.grass_energies[tracked_grass] - energy_after_abundant_phase
-
-    assert energy_after_abundant_phase == pytest.approx(season_length_steps * base_gain * high_multiplier)
-    assert growth_in_scarce_phase == pytest.approx(season_length_steps * base_gain * low_multiplier)
-    assert energy_after_abundant_phase > growth_in_scarce_phase
-
-
-def test_base_config_has_no_seasonal_cycle():
-    env = PredPreyGrass(base_config, _library=library())
-    env.current_step = 45
-    assert env._current_season_multiplier() == 1.0
+@pytest.mark.parametrize("length,high,low,calls,start", REGROWTH)
+def test_regrowth_of_an_untouched_patch_follows_the_wave(length, high, low, calls, start):
+    """A patch nobody stands on, everybody told to stay put: after every call its energy is min(cap, previous + gain(step))."""
+    env = make(season_length_steps=length, season_high_multiplier=high, season_low_multiplier=low)
+    obs, _ = env.reset(seed=3)
+    taken = set(env.agent_positions.values())
+    patch = next(g for g, pos in env.grass_positions.items() if pos not in taken)
+    env.set_grass_energy(patch, start)
+    live, want = list(obs), start
+    for step in range(calls):
+        o, _, term, _, _ = env.step({a: 4 for a in live})     # action 4 = (0, 0)
+        live = [a for a in o if not term[a]]
+        mult = high if (step // length) % 2 == 0 else low
+        want = min(CAP, want + GAIN * mult)                    # the reference's float64 arithmetic, in its order
+        assert env.grass_energies[patch] == want, (step, env.grass_energies[patch], want)
