@@ -456,6 +456,7 @@ def main(argv=None, backend=None):
 
     # ---- optional legs: the ONE RCCL all-gather per step north_star specifies (N > 1 only) -------------------------
     gather_info = gather_overlapped = None
+    extra_legs = {}
     if distributed and args.gather_steps > 0:
         from predpreygrass_amd.distributed import ObservationGatherer
         wire = torch.float32 if args.gather_wire == "f32" else None
@@ -465,8 +466,14 @@ def main(argv=None, backend=None):
         dist.all_reduce(want, op=dist.ReduceOp.MAX)
         rows_per_env = tuple(float(v) for v in want.tolist())
 
-        def leg(overlapped):
-            g = ObservationGatherer(group.subs, wire_dtype=wire, rows_per_env=rows_per_env)
+        def leg(overlapped, mode="all_gather", include_obs=True):
+            g = ObservationGatherer(group.subs, wire_dtype=wire, rows_per_env=rows_per_env, mode=mode, include_obs=include_obs)
+            # untimed: one gather, then the image is sized from what it really used (max over the ranks + 15 %)
+            one_step()
+            if not dry:
+                group.wait(backend.current_stream(device))
+            if g.fit(g.gather()):
+                g.gather()
             cuda = not dry
             cur = backend.current_stream(device) if cuda else None
             side = backend.new_stream(device) if (cuda and overlapped) else None
@@ -498,18 +505,25 @@ def main(argv=None, backend=None):
                     "image_bytes_used_last_step": [int(h.bytes_used) for h in hs],
                     "image_overflows": int(sum(h.overflow for h in hs)),
                     "wire_obs_dtype": "f32" if (wire is not None or obs_dtype == torch.float32) else "f64",
-                    "what": ("one all_gather_into_tensor (RCCL) of the packed observation image per step" +
+                    "what": (("one all_gather_into_tensor (RCCL) of the packed observation image per step" if mode == "all_gather" else
+                              "one gather of the packed observation image to rank 0 per step (every other rank sends once, receives nothing)") +
+                             ("" if include_obs else " WITHOUT the observation sections (PPG_PACK_NO_OBS: env words, ids, rewards, flags -- "
+                              "what leaves a GPU when the policy runs next to the env)") +
                              (", the collective of step t overlapped with step t+1 (side stream, two image slots)" if overlapped
                               else ", synchronous: the next step waits for it"))}
-        for name, ov in (("sync", False), ("overlapped", True)):
+        for name, kw in (("sync", dict(overlapped=False)), ("overlapped", dict(overlapped=True)),
+                         ("obs_gather_to_root", dict(overlapped=False, mode="gather")),
+                         ("ids_rewards_gather", dict(overlapped=False, include_obs=False))):
             try:   # never lose the main measurement to an optional leg
-                res = leg(ov)
+                res = leg(**kw)
             except Exception as ex:
                 res = {"error": repr(ex)[:300]}
-            if ov:
+            if name == "overlapped":
                 gather_overlapped = res
-            else:
+            elif name == "sync":
                 gather_info = res
+            else:
+                extra_legs[name] = res
 
     # ---- accounting ------------------------------------------------------------------
     status = int(np.bitwise_or.reduce(es[:, _abi.ENV_STATUS]))
@@ -627,6 +641,8 @@ def main(argv=None, backend=None):
             out["obs_gather"] = gather_info
         if gather_overlapped is not None:
             out["obs_gather_overlapped"] = gather_overlapped
+        if gather_info is not None:
+            out.update(extra_legs)
         if not args.no_cpu_baseline and not dry:   # rank 0's host cores, also next to the N > 1 curve (north_star)
             out["cpu_baseline"] = cpu_baseline(cfg, args.seed, seconds=args.cpu_seconds, workload=args.workload)
         print(json.dumps(out), flush=True)

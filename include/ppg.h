@@ -278,6 +278,22 @@ int ppg_create_gen2(const ppg_config_gen2 *cfg, int32_t batch, int32_t device, c
  * the Philox episode counter to start from (normally 0). */
 int ppg_reset(ppg_handle *h, const uint64_t *seeds, uint32_t episode, void *stream);
 
+/* reset() (BASE:129-217) of every env with a GIVEN placement -- the `const ppg_init_state*` form of ppg_reset: what
+ * the reference's reset(seed) produces once its cells are known (its PCG64 + set-order placement is captured input, not arithmetic:
+ * predpreygrass_amd.placement.reference_placement re-does it on the host).  HOST arrays, cells as (x << 8) | y:
+ * predators / prey in id order (agent i of its species gets id i and initial_energy_*), grass patches in patch order
+ * (initial_energy_grass each).  grid[type, cell] = energy in id order, so of several agents of one species on a cell the last one
+ * owns it (BASE:190-200).  Writes the row tables, the grass table and the env words, then computes the observations (one
+ * ppg_observe launch); env_seed is left alone (it keys the device-side random actions).  Base-family handles. */
+typedef struct ppg_init_state {
+    const uint16_t *pred_xy;   /* [B][n_initial_predators] */
+    const uint16_t *prey_xy;   /* [B][n_initial_prey] */
+    const uint16_t *grass_xy;  /* [B][n_grass], unique within an env */
+    uint32_t episode;          /* Philox episode counter to start from (normally 0) */
+    uint32_t reserved_;
+} ppg_init_state;
+int ppg_reset_from_state(ppg_handle *h, const ppg_init_state *init, void *stream);
+
 /* Observations for all live rows from the state currently in the buffers
  * (reset() tail BASE:215; _get_observation BASE:511; used after the host wrote
  * a captured placement or restored a snapshot, BASE:788-804). */
@@ -290,11 +306,12 @@ int ppg_observe(ppg_handle *h, void *stream);
  * which is the order of the previous observation dict (RLlib's protocol). */
 int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream);
 
-/* n_steps transitions in ONE launch -- exactly what n_steps calls of ppg_step would do, each step
- * writing its observations / rewards / flags / tables to the same buffers -- for policies that live on
- * the device: PPG_STEP_RANDOM_ACTIONS (uniform random policy), or an open-loop action tape
- * `actions` = device int8 [n_steps,B,S].  The agent table stays in registers and the grass table in LDS
- * between steps, and a wavefront's observation stores drain while it computes its next step. */
+/* DIAGNOSTIC, not a fast path: n_steps transitions in ONE launch -- exactly what n_steps calls of ppg_step would do, each step
+ * writing its observations / rewards / flags / tables to the same buffers -- with the device-side uniform random policy
+ * (PPG_STEP_RANDOM_ACTIONS) or an open-loop action tape `actions` = device int8 [n_steps,B,S].  It is bit-identical to n_steps
+ * ppg_step calls and SLOWER than them (96 vs 81 us per 4096-env step when last measured): one wavefront per
+ * env, none of the multi-wave / cooperative kernels, base family without the kickback / drive variants only.  It exists to show
+ * that a step keeps no host-side state between launches; use ppg_step (or ppg_step_many) for throughput. */
 int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t flags, void *stream);
 
 /* Same, for an action dict whose iteration order differs from the previous observation dict
@@ -383,6 +400,9 @@ int ppg_import_state(ppg_handle *h, int32_t env, const void *blob, uint64_t size
 #define PPG_PACK_MAGIC 0x4B475050u /* "PPGK" */
 #define PPG_PACK_VERSION 1u
 #define PPG_PACK_F32 0x1u /* float64 observations travel as float32 (observations that already are float32 are copied) */
+#define PPG_PACK_NO_OBS 0x2u /* no observation sections (header blk_pred = blk_prey = 0): env words, row offsets, ids, rewards and
+                              * flags only, 13 bytes per agent row + 88 per env -- what a learner or logger needs from a rollout whose
+                              * policy runs next to the env (ppg_policy_act): ~2 MB per 4096-env shard and step instead of ~370 MB */
 #define PPG_PACK_MAX_HANDLES 8
 typedef struct ppg_pack_header {
     uint32_t magic, version;

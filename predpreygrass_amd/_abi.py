@@ -86,6 +86,7 @@ class PpgConfigGen2(C.Structure):
 
 
 PACK_MAGIC, PACK_VERSION, PACK_F32, PACK_MAX_HANDLES = 0x4B475050, 1, 0x1, 8
+PACK_NO_OBS = 0x2
 STATE_MAGIC, STATE_VERSION = 0x53475050, 1
 
 
@@ -116,6 +117,11 @@ class PpgBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _BUF_FIELDS]
 
 
+class PpgInitState(C.Structure):
+    """include/ppg.h: struct ppg_init_state (host uint16 arrays, cells as (x << 8) | y)."""
+    _fields_ = [("pred_xy", C.c_void_p), ("prey_xy", C.c_void_p), ("grass_xy", C.c_void_p), ("episode", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
 class PpgPolicyWeights(C.Structure):
     """include/ppg.h: struct ppg_policy_weights (host float32 pointers, PyTorch layouts)."""
     _fields_ = [("conv_w", C.c_void_p * 3), ("conv_b", C.c_void_p * 3), ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3)]
@@ -128,7 +134,7 @@ POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_d
 
 
 EXPORTED_SYMBOLS = [
-    "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_get_buffers", "ppg_reset", "ppg_observe", "ppg_step", "ppg_step_many",
+    "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_get_buffers", "ppg_reset", "ppg_reset_from_state", "ppg_observe", "ppg_step", "ppg_step_many",
     "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_set_wave_plan",
     "ppg_get_wave_plan", "ppg_rebalance",
     "ppg_export_grid", "ppg_walls_changed", "ppg_state_bytes", "ppg_export_state", "ppg_import_state", "ppg_pack_bytes", "ppg_pack",
@@ -145,6 +151,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_destroy.argtypes = [C.c_void_p]
     lib.ppg_reset.restype = C.c_int
     lib.ppg_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ppg_reset_from_state.restype = C.c_int
+    lib.ppg_reset_from_state.argtypes = [C.c_void_p, C.POINTER(PpgInitState), C.c_void_p]
     lib.ppg_observe.restype = C.c_int
     lib.ppg_observe.argtypes = [C.c_void_p, C.c_void_p]
     lib.ppg_step.restype = C.c_int

@@ -236,49 +236,16 @@ class BatchedPredPreyGrass:
         for b in range(B):
             if len(np.unique(gcell[b])) != self.n_grass:
                 raise ValueError("grass positions must be unique")
-        S, cp = self.S, self.pred_capacity
-        xy = np.zeros((B, S), dtype=np.int16)
-        en = np.zeros((B, S), dtype=np.float64)
-        ids = np.zeros((B, S), dtype=np.int32)
-        keys = np.zeros((B, S), dtype=np.int32)
-        fl = np.zeros((B, S), dtype=np.uint8)
-        xy[:, : self.P0] = (pred[..., 0] << 8 | pred[..., 1]).astype(np.int16)
-        xy[:, cp: cp + self.Q0] = (prey[..., 0] << 8 | prey[..., 1]).astype(np.int16)
-        en[:, : self.P0] = float(self.config["initial_energy_predator"])
-        en[:, cp: cp + self.Q0] = float(self.config["initial_energy_prey"])
-        ids[:, : self.P0] = np.arange(self.P0)
-        ids[:, cp: cp + self.Q0] = np.arange(self.Q0)
-        keys[:, : self.P0] = lexkey(np.arange(self.P0))
-        keys[:, cp: cp + self.Q0] = lexkey(np.arange(self.Q0))
-        # grid[type, pos] = energy in id order (predpreygrass_rllib_env.py:190-200): the last agent
-        # written to a cell owns it
-        for b in range(B):
-            for lo, arr in ((0, pred[b]), (cp, prey[b])):
-                owner = {}
-                for i, (x, y) in enumerate(arr):
-                    owner[(int(x), int(y))] = i
-                for i in owner.values():
-                    fl[b, lo + i] = _abi.ROW_OWNS
-        es = np.zeros((B, _abi.ENV_WORDS), dtype=np.int32)
-        es[:, _abi.ENV_N_PRED_ROWS] = self.P0
-        es[:, _abi.ENV_N_PREY_ROWS] = self.Q0
-        es[:, _abi.ENV_NEXT_PRED_ID] = self.P0
-        es[:, _abi.ENV_NEXT_PREY_ID] = self.Q0
-        es[:, _abi.ENV_N_PRED_ALIVE] = self.P0
-        es[:, _abi.ENV_N_PREY_ALIVE] = self.Q0
-        es[:, _abi.ENV_FLAGS] = _abi.ENVF_WAS_RESET | _abi.ENVF_LIST_IS_ROW_ORDER
-        es[:, _abi.ENV_EPISODE] = int(episode)
-        gxy = np.zeros((B, self.grass_capacity), dtype=np.int16)
-        ge = np.zeros((B, self.grass_capacity), dtype=np.float64)
-        gxy[:, : self.n_grass] = (grass[..., 0] << 8 | grass[..., 1]).astype(np.int16)
-        ge[:, : self.n_grass] = float(self.config["initial_energy_grass"])
-        for t, a in ((self.row_xy, xy), (self.row_energy, en), (self.row_id, ids), (self.row_key, keys),
-                     (self.row_flags, fl), (self.env_state, es), (self.grass_xy, gxy), (self.grass_energy, ge)):
-            t.copy_(torch.from_numpy(a))
-        self.row_cumrew.zero_()
-        self.row_reward.zero_()
-        self.row_parent.fill_(-1)
-        self.observe()
+        # the tables are built by the library (`ppg_reset_from_state`: row tables, OWNS bits in id order, grass table, env words,
+        # then one ppg_observe launch)
+        arrays = [np.ascontiguousarray((a[..., 0] << 8 | a[..., 1]).astype(np.uint16)) for a in (pred, prey, grass)]
+        init = _abi.PpgInitState()
+        init.pred_xy, init.prey_xy, init.grass_xy = (a.ctypes.data for a in arrays)
+        init.episode = int(episode)
+        rc = self._lib.ppg_reset_from_state(self._handle, C.byref(init), self._stream())
+        if rc == -1:
+            raise ValueError(self._lib.ppg_last_error(self._handle).decode())
+        self._check(rc, "ppg_reset_from_state")
         return self
 
     def set_wave_plan(self, waves=0, helper_min_rows=0, coop_envs=0):

@@ -510,6 +510,67 @@ int ppg_reset(ppg_handle *h, const uint64_t *seeds, uint32_t episode, void *stre
     return backend_launch(h, ppg::MODE_RESET, P, stream);
 }
 
+int ppg_observe(ppg_handle *h, void *stream);
+
+int ppg_reset_from_state(ppg_handle *h, const ppg_init_state *init, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!init || !init->grass_xy || (!init->pred_xy && h->cfg.n_initial_predators > 0) || (!init->prey_xy && h->cfg.n_initial_prey > 0))
+        return ppg_fail(h, PPG_EINVAL, "ppg_reset_from_state: an array of ppg_init_state is NULL");
+    if (h->gen2) return ppg_fail(h, PPG_EINVAL, "ppg_reset_from_state takes base-family handles (second generation: write the tensors, then ppg_observe)");
+    const ppg::KParams &P = h->base;
+    const size_t B = (size_t)h->batch, S = (size_t)P.S, NG = (size_t)P.cap_grass;
+    const int P0 = h->cfg.n_initial_predators, Q0 = h->cfg.n_initial_prey, n_grass = h->cfg.n_grass, G = P.G;
+    std::vector<uint16_t> xy(B * S, 0), gxy(B * NG, 0);
+    std::vector<double> en(B * S, 0.0), zeros(B * S, 0.0), ge(B * NG, 0.0);
+    std::vector<int32_t> ids(B * S, 0), par(B * S, -1), es(B * PPG_ENV_WORDS, 0);
+    std::vector<uint32_t> keys(B * S, 0);
+    std::vector<uint8_t> fl(B * S, 0);
+    std::vector<int32_t> owner((size_t)G * G);
+    for (size_t b = 0; b < B; ++b) {
+        for (int t = 0; t < 2; ++t) {
+            const int n = t ? Q0 : P0, lo = t ? P.cap_pred : 0;
+            const uint16_t *src = (t ? init->prey_xy : init->pred_xy) + b * (size_t)n;
+            std::fill(owner.begin(), owner.end(), -1);
+            for (int i = 0; i < n; ++i) {
+                const int x = src[i] >> 8, y = src[i] & 255;
+                if (x >= G || y >= G) return ppg_fail(h, PPG_EINVAL, "env %zu: %s %d at (%d, %d) is outside the %dx%d grid", b, t ? "prey" : "predator", i, x, y, G, G);
+                const size_t s = b * S + lo + i;
+                xy[s] = src[i]; en[s] = t ? h->cfg.initial_energy_prey : h->cfg.initial_energy_predator;
+                ids[s] = i; keys[s] = ppg_host_lexkey((uint32_t)i);
+                owner[(size_t)x * G + y] = i;    // grid[type, pos] = energy in id order: the last writer owns the cell (BASE:190-200)
+            }
+            for (int c = 0; c < G * G; ++c) if (owner[c] >= 0) fl[b * S + lo + owner[c]] = PPG_ROW_OWNS;
+        }
+        std::fill(owner.begin(), owner.end(), -1);
+        for (int p = 0; p < n_grass; ++p) {
+            const uint16_t c = init->grass_xy[b * (size_t)n_grass + p];
+            const int x = c >> 8, y = c & 255;
+            if (x >= G || y >= G) return ppg_fail(h, PPG_EINVAL, "env %zu: grass patch %d at (%d, %d) is outside the grid", b, p, x, y);
+            if (owner[(size_t)x * G + y] >= 0) return ppg_fail(h, PPG_EINVAL, "env %zu: grass positions must be unique", b);
+            owner[(size_t)x * G + y] = p;
+            gxy[b * NG + p] = c; ge[b * NG + p] = h->cfg.initial_energy_grass;
+        }
+        int32_t *w = &es[b * PPG_ENV_WORDS];
+        w[PPG_ENV_N_PRED_ROWS] = P0; w[PPG_ENV_N_PREY_ROWS] = Q0; w[PPG_ENV_NEXT_PRED_ID] = P0; w[PPG_ENV_NEXT_PREY_ID] = Q0;   // BASE:153-154
+        w[PPG_ENV_N_PRED_ALIVE] = P0; w[PPG_ENV_N_PREY_ALIVE] = Q0;                                                             // BASE:210-211
+        w[PPG_ENV_FLAGS] = PPG_ENVF_WAS_RESET | PPG_ENVF_LIST_IS_ROW_ORDER;
+        w[PPG_ENV_EPISODE] = (int32_t)init->episode;
+    }
+    const ppg_buffers &bf = h->bufs;
+    const struct { void *dst; const void *src; size_t bytes; } copies[] = {
+        {bf.row_xy, xy.data(), B * S * 2}, {bf.row_energy, en.data(), B * S * 8}, {bf.row_id, ids.data(), B * S * 4},
+        {bf.row_key, keys.data(), B * S * 4}, {bf.row_flags, fl.data(), B * S}, {bf.row_cumrew, zeros.data(), B * S * 8},
+        {bf.row_reward, zeros.data(), B * S * 8}, {bf.row_parent, par.data(), B * S * 4}, {bf.env_state, es.data(), B * PPG_ENV_WORDS * 4},
+        {bf.grass_xy, gxy.data(), B * NG * 2}, {bf.grass_energy, ge.data(), B * NG * 8}};
+    for (const auto &c : copies) {
+        const int rc = backend_copy(h, c.dst, c.src, c.bytes, true, stream);
+        if (rc != PPG_OK) return rc;
+    }
+    int rc = backend_sync(h, stream);   // (the staging vectors die with this call)
+    if (rc != PPG_OK) return rc;
+    return ppg_observe(h, stream);
+}
+
 int ppg_observe(ppg_handle *h, void *stream) {
     if (!h) return PPG_EINVAL;
     ppg::KParams P = h->base;
@@ -741,6 +802,7 @@ static int ppg_pack_geometry(const ppg_handle *h, uint32_t flags, int &blk_p, in
     const int channels = (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
     blk_p = (drive ? 4 + P.n_drive[0] : channels) * P.Rp * P.Rp;
     blk_q = (drive ? 4 + P.n_drive[1] : channels) * P.Rq * P.Rq;
+    if (flags & PPG_PACK_NO_OBS) blk_p = blk_q = 0;   // an image without observation sections
     src_elem = P.obs_f32 ? 4 : 8;
     dst_elem = (flags & PPG_PACK_F32) ? 4 : src_elem;
     return PPG_OK;
@@ -758,7 +820,7 @@ int ppg_pack(ppg_handle *const *handles, int32_t n, void *out, uint64_t capacity
     ppg_handle *h0 = handles[0];
     if (n > PPG_PACK_MAX_HANDLES) return ppg_fail(h0, PPG_EINVAL, "ppg_pack takes at most %d handles", PPG_PACK_MAX_HANDLES);
     if (!out || ((uintptr_t)out & 15u)) return ppg_fail(h0, PPG_EINVAL, "out must be a 16-byte aligned device pointer");
-    if (flags & ~PPG_PACK_F32) return ppg_fail(h0, PPG_EINVAL, "unknown pack flags 0x%x", flags);
+    if (flags & ~(PPG_PACK_F32 | PPG_PACK_NO_OBS)) return ppg_fail(h0, PPG_EINVAL, "unknown pack flags 0x%x", flags);
     ppg::PackParams K;
     memset(&K, 0, sizeof K);
     ppg_pack_geometry(h0, flags, K.blk_pred, K.blk_prey, K.src_elem, K.dst_elem);

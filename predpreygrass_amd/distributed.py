@@ -18,6 +18,16 @@ Bandwidth note: float64 observations are ~2.4 KB per agent; at ~36 a
 aggregate far below the compute rate -- gather only when a single consumer really needs every
 observation, prefer float32 on the wire, and overlap the collective of step t with step t+1
 (`pack()` on the env's stream, `gather()` on a side stream; two image slots alternate).
+
+Three things keep the bytes on the wire down to what the consumer needs:
+  * `include_obs=False` (PPG_PACK_NO_OBS): ids / rewards / flags / env words only, ~2 MB per 4096-env shard -- the image for rollouts
+    whose policy runs next to the env (`policy.FusedPolicy`), where no observation ever has to leave its GPU;
+  * `mode="gather"`: only rank `dst` receives (one consumer), every other rank sends its image once over its own xGMI link and
+    receives nothing -- 1/8 of the all-gather's ingress per rank;  `mode="all_pairs"`: the all-gather spelled as grouped
+    point-to-point copies (every rank sends its image straight to every other rank: the direct algorithm SURVEY 8(e) asks for on
+    the fully connected xGMI mesh, whatever ring / tree RCCL would pick for the collective);
+  * `fit()`: the capacity every rank sends follows the bytes the previous step really used (header bytes_used, maximum over the
+    ranks, plus head room) instead of a worst-case size.
 """
 from __future__ import annotations
 
@@ -78,7 +88,7 @@ class ObservationGatherer:
     rows_per_env: sizing of the image in (predator, prey) rows per env -- None = three times the initial
     population, at most the row capacity; `grow()` enlarges it when a header reports an overflow."""
 
-    def __init__(self, envs, group=None, wire_dtype=None, rows_per_env=None, slots=2):
+    def __init__(self, envs, group=None, wire_dtype=None, rows_per_env=None, slots=2, include_obs=True, mode="all_gather", dst=0):
         self.envs = list(envs) if isinstance(envs, (list, tuple)) else [envs]
         e0 = self.envs[0]
         self.group = group
@@ -90,25 +100,36 @@ class ObservationGatherer:
         self.flags = _abi.PACK_F32 if (wire_dtype == torch.float32 and e0.obs_dtype == torch.float64) else 0
         if wire_dtype not in (None, torch.float32, e0.obs_dtype):
             raise ValueError("wire_dtype must be None, torch.float32 or the envs' observation dtype")
+        if not include_obs:
+            self.flags |= _abi.PACK_NO_OBS
+        if mode not in ("all_gather", "gather", "all_pairs"):
+            raise ValueError("mode must be 'all_gather', 'gather' or 'all_pairs'")
+        self.mode, self.dst = mode, int(dst)
         self._handles = (C.c_void_p * len(self.envs))(*[e._handle for e in self.envs])
         if rows_per_env is None:
             rows_per_env = (min(e0.pred_capacity, 3 * max(e0.P0, 2)), min(e0.prey_capacity, 3 * max(e0.Q0, 2)))
-        # every rank must use the same capacity (all_gather_into_tensor): size it for the largest shard
-        n_max = -(-self._total_envs() // self.world)
+        # every rank must use the same capacity (all_gather_into_tensor): size it for the largest shard there is
+        n_max = self._max_envs()
         self._set_capacity(int(self._lib.ppg_pack_bytes(e0._handle, n_max, int(n_max * rows_per_env[0]),
                                                         int(n_max * rows_per_env[1]), self.flags)), slots)
         self.last_bytes = 0
 
-    def _total_envs(self):
+    def _max_envs(self):
         t = torch.tensor([self.n_envs], dtype=torch.int64, device=self.device)
-        dist.all_reduce(t, group=self.group)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
     def _set_capacity(self, capacity, slots=None):
+        # a collective issued on a side stream may still be reading the old buffers: wait for every slot's last one before the
+        # caching allocator gets the memory back
+        for ev in getattr(self, "_done", []):
+            if ev is not None:
+                ev.synchronize()
         self.capacity = (int(capacity) + 255) // 256 * 256
         slots = slots or len(self._local)
+        receives = self.mode != "gather" or self.rank == self.dst      # gather-to-root: only the root holds the other ranks' images
         self._local = [torch.zeros(self.capacity, dtype=torch.uint8, device=self.device) for _ in range(slots)]
-        self._all = [torch.zeros(self.world * self.capacity, dtype=torch.uint8, device=self.device) for _ in range(slots)]
+        self._all = [torch.zeros((self.world if receives else 1) * self.capacity, dtype=torch.uint8, device=self.device) for _ in range(slots)]
         self._slot = 0
         self._cuda = self.device.type == "cuda"
         self._done = [None] * slots
@@ -136,7 +157,23 @@ class ObservationGatherer:
             slot = self.pack()
         elif slot is None:
             slot = self._slot
-        dist.all_gather_into_tensor(self._all[slot], self._local[slot], group=self.group)
+        if self.mode == "all_gather":
+            dist.all_gather_into_tensor(self._all[slot], self._local[slot], group=self.group)
+        elif self.mode == "gather":
+            if self.rank == self.dst:
+                dist.gather(self._local[slot], list(self._all[slot].view(self.world, self.capacity).unbind(0)), dst=self.dst, group=self.group)
+            else:
+                dist.gather(self._local[slot], None, dst=self.dst, group=self.group)
+        else:   # all_pairs: every image straight to every other rank, one grouped batch of point-to-point copies
+            rows = self._all[slot].view(self.world, self.capacity)
+            rows[self.rank].copy_(self._local[slot])
+            ops = []
+            for r in range(self.world):
+                if r != self.rank:
+                    ops.append(dist.P2POp(dist.isend, self._local[slot], r, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, rows[r], r, group=self.group))
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
         if self._cuda:   # (the calling stream waits for the collective; an event behind it marks the slot as free again)
             self._done[slot] = torch.cuda.Event()
             self._done[slot].record(torch.cuda.current_stream(self.device))
@@ -144,14 +181,30 @@ class ObservationGatherer:
         self._gathered = slot
         return slot
 
+    @property
+    def holds_all(self):
+        """This rank has every rank's image after `gather()` (always, except on the non-root ranks of mode "gather")."""
+        return self.mode != "gather" or self.rank == self.dst
+
     def image(self, rank, slot=None):
         slot = self._gathered if slot is None else slot
+        if not self.holds_all:
+            if rank != self.rank:
+                raise RuntimeError(f"mode 'gather': only rank {self.dst} holds the other ranks' images")
+            return self._local[slot]
         return self._all[slot][rank * self.capacity: (rank + 1) * self.capacity]
 
     def headers(self, slot=None):
-        """The headers of all ranks' images (one device->host copy of world x 64 bytes)."""
+        """The headers of all ranks' images (one device->host copy of world x 64 bytes).  On a rank that did not receive them
+        (mode "gather") the headers are exchanged with one small all-gather, so that `grow()` / `fit()` decide the same thing
+        on every rank."""
         slot = self._gathered if slot is None else slot
-        h = self._all[slot].view(self.world, self.capacity)[:, :64].cpu().numpy()
+        if self.holds_all and self.mode != "gather":
+            h = self._all[slot].view(self.world, self.capacity)[:, :64].cpu().numpy()
+        else:
+            allh = torch.zeros(self.world * 64, dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(allh, self._local[slot][:64].contiguous(), group=self.group)
+            h = allh.view(self.world, 64).cpu().numpy()
         return [_abi.PpgPackHeader.from_buffer_copy(h[r].tobytes()) for r in range(self.world)]
 
     def views(self, rank, slot=None):
@@ -165,6 +218,19 @@ class ObservationGatherer:
             return False
         self._set_capacity(int(need * margin))
         return True
+
+    def fit(self, slot=None, margin=1.15, shrink_below=0.8):
+        """Size the image from what the last step really used: capacity = max over the ranks of header.bytes_used x margin.
+        Grows when an image overflowed (like `grow()`: that step has to be gathered again -> returns True) and SHRINKS when the
+        largest image fills less than `shrink_below` of the capacity (returns False: nothing to redo).  Populations drift
+        slowly, so calling this every few hundred steps keeps the wire bytes within ~15 % of the payload."""
+        need = max(int(h.bytes_used) for h in self.headers(slot))
+        if need > self.capacity:
+            self._set_capacity(int(need * margin))
+            return True
+        if need * margin < shrink_below * self.capacity:
+            self._set_capacity(int(need * margin))
+        return False
 
     # ------------------------------------------------------------------
     def gather_dict(self):

@@ -93,6 +93,78 @@ def test_sharding_and_single_collective_observation_gather(tmp_path, world, n_su
     mp.spawn(_worker, args=(world, port, str(tmp_path), n_sub, wire_f32), nprocs=world, join=True)
 
 
+def _worker_modes(rank, world, port, tmpdir):
+    """The image without observations (PPG_PACK_NO_OBS), gather-to-root and the all-pairs spelling of the all-gather, `fit()`
+    sizing from bytes_used, shards of very different sizes (rank 0 holds 5 envs, the others 1)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from predpreygrass_amd import _abi
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.config import config_env
+    from predpreygrass_amd.distributed import ObservationGatherer
+    from tests.emu_backend import library
+
+    env = BatchedPredPreyGrass(config_env, batch_size=5 if rank == 0 else 1, _library=library(), seed=40 + 10 * rank)
+    env.reset()
+    for _ in range(20):
+        env.step(random_actions=True, auto_reset=True)
+    want = local_rows_reference(env)
+    np.savez(os.path.join(tmpdir, f"m{rank}.npz"), **{k: v.numpy() for k, v in want.items()})
+    dist.barrier()
+    refs = [np.load(os.path.join(tmpdir, f"m{r}.npz")) for r in range(world)]
+
+    # 1. no observations on the wire: sized for the LARGEST shard (5 envs) on every rank, a few hundred bytes per env
+    g = ObservationGatherer(env, include_obs=False)
+    res = g.gather_dict()
+    full = ObservationGatherer(env)
+    assert g.capacity * 20 < full.capacity
+    for r in range(world):
+        for k in ("env_state", "id_pred", "id_prey", "reward_pred", "reward_prey", "flags_pred", "flags_prey"):
+            assert np.array_equal(res[k][r].numpy(), refs[r][k]), (rank, r, k)
+        assert res["obs_prey"][r].shape[1] == 0 and res["obs_pred"][r].shape[1] == 0
+        assert g.headers()[r].blk_pred == 0
+
+    # 2. gather-to-root: rank 1 receives everything, the others nothing
+    g = ObservationGatherer(env, mode="gather", dst=1)
+    slot = g.gather()
+    assert g.holds_all == (rank == 1)
+    assert [int(h.n_envs) for h in g.headers(slot)] == [5] + [1] * (world - 1)     # (headers are exchanged on every rank)
+    if rank == 1:
+        for r in range(world):
+            v = g.views(r, slot)
+            assert np.array_equal(v["obs_prey"].numpy(), refs[r]["obs_prey"]) and np.array_equal(v["id_pred"].numpy(), refs[r]["id_pred"])
+    else:
+        assert np.array_equal(g.views(rank, slot)["obs_prey"].numpy(), refs[rank]["obs_prey"])     # its own image only
+        with pytest.raises(RuntimeError):
+            g.image((rank + 1) % world, slot)
+
+    # 3. the all-gather as grouped point-to-point copies; fit(): grows after an overflow, shrinks to what is used
+    g = ObservationGatherer(env, mode="all_pairs", rows_per_env=(1, 1))
+    slot = g.gather()
+    assert g.fit(slot)                                  # overflowed -> grown, gather again
+    slot = g.gather()
+    for r in range(world):
+        assert np.array_equal(g.views(r, slot)["obs_pred"].numpy(), refs[r]["obs_pred"])
+    big = ObservationGatherer(env, mode="all_pairs", rows_per_env=(60, 120))
+    slot = big.gather()
+    cap0 = big.capacity
+    used = max(int(h.bytes_used) for h in big.headers(slot))
+    assert not big.fit(slot) and big.capacity < cap0    # shrunk, nothing to redo
+    assert used <= big.capacity <= int(used * 1.16) + 256
+    slot = big.gather()
+    for r in range(world):
+        assert np.array_equal(big.views(r, slot)["obs_prey"].numpy(), refs[r]["obs_prey"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_modes_no_obs_image_and_fit(tmp_path, world):
+    port = 30100 + (os.getpid() * 5 + world) % 400
+    mp.spawn(_worker_modes, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+
+
 def test_shard_range_partitions_exactly():
     from predpreygrass_amd.distributed import shard_range
     for total in (1, 7, 4096, 32768):
@@ -147,10 +219,13 @@ def test_bench_two_ranks_dry_run_with_gather_leg(launcher):
     d = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--envs", "5", "--streams", "2",
                     "--gather-steps", "3", "--preroll-min", "64", "--preroll-max", "64"], 2, launcher=launcher)
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 5
-    for leg in ("obs_gather", "obs_gather_overlapped"):
+    for leg in ("obs_gather", "obs_gather_overlapped", "obs_gather_to_root", "ids_rewards_gather"):
         assert leg in d and "error" not in d[leg], d.get(leg)
         assert d[leg]["steps"] == 3 and d[leg]["collectives_per_step"] == 1 and d[leg]["image_overflows"] == 0
         assert d[leg]["wire_bytes_per_step_per_rank"] > 0 and len(d[leg]["image_bytes_used_last_step"]) == 2
+    # the image without observations is two orders of magnitude smaller; images are sized from what a step really used
+    assert d["ids_rewards_gather"]["wire_bytes_per_step_per_rank"] * 20 < d["obs_gather"]["wire_bytes_per_step_per_rank"]
+    assert d["obs_gather"]["wire_bytes_per_step_per_rank"] < 1.25 * max(d["obs_gather"]["image_bytes_used_last_step"]) + 512
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
