@@ -59,6 +59,23 @@ class PredPreyGrassParallelEnv(_ParallelBase):
     def unwrapped(self):
         return self
 
+    # (pettingzoo's base classes provide these; spelled out because the package may be absent)
+    @property
+    def num_agents(self):
+        return len(self.agents)
+
+    @property
+    def max_num_agents(self):
+        return len(self.possible_agents)
+
+    @property
+    def observation_spaces(self):
+        return self._env.observation_spaces
+
+    @property
+    def action_spaces(self):
+        return self._env.action_spaces
+
 
 class PredPreyGrassAECEnv(_AECBase):
     """Agent-environment-cycle view: actions are buffered per agent; the underlying parallel step
@@ -109,7 +126,11 @@ class PredPreyGrassAECEnv(_AECBase):
         if self.terminations[a] or self.truncations[a]:
             # dead-step: the agent is removed (PettingZoo's _was_dead_step); action must be None.  The cursor stays: the
             # next agent of the cycle has moved into this position.
+            if action is not None:
+                raise ValueError("when an agent is dead, the only valid action is None")
             self.agents.remove(a)
+            for d in (self.rewards, self._cumulative_rewards, self.terminations, self.truncations, self.infos):
+                d.pop(a, None)
             del self._order[self._cursor]
         else:
             self._cumulative_rewards[a] = 0.0
@@ -133,6 +154,18 @@ class PredPreyGrassAECEnv(_AECBase):
 
     def close(self):
         self._par.close()
+
+    @property
+    def num_agents(self):
+        return len(self.agents)
+
+    @property
+    def max_num_agents(self):
+        return len(self.possible_agents)
+
+    @property
+    def unwrapped(self):
+        return self
 
 
 def parallel_env(config=None, **kw):
