@@ -219,6 +219,7 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
         static const ppg_kernel_fn c[4][2] = {{ppgc_step_q1, ppgc_step_q2}, {ppgc8_step_q1, ppgc8_step_q2}, {ppgc16_step_q1, ppgc16_step_q2},
                                               {ppgc6_step_q1, ppgc6_step_q2}};
         fn = c[wp.nw == 8 ? 1 : wp.nw == 16 ? 2 : wp.nw == 6 ? 3 : 0][h->nq == 1 ? 0 : 1];
+        if (h->gen2) fn = h->nq == 1 ? ppgc2_step_q1 : ppgc2_step_q2;   // (second generation: four-wave cooperative kernels)
         block = 64u * (unsigned)wp.nw;
         grid = (unsigned)((h->batch + P.coop_e - 1) / P.coop_e);
         if (P.lds_bytes > 64 * 1024)

@@ -379,9 +379,10 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         p = h->forced;
         if (walls || h->drive) { p.nw = p.nw > 1 ? 4 : 1; p.min_rows = 0; p.coop_e = 0; }   // (four-wave kernels only, helpers always stay)
         if (h->cfg.kickback) { p.nw = 1; p.coop_e = 0; }
-        if (p.coop_e > 0 && (!h->coop_ok || h->gen2)) p.coop_e = 0;
+        if (p.coop_e > 0 && !h->coop_ok) p.coop_e = 0;
         if (p.coop_e > 0) {
             if (p.nw != 4 && p.nw != 6 && p.nw != 8 && p.nw != 16) p.nw = 4;
+            if (h->gen2) p.nw = 4;   // (the second generation has four-wave cooperative kernels only)
             if (p.coop_e > p.nw) p.coop_e = p.nw;
             p.min_rows = 0;
         } else {
@@ -404,10 +405,12 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         if (in_flight <= 256 && !h->gen2 && h->base.nch_p <= 2 && h->base.nch_q <= 3 && h->nq <= 2) p.nw = 16;
     } else if (in_flight <= 3072) {
         p.nw = 4;
-    } else if (h->gen2) {
+    } else if (h->gen2 && !(h->coop_ok && ppg_coop_lds_bytes(h, 2) * 6 <= 160 * 1024)) {
         p.nw = 4;
         p.min_rows = 72;
     } else if (h->coop_ok && ppg_coop_lds_bytes(h, 2) * 6 <= 160 * 1024) {
+        // (second generation, float32 observations, 3 sub-batches on one box: 56.5 us per 4096-env step against 68.1 for its
+        // four-wave kernel with helpers from 72 rows; four envs per workgroup 71.7, three 63.7)
         // cooperative kernels, TWO envs per four-wave workgroup (six workgroups = 24 waves = 12 envs per CU): two waves run a
         // transition each, the other two wait at the barrier, then all four write both envs' observations as whole 1 KB pieces.
         // Interleaved A/B on one box (tools/ab_plans.py, 4096 envs, 2 / 3 sub-batches): 68.3 / 71.2 us per step against 74.0 /
@@ -578,11 +581,8 @@ int ppg_observe(ppg_handle *h, void *stream) {
     return backend_launch(h, ppg::MODE_OBSERVE, P, stream);
 }
 
-int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream) {
-    if (!h) return PPG_EINVAL;
-    if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
-    if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
-    const int mode = h->cfg.kickback ? ppg::MODE_STEP_KICK : ppg::MODE_STEP;
+// the parameter block of a row-order step as the handle's wave plan wants it launched
+static ppg::KParams ppg_planned_step_params(const ppg_handle *h) {
     const ppg_wave_plan_t &wp = h->plan;
     ppg::KParams P = wp.coop_e > 0 ? h->coop : h->base;
     if (wp.coop_e > 0) {   // cooperative kernels: wp.coop_e env regions, then the workgroup's descriptor table and control words
@@ -591,9 +591,19 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
         P.off_ctl = P.off_lut2 + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16;
         P.lds_bytes = ppg_coop_lds_bytes(h, wp.coop_e);
         P.env_order = h->base.env_order;
+        P.vis_masks = h->base.vis_masks;
     }
-    P.mode = mode; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
     P.helper_min_rows = wp.min_rows;
+    return P;
+}
+
+int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
+    if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
+    const int mode = h->cfg.kickback ? ppg::MODE_STEP_KICK : ppg::MODE_STEP;
+    ppg::KParams P = ppg_planned_step_params(h);
+    P.mode = mode; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
     return backend_launch(h, mode, P, stream);
 }
 
@@ -639,7 +649,7 @@ int ppg_step_uniforms(ppg_handle *h, const int8_t *actions, const uint8_t *act_r
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
     if (act_rank && (flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "act_rank with PPG_STEP_RANDOM_ACTIONS");
-    ppg::KParams P = h->base;
+    ppg::KParams P = act_rank ? h->base : ppg_planned_step_params(h);   // (row order: the kernel the wave plan picks, like ppg_step)
     const int mode = act_rank ? ppg::MODE_STEP_ORDERED : ppg::MODE_STEP;
     P.mode = mode; P.actions = actions; P.act_rank = act_rank; P.flags = flags; P.prof = h->prof_dev; P.n_steps = 1;
     P.uniforms = uniforms; P.uniforms_per_env = uniforms_per_env;
@@ -713,7 +723,7 @@ const char *ppg_step_kernel_name(ppg_handle *h) {
     if (!h) return "";
     const ppg_wave_plan_t wp = h->plan;
     if (wp.coop_e > 0) {   // ppgc_step_q<NQ> (4 waves) / ppgc8_ / ppgc16_
-        snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc%s_step_q%d", wp.nw == 8 ? "8" : wp.nw == 16 ? "16" : wp.nw == 6 ? "6" : "", h->nq);
+        snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc%s_step_q%d", h->gen2 ? "2" : wp.nw == 8 ? "8" : wp.nw == 16 ? "16" : wp.nw == 6 ? "6" : "", h->nq);
         return h->kernel_name;
     }
     const bool walls = h->gen2 && h->cfg2.walls, fast = h->base.nch_p <= 2 && h->base.nch_q <= 3 && !walls && !h->drive;

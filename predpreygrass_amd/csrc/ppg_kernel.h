@@ -2216,7 +2216,7 @@ struct Env {
         }
         // every lane has its start-of-step values before any row is overwritten (CARRY_CUM: nothing was read here unless the dense
         // reward modes looked up the start-of-step energies)
-        if (transition && (!CARRY_CUM || dense || GEN2)) wv::drain_loads();
+        if (transition && (!CARRY_CUM || dense)) wv::drain_loads();
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             const int i = row_of(r, ln);

@@ -71,6 +71,32 @@ def test_cooperative_big_windows_and_float32():
     rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=5, n_calls=45, check_grid=True)
 
 
+@pytest.mark.parametrize("name", ["rq_mixed_types_seed7", "rq_base_seed3", "rq_pool_exhaust_seed2"])
+def test_second_generation_golden_cases_cooperative(name):
+    """The red_queen env's golden episodes (recorded PCG64 uniforms through ppg_step_uniforms) on the cooperative kernels."""
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+    from tests.parity_utils_rq import replay_golden_case
+
+    def make(cfg, B, **kw):
+        env = BatchedRedQueen(cfg, batch_size=B, _library=emu_backend.library(), **kw)
+        env.set_wave_plan(4, 0, 2)
+        assert env.wave_plan() == (4, 0, 2) and env.step_kernel_name() == "ppgc2_step_q2"
+        return env
+    replay_golden_case(make, name, max_calls=120)
+
+
+def test_second_generation_cooperative_rollout_matches_oracle():
+    from oracle.rq_oracle import RQOracleEnv
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+    from tests.golden_io_rq import RQGoldenCase
+    from tests.parity_utils_rq import rollout_vs_oracle as rq_rollout_vs_oracle
+    cfg = RQGoldenCase("rq_mixed_types_seed7").config
+    env = BatchedRedQueen(cfg, batch_size=5, _library=emu_backend.library())
+    env.set_wave_plan(4, 0, 4)
+    n_resets, stats = rq_rollout_vs_oracle(env, lambda: RQOracleEnv(cfg), seed0=47, n_calls=90, check_every=1, check_grid=True)
+    assert stats["births"] > 3
+
+
 def test_configurations_without_cooperative_kernels_fall_back():
     """Even windows, drive channels and the kickback variant keep their element-descriptor kernels: the plan drops coop_envs."""
     for extra in ({"predator_obs_range": 6}, {"enable_drive_channels": True}, {"kickback_reward_predator": 1.0}):

@@ -44,6 +44,28 @@ def test_random_rollout_matches_oracle_on_gpu(cfg, B, calls, cap, every):
     assert stats["births"] > 0
 
 
+def make_coop(coop):
+    def make(cfg, B, **kw):
+        env = make_env(cfg, B, **kw)
+        env.set_wave_plan(4, 0, coop)
+        assert env.wave_plan() == (4, 0, coop) and env.step_kernel_name().startswith("ppgc2_step_q")
+        return env
+    return make
+
+
+@pytest.mark.parametrize("name", [n for n in case_names() if "shuffled" not in n])
+def test_golden_cases_through_the_cooperative_kernels(name):
+    """The red_queen env's golden episodes (recorded uniforms, ppg_step_uniforms) on ppgc2_step: two envs per four-wave workgroup."""
+    replay_golden_case(make_coop(2), name)
+
+
+@pytest.mark.parametrize("cfg,B,calls,cap,coop", [(config_env_base, 63, 300, 128, 2), (MIXED, 64, 300, 128, 4), (POOL, 31, 250, 64, 3)])
+def test_cooperative_random_rollout_matches_oracle_on_gpu(cfg, B, calls, cap, coop):
+    env = make_coop(coop)(cfg, B, prey_capacity=cap)
+    n_resets, stats = rollout_vs_oracle(env, lambda: RQOracleEnv(cfg), seed0=4243, n_calls=calls, check_every=5, check_grid=True)
+    assert stats["births"] > 0
+
+
 def test_float64_observations_on_gpu():
     env = make_env(MIXED, 8, obs_dtype=torch.float64)
     rollout_vs_oracle(env, lambda: RQOracleEnv(MIXED), seed0=5, n_calls=80, check_every=4)

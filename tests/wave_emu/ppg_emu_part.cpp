@@ -25,11 +25,11 @@ void run_nw(const ppg::KParams &P) {
     ppg::env_main<NQ, ppg::MODE_STEP, FAST, GEN2, WALLS, DRIVE, NW>(P, lds);
 }
 
-#if PPG_EMU_FAMILY == 0 && PPG_EMU_NQ <= 2
+#if PPG_EMU_FAMILY <= 1 && PPG_EMU_NQ <= 2
 template <int NW>
 void run_coop(const ppg::KParams &P) {
     PPG_DYNAMIC_LDS(lds);
-    ppg::coop_main<NQ, false, NW>(P, lds);
+    ppg::coop_main<NQ, GEN2, NW>(P, lds);
 }
 #endif
 
@@ -40,6 +40,8 @@ void run(const ppg::KParams &P, int mode, int nw) {
         if (nw == 16) run_coop<16>(P); else if (nw == 8) run_coop<8>(P); else if (nw == 6) run_coop<6>(P); else run_coop<4>(P);
         return;
     }
+#elif PPG_EMU_FAMILY == 1 && PPG_EMU_NQ <= 2
+    if (P.coop_e > 0) { run_coop<4>(P); return; }
 #endif
     if (nw == 4) { run_nw<FAST, 4>(P); return; }
 #if PPG_EMU_FAMILY == 0

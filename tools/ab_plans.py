@@ -37,8 +37,14 @@ plans = []
 for spec in args.plans:
     name, v = spec.split(":")
     plans.append((name, [int(x) for x in v.split(",")]))
+kw = {}
+if args.workload == "red_queen":   # the second-generation env on its reference config, float32 observations like the reference
+    from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
+    cfg, kw = dict(config_env_base), {"env_class": BatchedRedQueen}
+    if "--obs-dtype" not in sys.argv:
+        args.obs_dtype = "f32"
 group = SubBatchedPredPreyGrass(cfg, batch_size=args.envs, n_sub=args.streams, device="cuda:0",
-                                obs_dtype=torch.float64 if args.obs_dtype == "f64" else torch.float32)
+                                obs_dtype=torch.float64 if args.obs_dtype == "f64" else torch.float32, **kw)
 group.reset()
 step_no = 0
 
