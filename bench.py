@@ -145,8 +145,9 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--obs-dtype", choices=["f64", "f32"], default=None,
-                    help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen)")
+    ap.add_argument("--obs-dtype", choices=["f64", "f32", "bf16"], default=None,
+                    help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen, bf16 -- the "
+                         "compact rows the policy kernels stage without conversion -- for policy_rollout)")
     ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls", "policy_rollout"], default="base",
                     help="base: BASELINE.json configs[2] (the headline); c4: configs[3] (64x64 grid, 16 predators / 32 prey, "
                          "7x7 windows); red_queen: the second-generation env (SURVEY 8(f) N2) with its reference config; "
@@ -203,8 +204,8 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
         raise SystemExit("policy_rollout needs the MFMA kernels: no dry run")
     cfg = dict(config_env)
     B = args.envs
-    obs_dtype = torch.float64 if (args.obs_dtype or "f64") == "f64" else torch.float32
-    args.obs_dtype = "f64" if obs_dtype == torch.float64 else "f32"
+    args.obs_dtype = args.obs_dtype or "bf16"
+    obs_dtype = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[args.obs_dtype]
     env = BatchedPredPreyGrass(cfg, batch_size=B, device=device, obs_dtype=obs_dtype, seed=args.seed + rank * B)
     torch.manual_seed(1234)
     nets = [PolicyNet(env.Rp), PolicyNet(env.Rq)]
@@ -263,7 +264,7 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
             },
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "ppg_policy_forward_f64" if obs_dtype == torch.float64 else "ppg_policy_forward_f32",
+                         "kernel": "ppg_policy_forward_" + args.obs_dtype,
                          "kernel_ms": round(pol_ms / args.steps, 5),
                          "flops_per_step": int(flops / args.steps),
                          "note": "flops = 2 x multiply-accumulates of the six layers (no padding counted) x observations evaluated; "
@@ -344,7 +345,7 @@ def main(argv=None, backend=None):
         if args.workload == "drive":
             cfg["enable_drive_channels"] = True
     B = args.envs
-    obs_dtype = torch.float64 if args.obs_dtype == "f64" else torch.float32
+    obs_dtype = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[args.obs_dtype]
     n_sub = max(1, args.streams)
     group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype, env_class=env_class,
                                     seed=args.seed + rank * B, **extra_kw, **backend.env_kwargs())
@@ -534,7 +535,7 @@ def main(argv=None, backend=None):
     n_obs_pred = int(es[:, _abi.ENV_OBS_PRED].sum())
     n_obs_prey = int(es[:, _abi.ENV_OBS_PREY].sum())
     G, Rp, Rq = env.grid_size, env.Rp, env.Rq
-    osz = 8 if obs_dtype == torch.float64 else 4
+    osz = {torch.float64: 8, torch.float32: 4, torch.bfloat16: 2}[obs_dtype]
     env_steps_rank = B * args.steps
     cp, cq = env.obs_pred.shape[2], env.obs_prey.shape[2]   # observation channels (4; more in the drive / walls variants)
     obs_bytes = n_obs_pred * cp * Rp * Rp * osz + n_obs_prey * cq * Rq * Rq * osz

@@ -115,7 +115,9 @@ typedef struct ppg_config {
     int32_t pred_capacity;        /* predator rows per env: 64 */
     int32_t prey_capacity;        /* prey rows per env: 64, 128 or 256 */
     int32_t grass_capacity;       /* >= n_grass, multiple of 64 */
-    int32_t obs_dtype;            /* 0: float64 (bit-exact with the reference), 1: float32 */
+    int32_t obs_dtype;            /* 0: float64 (bit-exact with the reference), 1: float32, 2: bfloat16 (the float64 value rounded to
+                                   * float32, then to bfloat16, both to nearest even: compact rows for ppg_policy_act, which stages them
+                                   * without conversion -- same logits as from the float64 rows, a quarter of the bytes) */
     double reward_predator_catch_prey;  /* BASE:29 */
     double reward_prey_eat_grass;       /* BASE:30 */
     double reward_predator_step;        /* BASE:31 */
@@ -213,7 +215,7 @@ typedef struct ppg_config_gen2 {
     int32_t pred_capacity;        /* 64 */
     int32_t prey_capacity;        /* 64, 128 or 256 */
     int32_t grass_capacity;
-    int32_t obs_dtype;            /* 0: float64, 1: float32 (the reference's dtype) */
+    int32_t obs_dtype;            /* 0: float64, 1: float32 (the reference's dtype), 2: bfloat16 (see ppg_config) */
     int32_t type_1_action_range;  /* RQ:85: odd, 1..7 */
     int32_t type_2_action_range;  /* RQ:86: odd, 1..7 (ignored when no type-2 agent can exist) */
     int32_t reproduction_cooldown_steps; /* RQ:696 */

@@ -86,7 +86,7 @@ class BatchedPredPreyGrass:
         c.n_possible_predators, c.n_possible_prey = int(cfg["n_possible_predators"]), int(cfg["n_possible_prey"])
         c.n_initial_predators, c.n_initial_prey, c.n_grass = self.P0, self.Q0, self.n_grass
         c.pred_capacity, c.prey_capacity, c.grass_capacity = self.pred_capacity, self.prey_capacity, NG
-        c.obs_dtype = 0 if obs_dtype == torch.float64 else 1
+        c.obs_dtype = {torch.float64: 0, torch.float32: 1, torch.bfloat16: 2}[obs_dtype]
         for k_cfg, k_abi in [
             ("reward_predator_catch_prey",) * 2, ("reward_prey_eat_grass",) * 2, ("reward_predator_step",) * 2,
             ("reward_prey_step",) * 2, ("penalty_prey_caught",) * 2, ("reproduction_reward_predator",) * 2,
@@ -130,8 +130,10 @@ class BatchedPredPreyGrass:
             # test hook (tests/wave_emu): the same kernel source compiled for the CPU wave emulator
             self._lib = _library
             self.device = torch.device("cpu")
-        if obs_dtype not in (torch.float64, torch.float32):
-            raise ValueError("obs_dtype must be torch.float64 or torch.float32")
+        # float64 = the reference's observations bit for bit; float32; bfloat16 = compact rows for a policy that runs next to the env
+        # (FusedPolicy stages them without conversion: its logits are bit-identical to those from the float64 rows)
+        if obs_dtype not in (torch.float64, torch.float32, torch.bfloat16):
+            raise ValueError("obs_dtype must be torch.float64, torch.float32 or torch.bfloat16")
         self.obs_dtype = obs_dtype
 
     def _alloc_buffers(self, prey_capacity):

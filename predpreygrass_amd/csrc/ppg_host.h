@@ -121,7 +121,9 @@ static int ppg_validate_and_layout(ppg_handle *h) {
         return ppg_fail(h, PPG_EINVAL, "Cannot place more unique positions than grid cells.");  // BASE:167-168
     if (c.n_possible_predators < 0 || c.n_possible_predators > 999999 || c.n_possible_prey < 0 || c.n_possible_prey > 999999)
         return ppg_fail(h, PPG_EINVAL, "n_possible_* must be in 0..999999");
-    if (c.obs_dtype != 0 && c.obs_dtype != 1) return ppg_fail(h, PPG_EINVAL, "obs_dtype must be 0 (f64) or 1 (f32)");
+    if (c.obs_dtype < 0 || c.obs_dtype > 2) return ppg_fail(h, PPG_EINVAL, "obs_dtype must be 0 (f64), 1 (f32) or 2 (bf16)");
+    if (c.obs_dtype == 2 && ((h->gen2 && h->cfg2.walls) || c.n_drive[0] > 0 || c.n_drive[1] > 0))
+        return ppg_fail(h, PPG_EINVAL, "bfloat16 observations (obs_dtype 2) are for the 4-channel observations of the base family and the second generation");
     if (c.max_steps < 0) return ppg_fail(h, PPG_EINVAL, "max_steps < 0");
     const ppg_buffers &b = h->bufs;
     if (!b.row_xy || !b.row_energy || !b.row_id || !b.row_key || !b.row_cumrew || !b.row_flags || !b.row_reward ||
@@ -813,8 +815,8 @@ static int ppg_pack_geometry(const ppg_handle *h, uint32_t flags, int &blk_p, in
     blk_p = (drive ? 4 + P.n_drive[0] : channels) * P.Rp * P.Rp;
     blk_q = (drive ? 4 + P.n_drive[1] : channels) * P.Rq * P.Rq;
     if (flags & PPG_PACK_NO_OBS) blk_p = blk_q = 0;   // an image without observation sections
-    src_elem = P.obs_f32 ? 4 : 8;
-    dst_elem = (flags & PPG_PACK_F32) ? 4 : src_elem;
+    src_elem = P.obs_f32 == 2 ? 2 : P.obs_f32 ? 4 : 8;
+    dst_elem = ((flags & PPG_PACK_F32) && src_elem == 8) ? 4 : src_elem;
     return PPG_OK;
 }
 

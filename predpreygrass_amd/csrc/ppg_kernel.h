@@ -67,7 +67,7 @@ struct KParams {
     int32_t G, Rp, Rq, max_steps;
     int32_t npos_pred, npos_prey, n_init_pred, n_init_prey, n_grass;
     int32_t cap_pred, cap_prey, cap_grass, S;
-    int32_t obs_f32;
+    int32_t obs_f32;   // observation dtype: 0 float64, 1 float32, 2 bfloat16 (ppg_config.obs_dtype)
     uint32_t g_magic;  // ceil(2^32 / G): cell / G == mulhi(cell, g_magic) for cell < G*G
     double r_catch, r_eat, r_pstep, r_qstep, r_caught, r_repro_p, r_repro_q;
     double loss_p, loss_q, thr_p, thr_q, e0_p, e0_q, e0_g, gain_g;
@@ -211,6 +211,32 @@ PPG_DEVICE double move_distance(int d2) {
     return d2 == 0 ? 0.0 : d2 == 1 ? 1.0 : d2 == 2 ? 1.4142135623730951 : d2 == 4 ? 2.0 : d2 == 5 ? 2.23606797749979
          : d2 == 8 ? 2.8284271247461903 : d2 == 9 ? 3.0 : d2 == 10 ? 3.1622776601683795 : d2 == 13 ? 3.605551275463989
          : 4.242640687119285;
+}
+
+// float -> bfloat16 bits, round to nearest even (finite values: energies and 0 / 1).  Exactly what v_cvt_pk_bf16_f32 and the
+// policy kernels' staging (`(__bf16)(float)x`) produce, so bf16 observation rows give bit-identical logits.
+PPG_DEVICE uint32_t bf16_bits(float f) {
+    uint32_t u;
+#ifdef PPG_WAVE_EMU
+    memcpy(&u, &f, 4);
+#else
+    u = __float_as_uint(f);
+#endif
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// elements o, o + 1 of an observation buffer (o even) as one vector store: float64 (the reference's dtype), float32, or bfloat16
+// (obs_dtype 2: the compact rows the policy kernels stage from -- SURVEY 8(f) N4)
+PPG_DEVICE void store_obs_pair(void *base, int obs_dtype, size_t o, double v0, double v1) {
+    if (obs_dtype == 1) {
+        float2 f; f.x = (float)v0; f.y = (float)v1;
+        *(float2 *)((float *)base + o) = f;
+    } else if (obs_dtype == 2) {
+        *(uint32_t *)((uint16_t *)base + o) = bf16_bits((float)v0) | (bf16_bits((float)v1) << 16);
+    } else {
+        double2 g; g.x = v0; g.y = v1;
+        *(double2 *)((double *)base + o) = g;
+    }
 }
 
 PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -1182,13 +1208,7 @@ struct Env {
             if (lutr[BASE + 2 * c] & 0x4000000u) {
                 const double v0 = one[c][0] ? 1.0 : v[c][0], v1 = one[c][1] ? 1.0 : v[c][1];
                 const size_t o = obase + (size_t)c * 128 + 2 * (size_t)ln;
-                if (P.obs_f32) {
-                    float2 f; f.x = (float)v0; f.y = (float)v1;
-                    *(float2 *)((float *)(TYPE ? P.obs_prey : P.obs_pred) + o) = f;
-                } else {
-                    double2 g; g.x = v0; g.y = v1;
-                    *(double2 *)((double *)(TYPE ? P.obs_prey : P.obs_pred) + o) = g;
-                }
+                store_obs_pair(TYPE ? P.obs_prey : P.obs_pred, P.obs_f32, o, v0, v1);
             }
         }
         wv::sync();
@@ -1482,13 +1502,7 @@ struct Env {
             for (int u = 0; u < U; ++u) {
                 const double v0 = vt[i0[u]], v1 = vt[i1[u]];
                 if (!on[u]) continue;
-                if (P.obs_f32) {
-                    float2 f; f.x = (float)v0; f.y = (float)v1;
-                    *(float2 *)((float *)(type ? P.obs_prey : P.obs_pred) + obase + o[u]) = f;
-                } else {
-                    double2 g; g.x = v0; g.y = v1;
-                    *(double2 *)((double *)(type ? P.obs_prey : P.obs_pred) + obase + o[u]) = g;
-                }
+                store_obs_pair(type ? P.obs_prey : P.obs_pred, P.obs_f32, obase + o[u], v0, v1);
             }
         }
     }
@@ -1648,13 +1662,7 @@ struct Env {
                 }
             } else if (d.x & 0x4000000u) {
                 const size_t o = obase + (size_t)ch * 128 + 2 * (size_t)ln;
-                if (P.obs_f32) {
-                    float2 f; f.x = (float)v[0]; f.y = (float)v[1];
-                    *(float2 *)((float *)(type ? P.obs_prey : P.obs_pred) + o) = f;
-                } else {
-                    double2 g; g.x = v[0]; g.y = v[1];
-                    *(double2 *)((double *)(type ? P.obs_prey : P.obs_pred) + o) = g;
-                }
+                store_obs_pair(type ? P.obs_prey : P.obs_pred, P.obs_f32, o, v[0], v[1]);
             }
         }
         wv::sync();  // reads done before the caller touches the maps again

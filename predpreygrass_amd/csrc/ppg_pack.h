@@ -137,6 +137,10 @@ PPG_DEVICE void pack_copy_obs(const KP &K, const unsigned char *src, unsigned ch
             const double *s = (const double *)src;
             double *d = (double *)dst;
             for (uint64_t i = (uint64_t)ln; i < n_elems; i += 64) d[i] = s[i];
+        } else if (K.src_elem == 2) {   // bfloat16 rows
+            const uint16_t *s = (const uint16_t *)src;
+            uint16_t *d = (uint16_t *)dst;
+            for (uint64_t i = (uint64_t)ln; i < n_elems; i += 64) d[i] = s[i];
         } else {
             const float *s = (const float *)src;
             float *d = (float *)dst;

@@ -477,7 +477,8 @@ __device__ __forceinline__ KPtr uniform(KPtr p) { return (KPtr)uniform((uintptr_
 // ---- phase A: the tile's sample table, then the convolutions, ST samples at a time -> scratch slot X ----
 // NCH = input channel slots a thread stages per position: 4 (channel-first: the four observation channels), 8 or 16 (channels-last:
 // R <= 8 / R <= 15 channels); conv1 reads CB1 = 1 or 2 channel blocks of 8.
-template <bool OBS_F32, int NCH>
+// OBS = element type of the observation rows: 0 float64, 1 float32, 2 bfloat16 (ppg_config.obs_dtype)
+template <int OBS, int NCH>
 __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, int n0_, int nt_samples_, __bf16 *xg_tile_) {
     constexpr int CB1 = NCH > 8 ? 2 : 1;
     const auto &K = *uniform(Kp);
@@ -499,7 +500,7 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
             const int e = lo, row = (int)(n - K.plan[PLAN_HDR + e]);
             const int k = handle_of(K.env_base, K.n_handles, e);
             const int b = e - K.env_base[k];
-            src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS_F32 ? 4 : 8));
+            src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS == 2 ? 2 : OBS == 1 ? 4 : 8));
             dst = (unsigned long long)(uintptr_t)(K.actions[k] + (size_t)b * K.S + K.slot0 + row);
         }
         tab[2 * tid] = src;
@@ -527,7 +528,11 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
             for (int c = 0; c < NCH; ++c) pre[j][c] = 0.0f;
             if (idx < ns * K.P && !(dbg & 4)) {
                 const int s = (int)__umulhi((uint32_t)idx, K.magic_P), p = idx - s * K.P;
-                if (OBS_F32) {
+                if (OBS == 2) {   // bfloat16 rows: what ppg_step rounded is what conv1 gets, bit for bit
+                    const GLOBAL_AS __bf16 *src = (const GLOBAL_AS __bf16 *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) if (NCH == 4 || c < K.cin) pre[j][c] = (float)src[c * K.c_stride];
+                } else if (OBS == 1) {
                     const GLOBAL_AS float *src = (const GLOBAL_AS float *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) if (NCH == 4 || c < K.cin) pre[j][c] = src[c * K.c_stride];
@@ -670,7 +675,7 @@ __device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0_, in
     }
 }
 
-template <bool OBS_F32, int NCH>
+template <int OBS, int NCH>
 __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
     const int N = (int)Kp->plan[0], n_full = (int)Kp->plan[1], ts = (int)Kp->plan[2];
     const int n_tiles = n_full + (N - n_full * TILE + ts - 1) / ts;
@@ -680,7 +685,7 @@ __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
         const int n0 = tile < n_full ? tile * TILE : n_full * TILE + (tile - n_full) * ts;
         const int nt_samples = (N - n0) < size ? (N - n0) : size;
         __syncthreads();   // the previous tile's readers of H / the table are done
-        phase_conv<OBS_F32, NCH>(Kp, lds, tile, n0, nt_samples, xg_tile);
+        phase_conv<OBS, NCH>(Kp, lds, tile, n0, nt_samples, xg_tile);
         if (size <= 32) { phase_fc1<1>(Kp, lds, xg_tile); phase_head<1>(Kp, lds, n0, nt_samples); }
         else if (size <= 64) { phase_fc1<2>(Kp, lds, xg_tile); phase_head<2>(Kp, lds, n0, nt_samples); }
         else if (size <= 96) { phase_fc1<3>(Kp, lds, xg_tile); phase_head<3>(Kp, lds, n0, nt_samples); }
@@ -688,17 +693,20 @@ __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
     }
 }
 
-#define PPG_POLICY_KERNEL(name, F32, NCH)                                                        \
+#define PPG_POLICY_KERNEL(name, OBS, NCH)                                                        \
     extern "C" __global__ void __launch_bounds__(256, 2) name(const PolParams K) {               \
         extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                      \
-        policy_main<F32, NCH>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);                \
+        policy_main<OBS, NCH>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);                \
     }
-PPG_POLICY_KERNEL(ppg_policy_forward_f64, false, 4)          // channel-first: R x R image, 4 channels
-PPG_POLICY_KERNEL(ppg_policy_forward_f32, true, 4)
-PPG_POLICY_KERNEL(ppg_policy_forward_hwc8_f64, false, 8)     // channels-last: 4 x R image, R <= 8 channels
-PPG_POLICY_KERNEL(ppg_policy_forward_hwc8_f32, true, 8)
-PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_f64, false, 16)   // channels-last, 9 <= R <= 15 channels (two channel blocks into conv1)
-PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_f32, true, 16)
+PPG_POLICY_KERNEL(ppg_policy_forward_f64, 0, 4)          // channel-first: R x R image, 4 channels
+PPG_POLICY_KERNEL(ppg_policy_forward_f32, 1, 4)
+PPG_POLICY_KERNEL(ppg_policy_forward_bf16, 2, 4)
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc8_f64, 0, 8)     // channels-last: 4 x R image, R <= 8 channels
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc8_f32, 1, 8)
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc8_bf16, 2, 8)
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_f64, 0, 16)   // channels-last, 9 <= R <= 15 channels (two channel blocks into conv1)
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_f32, 1, 16)
+PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_bf16, 2, 16)
 
 }  // namespace ppgpol
 
@@ -890,8 +898,11 @@ int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_action
     }
     K.xg = p->xg;
     for (const void *fn : {(const void *)ppgpol::ppg_policy_forward_f64, (const void *)ppgpol::ppg_policy_forward_f32,
+                           (const void *)ppgpol::ppg_policy_forward_bf16,
                            (const void *)ppgpol::ppg_policy_forward_hwc8_f64, (const void *)ppgpol::ppg_policy_forward_hwc8_f32,
-                           (const void *)ppgpol::ppg_policy_forward_hwc16_f64, (const void *)ppgpol::ppg_policy_forward_hwc16_f32})
+                           (const void *)ppgpol::ppg_policy_forward_hwc8_bf16,
+                           (const void *)ppgpol::ppg_policy_forward_hwc16_f64, (const void *)ppgpol::ppg_policy_forward_hwc16_f32,
+                           (const void *)ppgpol::ppg_policy_forward_hwc16_bf16})
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
     *out = p;
     return PPG_OK;
@@ -970,11 +981,11 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     K.logits = logits;
     hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
     typedef void (*fwd_fn)(const ppgpol::PolParams);
-    const fwd_fn fwd[3][2] = {{ppgpol::ppg_policy_forward_f64, ppgpol::ppg_policy_forward_f32},
-                              {ppgpol::ppg_policy_forward_hwc8_f64, ppgpol::ppg_policy_forward_hwc8_f32},
-                              {ppgpol::ppg_policy_forward_hwc16_f64, ppgpol::ppg_policy_forward_hwc16_f32}};
+    const fwd_fn fwd[3][3] = {{ppgpol::ppg_policy_forward_f64, ppgpol::ppg_policy_forward_f32, ppgpol::ppg_policy_forward_bf16},
+                              {ppgpol::ppg_policy_forward_hwc8_f64, ppgpol::ppg_policy_forward_hwc8_f32, ppgpol::ppg_policy_forward_hwc8_bf16},
+                              {ppgpol::ppg_policy_forward_hwc16_f64, ppgpol::ppg_policy_forward_hwc16_f32, ppgpol::ppg_policy_forward_hwc16_bf16}};
     const int variant = p->layout == PPG_POLICY_LAYOUT_HWC ? (p->cin > 8 ? 2 : 1) : 0;
-    hipLaunchKernelGGL(fwd[variant][K.obs_f32 ? 1 : 0], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
+    hipLaunchKernelGGL(fwd[variant][K.obs_f32 == 2 ? 2 : K.obs_f32 ? 1 : 0], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     PPG_POL_TRY(p, hipGetLastError());
     return PPG_OK;
 }

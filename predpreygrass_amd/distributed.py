@@ -64,7 +64,7 @@ def parse_image(image: torch.Tensor, header: _abi.PpgPackHeader = None):
     n, np_, nq = header.n_envs, header.n_pred_rows, header.n_prey_rows
     elem = header.obs_elem_bytes
     L = _abi.pack_layout(n, np_, nq, header.blk_pred, header.blk_prey, elem)
-    odt = torch.float32 if elem == 4 else torch.float64
+    odt = {2: torch.bfloat16, 4: torch.float32, 8: torch.float64}[elem]
 
     def view(name, count, dtype):
         nbytes = count * torch.empty((), dtype=dtype).element_size()

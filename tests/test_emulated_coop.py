@@ -97,6 +97,27 @@ def test_second_generation_cooperative_rollout_matches_oracle():
     assert stats["births"] > 3
 
 
+@pytest.mark.parametrize("waves,coop", [(1, 0), (4, 0), (4, 2)])
+def test_bfloat16_observation_rows_are_the_rounded_float64_rows(waves, coop):
+    """obs_dtype bfloat16 (compact rows for a policy next to the env): every kernel family writes round-to-nearest-even of the
+    float32 of the float64 value -- what torch's .float().bfloat16() gives -- and nothing else changes."""
+    cfg = {**config_env, "max_steps": 30}
+    envs = []
+    for dt in (torch.float64, torch.bfloat16):
+        env = maker(waves, coop, obs_dtype=dt)(cfg, 5) if waves > 1 else BatchedPredPreyGrass(cfg, batch_size=5, _library=emu_backend.library(), obs_dtype=dt)
+        env.reset(seed=9)
+        for _ in range(45):
+            env.step(random_actions=True, auto_reset=True)
+        envs.append(env)
+    a, b = envs
+    assert b.obs_prey.dtype == torch.bfloat16
+    for n in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "grass_energy"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+    assert torch.equal(a.obs_pred.float().bfloat16().view(torch.int16), b.obs_pred.view(torch.int16))
+    assert torch.equal(a.obs_prey.float().bfloat16().view(torch.int16), b.obs_prey.view(torch.int16))
+    assert bool((b.obs_prey.float() != 0).any())
+
+
 def test_configurations_without_cooperative_kernels_fall_back():
     """Even windows, drive channels and the kickback variant keep their element-descriptor kernels: the plan drops coop_envs."""
     for extra in ({"predator_obs_range": 6}, {"enable_drive_channels": True}, {"kickback_reward_predator": 1.0}):

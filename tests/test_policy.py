@@ -221,6 +221,37 @@ def test_channels_last_networks_match_fp32_reference(Rp, Rq):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["chw", "hwc"])
+def test_bfloat16_observation_rows_give_bit_identical_logits(layout):
+    """obs_dtype bfloat16: ppg_step writes the rows the policy stages -- the float64 value rounded exactly as the policy kernels
+    round it -- a quarter of the bytes, the SAME logits and actions bit for bit (no float64 row is written or read
+    in a rollout whose policy runs next to the env)."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy
+    nets = make_nets(seed=21, layout=layout)
+    fused = FusedPolicy(nets[0], nets[1])
+    out = []
+    for dt in (torch.float64, torch.bfloat16):
+        env = BatchedPredPreyGrass(dict(config_env), batch_size=300, device="cuda:0", obs_dtype=dt, seed=4)
+        env.reset()
+        for _ in range(50):
+            env.step(random_actions=True, auto_reset=True)
+        lg = fused.act(env, want_logits=True)
+        torch.cuda.synchronize()
+        out.append((env, lg[0].clone(), lg[1].clone(), env.actions.clone()))
+    (e64, p64, q64, a64), (e16, p16, q16, a16) = out
+    assert torch.equal(e64.obs_prey.float().bfloat16().view(torch.int16), e16.obs_prey.view(torch.int16))
+    assert torch.equal(p64, p16) and torch.equal(q64, q16) and torch.equal(a64, a16)
+    assert bool(q16.abs().sum() > 0)
+    # and a closed loop on the bfloat16 rows stays legal
+    for t in range(30):
+        fused.act(e16, sample=True, seed=t)
+        e16.step(e16.actions, auto_reset=True)
+    torch.cuda.synchronize()
+    assert (e16.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()
+
+
+@pytest.mark.gpu
 def test_sampled_actions_do_not_depend_on_where_they_are_written():
     """PPG_POLICY_SAMPLE is keyed by (seed, env, row): the same seed gives the same actions in another tensor, in another
     process, on another rank; split into sub-batches the envs keep their draws."""
