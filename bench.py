@@ -176,6 +176,10 @@ def parse_args(argv):
     ap.add_argument("--preroll-max", type=int, default=8192,
                     help="the pre-roll continues in 64-step windows until the mean rows per env of two consecutive windows "
                          "differ by < 1 %%, at most this many steps (0 = no pre-roll: measures the post-reset transient)")
+    ap.add_argument("--device-warm-seconds", type=float, default=2.0,
+                    help="the untimed pre-roll lasts at least this long (wall clock): a GPU that has been idle needs about a second of "
+                         "load to reach its sustained clocks -- the first bench process on a fresh box measured 75 us per step where "
+                         "every later one measured 66-68 (profiles/r03) -- and the workload is defined in its steady state")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even for one rank, so that the gather legs run (needs torchrun)")
     ap.add_argument("--gather-steps", type=int, default=50,
@@ -380,8 +384,9 @@ def main(argv=None, backend=None):
     # ---- untimed pre-roll to the steady-state population -------------------------------------------
     WINDOW = 64
     preroll, trace = 0, []
+    t_pre = time.perf_counter()
     if args.preroll_max > 0:
-        while preroll < args.preroll_max:
+        while True:   # (every exit decision below is agreed between the ranks)
             backend.synchronize(device)
             zero_obs_counters()
             for _ in range(WINDOW):
@@ -394,7 +399,12 @@ def main(argv=None, backend=None):
                 t = torch.tensor([0 if stationary else 1], dtype=torch.int64, device=device)
                 dist.all_reduce(t)
                 stationary = int(t.item()) == 0
-            if preroll >= args.preroll_min and stationary:
+            warm = dry or time.perf_counter() - t_pre >= args.device_warm_seconds
+            if distributed:   # (the clocks differ: leave together)
+                t = torch.tensor([0 if warm else 1], dtype=torch.int64, device=device)
+                dist.all_reduce(t)
+                warm = int(t.item()) == 0
+            if warm and ((preroll >= args.preroll_min and stationary) or preroll >= args.preroll_max):
                 break
 
     for _ in range(args.warmup):

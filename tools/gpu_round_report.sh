@@ -1,17 +1,24 @@
 #!/bin/bash
 # On the GPU box: the end-of-round evidence run.  usage: tools/gpu_round_report.sh <tag>
 set -u
-tag=${1:-r02c}
+tag=${1:-r03a}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${tag}_pytest.log
+# the driver's command first, on the box as it comes (pytest afterwards: a box is 15-20 % slower once it has been under load)
 bash tools/gpu_profile_driver_cmd.sh ${tag} > gpurun_out/${tag}_profile.log 2>&1
+./tools/store_patterns4.bin 4096 36 300 0 2,4,18 1,2,9 2>&1 | grep "streams" > gpurun_out/${tag}_bare_pattern.txt
+python3 tools/ab_plans.py --streams 2 --rounds 5 coop42:4,0,2 pair:2,0,0 coop44:4,0,4 one:1,0,0 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_ab_plans.txt
+python3 tools/ab_plans.py --streams 3 --rounds 5 coop42:4,0,2 pair:2,0,0 2>&1 | grep -v amdgpu.ids >> gpurun_out/${tag}_ab_plans.txt
+python3 tools/ab_plans.py --workload red_queen --streams 3 --rounds 5 coop42:4,0,2 w2:4,72,0 2>&1 | grep -v amdgpu.ids >> gpurun_out/${tag}_ab_plans.txt
+./tools/store_patterns4.bin 4096 36 300 0 2,4,18 1,2,9 2>&1 | grep "streams" >> gpurun_out/${tag}_bare_pattern.txt
+python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${tag}_pytest.log
 for w in c4 red_queen drive walls; do
-  python3 bench.py --workload $w --steps 1000 --warmup 100 > gpurun_out/${tag}_bench_$w.json 2>> gpurun_out/${tag}_bench.err
+  python3 bench.py --workload $w --steps 1000 --warmup 100 --sustained-steps 0 > gpurun_out/${tag}_bench_$w.json 2>> gpurun_out/${tag}_bench.err
 done
 python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --cpu-seconds 8 > gpurun_out/${tag}_bench_policy_rollout.json 2>> gpurun_out/${tag}_bench.err
-python3 bench.py --envs 256 --steps 2000 --warmup 100 --no-cpu-baseline > gpurun_out/${tag}_bench_c2_256envs.json 2>> gpurun_out/${tag}_bench.err
+python3 bench.py --workload policy_rollout --obs-dtype f64 --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_policy_rollout_f64.json 2>> gpurun_out/${tag}_bench.err
+python3 bench.py --envs 256 --steps 2000 --warmup 100 --no-cpu-baseline --sustained-steps 0 > gpurun_out/${tag}_bench_c2_256envs.json 2>> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_ptrace -o t -- python3 bench.py --workload policy_rollout --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_policy_under_trace.json 2> gpurun_out/${tag}_ptrace.err
 find gpurun_out/${tag}_ptrace -name '*kernel_stats.csv' -exec cp {} gpurun_out/${tag}_kernel_stats_policy.csv \;
 rm -rf gpurun_out/${tag}_ptrace
@@ -21,10 +28,10 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r = d["roofline"]
-    print(sys.argv[1].split("/")[-1], d["value"], d["ms_per_step"], r.get("kernel"), r["kernel_ms"], r["frac"], d["config"].get("mean_agents_per_env"))
+    print(sys.argv[1].split("/")[-1], d["value"], d["ms_per_step"], r.get("kernel"), r["kernel_ms"], r["frac"], r.get("frac_sustained"), d["config"].get("mean_agents_per_env"))
 except Exception as e:
     print(sys.argv[1], "ERR", e)
 PY
 done
-tail -c 600 gpurun_out/${tag}_summary.log
-head -5 gpurun_out/${tag}_kernel_stats_policy.csv | cut -c1-200
+tail -c 900 gpurun_out/${tag}_summary.log
+cat gpurun_out/${tag}_ab_plans.txt gpurun_out/${tag}_bare_pattern.txt
