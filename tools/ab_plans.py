@@ -43,8 +43,19 @@ if args.workload == "red_queen":   # the second-generation env on its reference 
     cfg, kw = dict(config_env_base), {"env_class": BatchedRedQueen}
     if "--obs-dtype" not in sys.argv:
         args.obs_dtype = "f32"
+if args.workload == "walls":       # the walls variant: the reference's zigzag layout with every line-of-sight option on
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+    from predpreygrass_amd.walls_occlusion import config_env_zigzag_walls
+    cfg, kw = dict(config_env_zigzag_walls), {"env_class": BatchedRedQueen, "walls": True}
+    if "--obs-dtype" not in sys.argv:
+        args.obs_dtype = "f32"
+if args.workload == "drive":
+    cfg["enable_drive_channels"] = True
 group = SubBatchedPredPreyGrass(cfg, batch_size=args.envs, n_sub=args.streams, device="cuda:0",
                                 obs_dtype=torch.float64 if args.obs_dtype == "f64" else torch.float32, **kw)
+if args.workload == "walls":
+    for e in group.subs:
+        e.set_walls(cfg["manual_wall_positions"])
 group.reset()
 step_no = 0
 
