@@ -138,6 +138,50 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def measure_traffic(argv, args, timeout=240):
+    """HBM bytes per launch of the step kernel ON THIS BOX, from the PMC counters: two CHILD runs of this very command under
+    `rocprofv3 --pmc WRITE_SIZE` / `--pmc FETCH_SIZE` (separate passes, counters only -- MI355X_MICROARCH.md's HBM section), started
+    before this process has touched the GPU.  Mean over the dispatches of the child's timed region; FETCH_SIZE doubled (gfx950
+    tallies 128-byte requests at 64 bytes), WRITE_SIZE exact for 16-byte-per-lane stores; units KB.  Returns None on any problem
+    (no rocprofv3, a refused profiler, a timeout): the line then falls back to the figure under profiles/."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    child_args = [a for a in argv if a not in ("--measure-traffic",)]
+    child_args += ["--no-cpu-baseline", "--sustained-steps", "0", "--traffic-child", "--device-warm-seconds", "0.5"]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="ppg_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "c", "--", sys.executable, os.path.abspath(__file__)] + child_args
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
+            line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if res.returncode != 0 or not line or not files:
+                return None
+            child = json.loads(line[-1])
+            kernel, steps, n_sub = child["roofline"]["kernel"], child["steps"], child["roofline"]["concurrent_launches"]
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if r["Kernel_Name"] == kernel and r["Counter_Name"] == counter]
+            vals = vals[-steps * n_sub:]
+            if len(vals) < steps * n_sub:
+                return None
+            out[counter] = sum(vals) / len(vals) * 1024.0
+            out["kernel"], out["counted"] = kernel, child["roofline"]["counted_bytes_per_launch"]
+        out["total"] = out["WRITE_SIZE"] + 2.0 * out["FETCH_SIZE"]
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +224,11 @@ def parse_args(argv):
                     help="the untimed pre-roll lasts at least this long (wall clock): a GPU that has been idle needs about a second of "
                          "load to reach its sustained clocks -- the first bench process on a fresh box measured 75 us per step where "
                          "every later one measured 66-68 (profiles/r03) -- and the workload is defined in its steady state")
+    ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=None,
+                    help="roofline.traffic from PMC passes of this command on THIS box (two child runs under rocprofv3 --pmc, ~25 s); "
+                         "default: on for the single-GPU headline workload, off otherwise")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even for one rank, so that the gather legs run (needs torchrun)")
     ap.add_argument("--gather-steps", type=int, default=50,
@@ -311,6 +360,11 @@ def main(argv=None, backend=None):
     world = int(env_world or "1")
     if env_world is not None and world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # PMC passes of this command in child processes, before this process touches the GPU (single-GPU headline workload only)
+    pmc = None
+    want_pmc = args.measure_traffic if args.measure_traffic is not None else (args.workload == "base" and args.envs == 4096)
+    if want_pmc and not args.traffic_child and world == 1 and not args.force_dist and not (backend and backend.dry):
+        pmc = measure_traffic(argv, args)
 
     import numpy as np
     import torch
@@ -562,7 +616,16 @@ def main(argv=None, backend=None):
     # HBM bytes per launch from rocprofv3 PMC passes of the driver's command (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md
     # HBM section), scaled by this run's own counted bytes relative to the profiled run's (same workload, same pre-roll)
     traffic = traffic_src = None
+    if pmc is not None:
+        scale = (run_bytes / args.steps / n_sub) / pmc["counted"]
+        traffic = int(pmc["total"] * scale)
+        traffic_src = (f"THIS run's box: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE passes (counters only, one child process each) of "
+                       f"this command; means over the timed dispatches of {pmc['kernel']}: WRITE_SIZE {pmc['WRITE_SIZE']:.0f} B + 2 x FETCH_SIZE "
+                       f"{pmc['FETCH_SIZE']:.0f} B = {pmc['total']:.0f} B per launch (the child counted {pmc['counted']} B), scaled x{scale:.4f} "
+                       "by this run's own counted bytes")
     try:
+        if pmc is not None:
+            raise LookupError   # measured on this box: no need for the committed profile
         prof = json.load(open(PROFILE_SUMMARY))
         same = (prof["envs_per_gpu"] == B and prof["concurrent_launches"] == n_sub and prof["obs_dtype"] == args.obs_dtype
                 and prof["workload"] == args.workload and not dry)
@@ -573,7 +636,8 @@ def main(argv=None, backend=None):
                            f"{prof['hbm_traffic_per_launch_bytes']['total_corrected']} B per launch at "
                            f"{prof['mean_agents_per_env']} agents/env, scaled x{scale:.4f} by this run's counted bytes")
     except Exception:
-        traffic = None
+        if pmc is None:
+            traffic = None
 
     if rank == 0:
         roof = {

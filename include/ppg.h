@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PPG_ABI_VERSION 4
+#define PPG_ABI_VERSION 5
 
 /* error codes */
 #define PPG_OK 0

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libppg_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # row_flags bits
 ROW_DIED, ROW_OWNS, ROW_NEWBORN, ROW_ATE, ROW_TRUNC, ROW_GRID_E0 = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
