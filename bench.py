@@ -20,7 +20,7 @@ N GPUs = N independent shards of 4096 envs (weak scaling, no data-path collectiv
 interact).  `python bench.py --gpus N` without a torch.distributed launcher starts the N ranks itself.
 For N>1 two extra legs measure the step followed by the ONE RCCL all-gather of the packed observation
 image that north_star specifies ("obs_gather", "obs_gather_overlapped"; bandwidth-bound on xGMI, see
-DESIGN.md).  Within one GPU the 4096 envs are stepped as --streams (default 2) independent sub-batches on
+DESIGN.md).  Within one GPU the 4096 envs are stepped as --streams (default 3) independent sub-batches on
 separate HIP streams.
 
 Prints ONE JSON line (rank 0).
@@ -201,9 +201,10 @@ def parse_args(argv):
                          "(SURVEY 8(f) N4; no observation leaves the GPU, roofline = bf16 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step); interleaved A/B on one "
-                         "box with the cooperative kernels: 2 sub-batches 68.3 us per 4096-env step, 3 sub-batches 71.2 (tools/ab_plans.py)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step).  2 vs 3 with the "
+                         "cooperative kernels, us per 4096-env step in one gpurun call each: GPU in its fast state 68.3 / 71.2, 67.2 / "
+                         "66.4; in its slow state 87.7 / 83.6, 76.8 / 71.0 -- three are never far behind and clearly ahead when it counts")
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="after the timed region: a second leg of this many steps timed with HIP events on the launch streams "
                          "(roofline.kernel_ms_sustained); 0 = skip")

@@ -386,6 +386,7 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
             if (p.nw != 4 && p.nw != 6 && p.nw != 8 && p.nw != 16) p.nw = 4;
             if (h->gen2) p.nw = 4;   // (the second generation has four-wave cooperative kernels only)
             if (p.coop_e > p.nw) p.coop_e = p.nw;
+            p.min_rows = 0;
         } else {
             if (p.nw != 1 && p.nw != 2 && p.nw != 4 && p.nw != 8 && p.nw != 16) p.nw = 4;
             if (p.nw == 2 && (h->gen2 || h->drive)) p.nw = 4;                                  // the pair kernels exist for the base family

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Assemble profiles/<round>/bench_driver_summary.json from rocprofv3 runs of THE DRIVER'S bench command
 (`python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`: untimed pre-roll to the steady state, 5 warm-up steps, 20 timed
-steps, then the sustained leg of 2000 steps; 2 sub-batches), taken on the GPU box by tools/gpu_profile_driver_cmd.sh:
+steps, then the sustained leg of 2000 steps; 3 sub-batches), taken on the GPU box by tools/gpu_profile_driver_cmd.sh:
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/<tag>_trace -o t -- python3 bench.py <args>
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/<tag>_w -o w -- python3 bench.py <args>
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/<tag>_f -o f -- python3 bench.py <args>
   python3 bench.py <args without --no-cpu-baseline> > gpurun_out/<tag>_bench.json        (unprofiled, same box)
 The sustained leg of each run = its last sustained x streams dispatches of the step kernel, the timed region = the steps x streams
 dispatches in front of them.
-usage: make_profile_summary.py <tag> <kernel name | auto = roofline.kernel of the bench line> <out.json> [steps=20] [streams=2] [sustained=2000]"""
+usage: make_profile_summary.py <tag> <kernel name | auto = roofline.kernel of the bench line> <out.json> [steps=20] [streams=3] [sustained=2000]"""
 import csv
 import glob
 import json
@@ -16,7 +16,7 @@ import sys
 
 tag, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-streams = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+streams = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 sustained = int(sys.argv[6]) if len(sys.argv) > 6 else 2000
 last = steps * streams
 tail = sustained * streams
