@@ -153,7 +153,7 @@ def measure_traffic(argv, args, timeout=240):
     if not os.path.exists(exe):
         return None
     child_args = [a for a in argv if a not in ("--measure-traffic",)]
-    child_args += ["--no-cpu-baseline", "--sustained-steps", "0", "--traffic-child", "--device-warm-seconds", "0.5"]
+    child_args += ["--no-cpu-baseline", "--sustained-steps", "0", "--fused-steps", "0", "--traffic-child", "--device-warm-seconds", "0.5"]
     out = {}
     tmp = tempfile.mkdtemp(prefix="ppg_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
@@ -221,6 +221,9 @@ def parse_args(argv):
     ap.add_argument("--preroll-max", type=int, default=8192,
                     help="the pre-roll continues in 64-step windows until the mean rows per env of two consecutive windows "
                          "differ by < 1 %%, at most this many steps (0 = no pre-roll: measures the post-reset transient)")
+    ap.add_argument("--fused-steps", type=int, default=100,
+                    help="third leg (headline workload on a cooperative plan): ppg_rollout with this many transitions per launch, for as "
+                         "many steps as the sustained leg (reported as `fused_rollout`, never as `value`); 0 = skip")
     ap.add_argument("--device-warm-seconds", type=float, default=2.0,
                     help="the untimed pre-roll lasts at least this long (wall clock): a GPU that has been idle needs about a second of "
                          "load to reach its sustained clocks -- the first bench process on a fresh box measured 75 us per step where "
@@ -520,6 +523,48 @@ def main(argv=None, backend=None):
                      "kernel_ms": sum(a.elapsed_time(b) for a, b in zip(s0, s1)) / len(s0) / args.sustained_steps,
                      "ms_per_step": ts / args.sustained_steps * 1e3}
 
+    # ---- third leg: the FUSED rollout -- ppg_rollout(n): n transitions per launch, the device-side random policy, observations
+    # written every step exactly as above (bit-identical to n ppg_step calls; tests).  Reported next to `value`, never as `value`:
+    # `value` is the per-step API, which also takes actions from outside.
+    fused = None
+    if args.fused_steps > 0 and not dry and args.workload == "base" and group.subs[0].wave_plan()[2] > 0:
+        n_f = args.fused_steps
+        launches = max(1, args.sustained_steps // n_f) if args.sustained_steps > 0 else 4
+        f0 = [backend.event() for _ in group.streams]
+        f1 = [backend.event() for _ in group.streams]
+        group.rollout(n_f, random_actions=True, auto_reset=True)      # (untimed: first launch of this kernel)
+        backend.synchronize(device)
+        zero_obs_counters()
+        backend.synchronize(device)
+        tf = time.perf_counter()
+        for st, e in zip(group.streams, f0):
+            e.record(st)
+        for _ in range(launches):
+            group.rollout(n_f, random_actions=True, auto_reset=True)
+        for st, e in zip(group.streams, f1):
+            e.record(st)
+        backend.synchronize(device)
+        tf = time.perf_counter() - tf
+        rows_f = rows_written()
+        G_, Rp_, Rq_ = env.grid_size, env.Rp, env.Rq
+        es_f = np.concatenate([e.env_state.cpu().numpy() for e in group.subs]).astype("int64")
+        npred_f, nprey_f = int(es_f[:, _abi.ENV_OBS_PRED].sum()), int(es_f[:, _abi.ENV_OBS_PREY].sum())
+        osz_f = {torch.float64: 8, torch.float32: 4, torch.bfloat16: 2}[obs_dtype]
+        bytes_f = (npred_f * 4 * Rp_ * Rp_ + nprey_f * 4 * Rq_ * Rq_) * osz_f + 62 * rows_f + B * launches * n_f * (env.n_grass * 18 + 2 * 64 + 8)
+        ms_f = sum(a.elapsed_time(b) for a, b in zip(f0, f1)) / len(f0)
+        fused = {"what": f"ppg_rollout({n_f}) x {launches} per sub-batch: {n_f} transitions per launch (ppgc_rollout: the workgroups of a launch run on "
+                         "from step to step, no launch boundary), device-side random policy, auto-reset, observations written every step; "
+                         "bit-identical to the same number of ppg_step calls (tests/test_hip_parity.py)",
+                 "steps": launches * n_f, "value": round(n_gpus * B * launches * n_f / tf, 1), "unit": "env-steps/s",
+                 "ms_per_step": round(tf / (launches * n_f) * 1e3, 5), "kernel_ms_per_step": round(ms_f / (launches * n_f), 5),
+                 "mean_agents_per_env": round(rows_f / (B * launches * n_f), 2),
+                 "bytes_written_per_second_over_hbm_peak": round(bytes_f / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "note": "NOT an HBM roofline figure and it may exceed 1: only the resident workgroups' envs are being stepped at any time "
+                         "(1024 workgroups x 2 envs x 94 KB of observations = 193 MB, inside the 256 MB Infinity Cache), no kernel boundary "
+                         "writes the caches back between steps, and every observation line is overwritten one step (~50 us) later -- much "
+                         "of it never reaches HBM.  What this leg shows is the step without launch boundaries; the HBM-bound number is "
+                         "`value` (per-step launches, every step's observations written back)."}
+
     # ---- optional legs: the ONE RCCL all-gather per step north_star specifies (N > 1 only) -------------------------
     gather_info = gather_overlapped = None
     extra_legs = {}
@@ -713,6 +758,8 @@ def main(argv=None, backend=None):
             },
             "roofline": roof,
         }
+        if fused is not None:
+            out["fused_rollout"] = fused
         if gather_info is not None:
             out["obs_gather"] = gather_info
         if gather_overlapped is not None:

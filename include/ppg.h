@@ -308,12 +308,15 @@ int ppg_observe(ppg_handle *h, void *stream);
  * which is the order of the previous observation dict (RLlib's protocol). */
 int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream);
 
-/* DIAGNOSTIC, not a fast path: n_steps transitions in ONE launch -- exactly what n_steps calls of ppg_step would do, each step
- * writing its observations / rewards / flags / tables to the same buffers -- with the device-side uniform random policy
- * (PPG_STEP_RANDOM_ACTIONS) or an open-loop action tape `actions` = device int8 [n_steps,B,S].  It is bit-identical to n_steps
- * ppg_step calls and SLOWER than them (96 vs 81 us per 4096-env step when last measured): one wavefront per
- * env, none of the multi-wave / cooperative kernels, base family without the kickback / drive variants only.  It exists to show
- * that a step keeps no host-side state between launches; use ppg_step (or ppg_step_many) for throughput. */
+/* n_steps transitions in ONE launch -- exactly what n_steps calls of ppg_step would do, each step writing its observations / rewards /
+ * flags / tables to the same buffers -- for action sources that live on the device: the uniform random policy
+ * (PPG_STEP_RANDOM_ACTIONS) or an open-loop action tape `actions` = device int8 [n_steps,B,S].  Bit-identical to n_steps ppg_step calls.
+ * On a handle whose wave plan is cooperative (a full GPU of 25x25 grids: the default) it runs the fused form of the cooperative step
+ * kernel: a workgroup's envs never interact with any other workgroup's, so the workgroups simply run on from step to step at their
+ * own pace -- no launch boundary at which everybody computes and nobody stores -- and ONE launch stream reaches 61 us per 4096-env
+ * step where per-step launches need three sub-batches in flight for 66-71.  On other handles (small batches,
+ * 64x64 grids) it is the round-1 one-wave-per-env loop, which is SLOWER than per-step launches and kept only as a diagnostic.  Base
+ * family without the kickback / drive variants. */
 int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t flags, void *stream);
 
 /* Same, for an action dict whose iteration order differs from the previous observation dict

@@ -21,6 +21,7 @@
 #define PPG_KW(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KW2(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KC(name, NQ, GEN2, NW) PPG_KERNEL_NW(name, 4, NW)(const ppg::KParams P);
+#define PPG_KCR(name, NQ, GEN2, NW) PPG_KERNEL_NW(name, 4, NW)(const ppg::KParams P);
 #include "ppg_kernel_list.h"
 
 PPG_DEFINE_KERNELSC(1)
@@ -215,11 +216,12 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
                        : h->cfg2.walls ? pick_kernel_walls(h->nq, mode) : pick_kernel_gen2(h->nq, mode, fast);
     unsigned block = 64, grid = (unsigned)h->batch;
     const ppg_wave_plan_t wp = h->plan;
-    if (mode == ppg::MODE_STEP && P.coop_e > 0) {   // cooperative kernels: coop_e envs per workgroup of wp.nw wavefronts
+    if ((mode == ppg::MODE_STEP || mode == ppg::MODE_ROLLOUT) && P.coop_e > 0) {   // cooperative kernels: coop_e envs per workgroup of wp.nw wavefronts
         static const ppg_kernel_fn c[4][2] = {{ppgc_step_q1, ppgc_step_q2}, {ppgc8_step_q1, ppgc8_step_q2}, {ppgc16_step_q1, ppgc16_step_q2},
                                               {ppgc6_step_q1, ppgc6_step_q2}};
         fn = c[wp.nw == 8 ? 1 : wp.nw == 16 ? 2 : wp.nw == 6 ? 3 : 0][h->nq == 1 ? 0 : 1];
         if (h->gen2) fn = h->nq == 1 ? ppgc2_step_q1 : ppgc2_step_q2;   // (second generation: four-wave cooperative kernels)
+        if (mode == ppg::MODE_ROLLOUT) fn = h->nq == 1 ? ppgc_rollout_q1 : ppgc_rollout_q2;   // (ppg_rollout: four waves, base family)
         block = 64u * (unsigned)wp.nw;
         grid = (unsigned)((h->batch + P.coop_e - 1) / P.coop_e);
         if (P.lds_bytes > 64 * 1024)

@@ -617,7 +617,8 @@ int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t 
     if (h->drive) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support the drive-conditioned variant");
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
-    ppg::KParams P = h->base;
+    // a handle whose plan is cooperative with four-wave workgroups runs the fused form of that kernel; else one wave per env
+    ppg::KParams P = (h->plan.coop_e > 0 && h->plan.nw == 4) ? ppg_planned_step_params(h) : h->base;
     P.mode = ppg::MODE_ROLLOUT; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = n_steps;
     return backend_launch(h, ppg::MODE_ROLLOUT, P, stream);
 }

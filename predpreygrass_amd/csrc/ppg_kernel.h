@@ -2645,4 +2645,44 @@ PPG_DEVICE void coop_main(const KParams &P, unsigned char *lds) {
     if (has_env) env.finish_stores();
 }
 
+// ppg_rollout on a handle whose plan is cooperative: P.n_steps transitions in one launch.  A workgroup's envs never interact with any
+// other workgroup's, so the workgroups of a launch simply run on, each at its own pace -- no launch boundary, and nothing that makes
+// all of them compute (and none of them store) at the same time.  The per-env context is rebuilt every iteration from laundered
+// roots (see env_main's MODE_ROLLOUT: left alone, hipcc hoists loop-invariant values out of the step loop and spills them).
+template <int NQ, bool GEN2, int NW>
+PPG_DEVICE void coop_main_fused(const KParams &P, unsigned char *lds) {
+    typedef Env<NQ, false, false, true, false, GEN2, false, false, NW, const KParams, const PPG_CONSTANT_AS KParams, true> CoopEnv;
+    const PPG_CONSTANT_AS KParams *Pk = PPG_KERNARG_PTR(KParams, P);
+    const int w = wv::wave_index();
+    const int ne = Pk->coop_e;
+    int b = PPG_BLOCK_INDEX() * ne + w;
+    const bool has_env = w < ne && b < P.batch;
+    if (has_env && Pk->env_order) b = (int)wv::first((uint32_t)Pk->env_order[b]);
+    const int n_it = Pk->n_steps;
+    for (int it = 0; it < n_it; ++it) {
+        const PPG_CONSTANT_AS KParams *Pc = PPG_KERNARG_PTR(KParams, P);
+        int bb = b, lane = wv::lane();
+        unsigned char *const l = lds;
+        PPG_LAUNDER_S(Pc);
+        PPG_LAUNDER_S(bb);
+        PPG_LAUNDER_V(lane);
+        // (NOT the LDS base: behind an opaque 64-bit pointer every LDS access becomes a flat instruction, and in these multi-wave
+        // workgroups that faulted on the device -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- while the emulator was happy.  With
+        // the three roots above laundered the loop already stays at 100 VGPRs without scratch; with none, 128 + 52 B.)
+        CoopEnv env(P, *Pc, has_env ? bb : 0, l + (size_t)(w < ne ? w : 0) * (size_t)Pc->lds_env_bytes, lane);
+        env.wave_idx = w;
+        env.lut2 = (uint32_t *)(l + Pc->off_lut2);
+        env.ctl = (uint32_t *)(l + Pc->off_ctl);
+        if (has_env) env.run_step(it);
+        else if (w < ne && lane == 0) env.ctl[CoopEnv::CTL_SLOT + 4 * w + 2] = 0xFFFFFFFFu;
+        wv::wg_barrier_lds();
+        env.coop_write_all(l);
+        if (has_env) env.finish_stores();
+        if (it + 1 < n_it) {
+            wv::drain_loads();       // this wave's table stores have been performed before it loads the same slots back
+            wv::wg_barrier_lds();    // every wave is done with the env regions before the next transitions rebuild them
+        }
+    }
+}
+
 }  // namespace ppg

@@ -42,6 +42,8 @@
     PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_DRIVE : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, 4>(P, lds); }
 #define PPG_KC(name, NQ, GEN2, NW)                                                           \
     PPG_KERNEL_NW(name, PPG_WPE, NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_main<NQ, GEN2, NW>(P, lds); }
+#define PPG_KCR(name, NQ, GEN2, NW)                                                          \
+    PPG_KERNEL_NW(name, PPG_WPE, NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_main_fused<NQ, GEN2, NW>(P, lds); }
 #include "ppg_kernel_list.h"
 
 #define PPG_APPLY(M, NQ) M(NQ)  // expands PPG_TU_NQ before the list pastes it into the kernel names

@@ -179,6 +179,35 @@ def test_fused_rollout_equals_single_steps_action_tape():
     _assert_same_state(_state(a), _state(b), a)
 
 
+@pytest.mark.parametrize("coop,B", [(2, 5), (4, 3)])
+def test_cooperative_fused_rollout_equals_single_steps(coop, B):
+    """ppg_rollout on a handle whose plan is cooperative runs the fused form of ppgc_step (ppgc_rollout: the workgroups run on from
+    step to step without a launch boundary): random policy with resets and truncations inside, and an action tape."""
+    import torch
+    cfg = {**config_env, "grid_size": 9, "n_initial_active_predator": 12, "n_initial_active_prey": 20, "initial_num_grass": 25,
+           "predator_obs_range": 5, "prey_obs_range": 7, "max_steps": 40}
+    a, b = make_env(cfg, B, seed=21), make_env(cfg, B, seed=21)
+    b.set_wave_plan(4, 0, coop)
+    a.reset()
+    b.reset()
+    for _ in range(90):
+        a.step(random_actions=True, auto_reset=True)
+    b.rollout(50, random_actions=True, auto_reset=True)
+    b.rollout(40, random_actions=True, auto_reset=True)
+    _assert_same_state(_state(a), _state(b), a)
+    cfg = {**config_env, "max_steps": 25}
+    K = 35
+    a, b = make_env(cfg, B, seed=5), make_env(cfg, B, seed=5)
+    b.set_wave_plan(4, 0, coop)
+    a.reset()
+    b.reset()
+    tape = torch.randint(-1, 9, (K, B, a.S), generator=torch.Generator().manual_seed(1), dtype=torch.int8)
+    for t in range(K):
+        a.step(tape[t].contiguous())
+    b.rollout(K, actions=tape)
+    _assert_same_state(_state(a), _state(b), a)
+
+
 def test_emulated_random_rollout_with_drive_channels_matches_oracle():
     """drive-conditioned variant: device reset, Philox actions, auto-reset; observations incl. the drive channels
     (window sums in numpy's pairwise order) against the oracle every call."""

@@ -321,6 +321,39 @@ def test_cooperative_step_kernels_give_identical_results(dtype):
             assert torch.equal(a, b), n
 
 
+def test_cooperative_fused_rollout_equals_single_steps_on_gpu():
+    """ppg_rollout on a cooperative plan (ppgc_rollout: the workgroups run on from step to step, no launch boundary) against the
+    same number of ppg_step calls: 4096 envs x 150 steps with resets inside, and an action tape on 300 envs."""
+    cfg = dict(config_env)
+    a, b = make_env(cfg, 4096, seed=77), make_env(cfg, 4096, seed=77)
+    assert b.wave_plan() == (4, 0, 2)
+    a.set_wave_plan(1)
+    a.reset()
+    b.reset()
+    for _ in range(150):
+        a.step(random_actions=True, auto_reset=True)
+    b.rollout(100, random_actions=True, auto_reset=True)
+    b.rollout(50, random_actions=True, auto_reset=True)
+    torch.cuda.synchronize()
+    for n in ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+    assert torch.equal(a.env_state[:, : _abi.ENV_CALLS], b.env_state[:, : _abi.ENV_CALLS])
+    del a, b
+    cfg = {**config_env, "max_steps": 30}
+    K, B = 45, 300
+    a, b = make_env(cfg, B, seed=5), make_env(cfg, B, seed=5)
+    b.set_wave_plan(4, 0, 4)
+    a.reset()
+    b.reset()
+    tape = torch.randint(-1, 9, (K, B, a.S), generator=torch.Generator().manual_seed(3), dtype=torch.int8).cuda()
+    for t in range(K):
+        a.step(tape[t].contiguous())
+    b.rollout(K, actions=tape)
+    torch.cuda.synchronize()
+    for n in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "obs_pred", "obs_prey"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+
+
 def test_default_wave_plans_give_identical_results():
     """What the library picks by itself -- sixteen waves per env at 200 envs, the cooperative kernel (two envs per four-wave
     workgroup) for a full GPU of 25x25 grids, a pair of waves with 8-bit maps for a full GPU of 64x64 grids, the second

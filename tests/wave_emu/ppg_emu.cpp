@@ -91,7 +91,7 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     EmuLaunch L{&P, h->nq, mode, h->drive ? 3 : h->gen2 ? (h->cfg2.walls ? 2 : 1) : 0, 1};
     // The HIP backend picks the multi-wave step kernels from the batch size (ppg_use_multiwave); here the tests ask for
     // them explicitly: PPG_EMU_WAVES=4|8 (walls / drive have a four-wave kernel only, as in the library).
-    if (mode == ppg::MODE_STEP && P.coop_e > 0) {   // cooperative kernels (ppg_set_wave_plan): coop_e envs per workgroup of plan.nw waves
+    if ((mode == ppg::MODE_STEP || mode == ppg::MODE_ROLLOUT) && P.coop_e > 0) {   // cooperative kernels (ppg_set_wave_plan): coop_e envs per workgroup of plan.nw waves
         L.nw = h->plan.nw;
         const int groups = (h->batch + P.coop_e - 1) / P.coop_e;
         for (int g = 0; g < groups; ++g) wv::run_block(lane_entry, &L, g, (size_t)P.lds_bytes, L.nw);

@@ -37,6 +37,7 @@ template <bool FAST>
 void run(const ppg::KParams &P, int mode, int nw) {
 #if PPG_EMU_FAMILY == 0 && PPG_EMU_NQ <= 2
     if (P.coop_e > 0) {   // cooperative kernels (Env's COOP)
+        if (mode == ppg::MODE_ROLLOUT) { PPG_DYNAMIC_LDS(lds); ppg::coop_main_fused<NQ, false, 4>(P, lds); return; }   // ppg_rollout
         if (nw == 16) run_coop<16>(P); else if (nw == 8) run_coop<8>(P); else if (nw == 6) run_coop<6>(P); else run_coop<4>(P);
         return;
     }

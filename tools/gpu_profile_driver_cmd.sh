@@ -6,7 +6,7 @@ tag=${1:-r03a}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --fused-steps 0 --no-measure-traffic"
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -o t -- python3 bench.py $ARGS > gpurun_out/${tag}_bench_under_trace.json 2> gpurun_out/${tag}_trace.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_w -o w -- python3 bench.py $ARGS > gpurun_out/${tag}_w.log 2>&1
