@@ -225,7 +225,7 @@ def parse_args(argv):
                     help="third leg (headline workload on a cooperative plan): ppg_rollout with this many transitions per launch, for as "
                          "many steps as the sustained leg (reported as `fused_rollout`, never as `value`); 0 = skip")
     ap.add_argument("--device-warm-seconds", type=float, default=2.0,
-                    help="the untimed pre-roll lasts at least this long (wall clock): a GPU that has been idle needs about a second of "
+                    help="before the pre-roll the envs are stepped for this long (wall clock) and then reset again: a GPU that has been idle needs about a second of "
                          "load to reach its sustained clocks -- the first bench process on a fresh box measured 75 us per step where "
                          "every later one measured 66-68 (profiles/r03) -- and the workload is defined in its steady state")
     ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=None,
@@ -442,7 +442,26 @@ def main(argv=None, backend=None):
     # ---- untimed pre-roll to the steady-state population -------------------------------------------
     WINDOW = 64
     preroll, trace = 0, []
-    t_pre = time.perf_counter()
+    # device warm-up FIRST, then a fresh reset: the pre-roll below then runs the same number of steps in every run (unprofiled,
+    # under the kernel trace, under the serialising PMC passes), so all of them time the same population
+    warm_steps = 0
+    if args.preroll_max > 0 and not dry and args.device_warm_seconds > 0:
+        t_pre = time.perf_counter()
+        while True:
+            for _ in range(WINDOW):
+                one_step()
+            backend.synchronize(device)
+            warm_steps += WINDOW
+            warm = time.perf_counter() - t_pre >= args.device_warm_seconds
+            if distributed:   # (the clocks differ: leave together)
+                t = torch.tensor([0 if warm else 1], dtype=torch.int64, device=device)
+                dist.all_reduce(t)
+                warm = int(t.item()) == 0
+            if warm:
+                break
+        group.reset()
+        group.synchronize()
+        step_no[0] = 0
     if args.preroll_max > 0:
         while True:   # (every exit decision below is agreed between the ranks)
             backend.synchronize(device)
@@ -457,12 +476,7 @@ def main(argv=None, backend=None):
                 t = torch.tensor([0 if stationary else 1], dtype=torch.int64, device=device)
                 dist.all_reduce(t)
                 stationary = int(t.item()) == 0
-            warm = dry or time.perf_counter() - t_pre >= args.device_warm_seconds
-            if distributed:   # (the clocks differ: leave together)
-                t = torch.tensor([0 if warm else 1], dtype=torch.int64, device=device)
-                dist.all_reduce(t)
-                warm = int(t.item()) == 0
-            if warm and ((preroll >= args.preroll_min and stationary) or preroll >= args.preroll_max):
+            if (preroll >= args.preroll_min and stationary) or preroll >= args.preroll_max:
                 break
 
     for _ in range(args.warmup):
@@ -748,7 +762,7 @@ def main(argv=None, backend=None):
                 "envs_per_gpu": B,
                 "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
                 "sub_batches_per_gpu": n_sub,
-                "preroll_steps": preroll,
+                "preroll_steps": preroll, "device_warm_steps": warm_steps,
                 "preroll_mean_agents_per_env_by_64_step_window": [round(v, 2) for v in trace[-8:]],
                 "mean_agents_per_env": round((n_obs_pred + n_obs_prey) / env_steps_rank, 2),
                 "status_bits": status,

@@ -34,6 +34,7 @@
 
 #include <math.h>
 
+#include <type_traits>
 #include <vector>
 
 namespace ppgpol {
@@ -42,6 +43,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #define GLOBAL_AS __attribute__((address_space(1)))   // pointers known to be global memory: global_* instead of flat_* instructions
 
 constexpr int TILE = 128;         // samples per workgroup tile
@@ -82,6 +84,9 @@ struct PolParams {
     uint32_t magic_P, magic_R;    // ceil(2^32 / P), ceil(2^32 / IW): n / P == mulhi(n, magic_P) for the small n used here
     __bf16 *xg;                   // [gridDim.x][TILE][K1]
     float *logits;                // optional [rows][n_actions]
+#ifdef PPG_EXPERIMENTS
+    unsigned long long *timeline; // diagnostic builds: [tile][64] = workgroup, hardware id, samples, 4 wall-clock stamps (10 ns units); [8 + 12 wave + i] cycles of wave in step i of the convolutions, [56 + 2 wave + i] FC1 wait / barrier cycles
+#endif
 };
 
 struct PlanParams {
@@ -204,28 +209,49 @@ struct ConvW {
             }
         }
     }
-    // element offset of k-step ks relative to (image of the sample, padded position, channel block h * [CBIN > 1]):
+    // element offset of k-step ks relative to (image of the sample, padded position, channel block in_blk + h * [CBIN > 1]):
     // K block q = 2 ks + h = tap * CBIN + cb.  For CBIN = 2: tap = ks, cb = h; for CBIN = 4: tap = ks >> 1, cb = 2 (ks & 1) + h --
     // the lane half only selects the channel block, which the caller folds into the base address, the rest is wave-uniform.
+    // `d23` (CBIN = 4) = element distance from the image block that holds channels 0-7 to the one that holds channels 16-23.
     template <class KP>
-    __device__ __forceinline__ int offset(const KP &K, int ks) const {
+    __device__ __forceinline__ int offset(const KP &K, int ks, int d23) const {
         if (CBIN == 1) return koff1[ks];
-        const int tap = CBIN == 2 ? ks : ks >> 1, cb0 = CBIN == 2 ? 0 : 2 * (ks & 1);
-        return (cb0 * K.Wp2 + (tap / 3 - 1) * K.Wp + tap % 3 - 1) * 8;
+        const int tap = CBIN == 2 ? ks : ks >> 1;
+        return (CBIN == 4 && (ks & 1) ? d23 : 0) + ((tap / 3 - 1) * K.Wp + tap % 3 - 1) * 8;
+    }
+    // The fragments were requested by load(): wait for them HERE, once, and hide their origin from the compiler.  Its wait-count
+    // bookkeeping cannot follow a load across a loop's back edge: left alone it puts s_waitcnt vmcnt(0) in front of the first MFMA
+    // of every position-tile loop -- which on this hardware also waits for every STORE the wavefront has issued since (conv3's, to
+    // the scratch slot: one memory round trip per sub-group).
+    __device__ __forceinline__ void landed() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4_t v = __builtin_bit_cast(u32x4_t, a[mt][ks]);
+                __asm__ volatile("" : "+v"(v));
+                a[mt][ks] = __builtin_bit_cast(bf16x8, v);
+            }
     }
 };
 
 // One convolution layer over the `ns` samples of a sub-group, this wavefront's share of the 32-position tiles.
 //   COUT_BLOCKS  channel blocks written: 2 (conv1), 4 (conv2), 8 (conv3)
 //   TO_GLOBAL    conv3: the result goes to the scratch slot X[sample][position][64] instead of an LDS image
-template <int CBIN, int MT, int COUT_BLOCKS, bool TO_GLOBAL, class KP>
-__device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W, const __bf16 *in,
-                                           int in_sample_stride, __bf16 *out, int out_sample_stride, GLOBAL_AS __bf16 *xg_tile,
+// The LDS image of a sample is six channel blocks of [padded position][8]; which of them a layer reads and writes rotates with
+// the sub-group (phase_conv): `in_blk` = the block of input channels 0-7 (8-15 in the next one; conv3's 16-31 always in blocks 2, 3),
+// `out_blk0` / `out_blk1` = where the lane halves h = 0 / 1 put output channels 16 h .. 16 h + 15 (two blocks each).
+template <int CBIN, int MT, int COUT_BLOCKS, bool TO_GLOBAL, int BATCH = 0, class KP>
+__device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W, __bf16 *img, int sample_stride, int in_blk,
+                                           int out_blk0, int out_blk1, GLOBAL_AS __bf16 *xg_tile,
                                            int s_local0, int ns, int nt_first, int nt_step, int lane, int mt_base = 0) {
     constexpr int KS = ConvW<CBIN, MT>::KS;
     const int h = lane >> 5, col = lane & 31;
     const int n_pos = ns * K.P;
     const int n_tiles = (n_pos + 31) / 32;
+    const __bf16 *in = img + (in_blk + (CBIN > 1 ? h : 0)) * K.Wp2 * 8;
+    __bf16 *out = img + (h ? out_blk1 : out_blk0) * K.Wp2 * 8;
+    const int d23 = (2 - in_blk) * K.Wp2 * 8;
     for (int nt = nt_first; nt < n_tiles; nt += nt_step) {
         const int n = 32 * nt + col;
         const bool valid = n < n_pos;
@@ -233,34 +259,63 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
         const int s = (int)__umulhi((uint32_t)nn, K.magic_P), p = nn - s * K.P;
         const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.IW;
         const int pidx = (y + 1) * K.Wp + (x + 1);
-        const __bf16 *base = in + (size_t)s * in_sample_stride + (pidx + (CBIN > 1 ? h * K.Wp2 : 0)) * 8;
+        const __bf16 *base = in + (size_t)s * sample_stride + pidx * 8;
         f32x16 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-        // all of the tile's B fragments are requested before the first MFMA: the LDS latency is paid once per tile, and while this
-        // wavefront's MFMA chain runs the SIMD's other wavefront has the LDS to itself.  (A software-pipelined version -- fragment k
-        // of tile t + 1 re-read right behind the MFMA of tile t that consumed it, MFMA / DS-read alternation pinned with
-        // sched_group_barrier, no lgkmcnt stall left in the loop -- measured the same: 1.39 vs 1.40 ms under load, 4.84 vs 4.92 ms
-        // with 64 workgroups alone on their CUs.  What a tile waits for is its epilogue and the barriers, not LDS.)
-        bf16x8 b[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        // the B fragment of k-step ks (the bias block's: {1, 1, 0 ...} in the lane half that holds it, zeros in the other)
+        auto fragment = [&](int ks) -> bf16x8 {
             constexpr int KSB = ConvW<CBIN, MT>::KS_BIAS, HB = ConvW<CBIN, MT>::H_BIAS;
-            if (ks == KSB && CBIN > 1) {       // the bias block's k-step: {1, 1, 0 ...} in the lane half that holds it, zeros in the other
-                b[ks] = zero8();
-                if (h == HB) { b[ks][0] = (__bf16)1.0f; b[ks][1] = (__bf16)1.0f; }
+            bf16x8 v;
+            if (ks == KSB && CBIN > 1) {
+                v = zero8();
+                if (h == HB) { v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
             } else {
-                b[ks] = *(const bf16x8 *)(base + W.offset(K, ks));
-                if (ks == KSB && h == HB) { b[ks] = zero8(); b[ks][0] = (__bf16)1.0f; b[ks][1] = (__bf16)1.0f; }
+                v = *(const bf16x8 *)(base + W.offset(K, ks, d23));
+                if (ks == KSB && h == HB) { v = zero8(); v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
+            }
+            return v;
+        };
+        if constexpr (BATCH == 0) {
+            // all of the tile's B fragments are requested before the first MFMA: the LDS latency is paid once per tile, and while this
+            // wavefront's MFMA chain runs the SIMD's other wavefront has the LDS to itself.  (A software-pipelined version -- fragment k
+            // of tile t + 1 re-read right behind the MFMA of tile t that consumed it, MFMA / DS-read alternation pinned with
+            // sched_group_barrier, no lgkmcnt stall left in the loop -- measured the same: 1.39 vs 1.40 ms under load, 4.84 vs 4.92 ms
+            // with 64 workgroups alone on their CUs.  What a tile waits for is its epilogue and the barriers, not LDS.)
+            bf16x8 b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[ks] = fragment(ks);
+            __builtin_amdgcn_sched_barrier(0);   // (keep the reads together: left alone, the scheduler re-pairs each with its MFMA)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][ks], b[ks], acc[mt], 0, 0, 0);
+        } else {
+            // conv3 (19 k-steps): the fragments come in batches of BATCH, batch n + 1 requested before the MFMAs of batch n -- two
+            // batches of registers instead of 76, which is what lets the weights of all three layers stay in registers
+            constexpr int NB = (KS + BATCH - 1) / BATCH;
+            bf16x8 b[2][BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) b[0][i] = fragment(i);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (nb + 1 < NB) {
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) if ((nb + 1) * BATCH + i < KS) b[(nb + 1) & 1][i] = fragment((nb + 1) * BATCH + i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i)
+                    if (nb * BATCH + i < KS) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][nb * BATCH + i], b[nb & 1][i], acc[mt], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // (keep the reads together: left alone, the scheduler re-pairs each with its MFMA)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][ks], b[ks], acc[mt], 0, 0, 0);
         if (!valid || (TO_GLOBAL && (K.debug_skip & 32))) continue;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -270,8 +325,8 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
                 if (TO_GLOBAL) {
                     // scratch slot X[sample][row tile][position][32]: a wavefront's 32 positions x 32 channels are 2 KB contiguous
                     *(GLOBAL_AS bf16x8 *)(xg_tile + (((size_t)(s_local0 + s) * 2 + (mt_base + mt)) * K.P + p) * 32 + 16 * h + 8 * j) = v;
-                } else if (4 * (mt_base + mt) + 2 * h + j < COUT_BLOCKS) {   // (conv1: 16 real output channels = blocks 0, 1)
-                    *(bf16x8 *)(out + (size_t)s * out_sample_stride + ((4 * (mt_base + mt) + 2 * h + j) * K.Wp2 + pidx) * 8) = v;
+                } else if (4 * (mt_base + mt) + 2 * h + j < COUT_BLOCKS) {   // (conv1: 16 real output channels: the h = 0 half only)
+                    *(bf16x8 *)(out + (size_t)s * sample_stride + (j * K.Wp2 + pidx) * 8) = v;
                 }
             }
     }
@@ -351,23 +406,39 @@ __device__ __forceinline__ void fc1_compute(const unsigned char *xb, const u32x4
     __builtin_amdgcn_sched_barrier(0);   // (or the next step's wait + barrier are scheduled in front of these MFMAs: nothing hidden)
 }
 
+#ifdef PPG_EXPERIMENTS
+struct FcTimes {   // diagnostic builds: cycles a wave spends in the chunk loop's wait / barrier / the rest
+    long long t[3] = {0, 0, 0}, prev = 0;
+    __device__ __forceinline__ void start() { prev = (long long)clock64(); }
+    __device__ __forceinline__ void add(int i) { const long long now = (long long)clock64(); t[i] += now - prev; prev = now; }
+};
+#else
+struct FcTimes {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void add(int) {}
+};
+#endif
+
 // one chunk: wait for it, meet, request W(c + 1) and X(c + 2) (compile-time switches: with a run-time condition around the loads
 // the compiler's own wait-count bookkeeping gives up at the join and drains ALL loads before the MFMAs), compute.
 template <int NT, bool ISSUE_W, bool ISSUE_X>
 __device__ __forceinline__ void fc1_step(const GLOBAL_AS bf16x8 *wlane, int K1, const __bf16 *xg_tile, unsigned char *stage, int c, int buf,
-                                         u32x4 (&w_cur)[2][2], u32x4 (&w_next)[2][2], f32x16 (&acc)[2][NT], int wave, int lane) {
+                                         u32x4 (&w_cur)[2][2], u32x4 (&w_next)[2][2], f32x16 (&acc)[2][NT], int wave, int lane, FcTimes &T) {
     if (ISSUE_W) __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fc1_landed(w_cur);
+    T.add(0);
     __builtin_amdgcn_s_barrier();   // everybody's X copies of chunk c are in LDS, and everybody is done with chunk c - 1's buffer
+    T.add(1);
     if (ISSUE_W) fc1_issue_w(wlane, c + 1, w_next);
     if (ISSUE_X) fc1_issue_x(K1, xg_tile, stage, c + 2, buf >= 1 ? buf - 1 : 2, wave, lane);
     fc1_compute<NT>(stage + (size_t)buf * FC1_BUF, w_cur, acc, lane);
+    T.add(2);
 }
 
 template <int NT>
 __device__ __forceinline__ void fc1_staged(const bf16x8 *w1, int K1, const __bf16 *xg_tile, unsigned char *stage, f32x16 (&acc)[2][NT],
-                                           int wave, int lane) {
+                                           int wave, int lane, FcTimes &T) {
     const int n_chunks = K1 / 32;    // = 2 R^2: even, >= 18
     const GLOBAL_AS bf16x8 *wlane = (const GLOBAL_AS bf16x8 *)w1 + (2 * wave) * 64 + lane;
     u32x4 w[2][2][2];
@@ -375,15 +446,16 @@ __device__ __forceinline__ void fc1_staged(const bf16x8 *w1, int K1, const __bf1
     fc1_issue_w(wlane, 0, w[0]);
     fc1_issue_x(K1, xg_tile, stage, 1, 1, wave, lane);
     int buf = 0;
+    T.start();
     for (int c = 0; c + 2 < n_chunks; c += 2) {   // (chunk c uses LDS buffer c % 3 and register set c % 2)
-        fc1_step<NT, true, true>(wlane, K1, xg_tile, stage, c, buf, w[0], w[1], acc, wave, lane);
+        fc1_step<NT, true, true>(wlane, K1, xg_tile, stage, c, buf, w[0], w[1], acc, wave, lane, T);
         buf = buf == 2 ? 0 : buf + 1;
-        fc1_step<NT, true, true>(wlane, K1, xg_tile, stage, c + 1, buf, w[1], w[0], acc, wave, lane);
+        fc1_step<NT, true, true>(wlane, K1, xg_tile, stage, c + 1, buf, w[1], w[0], acc, wave, lane, T);
         buf = buf == 2 ? 0 : buf + 1;
     }
-    fc1_step<NT, true, false>(wlane, K1, xg_tile, stage, n_chunks - 2, buf, w[0], w[1], acc, wave, lane);
+    fc1_step<NT, true, false>(wlane, K1, xg_tile, stage, n_chunks - 2, buf, w[0], w[1], acc, wave, lane, T);
     buf = buf == 2 ? 0 : buf + 1;
-    fc1_step<NT, false, false>(wlane, K1, xg_tile, stage, n_chunks - 1, buf, w[1], w[0], acc, wave, lane);
+    fc1_step<NT, false, false>(wlane, K1, xg_tile, stage, n_chunks - 1, buf, w[1], w[0], acc, wave, lane, T);
     __syncthreads();
 }
 
@@ -474,6 +546,25 @@ template <class T>
 __device__ __forceinline__ T *uniform(T *p) { return (T *)uniform((uintptr_t)p); }
 __device__ __forceinline__ KPtr uniform(KPtr p) { return (KPtr)uniform((uintptr_t)p); }
 
+// How phase A keeps the observation values it has requested for the next sub-group: in the rows' own element type (the
+// conversion to bf16 -- via float, round to nearest even both times, as ppg_step's bfloat16 rows are made -- happens when they are
+// written to LDS, one sub-group later); the 16-channel float64 variant converts to float at once (64 registers otherwise).
+template <int OBS, int NCH>
+struct ObsRaw {
+    typedef typename std::conditional<OBS == 2, uint16_t, typename std::conditional<OBS == 1, float, double>::type>::type elem;
+    // (bfloat16 rows travel as the zero-extended 16 bits in a register of their own: two 16-bit values in one register would be
+    //  packed as soon as they are loaded, i.e. waited for)
+    typedef typename std::conditional<OBS == 2, uint32_t, typename std::conditional<OBS == 0 && (NCH > 8), float, elem>::type>::type type;
+    // (the empty asm pins the conversion -- and with it the wait for the load -- to the place where the value is staged: a pure
+    //  function of a loaded value is otherwise scheduled right behind its load)
+    static __device__ __forceinline__ __bf16 to_bf16(type v) {
+        __asm__ volatile("" : "+v"(v));
+        if constexpr (OBS == 2) return __builtin_bit_cast(__bf16, (uint16_t)v);
+        else return (__bf16)(float)v;
+    }
+};
+
+
 // ---- phase A: the tile's sample table, then the convolutions, ST samples at a time -> scratch slot X ----
 // NCH = input channel slots a thread stages per position: 4 (channel-first: the four observation channels), 8 or 16 (channels-last:
 // R <= 8 / R <= 15 channels); conv1 reads CB1 = 1 or 2 channel blocks of 8.
@@ -487,9 +578,24 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long *tab = (unsigned long long *)lds;
     __bf16 *img = (__bf16 *)(lds + TILE * 16);
-    const int x_stride = 4 * K.Wp2 * 8, y_stride = 2 * K.Wp2 * 8;    // elements per sample
-    __bf16 *X = img, *Y = img + (size_t)K.ST * x_stride;
-    const int img_elems = K.ST * (x_stride + y_stride);
+    const int blk = K.Wp2 * 8, sample_stride = 6 * blk;    // elements per channel block and per sample: six blocks of [padded position][8]
+    const int img_elems = K.ST * sample_stride;
+#ifdef PPG_EXPERIMENTS
+    long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = (long long)clock64();
+#define PPG_TA(i) do { const long long now_ = (long long)clock64(); tacc[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define PPG_TA(i) do { } while (0)
+#endif
+    // conv3: wavefronts 0, 1 compute output channels 0-31, wavefronts 2, 3 channels 32-63, each for every other position tile --
+    // so a wavefront needs ONE row tile's weight fragments (76 registers).  With those of conv1 / conv2 (20 - 40 / 40 registers)
+    // they stay in registers for the whole sample tile (requested here, awaited behind the table and the zero fill).
+    ConvW<4, 1> w3c;
+    ConvW<CB1, 1> w1c;
+    ConvW<2, 1> w2c;
+    w3c.load(K, K.wc3, lane, wave >> 1);
+    w1c.load(K, K.wc1, lane);
+    w2c.load(K, K.wc2, lane);
+    const int dbg = K.debug_skip;
     // sample -> (handle, env, row): walk forward from the tile's first env (a tile spans a handful of envs)
     if (tid < TILE) {
         unsigned long long src = 0, dst = 0;
@@ -508,49 +614,38 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
     }
     // halo rings (and the unused channels of the input image) are zero and stay zero: only interiors are ever written
     for (int i = tid; i < img_elems / 8; i += 256) ((bf16x8 *)img)[i] = zero8();
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    w3c.landed();
+    w1c.landed();
+    w2c.landed();
     __syncthreads();
-    // conv3: wavefronts 0, 1 compute output channels 0-31, wavefronts 2, 3 channels 32-63, each for every other position tile --
-    // so a wavefront needs ONE row tile's weight fragments (72 registers) and keeps them for the whole sample tile.  Those of
-    // conv1 / conv2 (20 / 36 registers) are re-read per sub-group, issued before the observation rows are staged so that their
-    // latency overlaps with that.
-    ConvW<4, 1> w3c;
-    w3c.load(K, K.wc3, lane, wave >> 1);
-    const int dbg = K.debug_skip;
-    // observation values of the NEXT sub-group are requested before conv3 of the current one and written to LDS after it: their
-    // HBM latency hides behind 72 % of the sub-group's matrix work.  A thread stages at most two positions (ST * P <= 512).
     GLOBAL_AS __bf16 *xg = (GLOBAL_AS __bf16 *)xg_tile;
-    float pre[2][NCH];
-    auto request = [&](int s0, int ns) {
+    // The observation values of a sub-group are REQUESTED two sub-groups ahead and WRITTEN to LDS one sub-group ahead (`stage`, into
+    // the image block conv1 will read), so neither wait meets anything young: on this hardware a wavefront's loads and stores
+    // complete in issue order and share one counter, so waiting for a load also waits for every store issued before... and, as the
+    // compiler cannot count the stores of a loop, for every one issued AFTER it too.  Here the youngest stores in front of a wait are
+    // conv3's of the previous sub-group, two layers old.  (The values stay in the rows' element type until they are staged: a
+    // conversion at request time would wait for the loads it has just issued.)  A thread stages at most two positions (ST * P <= 512).
+    typedef typename ObsRaw<OBS, NCH>::type raw_t;
+    raw_t pre[2][NCH];
+    auto request = [&](int s0) {
+        const int left = nt_samples - s0, ns = left < K.ST ? left : K.ST;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + 256 * j;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) pre[j][c] = 0.0f;
+            for (int c = 0; c < NCH; ++c) pre[j][c] = (raw_t)0;
             if (idx < ns * K.P && !(dbg & 4)) {
                 const int s = (int)__umulhi((uint32_t)idx, K.magic_P), p = idx - s * K.P;
-                if (OBS == 2) {   // bfloat16 rows: what ppg_step rounded is what conv1 gets, bit for bit
-                    const GLOBAL_AS __bf16 *src = (const GLOBAL_AS __bf16 *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
+                typedef typename ObsRaw<OBS, NCH>::elem elem_t;   // bfloat16 rows: what ppg_step rounded is what conv1 gets, bit for bit
+                const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) if (NCH == 4 || c < K.cin) pre[j][c] = (float)src[c * K.c_stride];
-                } else if (OBS == 1) {
-                    const GLOBAL_AS float *src = (const GLOBAL_AS float *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) if (NCH == 4 || c < K.cin) pre[j][c] = src[c * K.c_stride];
-                } else {
-                    const GLOBAL_AS double *src = (const GLOBAL_AS double *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) if (NCH == 4 || c < K.cin) pre[j][c] = (float)src[c * K.c_stride];
-                }
+                for (int c = 0; c < NCH; ++c) if (NCH == 4 || c < K.cin) pre[j][c] = (raw_t)src[c * K.c_stride];
             }
         }
     };
-    if (!(dbg & 1)) request(0, nt_samples < K.ST ? nt_samples : K.ST);
-    for (int s0 = 0; s0 < nt_samples && !(dbg & 1); s0 += K.ST) {
-        const int ns = (nt_samples - s0) < K.ST ? (nt_samples - s0) : K.ST;
-        ConvW<CB1, 1> w1c;
-        ConvW<2, 1> w2c;
-        w1c.load(K, K.wc1, lane);
-        w2c.load(K, K.wc2, lane);
+    auto stage = [&](int s0, int in_blk) {
+        const int left = nt_samples - s0, ns = left < K.ST ? left : K.ST;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + 256 * j;
@@ -561,22 +656,44 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
                 for (int cb = 0; cb < CB1; ++cb) {
                     bf16x8 v = zero8();
 #pragma unroll
-                    for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = (__bf16)pre[j][8 * cb + c];
-                    *(bf16x8 *)(X + (size_t)s * x_stride + (cb * K.Wp2 + (y + 1) * K.Wp + (x + 1)) * 8) = v;
+                    for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = ObsRaw<OBS, NCH>::to_bf16(pre[j][8 * cb + c]);
+                    *(bf16x8 *)(img + (size_t)s * sample_stride + ((in_blk + cb) * K.Wp2 + (y + 1) * K.Wp + (x + 1)) * 8) = v;
                 }
             }
         }
+    };
+    // Which image blocks a layer uses alternates with the sub-group k, so that the NEXT sub-group's input can be staged while conv3
+    // still reads its own:        conv1: in -> c1, c1 + 1     conv2: c1, c1 + 1 -> in, in + 1, 2, 3     conv3: in, in + 1, 2, 3 -> scratch slot
+    // with (in, c1) = (4, 0) for even k and (0, 4) for odd k; the input of sub-group k + 1 goes to block c1 (+ 1) once conv2 is done.
+    if (!(dbg & 1)) {
+        request(0);
+        stage(0, 4);
+        if (K.ST < nt_samples) request(K.ST);
+    }
+    __syncthreads();
+    PPG_TA(0);
+    int in_blk = 4, c1_blk = 0;
+    for (int s0 = 0; s0 < nt_samples && !(dbg & 1); s0 += K.ST) {
+        const int ns = (nt_samples - s0) < K.ST ? (nt_samples - s0) : K.ST;
+        if (!(dbg & 16)) conv_layer<CB1, 1, 2, false>(K, w1c, img, sample_stride, in_blk, c1_blk, c1_blk, nullptr, 0, ns, wave, 4, lane);
+        PPG_TA(3);
         __syncthreads();
-        if (!(dbg & 16)) conv_layer<CB1, 1, 2, false>(K, w1c, X, x_stride, Y, y_stride, nullptr, 0, ns, wave, 4, lane);
+        PPG_TA(4);
+        if (!(dbg & 16)) conv_layer<2, 1, 4, false>(K, w2c, img, sample_stride, c1_blk, in_blk, 2, nullptr, 0, ns, wave, 4, lane);
+        PPG_TA(5);
         __syncthreads();
-        if (!(dbg & 16)) conv_layer<2, 1, 4, false>(K, w2c, Y, y_stride, X, x_stride, nullptr, 0, ns, wave, 4, lane);
-        __syncthreads();
+        PPG_TA(6);
         if (s0 + K.ST < nt_samples) {
-            const int left = nt_samples - s0 - K.ST;
-            request(s0 + K.ST, left < K.ST ? left : K.ST);
+            stage(s0 + K.ST, c1_blk);
+            PPG_TA(1);
+            if (s0 + 2 * K.ST < nt_samples) request(s0 + 2 * K.ST);
         }
-        if (!(dbg & 8)) conv_layer<4, 1, 8, true>(K, w3c, X, x_stride, nullptr, 0, xg, s0, ns, wave & 1, 2, lane, wave >> 1);
+        PPG_TA(7);
+        if (!(dbg & 8)) conv_layer<4, 1, 8, true, 5>(K, w3c, img, sample_stride, in_blk, 0, 0, xg, s0, ns, wave & 1, 2, lane, wave >> 1);
+        PPG_TA(8);
         __syncthreads();
+        PPG_TA(9);
+        const int t_ = in_blk; in_blk = c1_blk; c1_blk = t_;
     }
     // rows of the scratch slot behind the last sample of a partial tile hold older data: finite bf16 values whose columns are
     // never stored.  (The slot is zero-filled at creation, so they are never NaN patterns.)
@@ -585,18 +702,32 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PPG_EXPERIMENTS
+    PPG_TA(0);   // (the drain + acquire at the end goes with the start-up work)
+    if (K.timeline && lane == 0)
+        for (int i = 0; i < 10; ++i) K.timeline[(size_t)tile * 64 + 8 + 12 * wave + i] = (unsigned long long)tacc[i];
+#endif
 }
 
 // ---- phase B: FC1 from the scratch slot, ReLU -> H ----
 template <int NT>
-__device__ __noinline__ void phase_fc1(KPtr Kp, unsigned char *lds, const __bf16 *xg_tile_) {
+__device__ __noinline__ void phase_fc1(KPtr Kp, unsigned char *lds, const __bf16 *xg_tile_, int tile_ = 0) {
     const auto &K = *uniform(Kp);
+    FcTimes T;
     const __bf16 *xg_tile = uniform(xg_tile_);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char *overlay = lds + TILE * 16;
     f32x16 acc[2][NT];
     fc_init<NT>(K.b1, acc, wave, lane);
-    if (!(K.debug_skip & 2)) fc1_staged<NT>(K.w1, K.K1, xg_tile, overlay, acc, wave, lane);   // (staging buffers overlay the images)
+    if (!(K.debug_skip & 2)) fc1_staged<NT>(K.w1, K.K1, xg_tile, overlay, acc, wave, lane, T);   // (staging buffers overlay the images)
+#ifdef PPG_EXPERIMENTS
+    if (K.timeline && lane == 0) {   // [8 + 12 wave + 10 / 11] = wait / barrier cycles of the chunk loop, [56 + wave] = the rest of it
+        unsigned long long *t = K.timeline + (size_t)uniform(tile_) * 64;
+        t[8 + 12 * wave + 10] = (unsigned long long)T.t[0];
+        t[8 + 12 * wave + 11] = (unsigned long long)T.t[1];
+        t[56 + wave] = (unsigned long long)T.t[2];
+    }
+#endif
     __syncthreads();
     fc_store<NT>(acc, (__bf16 *)overlay, wave, lane);      // (so does H)
     __syncthreads();
@@ -685,11 +816,21 @@ __device__ __forceinline__ void policy_main(KPtr Kp, unsigned char *lds) {
         const int n0 = tile < n_full ? tile * TILE : n_full * TILE + (tile - n_full) * ts;
         const int nt_samples = (N - n0) < size ? (N - n0) : size;
         __syncthreads();   // the previous tile's readers of H / the table are done
+#ifdef PPG_EXPERIMENTS
+        unsigned long long *tl = Kp->timeline ? Kp->timeline + (size_t)tile * 64 : nullptr;
+        const bool stamp = tl && threadIdx.x == 0;
+        if (stamp) { tl[0] = blockIdx.x; tl[1] = (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); tl[2] = (unsigned)nt_samples; tl[3] = wall_clock64(); }
+#define PPG_POL_STAMP(i) do { if (stamp) tl[i] = wall_clock64(); } while (0)
+#else
+#define PPG_POL_STAMP(i) do { } while (0)
+#endif
         phase_conv<OBS, NCH>(Kp, lds, tile, n0, nt_samples, xg_tile);
-        if (size <= 32) { phase_fc1<1>(Kp, lds, xg_tile); phase_head<1>(Kp, lds, n0, nt_samples); }
-        else if (size <= 64) { phase_fc1<2>(Kp, lds, xg_tile); phase_head<2>(Kp, lds, n0, nt_samples); }
-        else if (size <= 96) { phase_fc1<3>(Kp, lds, xg_tile); phase_head<3>(Kp, lds, n0, nt_samples); }
-        else { phase_fc1<4>(Kp, lds, xg_tile); phase_head<4>(Kp, lds, n0, nt_samples); }
+        PPG_POL_STAMP(4);
+        if (size <= 32) { phase_fc1<1>(Kp, lds, xg_tile, tile); PPG_POL_STAMP(5); phase_head<1>(Kp, lds, n0, nt_samples); }
+        else if (size <= 64) { phase_fc1<2>(Kp, lds, xg_tile, tile); PPG_POL_STAMP(5); phase_head<2>(Kp, lds, n0, nt_samples); }
+        else if (size <= 96) { phase_fc1<3>(Kp, lds, xg_tile, tile); PPG_POL_STAMP(5); phase_head<3>(Kp, lds, n0, nt_samples); }
+        else { phase_fc1<4>(Kp, lds, xg_tile, tile); PPG_POL_STAMP(5); phase_head<4>(Kp, lds, n0, nt_samples); }
+        PPG_POL_STAMP(6);
     }
 }
 
@@ -979,6 +1120,20 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     }
 #endif
     K.logits = logits;
+#ifdef PPG_EXPERIMENTS   // PPG_POLICY_TIMELINE=<file prefix>: per-tile phase stamps of launch number PPG_POLICY_TIMELINE_RUN (default 300) of each species
+    static int tl_runs[2] = {0, 0};
+    static unsigned long long *tl_buf[2] = {nullptr, nullptr};
+    const char *tl_path = getenv("PPG_POLICY_TIMELINE");
+    const int tl_at = getenv("PPG_POLICY_TIMELINE_RUN") ? atoi(getenv("PPG_POLICY_TIMELINE_RUN")) : 300;
+    const size_t tl_tiles = ((size_t)total * K.cap + 31) / 32 + 1;
+    if (tl_path && !tl_buf[species]) {
+        PPG_POL_TRY(p, hipMalloc((void **)&tl_buf[species], tl_tiles * 512));
+        PPG_POL_TRY(p, hipMemset(tl_buf[species], 0, tl_tiles * 512));
+        PPG_POL_TRY(p, hipDeviceSynchronize());
+    }
+    const bool tl_now = tl_path && ++tl_runs[species] == tl_at;
+    K.timeline = tl_now ? tl_buf[species] : nullptr;
+#endif
     hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
     typedef void (*fwd_fn)(const ppgpol::PolParams);
     const fwd_fn fwd[3][3] = {{ppgpol::ppg_policy_forward_f64, ppgpol::ppg_policy_forward_f32, ppgpol::ppg_policy_forward_bf16},
@@ -987,6 +1142,19 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     const int variant = p->layout == PPG_POLICY_LAYOUT_HWC ? (p->cin > 8 ? 2 : 1) : 0;
     hipLaunchKernelGGL(fwd[variant][K.obs_f32 == 2 ? 2 : K.obs_f32 ? 1 : 0], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     PPG_POL_TRY(p, hipGetLastError());
+#ifdef PPG_EXPERIMENTS
+    if (tl_now && species == 0) {   // (the predators' launch is the second of a step: both species' stamps are complete after a device sync)
+        PPG_POL_TRY(p, hipDeviceSynchronize());
+        for (int sp = 0; sp < 2; ++sp) {
+            if (!tl_buf[sp]) continue;
+            std::vector<unsigned long long> host(tl_tiles * 64);
+            PPG_POL_TRY(p, hipMemcpy(host.data(), tl_buf[sp], tl_tiles * 512, hipMemcpyDeviceToHost));
+            char name[512];
+            snprintf(name, sizeof name, "%s.%s", tl_path, sp ? "prey" : "pred");
+            if (FILE *f = fopen(name, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        }
+    }
+#endif
     return PPG_OK;
 }
 
