@@ -81,7 +81,7 @@ struct PolParams {
                                   // resident workgroups), [2] = samples per tile of the last round (32 / 64 / 96 / 128),
                                   // [PLAN_HDR + e] = exclusive prefix sum of env e
     const uint32_t *tile_env;     // [tile] = env of the tile's first sample
-    uint32_t magic_P, magic_R;    // ceil(2^32 / P), ceil(2^32 / IW): n / P == mulhi(n, magic_P) for the small n used here
+    uint32_t magic_P, magic_R;    // ceil(2^18 / P), ceil(2^18 / IW): div_small()
     __bf16 *xg;                   // [gridDim.x][TILE][K1]
     float *logits;                // optional [rows][n_actions]
 #ifdef PPG_EXPERIMENTS
@@ -169,18 +169,30 @@ __device__ __forceinline__ bf16x8 zero8() {
     return v;
 }
 
-// ReLU + round 8 accumulator registers to bf16
+// ReLU + round 8 accumulator registers to bf16: round first (v_cvt_pk_bf16_f32, two values per instruction), then ReLU on the PACKED
+// pair -- a bf16 with the sign bit set is a negative 16-bit integer, so one v_pk_max_i16 with 0 clears both halves.  (Same values
+// as ReLU before rounding: a negative number rounds to a negative number or -0, a positive one is untouched.)  12 instructions per
+// 8 values instead of 8 v_max + 4 conversions... and half the v_max: the epilogues are a fifth of the convolutions' time.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8 relu_pack8(const f32x16 &a, int r0) {
-    bf16x8 v;
+    u32x4_t w;
 #pragma unroll
-    // ReLU on the bits: a float with the sign bit set is a negative INTEGER, so one v_max_i32 with 0 clears it (x > 0 ? x : 0 and
-    // v_med3_f32 both compile to two v_max_f32: canonicalise, then max)
-    for (int j = 0; j < 8; ++j) {
-        const int b = __float_as_int(a[r0 + j]);
-        v[j] = (__bf16)__int_as_float(b > 0 ? b : 0);
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 f = {a[r0 + 2 * j], a[r0 + 2 * j + 1]};
+        const s16x2 zero = {0, 0};
+        const s16x2 q = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(f, bf16x2)), zero);
+        w[j] = __builtin_bit_cast(uint32_t, q);
     }
-    return v;
+    return __builtin_bit_cast(bf16x8, w);
 }
+
+// n / d for 0 <= n < 1024, 1 <= d <= 255 with ONE full-rate instruction pair: (n * ceil(2^18 / d)) >> 18 (v_mul_u32_u24; the 32-bit
+// multiplies and v_mul_hi the position arithmetic used before are quarter rate).  Exact: the error term n * (d ceil(2^18 / d) - 2^18)
+// stays below 2^18.  The other products of the position arithmetic are 24-bit multiplies too.
+constexpr int DIV_SHIFT = 18;
+__device__ __forceinline__ int div_small(int n, uint32_t magic) { return (int)(__umul24((uint32_t)n, magic) >> DIV_SHIFT); }
 
 // The weight fragments of one convolution layer and, per k-step, the offset of this lane half's K block: in registers.
 //   CBIN   channel blocks (of 8) of the input image: 1 (4 real channels), 2, 4        K = 9 taps x CBIN blocks
@@ -235,6 +247,17 @@ struct ConvW {
     }
 };
 
+#ifdef PPG_EXPERIMENTS   // ablation builds (-DPPG_ABLATE=bits, timing only): 64 no ReLU / pack / stores, 128 the convolutions' MFMAs become one
+// v_add per fragment, 256 no LDS fragment reads, 512 no position arithmetic
+#ifndef PPG_ABLATE
+#define PPG_ABLATE 0
+#endif
+#define PPG_MFMA(a, b, c) ((PPG_ABLATE & 128) ? ppg_fake_mfma(a, b, c) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0))
+__device__ __forceinline__ f32x16 ppg_fake_mfma(bf16x8 a, bf16x8 b, f32x16 c) { c[0] += (float)a[0] + (float)b[0]; return c; }
+#else
+#define PPG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
 // One convolution layer over the `ns` samples of a sub-group, this wavefront's share of the 32-position tiles.
 //   COUT_BLOCKS  channel blocks written: 2 (conv1), 4 (conv2), 8 (conv3)
 //   TO_GLOBAL    conv3: the result goes to the scratch slot X[sample][position][64] instead of an LDS image
@@ -256,10 +279,20 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
         const int n = 32 * nt + col;
         const bool valid = n < n_pos;
         const int nn = valid ? n : 0;
-        const int s = (int)__umulhi((uint32_t)nn, K.magic_P), p = nn - s * K.P;
-        const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.IW;
-        const int pidx = (y + 1) * K.Wp + (x + 1);
-        const __bf16 *base = in + (size_t)s * sample_stride + pidx * 8;
+#ifdef PPG_EXPERIMENTS
+        int s, p, pidx;
+        if (PPG_ABLATE & 512) { s = 0; p = col; pidx = K.Wp + 1 + col; }   // ablation: no position arithmetic
+        else {
+            s = div_small(nn, K.magic_P); p = nn - __mul24(s, K.P);
+            const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
+            pidx = __mul24(y + 1, K.Wp) + (x + 1);
+        }
+#else
+        const int s = div_small(nn, K.magic_P), p = nn - __mul24(s, K.P);
+        const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
+        const int pidx = __mul24(y + 1, K.Wp) + (x + 1);
+#endif
+        const __bf16 *base = in + __mul24(s, sample_stride) + pidx * 8;
         f32x16 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -273,6 +306,9 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
                 v = zero8();
                 if (h == HB) { v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
             } else {
+#ifdef PPG_EXPERIMENTS
+                if (PPG_ABLATE & 256) v = zero8(); else   // ablation: no LDS fragment reads
+#endif
                 v = *(const bf16x8 *)(base + W.offset(K, ks, d23));
                 if (ks == KSB && h == HB) { v = zero8(); v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
             }
@@ -291,7 +327,7 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][ks], b[ks], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = PPG_MFMA(W.a[mt][ks], b[ks], acc[mt]);
         } else {
             // conv3 (19 k-steps): the fragments come in batches of BATCH, batch n + 1 requested before the MFMAs of batch n -- two
             // batches of registers instead of 76, which is what lets the weights of all three layers stay in registers
@@ -311,12 +347,18 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
                     if (nb * BATCH + i < KS) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][nb * BATCH + i], b[nb & 1][i], acc[mt], 0, 0, 0);
+                            acc[mt] = PPG_MFMA(W.a[mt][nb * BATCH + i], b[nb & 1][i], acc[mt]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (!valid || (TO_GLOBAL && (K.debug_skip & 32))) continue;
+#ifdef PPG_EXPERIMENTS
+        if (PPG_ABLATE & 64) {   // ablation: no ReLU / pack / stores (one value stored so that the MFMAs stay)
+            if (acc[0][0] == 123.0f) *(float *)(img) = acc[0][0];
+            continue;
+        }
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -326,7 +368,7 @@ __device__ __forceinline__ void conv_layer(const KP &K, const ConvW<CBIN, MT> &W
                     // scratch slot X[sample][row tile][position][32]: a wavefront's 32 positions x 32 channels are 2 KB contiguous
                     *(GLOBAL_AS bf16x8 *)(xg_tile + (((size_t)(s_local0 + s) * 2 + (mt_base + mt)) * K.P + p) * 32 + 16 * h + 8 * j) = v;
                 } else if (4 * (mt_base + mt) + 2 * h + j < COUT_BLOCKS) {   // (conv1: 16 real output channels: the h = 0 half only)
-                    *(bf16x8 *)(out + (size_t)s * sample_stride + (j * K.Wp2 + pidx) * 8) = v;
+                    *(bf16x8 *)(out + __mul24(s, sample_stride) + (j * K.Wp2 + pidx) * 8) = v;
                 }
             }
     }
@@ -636,7 +678,7 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
 #pragma unroll
             for (int c = 0; c < NCH; ++c) pre[j][c] = (raw_t)0;
             if (idx < ns * K.P && !(dbg & 4)) {
-                const int s = (int)__umulhi((uint32_t)idx, K.magic_P), p = idx - s * K.P;
+                const int s = div_small(idx, K.magic_P), p = idx - __mul24(s, K.P);
                 typedef typename ObsRaw<OBS, NCH>::elem elem_t;   // bfloat16 rows: what ppg_step rounded is what conv1 gets, bit for bit
                 const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
 #pragma unroll
@@ -650,14 +692,14 @@ __device__ __noinline__ void phase_conv(KPtr Kp, unsigned char *lds, int tile_, 
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + 256 * j;
             if (idx < ns * K.P) {
-                const int s = (int)__umulhi((uint32_t)idx, K.magic_P), p = idx - s * K.P;
-                const int y = (int)__umulhi((uint32_t)p, K.magic_R), x = p - y * K.IW;
+                const int s = div_small(idx, K.magic_P), p = idx - __mul24(s, K.P);
+                const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
 #pragma unroll
                 for (int cb = 0; cb < CB1; ++cb) {
                     bf16x8 v = zero8();
 #pragma unroll
                     for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = ObsRaw<OBS, NCH>::to_bf16(pre[j][8 * cb + c]);
-                    *(bf16x8 *)(img + (size_t)s * sample_stride + ((in_blk + cb) * K.Wp2 + (y + 1) * K.Wp + (x + 1)) * 8) = v;
+                    *(bf16x8 *)(img + __mul24(s, sample_stride) + ((in_blk + cb) * K.Wp2 + __mul24(y + 1, K.Wp) + (x + 1)) * 8) = v;
                 }
             }
         }
@@ -1002,8 +1044,8 @@ int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_action
 #ifdef PPG_EXPERIMENTS   // ablation builds only (hipcc -DPPG_EXPERIMENTS): skip phases -- the results are then meaningless
     if (const char *dbg = getenv("PPG_POLICY_SKIP")) K.debug_skip = atoi(dbg);
 #endif
-    K.magic_P = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
-    K.magic_R = (uint32_t)((0x100000000ull + (uint64_t)IW - 1) / (uint64_t)IW);
+    K.magic_P = (uint32_t)(((1u << ppgpol::DIV_SHIFT) + P - 1) / P);
+    K.magic_R = (uint32_t)(((1u << ppgpol::DIV_SHIFT) + IW - 1) / IW);
     K.R = R; K.P = P; K.Wp = IW + 2; K.Wp2 = (IH + 2) * (IW + 2); K.K1 = K1; K.n_actions = n_actions;
     K.IH = IH; K.IW = IW; K.cin = CIN; K.obs_elems = 4 * R * R;
     // observation element [a][b][c] of the (4,R,R) row: channel-first = (channel a, position b * R + c); channels-last = (position
