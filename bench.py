@@ -541,7 +541,8 @@ def main(argv=None, backend=None):
     # written every step exactly as above (bit-identical to n ppg_step calls; tests).  Reported next to `value`, never as `value`:
     # `value` is the per-step API, which also takes actions from outside.
     fused = None
-    if args.fused_steps > 0 and not dry and args.workload == "base" and group.subs[0].wave_plan()[2] > 0:
+    if args.fused_steps > 0 and not dry and args.workload in ("base", "red_queen") and group.subs[0].wave_plan()[2] > 0 \
+            and group.subs[0].wave_plan()[0] == 4:
         n_f = args.fused_steps
         launches = max(1, args.sustained_steps // n_f) if args.sustained_steps > 0 else 4
         f0 = [backend.event() for _ in group.streams]
@@ -566,7 +567,7 @@ def main(argv=None, backend=None):
         osz_f = {torch.float64: 8, torch.float32: 4, torch.bfloat16: 2}[obs_dtype]
         bytes_f = (npred_f * 4 * Rp_ * Rp_ + nprey_f * 4 * Rq_ * Rq_) * osz_f + 62 * rows_f + B * launches * n_f * (env.n_grass * 18 + 2 * 64 + 8)
         ms_f = sum(a.elapsed_time(b) for a, b in zip(f0, f1)) / len(f0)
-        fused = {"what": f"ppg_rollout({n_f}) x {launches} per sub-batch: {n_f} transitions per launch (ppgc_rollout: the workgroups of a launch run on "
+        fused = {"what": f"ppg_rollout({n_f}) x {launches} per sub-batch: {n_f} transitions per launch (ppgc_rollout / ppgc2_rollout: the workgroups of a launch run on "
                          "from step to step, no launch boundary), device-side random policy, auto-reset, observations written every step; "
                          "bit-identical to the same number of ppg_step calls (tests/test_hip_parity.py)",
                  "steps": launches * n_f, "value": round(n_gpus * B * launches * n_f / tf, 1), "unit": "env-steps/s",

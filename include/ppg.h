@@ -270,7 +270,8 @@ int ppg_get_buffers(const ppg_handle *h, ppg_buffers *out);
 
 /* Second generation: replaces PredPreyGrass.__init__ of the red_queen env (RQ:15-86).  bufs->row_lastrep is required.
  * The handle works with ppg_reset / ppg_observe / ppg_step / ppg_step_ordered / ppg_step_many / ppg_export_grid
- * (reproduction uniforms from Philox, keyed like the random actions) and with ppg_step_uniforms; not with ppg_rollout. */
+ * (reproduction uniforms from Philox, keyed like the random actions) and with ppg_step_uniforms; with ppg_rollout on a cooperative
+ * four-wave plan (no walls). */
 int ppg_create_gen2(const ppg_config_gen2 *cfg, int32_t batch, int32_t device, const ppg_buffers *bufs, ppg_handle **out);
 
 /* reset() (BASE:129-217) for every env: unique random placement (Philox
@@ -316,7 +317,8 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
  * own pace -- no launch boundary at which everybody computes and nobody stores -- and ONE launch stream reaches 61 us per 4096-env
  * step where per-step launches need three sub-batches in flight for 66-71.  On other handles (small batches,
  * 64x64 grids) it is the round-1 one-wave-per-env loop, which is SLOWER than per-step launches and kept only as a diagnostic.  Base
- * family without the kickback / drive variants. */
+ * family without the kickback / drive variants; second-generation handles (ppg_create_gen2, no walls) on a cooperative four-wave plan
+ * only (PPG_EINVAL otherwise), reproduction uniforms from the device's Philox streams as in ppg_step. */
 int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t flags, void *stream);
 
 /* Same, for an action dict whose iteration order differs from the previous observation dict

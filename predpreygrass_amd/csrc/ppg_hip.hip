@@ -209,7 +209,8 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
     const bool fast = P.nch_p <= 2 && P.nch_q <= 3;
-    if (h->gen2 && mode > ppg::MODE_STEP_ORDERED && !(mode == ppg::MODE_VIS && h->cfg2.walls))
+    if (h->gen2 && mode > ppg::MODE_STEP_ORDERED && !(mode == ppg::MODE_VIS && h->cfg2.walls) &&
+        !(mode == ppg::MODE_ROLLOUT && !h->cfg2.walls && P.coop_e > 0))
         return ppg_fail(h, PPG_EINVAL, "mode %d is not available for second-generation handles", mode);
     if (h->drive && mode > ppg::MODE_STEP_ORDERED) return ppg_fail(h, PPG_EINVAL, "mode %d is not available for the drive-conditioned variant", mode);
     ppg_kernel_fn fn = h->drive ? pick_kernel_drive(h->nq, mode) : !h->gen2 ? pick_kernel(h->nq, mode, fast)
@@ -221,7 +222,8 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
                                               {ppgc6_step_q1, ppgc6_step_q2}};
         fn = c[wp.nw == 8 ? 1 : wp.nw == 16 ? 2 : wp.nw == 6 ? 3 : 0][h->nq == 1 ? 0 : 1];
         if (h->gen2) fn = h->nq == 1 ? ppgc2_step_q1 : ppgc2_step_q2;   // (second generation: four-wave cooperative kernels)
-        if (mode == ppg::MODE_ROLLOUT) fn = h->nq == 1 ? ppgc_rollout_q1 : ppgc_rollout_q2;   // (ppg_rollout: four waves, base family)
+        if (mode == ppg::MODE_ROLLOUT)   // (ppg_rollout: the fused form of the four-wave cooperative kernels)
+            fn = h->gen2 ? (h->nq == 1 ? ppgc2_rollout_q1 : ppgc2_rollout_q2) : (h->nq == 1 ? ppgc_rollout_q1 : ppgc_rollout_q2);
         block = 64u * (unsigned)wp.nw;
         grid = (unsigned)((h->batch + P.coop_e - 1) / P.coop_e);
         if (P.lds_bytes > 64 * 1024)

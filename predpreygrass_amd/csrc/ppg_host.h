@@ -613,7 +613,10 @@ int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t 
     if (!h) return PPG_EINVAL;
     if (n_steps < 1) return ppg_fail(h, PPG_EINVAL, "n_steps must be >= 1");
     if (h->cfg.kickback) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support the kickback variant");
-    if (h->gen2) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support second-generation handles");
+    // second generation: only as the fused form of its cooperative kernel (reproduction uniforms from the device's Philox streams,
+    // as in ppg_step); the walls variant has no cooperative kernel
+    if (h->gen2 && (h->cfg2.walls || !(h->plan.coop_e > 0 && h->plan.nw == 4)))
+        return ppg_fail(h, PPG_EINVAL, "ppg_rollout on a second-generation handle needs a cooperative four-wave plan (ppg_set_wave_plan) and no walls");
     if (h->drive) return ppg_fail(h, PPG_EINVAL, "ppg_rollout does not support the drive-conditioned variant");
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);

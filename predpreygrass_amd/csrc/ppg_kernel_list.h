@@ -37,7 +37,8 @@
     PPG_KC(ppgc8_step_q##NQ, NQ, false, 8)                            \
     PPG_KC(ppgc16_step_q##NQ, NQ, false, 16)                          \
     PPG_KC(ppgc2_step_q##NQ, NQ, true, 4)                             \
-    PPG_KCR(ppgc_rollout_q##NQ, NQ, false, 4)
+    PPG_KCR(ppgc_rollout_q##NQ, NQ, false, 4)                         \
+    PPG_KCR(ppgc2_rollout_q##NQ, NQ, true, 4)
 
 #define PPG_DEFINE_KERNELSW2(NQ)                                      \
     PPG_KW2(ppgw2_step_q##NQ, NQ, true, 4)                            \

@@ -286,8 +286,12 @@ class BatchedRedQueen(BatchedPredPreyGrass):
                                                 int(uniforms.shape[1]), flags, self._stream(stream)), "ppg_step_uniforms")
         return self
 
-    def rollout(self, *a, **k):
-        raise NotImplementedError("ppg_rollout is not available for the second-generation env")
+    def rollout(self, n_steps, actions=None, random_actions=False, auto_reset=False, stream=None):
+        """`n_steps` transitions in ONE launch: the fused form of the cooperative step kernel (the handle's wave plan must be
+        cooperative with four waves -- the default on a full GPU, else `set_wave_plan(4, 0, 2)`; not for the walls variant).  Same
+        result as `n_steps` calls of step(): actions from the device-side uniform random policy or an int8 tape [n_steps, B, S],
+        reproduction uniforms from the device's Philox streams."""
+        return super().rollout(n_steps, actions=actions, random_actions=random_actions, auto_reset=auto_reset, stream=stream)
 
     # ------------------------------------------------------------------
     def host_tables(self, b=None):

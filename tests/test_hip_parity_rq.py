@@ -66,6 +66,39 @@ def test_cooperative_random_rollout_matches_oracle_on_gpu(cfg, B, calls, cap, co
     assert stats["births"] > 0
 
 
+@pytest.mark.parametrize("cfg,B,coop,cap", [(config_env_base, 4096, 2, 128), (MIXED, 130, 2, 128), (POOL, 61, 4, 64)])
+def test_fused_rollout_equals_single_steps_on_gpu(cfg, B, coop, cap):
+    """ppg_rollout on a second-generation handle (ppgc2_rollout: the fused form of the cooperative kernel) against the same number of
+    ppg_step launches: random policy, reproduction from the device's Philox uniforms, truncations and auto-resets inside the
+    launches; at 4096 envs the workgroups drift apart by whole steps.  Then an action tape."""
+    cfg = dict(cfg, max_steps=60)
+    a, b = make_env(cfg, B, prey_capacity=cap, seed=77), make_env(cfg, B, prey_capacity=cap, seed=77)
+    b.set_wave_plan(4, 0, coop)
+    a.reset()
+    b.reset()
+    for _ in range(150):
+        a.step(random_actions=True, auto_reset=True)
+    b.rollout(90, random_actions=True, auto_reset=True)
+    b.rollout(60, random_actions=True, auto_reset=True)
+    names = ("row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_lastrep", "grass_energy",
+             "obs_pred", "obs_prey")
+    for n in names:
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+    assert torch.equal(a.env_state[:, : _abi.ENV_CALLS], b.env_state[:, : _abi.ENV_CALLS])
+    K = 40
+    tape = torch.randint(-1, 9, (K, B, a.S), generator=torch.Generator().manual_seed(4), dtype=torch.int8).to("cuda:0")
+    for t in range(K):
+        a.step(tape[t])
+    b.rollout(K, actions=tape)
+    for n in names:
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+    env = make_env(cfg, 4)
+    env.set_wave_plan(1, 0, 0)
+    env.reset()
+    with pytest.raises(RuntimeError, match="cooperative"):
+        env.rollout(2, random_actions=True)
+
+
 def test_float64_observations_on_gpu():
     env = make_env(MIXED, 8, obs_dtype=torch.float64)
     rollout_vs_oracle(env, lambda: RQOracleEnv(MIXED), seed0=5, n_calls=80, check_every=4)

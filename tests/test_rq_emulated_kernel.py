@@ -101,3 +101,57 @@ def test_second_generation_kernels_are_clean_under_ubsan():
         "print('UBSAN-CLEAN')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and "UBSAN-CLEAN" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+RQ_STATE = ("row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_lastrep", "env_state",
+            "grass_xy", "grass_energy", "obs_pred", "obs_prey")
+
+
+def _same_tables(a, b):
+    for n in RQ_STATE:
+        ta, tb = getattr(a, n), getattr(b, n)
+        assert ta.cpu().numpy().tobytes() == tb.cpu().numpy().tobytes(), n
+
+
+@pytest.mark.parametrize("coop,B", [(2, 5), (4, 3)])
+def test_cooperative_fused_rollout_equals_single_steps(coop, B):
+    """ppg_rollout on a second-generation handle = the fused form of its cooperative kernel (ppgc2_rollout): random policy with
+    reproduction (device Philox uniforms), truncations and auto-resets inside the launch, then an action tape -- every table,
+    status word and observation equal to the same number of ppg_step calls."""
+    cfg = dict(RQGoldenCase("rq_mixed_types_seed7").config, max_steps=35)
+    a, b = make_env(cfg, B, seed=13), make_env(cfg, B, seed=13)
+    b.set_wave_plan(4, 0, coop)
+    assert b.wave_plan() == (4, 0, coop)
+    a.reset()
+    b.reset()
+    for _ in range(80):
+        a.step(random_actions=True, auto_reset=True)
+    b.rollout(45, random_actions=True, auto_reset=True)
+    b.rollout(35, random_actions=True, auto_reset=True)
+    _same_tables(a, b)
+    K = 30
+    a, b = make_env(cfg, B, seed=3), make_env(cfg, B, seed=3)
+    b.set_wave_plan(4, 0, coop)
+    a.reset()
+    b.reset()
+    n_act = int(max(cfg.get("type_1_action_range", 3), cfg.get("type_2_action_range", 3))) ** 2
+    tape = torch.randint(-1, min(n_act, 9), (K, B, a.S), generator=torch.Generator().manual_seed(2), dtype=torch.int8)
+    for t in range(K):
+        a.step(tape[t].contiguous())
+    b.rollout(K, actions=tape)
+    _same_tables(a, b)
+
+
+def test_fused_rollout_needs_a_cooperative_plan_and_no_walls():
+    cfg = RQGoldenCase("rq_base_seed3").config
+    env = make_env(cfg, 2)
+    env.set_wave_plan(1, 0, 0)
+    env.reset()
+    with pytest.raises(RuntimeError, match="cooperative"):
+        env.rollout(3, random_actions=True)
+    case = RQGoldenCase("wo_los_two_types_seed5")
+    wenv = make_env(case.config, 2, walls=True)
+    wenv.set_walls(case.wall_xy)
+    wenv.reset()
+    with pytest.raises(RuntimeError, match="cooperative"):
+        wenv.rollout(3, random_actions=True)

@@ -42,7 +42,11 @@ void run(const ppg::KParams &P, int mode, int nw) {
         return;
     }
 #elif PPG_EMU_FAMILY == 1 && PPG_EMU_NQ <= 2
-    if (P.coop_e > 0) { run_coop<4>(P); return; }
+    if (P.coop_e > 0) {
+        if (mode == ppg::MODE_ROLLOUT) { PPG_DYNAMIC_LDS(lds); ppg::coop_main_fused<NQ, true, 4>(P, lds); return; }   // ppg_rollout
+        run_coop<4>(P);
+        return;
+    }
 #endif
     if (nw == 4) { run_nw<FAST, 4>(P); return; }
 #if PPG_EMU_FAMILY == 0
