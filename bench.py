@@ -228,6 +228,11 @@ def parse_args(argv):
                     help="before the pre-roll the envs are stepped for this long (wall clock) and then reset again: a GPU that has been idle needs about a second of "
                          "load to reach its sustained clocks -- the first bench process on a fresh box measured 75 us per step where "
                          "every later one measured 66-68 (profiles/r03) -- and the workload is defined in its steady state")
+    ap.add_argument("--placement-candidates", type=int, default=4,
+                    help="SubBatchedPredPreyGrass(placement_candidates=K): where the driver puts the observation tensors in HBM decides "
+                         "whether the step's scattered writes run in 62-66 or 76-81 us (same box, same process, same kernel: "
+                         "profiles/r03/e_placement_experiments.txt); the constructor steps K candidate buffer sets for a few milliseconds "
+                         "each and keeps the fastest.  1 = take the first allocation as it comes")
     ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=None,
                     help="roofline.traffic from PMC passes of this command on THIS box (two child runs under rocprofv3 --pmc, ~25 s); "
                          "default: on for the single-GPU headline workload, off otherwise")
@@ -409,11 +414,10 @@ def main(argv=None, backend=None):
     B = args.envs
     obs_dtype = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[args.obs_dtype]
     n_sub = max(1, args.streams)
+    setup = (lambda e: e.set_walls(cfg["manual_wall_positions"])) if args.workload == "walls" else None
     group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype, env_class=env_class,
-                                    seed=args.seed + rank * B, **extra_kw, **backend.env_kwargs())
-    if args.workload == "walls":
-        for e in group.subs:
-            e.set_walls(cfg["manual_wall_positions"])
+                                    seed=args.seed + rank * B, placement_candidates=1 if dry else args.placement_candidates,
+                                    placement_setup=setup, **extra_kw, **backend.env_kwargs())
     if args.wave_plan:
         wp = [int(v) for v in args.wave_plan.split(",")]
         for e in group.subs:
@@ -764,6 +768,7 @@ def main(argv=None, backend=None):
                 "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
                 "sub_batches_per_gpu": n_sub,
                 "preroll_steps": preroll, "device_warm_steps": warm_steps,
+                "placement_candidates_us_per_step": None if group.placement_probe_us is None else [round(v, 1) for v in group.placement_probe_us],
                 "preroll_mean_agents_per_env_by_64_step_window": [round(v, 2) for v in trace[-8:]],
                 "mean_agents_per_env": round((n_obs_pred + n_obs_prey) / env_steps_rank, 2),
                 "status_bits": status,

@@ -11,6 +11,14 @@ Each sub-batch is an ordinary `BatchedPredPreyGrass`; env b of the whole batch i
 b - offset[k] of sub-batch k.  Sub-batches never wait for each other -- exactly the asynchronous
 vector-env pattern RL frameworks use; call `synchronize()` (or use the per-sub-batch streams) before
 reading tensors from another stream.
+
+Placement (`placement_candidates`): where the driver puts a sub-batch's observation tensors in HBM decides how fast the step's
+scattered 1 KB pieces can be written -- on one MI355X, in one process, with one kernel, env groups that differ only in their
+buffers step in 62-66 us or in 76-81 us, persistently, while a linear fill of the same tensors runs at the same 6.3 TB/s
+(`tools/exp_placement.py`, profiles/r03/e_placement_experiments.txt; the time follows the observation tensors when new handles
+and row tables are put on them).  Physical placement cannot be asked for, but it can be measured: with `placement_candidates=K`
+the constructor builds up to K candidate sets of sub-batches, steps each for a few milliseconds, keeps the fastest and frees
+the others (at most two sets exist at a time).  Results never depend on it: the caller's `reset()` re-creates every env's state.
 """
 from __future__ import annotations
 
@@ -24,17 +32,63 @@ from .distributed import shard_range
 
 
 class SubBatchedPredPreyGrass:
-    def __init__(self, config=None, batch_size=4096, n_sub=2, device="cuda:0", seed=0, env_class=BatchedPredPreyGrass, **kw):
-        """env_class: BatchedPredPreyGrass (base family) or red_queen.BatchedRedQueen (second generation)."""
+    def __init__(self, config=None, batch_size=4096, n_sub=2, device="cuda:0", seed=0, env_class=BatchedPredPreyGrass,
+                 placement_candidates=1, placement_setup=None, **kw):
+        """env_class: BatchedPredPreyGrass (base family) or red_queen.BatchedRedQueen (second generation).
+        placement_candidates: > 1 = build that many candidate buffer sets and keep the one that steps fastest (module docstring);
+        placement_setup(env): called on every candidate sub-batch before it is measured (e.g. set_walls)."""
         self.device = torch.device(device)
         self.batch_size = int(batch_size)
         self.offsets = [shard_range(self.batch_size, k, n_sub) for k in range(n_sub)]
-        self.subs = [env_class(config, batch_size=hi - lo, device=device, seed=seed + lo, **kw)
-                     for lo, hi in self.offsets]
-        for e in self.subs:   # the sub-batches run concurrently: kernel selection should look at all of them together
-            e._lib.ppg_set_envs_in_flight(e._handle, self.batch_size)
         cuda = self.device.type == "cuda"   # (the CPU case exists only for the emulated-kernel tests)
-        self.streams = [torch.cuda.Stream(device=self.device) if cuda else None for _ in self.subs]
+        self.streams = [torch.cuda.Stream(device=self.device) if cuda else None for _ in self.offsets]
+
+        def build():
+            subs = [env_class(config, batch_size=hi - lo, device=device, seed=seed + lo, **kw) for lo, hi in self.offsets]
+            for e in subs:   # the sub-batches run concurrently: kernel selection should look at all of them together
+                e._lib.ppg_set_envs_in_flight(e._handle, self.batch_size)
+                if placement_setup is not None:
+                    placement_setup(e)
+            return subs
+
+        self.subs = build()
+        self.placement_probe_us = None
+        if cuda and int(placement_candidates) > 1:
+            self.placement_probe_us = [self._probe_placement()]
+            for _ in range(int(placement_candidates) - 1):
+                best = self.subs
+                self.subs = build()
+                self._forget_handles()
+                t = self._probe_placement()
+                if t < min(self.placement_probe_us):
+                    drop = best
+                else:
+                    drop, self.subs = self.subs, best
+                self.placement_probe_us.append(t)
+                self._forget_handles()
+                for e in drop:
+                    e.close()
+                del drop, best
+
+    def _forget_handles(self):
+        for name in ("_c_handles", "_c_streams", "_c_own_actions"):
+            if hasattr(self, name):
+                delattr(self, name)
+
+    def _probe_placement(self, warm_steps=640, probe_steps=192):
+        """Microseconds per full step of the current sub-batches on their current buffers: device reset, `warm_steps` untimed steps
+        of the device-side random policy with auto-reset (the population has to grow: right after a reset an env writes a third of
+        the rows it writes later, and the placements do not differ yet), then `probe_steps` timed ones (about 60 ms in all)."""
+        import time
+        self.reset()
+        for _ in range(warm_steps):
+            self.step(random_actions=True, auto_reset=True)
+        self.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(probe_steps):
+            self.step(random_actions=True, auto_reset=True)
+        self.synchronize()
+        return (time.perf_counter() - t0) / probe_steps * 1e6
 
     def reset(self, seed=None):
         for k, (e, s) in enumerate(zip(self.subs, self.streams)):

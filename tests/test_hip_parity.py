@@ -529,3 +529,30 @@ def test_steps_captured_in_a_hip_graph_replay_bit_identically():
     torch.cuda.synchronize()
     for n in names:
         assert torch.equal(getattr(a, n), getattr(b, n)), n
+
+
+def test_placement_candidates_change_no_result():
+    """SubBatchedPredPreyGrass(placement_candidates=K) steps K candidate buffer sets and keeps the fastest: scheduling only.  After the
+    caller's reset() the kept envs are in exactly the state of envs that were never probed."""
+    from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
+    cfg = {**config_env, "max_steps": 50}
+    plain = SubBatchedPredPreyGrass(cfg, batch_size=300, n_sub=3, device="cuda:0", seed=5)
+    picked = SubBatchedPredPreyGrass(cfg, batch_size=300, n_sub=3, device="cuda:0", seed=5, placement_candidates=4)
+    assert picked.placement_probe_us is not None and len(picked.placement_probe_us) == 4 and plain.placement_probe_us is None
+    for g in (plain, picked):
+        g.reset()
+        for _ in range(70):
+            g.step(random_actions=True, auto_reset=True)
+        g.synchronize()
+    for a, b in zip(plain.subs, picked.subs):
+        assert torch.equal(a.env_state[:, : _abi.ENV_CALLS], b.env_state[:, : _abi.ENV_CALLS])
+        slot = torch.arange(a.S, device="cuda:0", dtype=torch.int32).unsqueeze(0)
+        n_pred = a.env_state[:, _abi.ENV_N_PRED_ROWS:_abi.ENV_N_PRED_ROWS + 1]
+        n_prey = a.env_state[:, _abi.ENV_N_PREY_ROWS:_abi.ENV_N_PREY_ROWS + 1]
+        live = torch.where(slot < a.pred_capacity, slot < n_pred, slot - a.pred_capacity < n_prey)   # (rows behind the counts keep old bytes)
+        assert int(live.sum()) > 300 * 10 // 3
+        for n in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "row_cumrew"):
+            assert torch.equal(getattr(a, n)[live], getattr(b, n)[live]), n
+        assert torch.equal(a.grass_energy, b.grass_energy)
+        assert torch.equal(a.obs_pred[live[:, : a.pred_capacity]], b.obs_pred[live[:, : a.pred_capacity]])
+        assert torch.equal(a.obs_prey[live[:, a.pred_capacity:]], b.obs_prey[live[:, a.pred_capacity:]])
