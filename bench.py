@@ -153,7 +153,8 @@ def measure_traffic(argv, args, timeout=240):
     if not os.path.exists(exe):
         return None
     child_args = [a for a in argv if a not in ("--measure-traffic",)]
-    child_args += ["--no-cpu-baseline", "--sustained-steps", "0", "--fused-steps", "0", "--traffic-child", "--device-warm-seconds", "0.5"]
+    child_args += ["--no-cpu-baseline", "--sustained-steps", "0", "--fused-steps", "0", "--traffic-child", "--device-warm-seconds", "0.5",
+                   "--placement-candidates", "1"]
     out = {}
     tmp = tempfile.mkdtemp(prefix="ppg_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
