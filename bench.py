@@ -229,11 +229,11 @@ def parse_args(argv):
                     help="before the pre-roll the envs are stepped for this long (wall clock) and then reset again: a GPU that has been idle needs about a second of "
                          "load to reach its sustained clocks -- the first bench process on a fresh box measured 75 us per step where "
                          "every later one measured 66-68 (profiles/r03) -- and the workload is defined in its steady state")
-    ap.add_argument("--placement-candidates", type=int, default=4,
+    ap.add_argument("--placement-candidates", type=int, default=8,
                     help="SubBatchedPredPreyGrass(placement_candidates=K): where the driver puts the observation tensors in HBM decides "
                          "whether the step's scattered writes run in 62-66 or 76-81 us (same box, same process, same kernel: "
-                         "profiles/r03/e_placement_experiments.txt); the constructor steps K candidate buffer sets for a few milliseconds "
-                         "each and keeps the fastest.  1 = take the first allocation as it comes")
+                         "profiles/r03/e_placement_experiments.txt); the constructor builds K candidate buffer sets side by side, steps each for "
+                         "~70 ms and keeps the fastest (0.6 s and 14 GB of transient memory at K = 8).  1 = take the first allocation as it comes")
     ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=None,
                     help="roofline.traffic from PMC passes of this command on THIS box (two child runs under rocprofv3 --pmc, ~25 s); "
                          "default: on for the single-GPU headline workload, off otherwise")

@@ -18,7 +18,7 @@ buffers step in 62-66 us or in 76-81 us, persistently, while a linear fill of th
 (`tools/exp_placement.py`, profiles/r03/e_placement_experiments.txt; the time follows the observation tensors when new handles
 and row tables are put on them).  Physical placement cannot be asked for, but it can be measured: with `placement_candidates=K`
 the constructor builds up to K candidate sets of sub-batches, steps each for a few milliseconds, keeps the fastest and frees
-the others (at most two sets exist at a time).  Results never depend on it: the caller's `reset()` re-creates every env's state.
+the others (K sets of buffers exist while they are measured: 1.8 GB each at 4096 default-config envs).  Results never depend on it: the caller's `reset()` re-creates every env's state.
 """
 from __future__ import annotations
 
@@ -54,21 +54,21 @@ class SubBatchedPredPreyGrass:
         self.subs = build()
         self.placement_probe_us = None
         if cuda and int(placement_candidates) > 1:
-            self.placement_probe_us = [self._probe_placement()]
-            for _ in range(int(placement_candidates) - 1):
-                best = self.subs
-                self.subs = build()
+            # all candidates exist side by side while they are measured (one that is freed first would hand its memory to the next)
+            sets = [self.subs] + [build() for _ in range(int(placement_candidates) - 1)]
+            self.placement_probe_us = []
+            for subs in sets:
+                self.subs = subs
                 self._forget_handles()
-                t = self._probe_placement()
-                if t < min(self.placement_probe_us):
-                    drop = best
-                else:
-                    drop, self.subs = self.subs, best
-                self.placement_probe_us.append(t)
-                self._forget_handles()
-                for e in drop:
-                    e.close()
-                del drop, best
+                self.placement_probe_us.append(self._probe_placement())
+            keep = min(range(len(sets)), key=lambda k: self.placement_probe_us[k])
+            self.subs = sets[keep]
+            self._forget_handles()
+            for k, subs in enumerate(sets):
+                if k != keep:
+                    for e in subs:
+                        e.close()
+            del sets, subs
 
     def _forget_handles(self):
         for name in ("_c_handles", "_c_streams", "_c_own_actions"):
