@@ -154,7 +154,7 @@ def measure_traffic(argv, args, timeout=240):
         return None
     child_args = [a for a in argv if a not in ("--measure-traffic",)]
     child_args += ["--no-cpu-baseline", "--sustained-steps", "0", "--fused-steps", "0", "--traffic-child", "--device-warm-seconds", "0.5",
-                   "--placement-candidates", "1"]
+                   "--placement-candidates", "1", "--obs-spread", "0"]
     out = {}
     tmp = tempfile.mkdtemp(prefix="ppg_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
@@ -229,7 +229,12 @@ def parse_args(argv):
                     help="before the pre-roll the envs are stepped for this long (wall clock) and then reset again: a GPU that has been idle needs about a second of "
                          "load to reach its sustained clocks -- the first bench process on a fresh box measured 75 us per step where "
                          "every later one measured 66-68 (profiles/r03) -- and the workload is defined in its steady state")
-    ap.add_argument("--placement-candidates", type=int, default=8,
+    ap.add_argument("--obs-spread", type=int, default=32,
+                    help="BatchedPredPreyGrass(obs_spread=N): the observation tensors live on 2 MB physical pages picked at random from N times "
+                         "their size of device memory (ppg_alloc_spread, HIP virtual memory management): 62-64 us per 4096-env step at N = "
+                         "32-64 where plain allocations draw from 62-91 us (profiles/r03/e_placement_experiments.txt).  N = 32 costs ~2.5 s and "
+                         "58 GB of transient device memory at the headline size.  0 = torch's allocator")
+    ap.add_argument("--placement-candidates", type=int, default=2,
                     help="SubBatchedPredPreyGrass(placement_candidates=K): where the driver puts the observation tensors in HBM decides "
                          "whether the step's scattered writes run in 62-66 or 76-81 us (same box, same process, same kernel: "
                          "profiles/r03/e_placement_experiments.txt); the constructor builds K candidate buffer sets side by side, steps each for "
@@ -416,9 +421,21 @@ def main(argv=None, backend=None):
     obs_dtype = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[args.obs_dtype]
     n_sub = max(1, args.streams)
     setup = (lambda e: e.set_walls(cfg["manual_wall_positions"])) if args.workload == "walls" else None
-    group = SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype, env_class=env_class,
-                                    seed=args.seed + rank * B, placement_candidates=1 if dry else args.placement_candidates,
-                                    placement_setup=setup, **extra_kw, **backend.env_kwargs())
+    def build_group(spread):
+        return SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype, env_class=env_class,
+                                       seed=args.seed + rank * B, placement_candidates=1 if dry else args.placement_candidates,
+                                       placement_setup=setup, **({} if dry else {"obs_spread": spread}), **extra_kw,
+                                       **backend.env_kwargs())
+
+    spread_note = None
+    try:
+        group = build_group(args.obs_spread)
+    except RuntimeError as exc:   # (the virtual-memory allocation is an optimisation: without it the run is slower, not wrong)
+        if args.obs_spread <= 1 or "ppg_alloc_spread" not in str(exc):
+            raise
+        spread_note = f"ppg_alloc_spread failed ({exc}); observation tensors from torch's allocator"
+        args.obs_spread = 0
+        group = build_group(0)
     if args.wave_plan:
         wp = [int(v) for v in args.wave_plan.split(",")]
         for e in group.subs:
@@ -769,6 +786,7 @@ def main(argv=None, backend=None):
                 "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
                 "sub_batches_per_gpu": n_sub,
                 "preroll_steps": preroll, "device_warm_steps": warm_steps,
+                "obs_spread": args.obs_spread, **({"obs_spread_note": spread_note} if spread_note else {}),
                 "placement_candidates_us_per_step": None if group.placement_probe_us is None else [round(v, 1) for v in group.placement_probe_us],
                 "preroll_mean_agents_per_env_by_64_step_window": [round(v, 2) for v in trace[-8:]],
                 "mean_agents_per_env": round((n_obs_pred + n_obs_prey) / env_steps_rank, 2),

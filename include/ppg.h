@@ -474,6 +474,18 @@ int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handle
 uint64_t ppg_policy_macs_per_observation(const ppg_policy *p);
 const char *ppg_policy_last_error(const ppg_policy *p);
 
+/* A device buffer for the caller-owned observation tensors whose physical pages are picked at random from a stretch of device
+ * memory `spread` times its size (HIP virtual memory management: spread x as many 2 MB chunks are created, a random subset is
+ * mapped in random order, the rest is given back at once).  Optional -- any device pointer works as obs_pred / obs_prey -- but where
+ * the pages of those two tensors lie decides how fast HBM takes the step's scattered 1 KB pieces: 62-64 us per 4096-env step with
+ * spread 32-64 against 62-91 us for what hipMalloc happens to return and 105-121 us for physically contiguous memory (DESIGN.md
+ * section 5.0).  Costs: spread 32 at 1.8 GB takes about 2.5 s and 58 GB of transient device memory; if the device cannot hold the
+ * pool the spread shrinks.  The memory is zero-filled by the driver.  Not in the CPU test build.  Returns PPG_OK or an error code
+ * (ppg_spread_last_error()). */
+int ppg_alloc_spread(int32_t device, uint64_t bytes, int32_t spread, uint64_t seed, void **out);
+int ppg_free_spread(void *ptr);
+const char *ppg_spread_last_error(void);
+
 /* Sort key of the decimal string of `id` (digits d: sum (d+1)*11^(5-pos)); host helper. */
 uint32_t ppg_lexkey(uint32_t id);
 

@@ -133,13 +133,14 @@ POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_d
                   "ppg_policy_last_error"]
 
 
+SPREAD_SYMBOLS = ["ppg_alloc_spread", "ppg_free_spread", "ppg_spread_last_error"]   # HIP library only, like the policy symbols
 EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_get_buffers", "ppg_reset", "ppg_reset_from_state", "ppg_observe", "ppg_step", "ppg_step_many",
     "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_set_wave_plan",
     "ppg_get_wave_plan", "ppg_rebalance",
     "ppg_export_grid", "ppg_walls_changed", "ppg_state_bytes", "ppg_export_state", "ppg_import_state", "ppg_pack_bytes", "ppg_pack",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_step_kernel_name", "ppg_last_error",
-] + POLICY_SYMBOLS
+] + POLICY_SYMBOLS + SPREAD_SYMBOLS
 
 
 def bind(lib: C.CDLL) -> C.CDLL:
@@ -191,6 +192,12 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_pack_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_uint32]
     lib.ppg_pack.restype = C.c_int
     lib.ppg_pack.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    if hasattr(lib, "ppg_alloc_spread"):
+        lib.ppg_alloc_spread.restype = C.c_int
+        lib.ppg_alloc_spread.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]
+        lib.ppg_free_spread.restype = C.c_int
+        lib.ppg_free_spread.argtypes = [C.c_void_p]
+        lib.ppg_spread_last_error.restype = C.c_char_p
     if hasattr(lib, "ppg_policy_create"):   # (the MFMA kernels exist in the HIP library only, not in the CPU test build)
         lib.ppg_policy_create.restype = C.c_int
         lib.ppg_policy_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(PpgPolicyWeights), C.POINTER(C.c_void_p)]

@@ -46,9 +46,14 @@ class BatchedPredPreyGrass:
     """
 
     def __init__(self, config=None, batch_size=1, device=None, obs_dtype=torch.float64,
-                 prey_capacity=128, seed=0, _library=None):
+                 prey_capacity=128, seed=0, _library=None, obs_spread=0):
+        """obs_spread = N > 1: the two observation tensors live in memory from `ppg_alloc_spread` (include/ppg.h) -- physical pages
+        picked at random from a stretch of device memory N times their size, which is what HBM wants for the step's scattered writes
+        (N = 32 costs a few seconds and N x the tensors' size of transient device memory).  They stay valid
+        until close()."""
         cfg = resolve_config(config)
         self.config = cfg
+        self._obs_spread = int(obs_spread)
         self.batch_size = int(batch_size)
         self._init_device(device, obs_dtype, _library)
         self.grid_size = int(cfg["grid_size"])
@@ -165,9 +170,34 @@ class BatchedPredPreyGrass:
         self.grass_energy = z((B, NG), torch.float64)
         nc = getattr(self, "obs_channels", 4)
         ncp, ncq = getattr(self, "obs_channels_pred", nc), getattr(self, "obs_channels_prey", nc)
-        self.obs_pred = z((B, self.pred_capacity, ncp, self.Rp, self.Rp), self.obs_dtype)
-        self.obs_prey = z((B, self.prey_capacity, ncq, self.Rq, self.Rq), self.obs_dtype)
+        self.obs_pred = self._obs_tensor((B, self.pred_capacity, ncp, self.Rp, self.Rp), seed_salt=1)
+        self.obs_prey = self._obs_tensor((B, self.prey_capacity, ncq, self.Rq, self.Rq), seed_salt=2)
         self.actions = torch.full((B, S), _abi.ACTION_NONE, dtype=torch.int8, device=dev)
+
+    def _obs_tensor(self, shape, seed_salt=0):
+        """An observation tensor: from torch's allocator, or (obs_spread > 1, HIP library) on spread physical pages."""
+        spread = getattr(self, "_obs_spread", 0)
+        if spread <= 1 or self.device.type != "cuda" or not hasattr(self._lib, "ppg_alloc_spread"):
+            return torch.zeros(shape, dtype=self.obs_dtype, device=self.device)
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=self.obs_dtype).element_size()
+        ptr = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        rc = self._lib.ppg_alloc_spread(dev_index, nbytes, spread, (id(self) << 4) ^ seed_salt, C.byref(ptr))
+        if rc != 0:
+            raise RuntimeError(f"ppg_alloc_spread failed ({rc}): {self._lib.ppg_spread_last_error().decode()}")
+
+        class _Holder:   # what torch.as_tensor needs to see device memory it does not own
+            pass
+
+        holder = _Holder()
+        holder.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
+        if not hasattr(self, "_spread_ptrs"):
+            self._spread_ptrs = []
+        self._spread_ptrs.append(ptr.value)
+        with torch.cuda.device(self.device):
+            t = torch.as_tensor(holder, device=self.device).view(self.obs_dtype).view(shape)
+            t.zero_()
+        return t
 
     def _create_handle(self, c, create_fn):
         bufs = _abi.PpgBuffers()
@@ -189,6 +219,9 @@ class BatchedPredPreyGrass:
         h, self._handle = getattr(self, "_handle", None), None
         if h:
             self._lib.ppg_destroy(h)
+        ptrs, self._spread_ptrs = getattr(self, "_spread_ptrs", []), []
+        for p in ptrs:   # (the observation tensors of an obs_spread env are dead from here on)
+            self._lib.ppg_free_spread(C.c_void_p(p))
 
     def __del__(self):
         try:

@@ -259,3 +259,6 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
 
 // policy inference next to the env (MFMA kernels + their host side)
 #include "ppg_policy.h"
+
+// observation buffers on physical pages spread over device memory
+#include "ppg_spread.h"

@@ -121,12 +121,13 @@ class BatchedRedQueen(BatchedPredPreyGrass):
     ``row_id``.  Observations default to float32, the reference's dtype (RQ:352-355)."""
 
     def __init__(self, config, batch_size=1, device=None, obs_dtype=torch.float32, prey_capacity=128, seed=0,
-                 walls=False, _library=None):
+                 walls=False, _library=None, obs_spread=0):
         """walls=True selects the walls_occlusion env ("WO"): observation channel 0 shows walls, wall / line-of-sight
         rules for moves and observations (config keys include_visibility_channel, respect_los_for_movement,
         mask_observation_with_visibility), per-agent move infos in `row_info`.  Walls are given with `set_walls`."""
         cfg = resolve_config(config)
         self.config = cfg
+        self._obs_spread = int(obs_spread)   # (BatchedPredPreyGrass: observation tensors on spread physical pages)
         self.walls = bool(walls)
         self.vis_channel = self.walls and bool(cfg.get("include_visibility_channel", False))   # WO:104
         self.obs_channels = 5 if self.vis_channel else 4

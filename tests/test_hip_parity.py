@@ -556,3 +556,30 @@ def test_placement_candidates_change_no_result():
         assert torch.equal(a.grass_energy, b.grass_energy)
         assert torch.equal(a.obs_pred[live[:, : a.pred_capacity]], b.obs_pred[live[:, : a.pred_capacity]])
         assert torch.equal(a.obs_prey[live[:, a.pred_capacity:]], b.obs_prey[live[:, a.pred_capacity:]])
+
+
+def test_spread_observation_tensors_change_no_result():
+    """obs_spread: the observation tensors on physical pages from ppg_alloc_spread (HIP virtual memory management) -- placement only.
+    Same results as on torch's allocator, for the step kernels, the fused rollout and an env that is closed and rebuilt."""
+    cfg = {**config_env, "max_steps": 60}
+    a = BatchedPredPreyGrass(cfg, batch_size=200, device="cuda:0", seed=9)
+    b = BatchedPredPreyGrass(cfg, batch_size=200, device="cuda:0", seed=9, obs_spread=4)
+    assert len(b._spread_ptrs) == 2 and b.obs_prey.data_ptr() in b._spread_ptrs and b.obs_prey.data_ptr() % (2 << 20) == 0
+    assert float(b.obs_prey.abs().sum()) == 0.0
+    for e in (a, b):
+        e.set_wave_plan(4, 0, 2)
+        e.reset()
+        for _ in range(80):
+            e.step(random_actions=True, auto_reset=True)
+        e.rollout(30, random_actions=True, auto_reset=True)
+    torch.cuda.synchronize()
+    for n in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+    b.close()
+    assert b._spread_ptrs == []
+    c = BatchedPredPreyGrass(cfg, batch_size=64, device="cuda:0", seed=9, obs_spread=2, obs_dtype=torch.bfloat16)
+    c.reset()
+    c.step(random_actions=True)
+    torch.cuda.synchronize()
+    assert bool((c.obs_prey.float() != 0).any())
+    c.close()

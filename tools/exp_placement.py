@@ -26,6 +26,8 @@ ap.add_argument("--spacer-mb", type=int, default=0, help="allocate (and keep) th
 ap.add_argument("--modes", default="torch", type=lambda v: v.split(","),
                 help="how group g allocates its observation tensors, cycled: torch (caching allocator), hipmalloc (hipExtMallocWithFlags default), "
                      "contiguous (hipDeviceMallocContiguous: physically contiguous)")
+ap.add_argument("--prey-caps", default="", type=lambda v: [int(x) for x in v.split(",")] if v else [],
+                help="prey row capacity of group g, cycled (default: the library's 128): the slab stride of obs_prey is capacity x 2592 bytes")
 ap.add_argument("--swap", action="store_true", help="second pass: NEW groups (fresh row tables, env words, handles) on the OLD groups' observation tensors")
 ap.add_argument("--arena-gb", type=float, default=0, help="first allocate one block of this size and give it back to torch's caching allocator: "
                                                         "every later tensor is then carved out of that ONE device allocation")
@@ -78,10 +80,14 @@ hip.hipMemSetAccess.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER
 hip.hipMemGetAllocationGranularity.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(MemAllocationProp), ctypes.c_int]
 
 
+hip.hipMemRelease.argtypes = [ctypes.c_void_p]
+
+
 class ScrambledDeviceBuffer:
     """A VA-contiguous buffer whose physical chunks (`chunk` bytes each, own hipMemCreate) are mapped in a pseudo-random order
-    (or in allocation order: scramble=False)."""
-    def __init__(self, nbytes, chunk=2 << 20, scramble=True, seed=1):
+    (or in allocation order: scramble=False).  spread = N > 1: N times as many chunks are created, a random n of them are mapped
+    and the others released again -- the buffer's physical pages then come from an N times larger stretch of device memory."""
+    def __init__(self, nbytes, chunk=2 << 20, scramble=True, seed=1, spread=1):
         prop = MemAllocationProp()
         prop.type = 1                    # hipMemAllocationTypePinned
         prop.location = MemLocation(1, 0)   # device 0
@@ -94,16 +100,25 @@ class ScrambledDeviceBuffer:
         base = ctypes.c_void_p()
         rc = hip.hipMemAddressReserve(ctypes.byref(base), size, 2 << 20, None, 0)
         assert rc == 0 and base.value, rc
+        import random
+        rng = random.Random(seed)
         order = list(range(n))
         if scramble:
-            import random
-            random.Random(seed).shuffle(order)
-        for i in range(n):   # chunk i (allocation order) goes to slot order[i] of the virtual range
+            rng.shuffle(order)
+        handles = []
+        for i in range(n * spread):
             h = ctypes.c_void_p()
             rc = hip.hipMemCreate(ctypes.byref(h), chunk, ctypes.byref(prop), 0)
             assert rc == 0, ("hipMemCreate", rc, i)
-            rc = hip.hipMemMap(ctypes.c_void_p(base.value + order[i] * chunk), chunk, 0, h, 0)
+            handles.append(h)
+        pick = sorted(rng.sample(range(n * spread), n)) if spread > 1 else list(range(n))
+        chosen = set(pick)
+        for j, i in enumerate(pick):   # the j-th chosen chunk (allocation order) goes to slot order[j] of the virtual range
+            rc = hip.hipMemMap(ctypes.c_void_p(base.value + order[j] * chunk), chunk, 0, handles[i], 0)
             assert rc == 0, ("hipMemMap", rc, i)
+        for i, h in enumerate(handles):
+            if i not in chosen:
+                hip.hipMemRelease(h)
         acc = MemAccessDesc(MemLocation(1, 0), 3)
         rc = hip.hipMemSetAccess(base, size, ctypes.byref(acc), 1)
         assert rc == 0, ("hipMemSetAccess", rc)
@@ -125,9 +140,16 @@ def _alloc_with_mode(self, prey_capacity):
         m = alloc_mode[0]
         if m.startswith("scrambled") or m.startswith("ordered"):   # scrambled[:chunk KB] / ordered[:chunk KB]
             kb = int(m.split(":")[1]) if ":" in m else 2048          # chunk size in KB
-            raw = ScrambledDeviceBuffer(nbytes, chunk=kb << 10, scramble=m.startswith("scrambled"), seed=id(self) & 0xFFFF)
+            spread = int(m.split(":")[2]) if m.count(":") > 1 else 1                   # scrambled:<chunk KB>:<spread>
+            raw = ScrambledDeviceBuffer(nbytes, chunk=kb << 10, scramble=m.startswith("scrambled"), seed=id(self) & 0xFFFF, spread=spread)
             if not hasattr(_alloc_with_mode, "said"):
                 _alloc_with_mode.said = print(f"({m}: {raw.chunks} chunks, granularity {raw.granularity})")
+        elif m.endswith("_off"):   # contiguous_off / hipmalloc_off: the tensor starts at a per-tensor pseudo-random multiple of 4 KB inside its allocation
+            _alloc_with_mode.count = getattr(_alloc_with_mode, "count", 0) + 1
+            delta = ((_alloc_with_mode.count * 2654435761) >> 7) % 1024 * 4096          # < 4 MB
+            raw = RawDeviceBuffer(nbytes + (4 << 20), {"contiguous_off": 0x4, "hipmalloc_off": 0x0}[m])
+            raw.ptr += delta
+            raw.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (raw.ptr, False), "version": 2}
         else:
             raw = RawDeviceBuffer(nbytes, {"contiguous": 0x4, "hipmalloc": 0x0}[m])
         new = torch.as_tensor(raw, device="cuda:0").view(t.dtype).view(t.shape)
@@ -141,8 +163,12 @@ ap2_modes = None
 groups, spacers = [], []
 for g in range(args.groups):
     alloc_mode[0] = args.modes[g % len(args.modes)]
-    grp = SubBatchedPredPreyGrass(dict(config_env), batch_size=args.envs, n_sub=args.streams, device="cuda:0", obs_dtype=torch.float64, seed=1000 * g)
+    kw = {"prey_capacity": args.prey_caps[g % len(args.prey_caps)]} if args.prey_caps else {}
+    t_alloc = time.perf_counter()
+    grp = SubBatchedPredPreyGrass(dict(config_env), batch_size=args.envs, n_sub=args.streams, device="cuda:0", obs_dtype=torch.float64, seed=1000 * g, **kw)
     grp.reset()
+    torch.cuda.synchronize()
+    print(f"group {g} [{alloc_mode[0]}] built in {time.perf_counter() - t_alloc:.2f} s")
     groups.append(grp)
     if args.spacer_mb:
         spacers.append(torch.empty(args.spacer_mb << 20, dtype=torch.uint8, device="cuda:0"))
@@ -173,7 +199,7 @@ for r in range(args.rounds):
 print(f"# {args.groups} env groups of {args.envs} envs ({args.streams} sub-batches each), {args.segment}-step segments, us per step")
 for g, v in enumerate(res):
     ptrs = [hex(e.obs_prey.data_ptr()) for e in groups[g].subs]
-    print(f"group {g} [{args.modes[g % len(args.modes)]:10s}]: median {statistics.median(v):7.2f}  all {[round(x, 1) for x in v]}   obs_prey at {ptrs}")
+    print(f"group {g} [{args.modes[g % len(args.modes)]:10s} cap {groups[g].subs[0].prey_capacity:3d}]: median {statistics.median(v):7.2f}  all {[round(x, 1) for x in v]}   obs_prey at {ptrs}")
 
 # does a plain fill of the same buffers see the same difference?  (a probe a constructor could run)
 def fill_time(tensors, reps=30):
