@@ -737,7 +737,9 @@ def main(argv=None, backend=None):
             "traffic": traffic,
             "traffic_source": traffic_src,
             "write_pattern_ceiling": "the same write pattern and launch structure with no compute (tools/store_patterns4.hip, "
-                                     "profiles/r03): 61-70 us per 4096-env step depending on the box and its state; linear fill 6.5 TB/s",
+                                     "profiles/r03) in plain hipMalloc memory: 61-73 us per 4096-env step depending on where the driver put "
+                                     "the buffer; a linear fill of the observation tensors: 6.3 TB/s = 61 us for the bytes of a step -- which is what "
+                                     "the step reaches on spread pages (config.obs_spread)",
             "kernel": kernel_name,
             "kernel_ms": round(kernel_s * 1e3, 5),
             "kernel_ms_sustained": None if sustained is None else round(sustained["kernel_ms"], 5),

@@ -27,6 +27,7 @@ ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--workload", default="base")
 ap.add_argument("--obs-dtype", default="f64")
 ap.add_argument("--rebalance-every", type=int, default=64)
+ap.add_argument("--obs-spread", type=int, default=32, help="BatchedPredPreyGrass(obs_spread=N): observation tensors on spread physical pages (0 = torch's allocator)")
 ap.add_argument("plans", nargs="+")
 args = ap.parse_args()
 
@@ -52,7 +53,7 @@ if args.workload == "walls":       # the walls variant: the reference's zigzag l
 if args.workload == "drive":
     cfg["enable_drive_channels"] = True
 group = SubBatchedPredPreyGrass(cfg, batch_size=args.envs, n_sub=args.streams, device="cuda:0",
-                                obs_dtype=torch.float64 if args.obs_dtype == "f64" else torch.float32, **kw)
+                                obs_dtype=torch.float64 if args.obs_dtype == "f64" else torch.float32, obs_spread=args.obs_spread, **kw)
 if args.workload == "walls":
     for e in group.subs:
         e.set_walls(cfg["manual_wall_positions"])
