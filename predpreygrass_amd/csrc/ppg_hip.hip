@@ -257,8 +257,8 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     return PPG_OK;
 }
 
+// device buffers on physical pages spread over device memory (observation tensors; the policy kernels' scratch slots)
+#include "ppg_spread.h"
+
 // policy inference next to the env (MFMA kernels + their host side)
 #include "ppg_policy.h"
-
-// observation buffers on physical pages spread over device memory
-#include "ppg_spread.h"

@@ -902,6 +902,7 @@ struct ppg_policy {
     ppgpol::PolParams base;
     void *dev_weights;     // one allocation: fragments + biases
     __bf16 *xg;            // scratch slots
+    bool xg_is_spread;     // (from ppg_alloc_spread)
     uint32_t *plan;        // [PLAN_HDR + plan_envs] header + prefix sums, then the first env of every tile
     int32_t plan_envs;
     int32_t grid;
@@ -1074,7 +1075,16 @@ int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_action
     if (const char *g = getenv("PPG_POLICY_GRID")) p->grid = atoi(g) > 0 ? atoi(g) : p->grid;   // resident workgroups
 #endif
     const size_t xg_bytes = (size_t)p->grid * ppgpol::TILE * K1 * 2;
-    if (hipMalloc((void **)&p->xg, xg_bytes) != hipSuccess || hipMemset(p->xg, 0, xg_bytes) != hipSuccess) {
+    // the scratch slots: 512 concurrent sequential streams, written by conv3 and read back by FC1 -- on spread physical pages like the
+    // env's observation tensors where the virtual-memory calls work (-DPPG_POLICY_XG_SPREAD=0: A/B builds)
+#ifndef PPG_POLICY_XG_SPREAD
+#define PPG_POLICY_XG_SPREAD 16
+#endif
+    const int xg_spread = PPG_POLICY_XG_SPREAD;
+    void *xg_ptr = nullptr;
+    p->xg_is_spread = xg_spread > 1 && ppg_alloc_spread(device, (uint64_t)xg_bytes, xg_spread, 0x5850u + (uint64_t)obs_range, &xg_ptr) == PPG_OK;
+    if (p->xg_is_spread) p->xg = (__bf16 *)xg_ptr;
+    if ((!p->xg_is_spread && hipMalloc((void **)&p->xg, xg_bytes) != hipSuccess) || hipMemset(p->xg, 0, xg_bytes) != hipSuccess) {
         (void)hipFree(p->dev_weights);
         delete p;
         return ppg_policy_fail(nullptr, PPG_EHIP, "hipMalloc of %zu bytes of scratch failed", xg_bytes);
@@ -1094,7 +1104,7 @@ int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_action
 int ppg_policy_destroy(ppg_policy *p) {
     if (!p) return PPG_OK;
     if (p->dev_weights) (void)hipFree(p->dev_weights);
-    if (p->xg) (void)hipFree(p->xg);
+    if (p->xg) { if (p->xg_is_spread) (void)ppg_free_spread(p->xg); else (void)hipFree(p->xg); }
     if (p->plan) (void)hipFree(p->plan);
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->fork) (void)hipEventDestroy(p->fork);
