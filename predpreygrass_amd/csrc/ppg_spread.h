@@ -124,10 +124,11 @@ int ppg_free_spread(void *ptr) {
         g_regions.erase(it);
     }
     (void)hipDeviceSynchronize();
-    hipError_t e = hipMemUnmap(ptr, r.size);
+    hipError_t e = hipMemUnmap(ptr, r.size);   // (gives the physical chunks back: their handles were released after mapping)
     if (e != hipSuccess) return fail(PPG_EHIP, "hipMemUnmap", e);
-    e = hipMemAddressFree(ptr, r.size);
-    if (e != hipSuccess) return fail(PPG_EHIP, "hipMemAddressFree", e);
+    // The virtual range is NOT handed back (hipMemAddressFree): a later reservation that got the same addresses read and wrote through
+    // stale translations of the old mapping (ROCm 7.2, gfx950: a fill of a re-used range left 13 % of it untouched --
+    // tests/test_hip_parity.py::test_spread_allocator_argument_errors).  A dead range costs address space only (47 bits of it exist).
     return PPG_OK;
 }
 

@@ -583,3 +583,26 @@ def test_spread_observation_tensors_change_no_result():
     torch.cuda.synchronize()
     assert bool((c.obs_prey.float() != 0).any())
     c.close()
+
+
+def test_spread_allocator_argument_errors():
+    import ctypes as C
+    lib = _abi.load_hip_library()
+    out = C.c_void_p()
+    assert lib.ppg_alloc_spread(0, 0, 4, 1, C.byref(out)) == -1            # PPG_EINVAL: no bytes
+    assert lib.ppg_alloc_spread(0, 1 << 20, 0, 1, C.byref(out)) == -1       # spread < 1
+    assert lib.ppg_alloc_spread(99, 1 << 20, 2, 1, C.byref(out)) == -4      # PPG_ENODEV
+    assert b"device" in lib.ppg_spread_last_error()
+    assert lib.ppg_free_spread(C.c_void_p(0x1000)) == -1                    # not ours
+    assert lib.ppg_free_spread(None) == 0
+    assert lib.ppg_alloc_spread(0, 5 << 20, 3, 7, C.byref(out)) == 0 and out.value and out.value % (2 << 20) == 0
+    t = torch.zeros(4, device="cuda:0")   # (the range is ordinary device memory)
+    import numpy as np
+    holder = type("H", (), {})()
+    holder.__cuda_array_interface__ = {"shape": (5 << 20,), "typestr": "|u1", "data": (out.value, False), "version": 2}
+    v = torch.as_tensor(holder, device="cuda:0")
+    v.fill_(7)
+    assert int(v.sum().item()) == 7 * (5 << 20) and float(t.sum()) == 0.0
+    del v
+    assert lib.ppg_free_spread(out) == 0
+    assert lib.ppg_free_spread(out) == -1                                    # twice
