@@ -21,7 +21,10 @@ interact).  `python bench.py --gpus N` without a torch.distributed launcher star
 For N>1 two extra legs measure the step followed by the ONE RCCL all-gather of the packed observation
 image that north_star specifies ("obs_gather", "obs_gather_overlapped"; bandwidth-bound on xGMI, see
 DESIGN.md).  Within one GPU the 4096 envs are stepped as --streams (default 3) independent sub-batches on
-separate HIP streams.
+separate HIP streams.  Their observation tensors are allocated with ppg_alloc_spread (--obs-spread, default 32: physical
+pages from a large stretch of device memory, which is what HBM wants for the step's scattered writes -- DESIGN.md 5.0), and
+of --placement-candidates (default 2) such buffer sets the faster one is kept; both are allocation choices, results never depend
+on them.
 
 Prints ONE JSON line (rank 0).
 """
