@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Soak run on a GPU: the cooperative step kernels (every wave plan the library ships), with the observation tensors on spread
+physical pages, long random rollouts with device reset / Philox actions / auto-reset, EVERY env compared with its CPU oracle on
+EVERY call; then ppg_rollout against the same number of steps.   usage: gpu_soak_coop.py [envs=96] [calls=400]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from oracle.ppg_oracle import OracleEnv  # noqa: E402
+from oracle.rq_oracle import RQOracleEnv  # noqa: E402
+from predpreygrass_amd.batched import BatchedPredPreyGrass  # noqa: E402
+from predpreygrass_amd.config import config_env  # noqa: E402
+from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base  # noqa: E402
+from tests import parity_utils as P1, parity_utils_rq as P2  # noqa: E402
+from tests.golden_io_rq import RQGoldenCase  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+t0 = time.time()
+short = {**config_env, "max_steps": 150}
+for plan in ((4, 0, 2), (4, 0, 4), (6, 0, 3), (8, 0, 2), (16, 0, 1)):
+    for cfg, dt in ((short, torch.float64), ({**short, "grid_size": 12, "initial_num_grass": 50}, torch.float32)):
+        env = BatchedPredPreyGrass(cfg, batch_size=B, device="cuda:0", obs_dtype=dt, obs_spread=4)
+        env.set_wave_plan(*plan)
+        assert env.wave_plan() == plan, (plan, env.wave_plan())
+        r = P1.rollout_vs_oracle(env, lambda cfg=cfg: OracleEnv(cfg), seed0=1000 + plan[0] * 10 + plan[2], n_calls=calls, check_grid=True)
+        print("base", plan, env.step_kernel_name(), cfg["grid_size"], str(dt)[6:], "resets", r, f"{time.time() - t0:.0f} s", flush=True)
+        env.close()
+mixed = dict(RQGoldenCase("rq_mixed_types_seed7").config, max_steps=120)
+for plan in ((4, 0, 2), (4, 0, 4)):
+    for cfg in (dict(config_env_base, max_steps=150), mixed):
+        env = BatchedRedQueen(cfg, batch_size=B, device="cuda:0", obs_spread=4)
+        env.set_wave_plan(*plan)
+        r = P2.rollout_vs_oracle(env, lambda cfg=cfg: RQOracleEnv(cfg), seed0=77 + plan[2], n_calls=calls, check_every=1, check_grid=True)
+        print("gen2", plan, env.step_kernel_name(), "resets/stats", r, f"{time.time() - t0:.0f} s", flush=True)
+        env.close()
+# fused rollouts at full size: 4096 envs, cooperative plan, spread pages, against per-step launches on plain tensors
+for cls, cfg, name in ((BatchedPredPreyGrass, {**config_env, "max_steps": 200}, "base"), (BatchedRedQueen, dict(config_env_base, max_steps=200), "gen2")):
+    a = cls(cfg, batch_size=4096, device="cuda:0", seed=5)
+    b = cls(cfg, batch_size=4096, device="cuda:0", seed=5, obs_spread=8)
+    b.set_wave_plan(4, 0, 2)
+    a.reset()
+    b.reset()
+    for _ in range(600):
+        a.step(random_actions=True, auto_reset=True)
+    for _ in range(6):
+        b.rollout(100, random_actions=True, auto_reset=True)
+    torch.cuda.synchronize()
+    for n in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), (name, n)
+    print(name, "4096 envs: 600 steps == 6 x ppg_rollout(100) on spread pages", f"{time.time() - t0:.0f} s", flush=True)
+print("soak ok", f"{time.time() - t0:.0f} s")
