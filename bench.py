@@ -23,7 +23,7 @@ image that north_star specifies ("obs_gather", "obs_gather_overlapped"; bandwidt
 DESIGN.md).  Within one GPU the 4096 envs are stepped as --streams (default 3) independent sub-batches on
 separate HIP streams.  Their observation tensors are allocated with ppg_alloc_spread (--obs-spread, default 32: physical
 pages from a large stretch of device memory, which is what HBM wants for the step's scattered writes -- DESIGN.md 5.0), and
-of --placement-candidates (default 2) such buffer sets the faster one is kept; both are allocation choices, results never depend
+of --placement-candidates (default 3) such buffer sets the fastest is kept; both are allocation choices, results never depend
 on them.
 
 Prints ONE JSON line (rank 0).
@@ -42,6 +42,31 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r03", "bench_driver_summary.json")
+
+
+def device_state():
+    """Clocks, package power and temperatures as `rocm-smi` reports them right now (one subprocess, ~0.3 s): printed next to the numbers so
+    that a slow run can be told from a hot or throttled GPU.  None if the tool is missing."""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showtemp", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+    except Exception:
+        return None
+    state = {}
+    for line in out.splitlines():
+        m = re.search(r"GPU\[0\]\s*:\s*(.+?):\s*(.+)$", line)
+        if not m:
+            continue
+        key, val = m.group(1).strip(), m.group(2).strip()
+        if key.startswith("Temperature"):
+            state["temp_" + key.split("(Sensor ")[-1].split(")")[0].strip().replace(" ", "_") + "_C"] = val
+        elif "clock level" in key and key.split()[0] in ("sclk", "mclk", "fclk", "socclk"):
+            mm = re.search(r"\((\d+)Mhz\)", val)
+            state[key.split()[0] + "_MHz"] = int(mm.group(1)) if mm else val
+        elif "Power" in key:
+            state["power_W"] = val
+    return state or None
 
 
 def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
@@ -237,7 +262,7 @@ def parse_args(argv):
                          "their size of device memory (ppg_alloc_spread, HIP virtual memory management): 62-64 us per 4096-env step at N = "
                          "32-64 where plain allocations draw from 62-91 us (profiles/r03/e_placement_experiments.txt).  N = 32 costs ~2.5 s and "
                          "58 GB of transient device memory at the headline size.  0 = torch's allocator")
-    ap.add_argument("--placement-candidates", type=int, default=2,
+    ap.add_argument("--placement-candidates", type=int, default=3,
                     help="SubBatchedPredPreyGrass(placement_candidates=K): where the driver puts the observation tensors in HBM decides "
                          "whether the step's scattered writes run in 62-66 or 76-81 us (same box, same process, same kernel: "
                          "profiles/r03/e_placement_experiments.txt); the constructor builds K candidate buffer sets side by side, steps each for "
@@ -562,6 +587,20 @@ def main(argv=None, backend=None):
                      "kernel_ms": sum(a.elapsed_time(b) for a, b in zip(s0, s1)) / len(s0) / args.sustained_steps,
                      "ms_per_step": ts / args.sustained_steps * 1e3}
 
+    # clocks / power / temperatures WHILE the same loop runs (untimed extra steps on rank 0 for as long as one rocm-smi call takes)
+    dev_state = None
+    if not dry and rank == 0 and not args.traffic_child and args.sustained_steps > 0:
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(state=device_state()))
+        th.start()
+        while th.is_alive():
+            for _ in range(64):
+                one_step()
+            backend.synchronize(device)
+        th.join()
+        dev_state = box.get("state")
+
     # ---- third leg: the FUSED rollout -- ppg_rollout(n): n transitions per launch, the device-side random policy, observations
     # written every step exactly as above (bit-identical to n ppg_step calls; tests).  Reported next to `value`, never as `value`:
     # `value` is the per-step API, which also takes actions from outside.
@@ -791,6 +830,7 @@ def main(argv=None, backend=None):
                 "parallelism": f"batch-sharded x{n_gpus}, no data-path collective",
                 "sub_batches_per_gpu": n_sub,
                 "preroll_steps": preroll, "device_warm_steps": warm_steps,
+                "device_state_under_load": dev_state,
                 "obs_spread": args.obs_spread, **({"obs_spread_note": spread_note} if spread_note else {}),
                 "placement_candidates_us_per_step": None if group.placement_probe_us is None else [round(v, 1) for v in group.placement_probe_us],
                 "preroll_mean_agents_per_env_by_64_step_window": [round(v, 2) for v in trace[-8:]],
