@@ -81,13 +81,15 @@ hip.hipMemGetAllocationGranularity.argtypes = [ctypes.POINTER(ctypes.c_size_t), 
 
 
 hip.hipMemRelease.argtypes = [ctypes.c_void_p]
+hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+hip.hipFree.argtypes = [ctypes.c_void_p]
 
 
 class ScrambledDeviceBuffer:
     """A VA-contiguous buffer whose physical chunks (`chunk` bytes each, own hipMemCreate) are mapped in a pseudo-random order
     (or in allocation order: scramble=False).  spread = N > 1: N times as many chunks are created, a random n of them are mapped
     and the others released again -- the buffer's physical pages then come from an N times larger stretch of device memory."""
-    def __init__(self, nbytes, chunk=2 << 20, scramble=True, seed=1, spread=1):
+    def __init__(self, nbytes, chunk=2 << 20, scramble=True, seed=1, spread=1, regions=1, gap_gb=0):
         prop = MemAllocationProp()
         prop.type = 1                    # hipMemAllocationTypePinned
         prop.location = MemLocation(1, 0)   # device 0
@@ -105,12 +107,19 @@ class ScrambledDeviceBuffer:
         order = list(range(n))
         if scramble:
             rng.shuffle(order)
-        handles = []
+        handles, spacers = [], []
+        per_region = (n * spread + regions - 1) // regions
         for i in range(n * spread):
+            if regions > 1 and i and i % per_region == 0:   # a spacer allocation between two parts of the pool: the next chunks come from beyond it
+                sp = ctypes.c_void_p()
+                if hip.hipMalloc(ctypes.byref(sp), int(gap_gb * (1 << 30))) == 0:
+                    spacers.append(sp)
             h = ctypes.c_void_p()
             rc = hip.hipMemCreate(ctypes.byref(h), chunk, ctypes.byref(prop), 0)
             assert rc == 0, ("hipMemCreate", rc, i)
             handles.append(h)
+        for sp in spacers:
+            hip.hipFree(sp)
         pick = sorted(rng.sample(range(n * spread), n)) if spread > 1 else list(range(n))
         chosen = set(pick)
         for j, i in enumerate(pick):   # the j-th chosen chunk (allocation order) goes to slot order[j] of the virtual range
@@ -140,8 +149,11 @@ def _alloc_with_mode(self, prey_capacity):
         m = alloc_mode[0]
         if m.startswith("scrambled") or m.startswith("ordered"):   # scrambled[:chunk KB] / ordered[:chunk KB]
             kb = int(m.split(":")[1]) if ":" in m else 2048          # chunk size in KB
-            spread = int(m.split(":")[2]) if m.count(":") > 1 else 1                   # scrambled:<chunk KB>:<spread>
-            raw = ScrambledDeviceBuffer(nbytes, chunk=kb << 10, scramble=m.startswith("scrambled"), seed=id(self) & 0xFFFF, spread=spread)
+            f = m.split(":")                                                              # scrambled:<chunk KB>:<spread>[:<regions>:<gap GB>]
+            spread = int(f[2]) if len(f) > 2 else 1
+            regions, gap = (int(f[3]), float(f[4])) if len(f) > 4 else (1, 0)
+            raw = ScrambledDeviceBuffer(nbytes, chunk=kb << 10, scramble=m.startswith("scrambled"), seed=id(self) & 0xFFFF, spread=spread,
+                                        regions=regions, gap_gb=gap)
             if not hasattr(_alloc_with_mode, "said"):
                 _alloc_with_mode.said = print(f"({m}: {raw.chunks} chunks, granularity {raw.granularity})")
         elif m.endswith("_off"):   # contiguous_off / hipmalloc_off: the tensor starts at a per-tensor pseudo-random multiple of 4 KB inside its allocation
