@@ -33,10 +33,12 @@ from .distributed import shard_range
 
 class SubBatchedPredPreyGrass:
     def __init__(self, config=None, batch_size=4096, n_sub=2, device="cuda:0", seed=0, env_class=BatchedPredPreyGrass,
-                 placement_candidates=1, placement_setup=None, **kw):
+                 placement_candidates=1, placement_setup=None, placement_target_us=None, placement_max_candidates=12, **kw):
         """env_class: BatchedPredPreyGrass (base family) or red_queen.BatchedRedQueen (second generation).
         placement_candidates: > 1 = build that many candidate buffer sets and keep the one that steps fastest (module docstring);
-        placement_setup(env): called on every candidate sub-batch before it is measured (e.g. set_walls)."""
+        placement_setup(env): called on every candidate sub-batch before it is measured (e.g. set_walls);
+        placement_target_us: if none of the candidates probes below this many microseconds per step, further candidates are drawn one
+        at a time until one does or `placement_max_candidates` have been tried (some boxes hand out mostly slow placements)."""
         self.device = torch.device(device)
         self.batch_size = int(batch_size)
         self.offsets = [shard_range(self.batch_size, k, n_sub) for k in range(n_sub)]
@@ -59,6 +61,12 @@ class SubBatchedPredPreyGrass:
             self.placement_probe_us = []
             for subs in sets:
                 self.subs = subs
+                self._forget_handles()
+                self.placement_probe_us.append(self._probe_placement())
+            while placement_target_us is not None and min(self.placement_probe_us) > float(placement_target_us) \
+                    and len(sets) < int(placement_max_candidates):
+                sets.append(build())
+                self.subs = sets[-1]
                 self._forget_handles()
                 self.placement_probe_us.append(self._probe_placement())
             keep = min(range(len(sets)), key=lambda k: self.placement_probe_us[k])
