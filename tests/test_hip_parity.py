@@ -606,3 +606,18 @@ def test_spread_allocator_argument_errors():
     del v
     assert lib.ppg_free_spread(out) == 0
     assert lib.ppg_free_spread(out) == -1                                    # twice
+
+
+def test_spread_allocator_gives_the_memory_back():
+    """More bytes than the device has, allocated and freed in turn: ppg_free_spread returns the physical memory (the virtual ranges are
+    retired, not re-used)."""
+    import ctypes as C
+    lib = _abi.load_hip_library()
+    total = torch.cuda.get_device_properties(0).total_memory
+    size, seen = 8 << 30, set()
+    for i in range(int(total * 1.25 / size) + 1):
+        out = C.c_void_p()
+        assert lib.ppg_alloc_spread(0, size, 1, i, C.byref(out)) == 0, (i, lib.ppg_spread_last_error())
+        assert out.value not in seen
+        seen.add(out.value)
+        assert lib.ppg_free_spread(out) == 0
