@@ -54,6 +54,11 @@ def device_state():
     except Exception:
         return None
     state = {}
+    try:   # which GPU of the node this is: the placements a process draws were seen to differ from GPU to GPU
+        import torch
+        state["gpu_uuid"] = str(torch.cuda.get_device_properties(torch.cuda.current_device()).uuid)
+    except Exception:
+        pass
     for line in out.splitlines():
         m = re.search(r"GPU\[0\]\s*:\s*(.+?):\s*(.+)$", line)
         if not m:

@@ -11,6 +11,7 @@ from predpreygrass_amd.config import config_env  # noqa: E402
 from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass  # noqa: E402
 
 spread = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+print("gpu", torch.cuda.get_device_properties(0).uuid, torch.cuda.get_device_name(0))
 for rnd in range(4):
     t0 = time.perf_counter()
     g = SubBatchedPredPreyGrass(dict(config_env), batch_size=4096, n_sub=3, device="cuda:0", obs_dtype=torch.float64, obs_spread=spread,

@@ -172,6 +172,7 @@ def _alloc_with_mode(self, prey_capacity):
 
 BatchedPredPreyGrass._alloc_buffers = _alloc_with_mode
 ap2_modes = None
+print("gpu", torch.cuda.get_device_properties(0).uuid)
 groups, spacers = [], []
 for g in range(args.groups):
     alloc_mode[0] = args.modes[g % len(args.modes)]
