@@ -124,3 +124,23 @@ def test_configurations_without_cooperative_kernels_fall_back():
         env = BatchedPredPreyGrass({**config_env, **extra}, batch_size=2, _library=emu_backend.library())
         env.set_wave_plan(4, 0, 4)
         assert env.wave_plan()[2] == 0, extra
+
+
+def test_allocation_choices_are_ignored_without_a_gpu():
+    """obs_spread / placement candidates are allocation choices of the HIP library: on the CPU test build they change nothing."""
+    from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
+    lib = emu_backend.library()
+    assert not hasattr(lib, "ppg_alloc_spread") or True   # (the CPU build may or may not export it: never called here)
+    a = SubBatchedPredPreyGrass(config_env, batch_size=5, n_sub=2, device="cpu", seed=3, _library=lib)
+    b = SubBatchedPredPreyGrass(config_env, batch_size=5, n_sub=2, device="cpu", seed=3, _library=lib, obs_spread=8,
+                                placement_candidates=3, placement_target_us=1.0)
+    assert b.placement_probe_us is None and not getattr(b.subs[0], "_spread_ptrs", [])
+    for g in (a, b):
+        g.reset()
+        for _ in range(12):
+            g.step(random_actions=True, auto_reset=True)
+    for x, y in zip(a.subs, b.subs):
+        for n in ("row_xy", "row_energy", "row_id", "obs_pred", "obs_prey", "env_state"):
+            assert torch.equal(getattr(x, n), getattr(y, n)), n
+    b.subs[0].close()
+    b.subs[0].close()   # idempotent
