@@ -226,6 +226,8 @@ def parse_args(argv):
     ap.add_argument("--obs-dtype", choices=["f64", "f32", "bf16"], default=None,
                     help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen, bf16 -- the "
                          "compact rows the policy kernels stage without conversion -- for policy_rollout)")
+    ap.add_argument("--policy-arch", choices=["rllib", "fc256", "r3"], default="rllib",
+                    help="policy_rollout: the network (rllib = what RLlib builds from the reference's model_config)")
     ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls", "policy_rollout"], default="base",
                     help="base: BASELINE.json configs[2] (the headline); c4: configs[3] (64x64 grid, 16 predators / 32 prey, "
                          "7x7 windows); red_queen: the second-generation env (SURVEY 8(f) N2) with its reference config; "
@@ -309,8 +311,17 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
     obs_dtype = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[args.obs_dtype]
     env = BatchedPredPreyGrass(cfg, batch_size=B, device=device, obs_dtype=obs_dtype, seed=args.seed + rank * B)
     torch.manual_seed(1234)
-    nets = [PolicyNet(env.Rp), PolicyNet(env.Rq)]
+    # --policy-arch rllib (default): what RLlib builds from tune_ppo_base_environment.py:106-141 -- channels-last reading, conv 3x3
+    # 16/32/64, ONE Linear head (tests/golden/rllib_checkpoint/); fc256: the same encoder with head_fcnet_hiddens [256, 256];
+    # r3: rounds 2-3's network (channel-first image, 256/256 head, channel-major flatten)
+    arch_kw = {"rllib": dict(), "fc256": dict(head_hiddens=(256, 256)), "r3": dict(layout="chw", head_hiddens=(256, 256))}[args.policy_arch]
+    nets = [PolicyNet(env.Rp, **arch_kw), PolicyNet(env.Rq, **arch_kw)]
     fused = FusedPolicy(nets[0], nets[1], device=device)
+    arch_text = {"rllib": "channels-last 4 x R image with R channels, conv 3x3 16/32/64, flatten, ONE Linear(flat, 9) head: what RLlib's "
+                          "DefaultPPOTorchRLModule builds from that model_config (fcnet_hiddens is ignored for image observations; pinned by the "
+                          "reference tree's own checkpoint, tests/golden/rllib_checkpoint/)",
+                 "fc256": "channels-last conv 3x3 16/32/64 + head_fcnet_hiddens [256, 256] + Linear(256, 9)",
+                 "r3": "rounds 2-3's reading: channel-first R x R image, conv 3x3 16/32/64 + FC 256/256/9"}[args.policy_arch]
     env.reset()
     t_step = [0]
 
@@ -356,8 +367,8 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {
                 "workload": (f"POLICY ROLLOUT, NOT the BASELINE.json headline config: {B} envs x {env.grid_size}x{env.grid_size} grid per GPU, "
-                             f"default config, every step = the two policy networks of the reference's PPO setup (conv 3x3 16/32/64 + FC "
-                             f"256/256/9, random-initialised, bf16 MFMA with fp32 accumulation) evaluated on the {args.obs_dtype} observation rows "
+                             f"default config, every step = the two policy networks of the reference's PPO setup ({arch_text}; "
+                             f"random-initialised, bf16 MFMA with fp32 accumulation) evaluated on the {args.obs_dtype} observation rows "
                              "in place, actions sampled on the device, then ppg_step with those actions and auto-reset"),
                 "envs_per_gpu": B, "parallelism": f"batch-sharded x{n_gpus}, no data-path collective", "preroll_steps": preroll,
                 "mean_agents_per_env": round((n_pred + n_prey) / (B * args.steps), 2),
@@ -365,10 +376,12 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
             },
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "ppg_policy_forward_" + args.obs_dtype,
+                         "kernel": ("ppg_policy_direct{8,16}_" if args.policy_arch == "rllib" else "ppg_policy_forward_") + args.obs_dtype,
+                         "policy_arch": args.policy_arch,
+                         "macs_per_observation": [fused.macs_per_observation(0), fused.macs_per_observation(1)],
                          "kernel_ms": round(pol_ms / args.steps, 5),
                          "flops_per_step": int(flops / args.steps),
-                         "note": "flops = 2 x multiply-accumulates of the six layers (no padding counted) x observations evaluated; "
+                         "note": "flops = 2 x multiply-accumulates of the network's layers (no padding counted) x observations evaluated; "
                                  "kernel_ms = both species' forward launches + their plan launches per step (HIP events on the stream)"},
         }
         if not args.no_cpu_baseline and n_gpus == 1:

@@ -427,14 +427,21 @@ uint64_t ppg_pack_bytes(const ppg_handle *h, int32_t n_envs, int64_t n_pred_rows
 int ppg_pack(ppg_handle *const *handles, int32_t n, void *out, uint64_t capacity, uint32_t flags, void *stream);
 
 /* ---- policy inference next to the env (base_environment/tune_ppo_base_environment.py:106-141) ----------
- * The reference trains two PPO policies (predator_policy / prey_policy) whose network is: conv 3x3 stride 1 "same" with
- * 16, 32, 64 filters (ReLU), flatten, fully connected 256, 256 (ReLU), n_actions logits.  ppg_policy_act evaluates such a
- * network for EVERY row in use of the handles' last call, reading the observation rows in place (obs_pred / obs_prey of
- * ppg_buffers, float64 or float32) and writing the chosen action into actions[b][slot] -- the observations never leave
- * the GPU and what a consumer has to move per agent is one byte.  Arithmetic: bf16 operands, fp32 accumulation, on the
- * matrix cores (v_mfma_f32_32x32x16_bf16); activations are rounded to bf16 between layers.  The reference's own module
- * (ray.rllib DefaultPPOTorchRLModule) is not importable here: parity is pinned against a float32 PyTorch module of the
- * architecture above on the same weights, within the tolerance the tests state. */
+ * The reference trains two PPO policies (predator_policy / prey_policy) with RLlib's DefaultPPOTorchRLModule and
+ * model_config {conv_filters [[16,[3,3],1],[32,[3,3],1],[64,[3,3],1]], fcnet_hiddens [256,256], fcnet_activation relu}.
+ * WHAT RLLIB BUILDS FROM THAT (pinned by the checkpoint the reference tree holds, .../shared_prey/experiments/PPO_v_APPO/.../
+ * checkpoint_000099/learner_group/learner/rl_module/type_1_predator/module_state.pkl, ray 2.52.1; tests/golden/rllib_checkpoint/):
+ * a 3-D Box is read channels-LAST -- the (C,R,R) observation is an image of C rows x R columns with R channels -- by a CNN encoder
+ * of one ZeroPad2d + Conv2d(3x3, stride 1) + ReLU per conv_filters entry (keys encoder.actor_encoder.net.0.cnn.{1,4,7,...}),
+ * whose output is permuted back to channels-last and flattened ([row][column][channel]); `fcnet_hiddens` is IGNORED for image
+ * observations and the policy head is ONE Linear(flat -> n_actions) (pi.net.mlp.0) unless `head_fcnet_hiddens` is set.
+ * ppg_policy_create_spec takes that network (and its variations: 1-6 convolutions, 0-2 hidden head layers, either image
+ * reading, either flatten order); ppg_policy_act evaluates it for EVERY row in use of the handles' last call, reading the
+ * observation rows in place (obs_pred / obs_prey of ppg_buffers) and writing the chosen action into actions[b][slot] -- the
+ * observations never leave the GPU and what a consumer has to move per agent is one byte.  Arithmetic: bf16 operands, fp32
+ * accumulation, on the matrix cores (v_mfma_f32_32x32x16_bf16 / 16x16x32); activations are rounded to bf16 between layers.
+ * RLlib itself is not importable here: parity is pinned against a float32 PyTorch module with RLlib's parameter names and
+ * shapes (predpreygrass_amd.policy.PolicyNet, loaded strictly from the real checkpoint) within the tolerance the tests state. */
 typedef struct ppg_policy_weights {   /* HOST pointers, float32, PyTorch layouts */
     const float *conv_w[3];  /* Conv2d.weight [cout][cin][3][3]: cin = C / 16 / 32, cout = 16 / 32 / 64 */
     const float *conv_b[3];  /* Conv2d.bias [cout] */
@@ -456,10 +463,38 @@ typedef struct ppg_policy ppg_policy;
 #define PPG_POLICY_ARGMAX 0x0u  /* action = argmax of the logits (first maximum) */
 #define PPG_POLICY_SAMPLE 0x1u  /* action ~ softmax(logits): Gumbel-max with Philox4x32-10 keyed by (seed, env, row) */
 
+/* How the convolution output [channel][position] is flattened into the first Linear layer's input:
+ *   PPG_POLICY_FLATTEN_NCHW  torch.flatten of a channel-first tensor: feature = channel * P + position
+ *   PPG_POLICY_FLATTEN_NHWC  RLlib: TorchCNN permutes its output back to channels-last before nn.Flatten: feature = position * C + channel */
+#define PPG_POLICY_FLATTEN_NCHW 0
+#define PPG_POLICY_FLATTEN_NHWC 1
+#define PPG_POLICY_MAX_CONV 6
+#define PPG_POLICY_MAX_FC 3
+
+typedef struct ppg_policy_spec {   /* weights: HOST pointers, float32, PyTorch layouts */
+    int32_t obs_channels;   /* C of the (C,R,R) observation rows: 4; 5 with the walls variant's visibility channel; <= 8 */
+    int32_t obs_range;      /* R <= 15 */
+    int32_t n_actions;      /* <= 32 */
+    int32_t layout;         /* PPG_POLICY_LAYOUT_* */
+    int32_t flatten;        /* PPG_POLICY_FLATTEN_* */
+    int32_t n_conv;         /* 1..PPG_POLICY_MAX_CONV convolutions 3x3, stride 1, "same" zero padding, ReLU */
+    int32_t conv_out[PPG_POLICY_MAX_CONV];   /* output channels per layer: <= 16, <= 32, then <= 64 (multiples of 8) */
+    int32_t n_fc;           /* 1..PPG_POLICY_MAX_FC Linear layers behind the flatten; the last one gives the logits, the others ReLU */
+    int32_t fc_out[PPG_POLICY_MAX_FC];       /* hidden widths (<= 256), then n_actions */
+    const float *conv_w[PPG_POLICY_MAX_CONV];  /* Conv2d.weight [cout][cin][3][3] */
+    const float *conv_b[PPG_POLICY_MAX_CONV];  /* Conv2d.bias [cout] */
+    const float *fc_w[PPG_POLICY_MAX_FC];      /* Linear.weight [out][in] */
+    const float *fc_b[PPG_POLICY_MAX_FC];      /* Linear.bias [out] */
+} ppg_policy_spec;
+
+/* The general form.  n_fc == 1 (what RLlib builds: no hidden head layer) runs entirely in LDS -- one persistent launch per species
+ * whose workgroups take the convolutions and the head of a few samples at a time; n_fc >= 2 needs n_conv == 3 with 16/32/64 channels
+ * (the hidden layers are zero-padded to 256 features).  PPG_EINVAL with a message names anything else. */
+int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_policy **out);
 /* obs_range: the R of the species' (4,R,R) observations; n_actions <= 32.  The weights are repacked into MFMA fragment
- * order (bf16) on the device; the host arrays may be freed afterwards. */
+ * order (bf16) on the device; the host arrays may be freed afterwards.  These two are ppg_policy_create_spec with 4 channels, three
+ * convolutions 16/32/64, two hidden layers of 256 and the NCHW flatten (rounds 2-3's network; kept for its callers). */
 int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, const ppg_policy_weights *w, ppg_policy **out);
-/* the same with the image layout stated (ppg_policy_create = PPG_POLICY_LAYOUT_CHW) */
 int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_actions, int32_t layout, const ppg_policy_weights *w,
                              ppg_policy **out);
 int ppg_policy_destroy(ppg_policy *p);

@@ -127,10 +127,23 @@ class PpgPolicyWeights(C.Structure):
     _fields_ = [("conv_w", C.c_void_p * 3), ("conv_b", C.c_void_p * 3), ("fc_w", C.c_void_p * 3), ("fc_b", C.c_void_p * 3)]
 
 
+POLICY_MAX_CONV, POLICY_MAX_FC = 6, 3
+
+
+class PpgPolicySpec(C.Structure):
+    """include/ppg.h: struct ppg_policy_spec (the general network description of ppg_policy_create_spec)."""
+    _fields_ = [("obs_channels", C.c_int32), ("obs_range", C.c_int32), ("n_actions", C.c_int32), ("layout", C.c_int32),
+                ("flatten", C.c_int32), ("n_conv", C.c_int32), ("conv_out", C.c_int32 * POLICY_MAX_CONV), ("n_fc", C.c_int32),
+                ("fc_out", C.c_int32 * POLICY_MAX_FC),
+                ("conv_w", C.c_void_p * POLICY_MAX_CONV), ("conv_b", C.c_void_p * POLICY_MAX_CONV),
+                ("fc_w", C.c_void_p * POLICY_MAX_FC), ("fc_b", C.c_void_p * POLICY_MAX_FC)]
+
+
 POLICY_ARGMAX, POLICY_SAMPLE = 0x0, 0x1
 POLICY_LAYOUT_CHW, POLICY_LAYOUT_HWC = 0, 1
-POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_destroy", "ppg_policy_act", "ppg_policy_macs_per_observation",
-                  "ppg_policy_last_error"]
+POLICY_FLATTEN_NCHW, POLICY_FLATTEN_NHWC = 0, 1
+POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_create_spec", "ppg_policy_destroy", "ppg_policy_act",
+                  "ppg_policy_macs_per_observation", "ppg_policy_last_error"]
 
 
 SPREAD_SYMBOLS = ["ppg_alloc_spread", "ppg_free_spread", "ppg_spread_last_error"]   # HIP library only, like the policy symbols
@@ -203,6 +216,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
         lib.ppg_policy_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(PpgPolicyWeights), C.POINTER(C.c_void_p)]
         lib.ppg_policy_create_layout.restype = C.c_int
         lib.ppg_policy_create_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PpgPolicyWeights), C.POINTER(C.c_void_p)]
+        lib.ppg_policy_create_spec.restype = C.c_int
+        lib.ppg_policy_create_spec.argtypes = [C.c_int32, C.POINTER(PpgPolicySpec), C.POINTER(C.c_void_p)]
         lib.ppg_policy_destroy.restype = C.c_int
         lib.ppg_policy_destroy.argtypes = [C.c_void_p]
         lib.ppg_policy_act.restype = C.c_int

@@ -84,6 +84,19 @@ struct PolParams {
     uint32_t magic_P, magic_R;    // ceil(2^18 / P), ceil(2^18 / IW): div_small()
     __bf16 *xg;                   // [gridDim.x][TILE][K1]
     float *logits;                // optional [rows][n_actions]
+    // hidden layers of the head (phase_head): 2 = FC1, FC2, logits; 1 = FC1, logits
+    int32_t n_hidden;
+    // ---- direct-head networks (ppg_policy_direct.h) ----
+    int32_t n_conv;               // convolution layers
+    int32_t cout_blocks[PPG_POLICY_MAX_CONV];   // real output channel blocks (of 8) per layer
+    int32_t off_x, off_y, off_f, off_d0, off_d1;   // element offsets of the areas in a sample's LDS region
+    int32_t sample_stride;        // elements per sample region
+    int32_t flat_c;               // channels per position of area F (8 * cout_blocks[n_conv - 1])
+    int32_t kflat_steps;          // k-steps of 32 features of the head: ceil(P * flat_c / 32)
+    int32_t head_mt;              // 16-row tiles of actions: 1 or 2
+    const bf16x8 *wcd[PPG_POLICY_MAX_CONV - 3];   // fragments of the convolutions behind the third (64 -> 64 channels)
+    const bf16x8 *wh;             // head fragments [action tile][k-step][lane]
+    const float *bh;              // head bias [32]
 #ifdef PPG_EXPERIMENTS
     unsigned long long *timeline; // diagnostic builds: [tile][64] = workgroup, hardware id, samples, 4 wall-clock stamps (10 ns units); [8 + 12 wave + i] cycles of wave in step i of the convolutions, [56 + 2 wave + i] FC1 wait / barrier cycles
 #endif
@@ -228,8 +241,10 @@ struct ConvW {
     template <class KP>
     __device__ __forceinline__ int offset(const KP &K, int ks, int d23) const {
         if (CBIN == 1) return koff1[ks];
-        const int tap = CBIN == 2 ? ks : ks >> 1;
-        return (CBIN == 4 && (ks & 1) ? d23 : 0) + ((tap / 3 - 1) * K.Wp + tap % 3 - 1) * 8;
+        // (CBIN = 8, the 64 -> 64 layers of ppg_policy_direct.h: four pairs of channel blocks d23 apart, tap = ks >> 2)
+        const int tap = CBIN == 2 ? ks : CBIN == 4 ? ks >> 1 : ks >> 2;
+        const int pr = CBIN == 2 ? 0 : CBIN == 4 ? (ks & 1) : (ks & 3);
+        return pr * d23 + ((tap / 3 - 1) * K.Wp + tap % 3 - 1) * 8;
     }
     // The fragments were requested by load(): wait for them HERE, once, and hide their origin from the compiler.  Its wait-count
     // bookkeeping cannot follow a load across a loop's back edge: left alone it puts s_waitcnt vmcnt(0) in front of the first MFMA
@@ -783,7 +798,7 @@ __device__ __noinline__ void phase_head(KPtr Kp, unsigned char *lds, int n0_, in
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long *tab = (const unsigned long long *)lds;
     __bf16 *H = (__bf16 *)(lds + TILE * 16);
-    {
+    if (K.n_hidden >= 2) {   // (one hidden layer: the logits come straight from FC1's output)
         f32x16 acc[2][NT];
         fc_init<NT>(K.b2, acc, wave, lane);
         fc_256<16, NT>(K.w2, H, (size_t)HSTRIDE, acc, wave, lane);
@@ -893,15 +908,21 @@ PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_bf16, 2, 16)
 
 }  // namespace ppgpol
 
+#include "ppg_policy_direct.h"
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------
 
 struct ppg_policy {
     int32_t device, R, n_actions, layout, cin;
+    int32_t obs_channels;  // C of the (C,R,R) rows this network reads
+    int32_t direct;        // 1: no hidden head layer, ppg_policy_direct.h (2: with more than three convolutions); 0: the FC chain
+    int32_t nch16;         // more than 8 input channels into conv1
+    uint64_t macs;         // real multiply-accumulates per observation
     ppgpol::PolParams base;
     void *dev_weights;     // one allocation: fragments + biases
-    __bf16 *xg;            // scratch slots
+    __bf16 *xg;            // scratch slots (FC chain only)
     bool xg_is_spread;     // (from ppg_alloc_spread)
     uint32_t *plan;        // [PLAN_HDR + plan_envs] header + prefix sums, then the first env of every tile
     int32_t plan_envs;
@@ -967,38 +988,71 @@ static void ppg_pack_conv(const float *w, const float *bias, int cout, int cin, 
             }
 }
 
-// Linear.weight [n_out][K] -> fragments [ks][mt][lane][8]: lane holds output feature 32 mt + r, inputs kmap(16 ks + 8 h + j)
-template <class KMap>
-static void ppg_pack_fc(const float *w, int n_out, int K, int mt_n, KMap kmap, std::vector<uint16_t> &out) {
+// A Linear layer -> fragments [ks][mt][lane][8] of the 32x32x16 MFMA: lane holds output feature o = 32 mt + row feature(lane & 31) and
+// inputs k = 16 ks + 8 h + j; `value(o, k)` returns the weight (0 for padding)
+template <class Value>
+static void ppg_pack_fc(int K, int mt_n, Value value, std::vector<uint16_t> &out) {
     const int KS = K / 16;
     out.assign((size_t)KS * mt_n * 64 * 8, 0);
     for (int ks = 0; ks < KS; ++ks)
         for (int mt = 0; mt < mt_n; ++mt)
             for (int lane = 0; lane < 64; ++lane) {
                 const int r = lane & 31, h = lane >> 5, o = 32 * mt + ppg_row_feature(r);
-                if (o >= n_out) continue;
                 for (int j = 0; j < 8; ++j)
-                    out[(((size_t)ks * mt_n + mt) * 64 + lane) * 8 + j] = ppg_bf16_bits(w[(size_t)o * K + kmap(16 * ks + 8 * h + j)]);
+                    out[(((size_t)ks * mt_n + mt) * 64 + lane) * 8 + j] = ppg_bf16_bits(value(o, 16 * ks + 8 * h + j));
             }
 }
 
 extern "C" {
 
+int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_policy **out);
+
 int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_actions, int32_t layout, const ppg_policy_weights *w,
-                             ppg_policy **out);
+                             ppg_policy **out) {
+    if (!w || !out) return ppg_policy_fail(nullptr, PPG_EINVAL, "null argument");
+    ppg_policy_spec sp;
+    memset(&sp, 0, sizeof sp);
+    sp.obs_channels = 4; sp.obs_range = obs_range; sp.n_actions = n_actions; sp.layout = layout; sp.flatten = PPG_POLICY_FLATTEN_NCHW;
+    sp.n_conv = 3; sp.conv_out[0] = 16; sp.conv_out[1] = 32; sp.conv_out[2] = 64;
+    sp.n_fc = 3; sp.fc_out[0] = 256; sp.fc_out[1] = 256; sp.fc_out[2] = n_actions;
+    for (int l = 0; l < 3; ++l) { sp.conv_w[l] = w->conv_w[l]; sp.conv_b[l] = w->conv_b[l]; sp.fc_w[l] = w->fc_w[l]; sp.fc_b[l] = w->fc_b[l]; }
+    return ppg_policy_create_spec(device, &sp, out);
+}
 
 int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, const ppg_policy_weights *w, ppg_policy **out) {
     return ppg_policy_create_layout(device, obs_range, n_actions, PPG_POLICY_LAYOUT_CHW, w, out);
 }
 
-int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_actions, int32_t layout, const ppg_policy_weights *w,
-                             ppg_policy **out) {
-    if (!w || !out) return ppg_policy_fail(nullptr, PPG_EINVAL, "null argument");
+int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_policy **out) {
+    if (!spec || !out) return ppg_policy_fail(nullptr, PPG_EINVAL, "null argument");
+    const ppg_policy_spec &sp = *spec;
+    const int layout = sp.layout, R = sp.obs_range, n_actions = sp.n_actions, C = sp.obs_channels;
     if (layout != PPG_POLICY_LAYOUT_CHW && layout != PPG_POLICY_LAYOUT_HWC) return ppg_policy_fail(nullptr, PPG_EINVAL, "unknown layout %d", layout);
-    if (obs_range < 1 || obs_range > 15) return ppg_policy_fail(nullptr, PPG_EINVAL, "obs_range %d outside 1..15", obs_range);
+    if (sp.flatten != PPG_POLICY_FLATTEN_NCHW && sp.flatten != PPG_POLICY_FLATTEN_NHWC) return ppg_policy_fail(nullptr, PPG_EINVAL, "unknown flatten order %d", sp.flatten);
+    if (R < 1 || R > 15) return ppg_policy_fail(nullptr, PPG_EINVAL, "obs_range %d outside 1..15", R);
+    if (C < 1 || C > 8) return ppg_policy_fail(nullptr, PPG_EINVAL, "obs_channels %d outside 1..8", C);
     if (n_actions < 1 || n_actions > 32) return ppg_policy_fail(nullptr, PPG_EINVAL, "n_actions %d outside 1..32", n_actions);
-    for (int l = 0; l < 3; ++l)
-        if (!w->conv_w[l] || !w->conv_b[l] || !w->fc_w[l] || !w->fc_b[l]) return ppg_policy_fail(nullptr, PPG_EINVAL, "a weight pointer is NULL");
+    if (sp.n_conv < 1 || sp.n_conv > PPG_POLICY_MAX_CONV) return ppg_policy_fail(nullptr, PPG_EINVAL, "n_conv %d outside 1..%d", sp.n_conv, PPG_POLICY_MAX_CONV);
+    if (sp.n_fc < 1 || sp.n_fc > PPG_POLICY_MAX_FC) return ppg_policy_fail(nullptr, PPG_EINVAL, "n_fc %d outside 1..%d", sp.n_fc, PPG_POLICY_MAX_FC);
+    for (int l = 0; l < sp.n_conv; ++l) {
+        const int lim = l == 0 ? 16 : l == 1 ? 32 : 64;
+        if (sp.conv_out[l] < 1 || sp.conv_out[l] > lim)
+            return ppg_policy_fail(nullptr, PPG_EINVAL, "convolution %d has %d output channels: the kernels take up to 16 / 32 / 64 / 64 ...", l + 1, sp.conv_out[l]);
+        if (!sp.conv_w[l] || !sp.conv_b[l]) return ppg_policy_fail(nullptr, PPG_EINVAL, "a convolution weight pointer is NULL");
+    }
+    for (int l = 0; l < sp.n_fc; ++l) {
+        if (!sp.fc_w[l] || !sp.fc_b[l]) return ppg_policy_fail(nullptr, PPG_EINVAL, "a linear weight pointer is NULL");
+        if (l + 1 < sp.n_fc && (sp.fc_out[l] < 1 || sp.fc_out[l] > 256))
+            return ppg_policy_fail(nullptr, PPG_EINVAL, "hidden head layer %d has %d features: the kernels take up to 256", l + 1, sp.fc_out[l]);
+    }
+    if (sp.fc_out[sp.n_fc - 1] != n_actions) return ppg_policy_fail(nullptr, PPG_EINVAL, "the last linear layer has %d outputs, n_actions is %d", sp.fc_out[sp.n_fc - 1], n_actions);
+    if (sp.n_fc > 1 && sp.n_conv != 3) return ppg_policy_fail(nullptr, PPG_EINVAL, "a head with hidden layers needs exactly three convolutions (found %d)", sp.n_conv);
+    // the image the convolutions run on: R x R with C channels, or (channels-last) C x R with R channels
+    const int hwc = layout == PPG_POLICY_LAYOUT_HWC;
+    const int IH = hwc ? C : R, IW = R, CIN = hwc ? R : C, CB1 = CIN > 8 ? 2 : 1;
+    const int P = IH * IW;
+    const bool direct = sp.n_fc == 1;
+    if (!direct && !hwc && C != 4) return ppg_policy_fail(nullptr, PPG_EINVAL, "channel-first networks with hidden head layers read 4-channel rows (found %d)", C);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return ppg_policy_fail(nullptr, PPG_ENODEV, "device %d not available", device);
     hipDeviceProp_t prop;
@@ -1007,57 +1061,147 @@ int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_action
     ppg_policy *p = new (std::nothrow) ppg_policy();
     if (!p) return ppg_policy_fail(nullptr, PPG_ENOMEM, "out of host memory");
     memset(p, 0, sizeof *p);
-    p->device = device; p->R = obs_range; p->n_actions = n_actions; p->layout = layout;
-    // the image the convolutions run on: R x R with 4 channels, or (channels-last) 4 x R with R channels
-    const int R = obs_range, hwc = layout == PPG_POLICY_LAYOUT_HWC;
-    const int IH = hwc ? 4 : R, IW = R, CIN = hwc ? R : 4, CB1 = CIN > 8 ? 2 : 1;
-    const int P = IH * IW, K1 = 64 * P;
-    p->cin = CIN;
-    std::vector<uint16_t> f[6];
-    ppg_pack_conv(w->conv_w[0], w->conv_b[0], 16, CIN, CB1, 1, f[0]);
-    ppg_pack_conv(w->conv_w[1], w->conv_b[1], 32, 16, 2, 1, f[1]);
-    ppg_pack_conv(w->conv_w[2], w->conv_b[2], 64, 32, 4, 2, f[2]);
-    // FC1: our K order is the scratch slot's [row tile of conv3][position][32 channels]; PyTorch flattens channel-major (c * P + p)
-    ppg_pack_fc(w->fc_w[0], 256, K1, 8, [P](int k) { return (32 * (k / (32 * P)) + k % 32) * P + (k % (32 * P)) / 32; }, f[3]);
-    ppg_pack_fc(w->fc_w[1], 256, 256, 8, [](int k) { return k; }, f[4]);
-    ppg_pack_fc(w->fc_w[2], n_actions, 256, 1, [](int k) { return k; }, f[5]);
-    std::vector<float> bias(32 + 32 + 64 + 256 + 256 + 32, 0.0f);
-    const int boff[6] = {0, 32, 64, 128, 384, 640};
-    const int bn[6] = {16, 32, 64, 256, 256, n_actions};
-    for (int l = 0; l < 3; ++l) for (int i = 0; i < bn[l]; ++i) bias[boff[l] + i] = w->conv_b[l][i];
-    for (int l = 0; l < 3; ++l) for (int i = 0; i < bn[3 + l]; ++i) bias[boff[3 + l] + i] = w->fc_b[l][i];
-    size_t off[7], total = 0;
-    for (int l = 0; l < 6; ++l) { off[l] = total; total += (f[l].size() * 2 + 255) / 256 * 256; }
-    off[6] = total; total += bias.size() * 4;
+    p->device = device; p->R = R; p->n_actions = n_actions; p->layout = layout; p->cin = CIN; p->obs_channels = C;
+    p->direct = direct ? (sp.n_conv > 3 ? 2 : 1) : 0;
+    p->nch16 = CIN > 8;
+    const int cout_last = sp.conv_out[sp.n_conv - 1];
+    const int flat = P * cout_last;   // features behind the flatten
+    {   // real multiply-accumulates per observation
+        uint64_t m = 0;
+        int ci = CIN;
+        for (int l = 0; l < sp.n_conv; ++l) { m += (uint64_t)P * sp.conv_out[l] * 9 * ci; ci = sp.conv_out[l]; }
+        int fi = flat;
+        for (int l = 0; l < sp.n_fc; ++l) { m += (uint64_t)fi * sp.fc_out[l]; fi = sp.fc_out[l]; }
+        p->macs = m;
+    }
+    ppgpol::PolParams &K = p->base;
+    // feature index of (channel c, position q) behind the flatten, or -1 for a padding channel
+    const int flatten = sp.flatten;
+    auto feature = [=](int c, int q) { return c >= cout_last ? -1 : flatten == PPG_POLICY_FLATTEN_NHWC ? q * cout_last + c : c * P + q; };
+    std::vector<uint16_t> f[PPG_POLICY_MAX_CONV + 3];   // conv layers, then up to three linear layers
+    std::vector<float> bias(256 + 256 + 32, 0.0f);      // FC chain: b1, b2, b3; direct: head bias at [512]
+    int ci = CIN;
+    for (int l = 0; l < sp.n_conv; ++l) {
+        ppg_pack_conv(sp.conv_w[l], sp.conv_b[l], sp.conv_out[l], ci, l == 0 ? CB1 : l == 1 ? 2 : l == 2 ? 4 : 8, l < 2 ? 1 : 2, f[l]);
+        K.cout_blocks[l] = (sp.conv_out[l] + 7) / 8;
+        ci = sp.conv_out[l];
+    }
+    const int FC0 = PPG_POLICY_MAX_CONV;
+    const int K1 = 64 * P;
+    if (direct) {
+        // head fragments of v_mfma_f32_16x16x32_bf16, [action tile][k-step][lane][8]: lane holds action 16 tile + (lane & 15) and the
+        // features of area F's elements 32 ks + 8 (lane >> 4) + j; F is [position][flat_c channels]
+        const int flat_c = 8 * K.cout_blocks[sp.n_conv - 1], ksteps = (P * flat_c + 31) / 32, head_mt = (n_actions + 15) / 16;
+        K.flat_c = flat_c; K.kflat_steps = ksteps; K.head_mt = head_mt;
+        f[FC0].assign((size_t)head_mt * ksteps * 64 * 8, 0);
+        const float *hw = sp.fc_w[0];
+        for (int mt = 0; mt < head_mt; ++mt)
+            for (int ks = 0; ks < ksteps; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int a = 16 * mt + (lane & 15);
+                    if (a >= n_actions) continue;
+                    for (int j = 0; j < 8; ++j) {
+                        const int e = 32 * ks + 8 * (lane >> 4) + j, q = e / flat_c, c = e % flat_c;
+                        const int ft = q < P ? feature(c, q) : -1;
+                        if (ft >= 0) f[FC0][(((size_t)mt * ksteps + ks) * 64 + lane) * 8 + j] = ppg_bf16_bits(hw[(size_t)a * flat + ft]);
+                    }
+                }
+        for (int a = 0; a < n_actions; ++a) bias[512 + a] = sp.fc_b[0][a];
+    } else {
+        // FC1: the K order is the scratch slot's [row tile of conv3][position][32 channels]; hidden widths are zero-padded to 256
+        const int h1 = sp.fc_out[0], h2 = sp.n_fc == 3 ? sp.fc_out[1] : 0;
+        const float *w1 = sp.fc_w[0];
+        ppg_pack_fc(K1, 8, [&](int o, int k) {
+            const int c = 32 * (k / (32 * P)) + k % 32, q = (k % (32 * P)) / 32, ft = feature(c, q);
+            return (o < h1 && ft >= 0) ? w1[(size_t)o * flat + ft] : 0.0f; }, f[FC0]);
+        for (int i = 0; i < h1; ++i) bias[i] = sp.fc_b[0][i];
+        if (sp.n_fc == 3) {
+            const float *w2 = sp.fc_w[1];
+            ppg_pack_fc(256, 8, [&](int o, int k) { return (o < h2 && k < h1) ? w2[(size_t)o * h1 + k] : 0.0f; }, f[FC0 + 1]);
+            for (int i = 0; i < h2; ++i) bias[256 + i] = sp.fc_b[1][i];
+        }
+        const float *w3 = sp.fc_w[sp.n_fc - 1];
+        const int hl = sp.n_fc == 3 ? h2 : h1;
+        ppg_pack_fc(256, 1, [&](int o, int k) { return (o < n_actions && k < hl) ? w3[(size_t)o * hl + k] : 0.0f; }, f[FC0 + 2]);
+        for (int i = 0; i < n_actions; ++i) bias[512 + i] = sp.fc_b[sp.n_fc - 1][i];
+        K.n_hidden = sp.n_fc - 1;
+    }
+    const int NF = PPG_POLICY_MAX_CONV + 3;
+    size_t off[NF + 1], total = 0;
+    for (int l = 0; l < NF; ++l) { off[l] = total; total += (f[l].size() * 2 + 255) / 256 * 256; }
+    off[NF] = total; total += bias.size() * 4;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&p->dev_weights, total) != hipSuccess) {
         delete p;
         return ppg_policy_fail(nullptr, PPG_EHIP, "hipMalloc of %zu bytes of weights failed", total);
     }
     std::vector<unsigned char> stage(total, 0);
-    for (int l = 0; l < 6; ++l) memcpy(stage.data() + off[l], f[l].data(), f[l].size() * 2);
-    memcpy(stage.data() + off[6], bias.data(), bias.size() * 4);
+    for (int l = 0; l < NF; ++l) if (!f[l].empty()) memcpy(stage.data() + off[l], f[l].data(), f[l].size() * 2);
+    memcpy(stage.data() + off[NF], bias.data(), bias.size() * 4);
     if (hipMemcpy(p->dev_weights, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(p->dev_weights);
         delete p;
         return ppg_policy_fail(nullptr, PPG_EHIP, "upload of the weights failed");
     }
-    ppgpol::PolParams &K = p->base;
 #ifdef PPG_EXPERIMENTS   // ablation builds only (hipcc -DPPG_EXPERIMENTS): skip phases -- the results are then meaningless
     if (const char *dbg = getenv("PPG_POLICY_SKIP")) K.debug_skip = atoi(dbg);
 #endif
     K.magic_P = (uint32_t)(((1u << ppgpol::DIV_SHIFT) + P - 1) / P);
     K.magic_R = (uint32_t)(((1u << ppgpol::DIV_SHIFT) + IW - 1) / IW);
-    K.R = R; K.P = P; K.Wp = IW + 2; K.Wp2 = (IH + 2) * (IW + 2); K.K1 = K1; K.n_actions = n_actions;
-    K.IH = IH; K.IW = IW; K.cin = CIN; K.obs_elems = 4 * R * R;
-    // observation element [a][b][c] of the (4,R,R) row: channel-first = (channel a, position b * R + c); channels-last = (position
+    K.R = R; K.P = P; K.K1 = K1; K.n_actions = n_actions;
+    K.IH = IH; K.IW = IW; K.cin = CIN; K.obs_elems = C * R * R;
+    K.n_conv = sp.n_conv;
+    // observation element [a][b][c] of the (C,R,R) row: channel-first = (channel a, position b * R + c); channels-last = (position
     // a * R + b, channel c)
     K.c_stride = hwc ? 1 : R * R; K.p_stride = hwc ? R : 1;
     const unsigned char *dw = (const unsigned char *)p->dev_weights;
     K.wc1 = (const ppgpol::bf16x8 *)(dw + off[0]); K.wc2 = (const ppgpol::bf16x8 *)(dw + off[1]);
-    K.wc3 = (const ppgpol::bf16x8 *)(dw + off[2]); K.w1 = (const ppgpol::bf16x8 *)(dw + off[3]);
-    K.w2 = (const ppgpol::bf16x8 *)(dw + off[4]); K.w3 = (const ppgpol::bf16x8 *)(dw + off[5]);
-    const float *db = (const float *)(dw + off[6]);
-    K.bc1 = db + boff[0]; K.bc2 = db + boff[1]; K.bc3 = db + boff[2]; K.b1 = db + boff[3]; K.b2 = db + boff[4]; K.b3 = db + boff[5];
+    K.wc3 = (const ppgpol::bf16x8 *)(dw + off[2]);
+    for (int l = 3; l < PPG_POLICY_MAX_CONV; ++l) K.wcd[l - 3] = (const ppgpol::bf16x8 *)(dw + off[l]);
+    K.w1 = (const ppgpol::bf16x8 *)(dw + off[FC0]); K.w2 = (const ppgpol::bf16x8 *)(dw + off[FC0 + 1]); K.w3 = (const ppgpol::bf16x8 *)(dw + off[FC0 + 2]);
+    K.wh = K.w1;
+    const float *db = (const float *)(dw + off[NF]);
+    K.bc1 = K.bc2 = K.bc3 = nullptr;   // (the convolutions' biases ride in their fragments)
+    K.b1 = db; K.b2 = db + 256; K.b3 = db + 512; K.bh = db + 512;
+    p->grid = 2 * prop.multiProcessorCount;
+#ifdef PPG_EXPERIMENTS
+    if (const char *g = getenv("PPG_POLICY_GRID")) p->grid = atoi(g) > 0 ? atoi(g) : p->grid;   // resident workgroups
+#endif
+    if (direct) {
+        // LDS region of a sample: X (4 blocks) | Y (2 blocks) | F | [D0 | D1] -- padded pitch W + 1 (ppg_policy_direct.h)
+        K.Wp = IW + 1; K.Wp2 = (IH + 2) * (IW + 1) + 1;
+        const int blk = K.Wp2 * 8, f_elems = K.kflat_steps * 32 + 8;   // (+ 8: consecutive samples' fragments fall into different banks)
+        K.off_x = 0; K.off_y = 4 * blk; K.off_f = 6 * blk; K.off_d0 = K.off_f + f_elems; K.off_d1 = K.off_d0 + 8 * blk;
+        K.sample_stride = K.off_f + f_elems + (sp.n_conv > 3 ? 8 * blk : 0) + (sp.n_conv > 4 ? 8 * blk : 0);
+        const int fixed = ppgpol::TILE * 16 + K.head_mt * 4096;
+        int st_max = (80 * 1024 - fixed) / (K.sample_stride * 2);
+        if (st_max > 16) st_max = 16;                // (the head's 16 sample columns)
+        while (st_max > 1 && st_max * P > 256) --st_max;   // a thread stages at most one position
+        if (st_max < 1) {
+            (void)hipFree(p->dev_weights);
+            delete p;
+            return ppg_policy_fail(nullptr, PPG_EINVAL, "a %d x %d image with %d convolutions needs %d bytes of LDS per sample: too large", IH, IW, sp.n_conv, K.sample_stride * 2);
+        }
+        // samples per sub-group: the most samples per round of position tiles (four wavefronts take a tile each)
+        int st = st_max;
+        double best = 0.0;
+        for (int c = st_max; c >= 1; --c) {
+            const int tiles = (c * P + 31) / 32, rounds = (tiles + 3) / 4;
+            const double score = (double)c / rounds;
+            if (score > best * 1.0001) { best = score; st = c; }
+        }
+        K.ST = st;
+        p->lds_bytes = fixed + st * K.sample_stride * 2;
+        for (const void *fn : {(const void *)ppgpol::ppg_policy_direct8_f64, (const void *)ppgpol::ppg_policy_direct8_f32,
+                               (const void *)ppgpol::ppg_policy_direct8_bf16, (const void *)ppgpol::ppg_policy_direct16_f64,
+                               (const void *)ppgpol::ppg_policy_direct16_f32, (const void *)ppgpol::ppg_policy_direct16_bf16,
+                               (const void *)ppgpol::ppg_policy_deep8_f64, (const void *)ppgpol::ppg_policy_deep8_f32,
+                               (const void *)ppgpol::ppg_policy_deep8_bf16, (const void *)ppgpol::ppg_policy_deep16_f64,
+                               (const void *)ppgpol::ppg_policy_deep16_f32, (const void *)ppgpol::ppg_policy_deep16_bf16})
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+        *out = p;
+        return PPG_OK;
+    }
+    K.Wp = IW + 2; K.Wp2 = (IH + 2) * (IW + 2);
     // LDS: tile table + max(activation images of ST samples, H); ST as large as 2 workgroups per CU (80 KB each) allow
     const int per_sample = 6 * K.Wp2 * 8 * 2;                       // X (4 blocks) + Y (2 blocks), bytes
     const int h_bytes = ppgpol::TILE * ppgpol::HSTRIDE * 2;
@@ -1070,10 +1214,6 @@ int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_action
     int overlay = img > h_bytes ? img : h_bytes;
     if (fc1_stage > overlay) overlay = fc1_stage;
     p->lds_bytes = ppgpol::TILE * 16 + overlay;
-    p->grid = 2 * prop.multiProcessorCount;
-#ifdef PPG_EXPERIMENTS
-    if (const char *g = getenv("PPG_POLICY_GRID")) p->grid = atoi(g) > 0 ? atoi(g) : p->grid;   // resident workgroups
-#endif
     const size_t xg_bytes = (size_t)p->grid * ppgpol::TILE * K1 * 2;
     // the scratch slots: 512 concurrent sequential streams, written by conv3 and read back by FC1 -- on spread physical pages like the
     // env's observation tensors where the virtual-memory calls work (-DPPG_POLICY_XG_SPREAD=0: A/B builds)
@@ -1082,7 +1222,7 @@ int ppg_policy_create_layout(int32_t device, int32_t obs_range, int32_t n_action
 #endif
     const int xg_spread = PPG_POLICY_XG_SPREAD;
     void *xg_ptr = nullptr;
-    p->xg_is_spread = xg_spread > 1 && ppg_alloc_spread(device, (uint64_t)xg_bytes, xg_spread, 0x5850u + (uint64_t)obs_range, &xg_ptr) == PPG_OK;
+    p->xg_is_spread = xg_spread > 1 && ppg_alloc_spread(device, (uint64_t)xg_bytes, xg_spread, 0x5850u + (uint64_t)R, &xg_ptr) == PPG_OK;
     if (p->xg_is_spread) p->xg = (__bf16 *)xg_ptr;
     if ((!p->xg_is_spread && hipMalloc((void **)&p->xg, xg_bytes) != hipSuccess) || hipMemset(p->xg, 0, xg_bytes) != hipSuccess) {
         (void)hipFree(p->dev_weights);
@@ -1113,11 +1253,7 @@ int ppg_policy_destroy(ppg_policy *p) {
     return PPG_OK;
 }
 
-uint64_t ppg_policy_macs_per_observation(const ppg_policy *p) {
-    if (!p) return 0;
-    const uint64_t P = p->layout == PPG_POLICY_LAYOUT_HWC ? 4 * (uint64_t)p->R : (uint64_t)p->R * p->R;
-    return P * (16 * 9 * (uint64_t)p->cin + 32 * 144 + 64 * 288) + 64 * P * 256 + 256 * 256 + 256 * (uint64_t)p->n_actions;
-}
+uint64_t ppg_policy_macs_per_observation(const ppg_policy *p) { return p ? p->macs : 0; }
 
 const char *ppg_policy_last_error(const ppg_policy *p) { return p ? p->err : g_ppg_policy_error; }
 
@@ -1140,8 +1276,9 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     for (int k = 0; k < n; ++k) {
         const ppg_handle *h = handles[k];
         if (!h) return ppg_policy_fail(p, PPG_EINVAL, "handle %d is NULL", k);
-        if (h->drive || (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel))
-            return ppg_policy_fail(p, PPG_EINVAL, "ppg_policy_act expects 4-channel observations");
+        const int channels = h->drive ? 4 + h->cfg.n_drive[species] : (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
+        if (channels != p->obs_channels)
+            return ppg_policy_fail(p, PPG_EINVAL, "the policy reads %d-channel observations, handle %d writes %d channels", p->obs_channels, k, channels);
         if ((species ? h->base.Rq : h->base.Rp) != R || h->base.S != K.S || h->base.obs_f32 != K.obs_f32 || h->device != p->device)
             return ppg_policy_fail(p, PPG_EINVAL, "handle %d has another geometry / dtype / device than handle 0", k);
         if (!actions[k]) return ppg_policy_fail(p, PPG_EINVAL, "actions[%d] is NULL", k);
@@ -1191,8 +1328,17 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     const fwd_fn fwd[3][3] = {{ppgpol::ppg_policy_forward_f64, ppgpol::ppg_policy_forward_f32, ppgpol::ppg_policy_forward_bf16},
                               {ppgpol::ppg_policy_forward_hwc8_f64, ppgpol::ppg_policy_forward_hwc8_f32, ppgpol::ppg_policy_forward_hwc8_bf16},
                               {ppgpol::ppg_policy_forward_hwc16_f64, ppgpol::ppg_policy_forward_hwc16_f32, ppgpol::ppg_policy_forward_hwc16_bf16}};
-    const int variant = p->layout == PPG_POLICY_LAYOUT_HWC ? (p->cin > 8 ? 2 : 1) : 0;
-    hipLaunchKernelGGL(fwd[variant][K.obs_f32 == 2 ? 2 : K.obs_f32 ? 1 : 0], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
+    const int dt = K.obs_f32 == 2 ? 2 : K.obs_f32 ? 1 : 0;
+    if (p->direct) {
+        const fwd_fn dir[4][3] = {{ppgpol::ppg_policy_direct8_f64, ppgpol::ppg_policy_direct8_f32, ppgpol::ppg_policy_direct8_bf16},
+                                  {ppgpol::ppg_policy_direct16_f64, ppgpol::ppg_policy_direct16_f32, ppgpol::ppg_policy_direct16_bf16},
+                                  {ppgpol::ppg_policy_deep8_f64, ppgpol::ppg_policy_deep8_f32, ppgpol::ppg_policy_deep8_bf16},
+                                  {ppgpol::ppg_policy_deep16_f64, ppgpol::ppg_policy_deep16_f32, ppgpol::ppg_policy_deep16_bf16}};
+        hipLaunchKernelGGL(dir[(p->direct == 2 ? 2 : 0) + (p->nch16 ? 1 : 0)][dt], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
+    } else {
+        const int variant = p->layout == PPG_POLICY_LAYOUT_HWC ? (p->cin > 8 ? 2 : 1) : 0;
+        hipLaunchKernelGGL(fwd[variant][dt], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
+    }
     PPG_POL_TRY(p, hipGetLastError());
 #ifdef PPG_EXPERIMENTS
     if (tl_now && species == 0) {   // (the predators' launch is the second of a step: both species' stamps are complete after a device sync)

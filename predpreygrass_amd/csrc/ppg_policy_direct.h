@@ -1,0 +1,372 @@
+// ppg_policy_direct.h -- the policy network RLlib REALLY builds for the reference's PPO setup, evaluated entirely in LDS.
+//
+// tune_ppo_base_environment.py:106-141 asks for conv_filters 16/32/64 and fcnet_hiddens [256, 256]; for an image observation RLlib's
+// catalog builds a CNN encoder from conv_filters, ignores fcnet_hiddens, and puts ONE Linear(flat -> n_actions) behind the flattened
+// encoder output as the policy head (pi.net.mlp.0; include/ppg.h, tests/golden/rllib_checkpoint/).  So per sample:
+//     (C,R,R) row, read as a C x R image with R channels -> L x [zero-pad 1, conv3x3, ReLU] -> flatten [row][column][channel]
+//                                                       -> Linear -> n_actions logits
+// and nothing in it needs a tile of 128 samples or a trip through HBM: no hidden fully connected layer, no weight matrix that
+// does not fit next to a CU.  (included from ppg_policy.h, namespace ppgpol; shares its fragment conventions, ConvW, the plan kernel)
+//
+// ONE persistent launch per species.  A workgroup (4 wavefronts, two per CU) walks over the plan's tiles of up to 128 samples in
+// SUB-GROUPS of ST samples (7-9 at the default windows: chosen so that ST * P positions are a multiple of four 32-position MFMA
+// tiles).  LDS per sample: area X = 4 channel blocks of [padded position][8] (the input image, then conv2's 32 channels), area
+// Y = 2 blocks (conv1's 16 channels), area F = the last convolution's output UNPADDED as [position][channels] -- exactly the
+// flatten order of RLlib, so the head's B fragment of k-step ks is 16 contiguous bytes at F + 64 ks -- and, for networks deeper than
+// three convolutions, areas D0 / D1 of 8 blocks each.  The padded pitch is W + 1 (a row's right halo cell IS the next row's
+// left one): (H + 2)(W + 1) + 1 cells per block instead of (H + 2)(W + 2).
+//   stage   the sub-group's observation rows (requested from HBM one sub-group earlier, converted to bf16 here) -> X
+//   conv1   X -> Y          every wavefront its share of the position tiles, weights resident in registers
+//   conv2   Y -> X
+//   conv3   X -> F (D0)     wavefronts 0,1 / 2,3 compute output channels 0-31 / 32-63 for every other tile
+//   [conv4.. D0 -> F ...    deeper layers: the weights of a layer are fetched from L2 per sub-group (148 registers per wavefront)]
+//   head    logits^T = W_head x F^T on v_mfma_f32_16x16x32_bf16: M = actions (1-2 tiles of 16), N = the sub-group's samples, K = the
+//           flattened features split over the four wavefronts; partial sums meet in LDS; one lane per sample adds bias, writes
+//           logits, picks the action (argmax / Gumbel-max) and stores one int8.
+// Four workgroup barriers per sub-group; the next sub-group's input is written into X while the head runs.
+#pragma once
+
+namespace ppgpol {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// timing-only ablation builds (tools/gpu_direct_ablate.sh; never defined in the product -- the results are then meaningless):
+// 1 no head k-loop, 2 no action selection, 4 no conv3, 8 no conv1 / conv2, 16 no observation staging
+#ifndef PPG_DIRECT_ABLATE
+#define PPG_DIRECT_ABLATE 0
+#endif
+
+// partial logits in LDS: [wavefront][action tile (head_mt of them)][action row][sample column] floats = head_mt * 4 KB
+
+// One convolution layer of the direct path over the `ns` samples of a sub-group, this wavefront's share of the 32-position tiles.
+//   in_off / out_off   element offsets of the input / output area inside a sample's LDS region (blocks of an area are contiguous)
+//   out_blocks         real output channel blocks (of 8) of the layer
+//   flat_c             0: the output is a padded image (the next convolution's input); > 0: the output is area F,
+//                      [position][flat_c channels] (the head's input)
+template <int CBIN, int MT, int BATCH, class KP>
+__device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __bf16 *img, int sample_stride, int in_off, int out_off,
+                                      int out_blocks, int flat_c, int ns, int nt_first, int nt_step, int lane, int mt_base) {
+    constexpr int KS = ConvW<CBIN, MT>::KS;
+    const int h = lane >> 5, col = lane & 31;
+    const int n_pos = ns * K.P;
+    const int n_tiles = (n_pos + 31) / 32;
+    const int blk = K.Wp2 * 8;
+    const __bf16 *in = img + in_off + (CBIN > 1 ? h : 0) * blk;
+    const int pair = 2 * blk;   // distance between the channel-block pairs a k-step's two lane halves read
+    for (int nt = nt_first; nt < n_tiles; nt += nt_step) {
+        const int n = 32 * nt + col;
+        const bool valid = n < n_pos;
+        const int nn = valid ? n : 0;
+        const int s = div_small(nn, K.magic_P), p = nn - __mul24(s, K.P);
+        const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
+        const int pidx = __mul24(y + 1, K.Wp) + (x + 1);
+        const __bf16 *base = in + __mul24(s, sample_stride) + pidx * 8;
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+        auto fragment = [&](int ks) -> bf16x8 {
+            constexpr int KSB = ConvW<CBIN, MT>::KS_BIAS, HB = ConvW<CBIN, MT>::H_BIAS;
+            bf16x8 v;
+            if (ks == KSB && CBIN > 1 && HB == 0) {   // (the whole k-step is the bias block + nothing)
+                v = zero8();
+                if (h == HB) { v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
+            } else {
+                v = *(const bf16x8 *)(base + W.offset(K, ks, pair));
+                if (ks == KSB && h == HB) { v = zero8(); v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
+            }
+            return v;
+        };
+        if constexpr (BATCH == 0) {
+            bf16x8 b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[ks] = fragment(ks);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][ks], b[ks], acc[mt], 0, 0, 0);
+        } else {
+            constexpr int NB = (KS + BATCH - 1) / BATCH;
+            bf16x8 b[2][BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) b[0][i] = fragment(i);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (nb + 1 < NB) {
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) if ((nb + 1) * BATCH + i < KS) b[(nb + 1) & 1][i] = fragment((nb + 1) * BATCH + i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i)
+                    if (nb * BATCH + i < KS) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][nb * BATCH + i], b[nb & 1][i], acc[mt], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!valid) continue;
+        __bf16 *dst = img + __mul24(s, sample_stride) + out_off;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {   // this lane's channels 32 (mt_base + mt) + 16 h + 8 j .. + 7 = channel block cb
+                const int cb = 4 * (mt_base + mt) + 2 * h + j;
+                if (cb >= out_blocks) continue;
+                const bf16x8 v = relu_pack8(acc[mt], 8 * j);
+                if (flat_c) *(bf16x8 *)(dst + __mul24(p, flat_c) + cb * 8) = v;
+                else *(bf16x8 *)(dst + (__mul24(cb, K.Wp2) + pidx) * 8) = v;
+            }
+    }
+}
+
+template <int OBS, int NCH, bool DEEP>
+__device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
+    constexpr int CB1 = NCH > 8 ? 2 : 1;
+    const auto &K = *Kp;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long *tab = (unsigned long long *)lds;                    // [TILE][2]: observation row, action slot
+    float *red = (float *)(lds + TILE * 16);
+    __bf16 *img = (__bf16 *)(lds + TILE * 16 + K.head_mt * 4096);
+    const int sample_stride = K.sample_stride;
+    const int n_conv = K.n_conv;
+    const int N = (int)K.plan[0], n_full = (int)K.plan[1], ts = (int)K.plan[2];
+    const int n_tiles = n_full + (N - n_full * TILE + ts - 1) / ts;
+    if ((int)blockIdx.x >= n_tiles) return;
+    // weights of the first three layers: resident in registers for the whole launch (DEEP: every layer's weights come per sub-group)
+    ConvW<CB1, 1> w1c;
+    ConvW<2, 1> w2c;
+    ConvW<4, 1> w3c;
+    if (!DEEP) {
+        w1c.load(K, K.wc1, lane);
+        if (n_conv > 1) w2c.load(K, K.wc2, lane);
+        if (n_conv > 2) w3c.load(K, K.wc3, lane, wave >> 1);
+    }
+    // halo cells (and area F's slack) are zero and stay zero: only interiors are ever written
+    for (int i = tid; i < (K.ST * sample_stride) / 8; i += 256) ((bf16x8 *)img)[i] = zero8();
+    if (!DEEP) {
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        w1c.landed();
+        if (n_conv > 1) w2c.landed();
+        if (n_conv > 2) w3c.landed();
+    }
+    typedef typename ObsRaw<OBS, NCH>::type raw_t;
+    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+        const int size = tile < n_full ? TILE : ts;
+        const int n0 = tile < n_full ? tile * TILE : n_full * TILE + (tile - n_full) * ts;
+        const int nt_samples = (N - n0) < size ? (N - n0) : size;
+        __syncthreads();   // the previous tile's last readers of the table are done
+        if (tid < TILE) {  // sample -> (handle, env, row): walk forward from the tile's first env
+            unsigned long long src = 0, dst = 0;
+            if (tid < nt_samples) {
+                const uint32_t n = (uint32_t)(n0 + tid);
+                int lo = (int)K.tile_env[tile];
+                while (lo + 1 < K.n_envs && K.plan[PLAN_HDR + 1 + lo] <= n) ++lo;
+                const int e = lo, row = (int)(n - K.plan[PLAN_HDR + e]);
+                const int k = handle_of(K.env_base, K.n_handles, e);
+                const int b = e - K.env_base[k];
+                src = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS == 2 ? 2 : OBS == 1 ? 4 : 8));
+                dst = (unsigned long long)(uintptr_t)(K.actions[k] + (size_t)b * K.S + K.slot0 + row);
+            }
+            tab[2 * tid] = src;
+            tab[2 * tid + 1] = dst;
+        }
+        __syncthreads();
+        raw_t pre[NCH];
+        auto request = [&](int s0) {   // (a thread stages at most ONE position: ST * P <= 256, ppg_policy_create_spec)
+            const int left = nt_samples - s0, ns = left < K.ST ? left : K.ST;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) pre[c] = (raw_t)0;
+            if (tid < ns * K.P) {
+                const int s = div_small(tid, K.magic_P), p = tid - __mul24(s, K.P);
+                typedef typename ObsRaw<OBS, NCH>::elem elem_t;
+                const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) if (c < K.cin) pre[c] = (raw_t)src[c * K.c_stride];
+            }
+        };
+        auto stage = [&](int s0) {
+            const int left = nt_samples - s0, ns = left < K.ST ? left : K.ST;
+            if (tid < ns * K.P) {
+                const int s = div_small(tid, K.magic_P), p = tid - __mul24(s, K.P);
+                const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
+#pragma unroll
+                for (int cb = 0; cb < CB1; ++cb) {
+                    bf16x8 v = zero8();
+#pragma unroll
+                    for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = ObsRaw<OBS, NCH>::to_bf16(pre[8 * cb + c]);
+                    *(bf16x8 *)(img + __mul24(s, sample_stride) + K.off_x + (cb * K.Wp2 + __mul24(y + 1, K.Wp) + (x + 1)) * 8) = v;
+                }
+            }
+        };
+        if (!(PPG_DIRECT_ABLATE & 16)) {
+            request(0);
+            stage(0);
+            if (K.ST < nt_samples) request(K.ST);
+        }
+        __syncthreads();
+        for (int s0 = 0; s0 < nt_samples; s0 += K.ST) {
+            const int ns = (nt_samples - s0) < K.ST ? (nt_samples - s0) : K.ST;
+            // ---- convolutions -------------------------------------------------------------------------------------------
+            if (!(PPG_DIRECT_ABLATE & 8)) {
+                if (DEEP) { w1c.load(K, K.wc1, lane); __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); w1c.landed(); }
+                dconv<CB1, 1, 0>(K, w1c, img, sample_stride, K.off_x, n_conv == 1 ? K.off_f : K.off_y, K.cout_blocks[0],
+                                 n_conv == 1 ? K.flat_c : 0, ns, wave, 4, lane, 0);
+                __syncthreads();
+            }
+            if (n_conv > 1 && !(PPG_DIRECT_ABLATE & 8)) {
+                if (DEEP) { w2c.load(K, K.wc2, lane); __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); w2c.landed(); }
+                dconv<2, 1, 0>(K, w2c, img, sample_stride, K.off_y, n_conv == 2 ? K.off_f : K.off_x, K.cout_blocks[1],
+                               n_conv == 2 ? K.flat_c : 0, ns, wave, 4, lane, 0);
+                __syncthreads();
+            }
+            if (n_conv > 2 && !(PPG_DIRECT_ABLATE & 4)) {
+                if (DEEP) { w3c.load(K, K.wc3, lane, wave >> 1); __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); w3c.landed(); }
+                dconv<4, 1, 3>(K, w3c, img, sample_stride, K.off_x, n_conv == 3 ? K.off_f : K.off_d0, K.cout_blocks[2],
+                               n_conv == 3 ? K.flat_c : 0, ns, wave & 1, 2, lane, wave >> 1);
+                __syncthreads();
+            }
+            if (DEEP) {
+                for (int l = 3; l < n_conv; ++l) {   // 64 -> 64 channels: D0 -> D1 -> D0 ..., the last one into F
+                    ConvW<8, 1> wd;
+                    wd.load(K, K.wcd[l - 3], lane, wave >> 1);
+                    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    wd.landed();
+                    const int in_off = (l & 1) ? K.off_d0 : K.off_d1, mid_off = (l & 1) ? K.off_d1 : K.off_d0;
+                    const bool last = l + 1 == n_conv;
+                    dconv<8, 1, 3>(K, wd, img, sample_stride, in_off, last ? K.off_f : mid_off, K.cout_blocks[l], last ? K.flat_c : 0,
+                                   ns, wave & 1, 2, lane, wave >> 1);
+                    __syncthreads();
+                }
+            }
+            // ---- head: partial logits of this wavefront's share of the k-steps; the next sub-group's input goes into X meanwhile ----
+            if (s0 + K.ST < nt_samples && !(PPG_DIRECT_ABLATE & 16)) {
+                stage(s0 + K.ST);
+                if (s0 + 2 * K.ST < nt_samples) request(s0 + 2 * K.ST);
+            }
+            {
+                const int kq = lane >> 4, colh = lane & 15;
+                const int per = (K.kflat_steps + 3) >> 2;
+                const int k_lo = wave * per, k_hi = (k_lo + per) < K.kflat_steps ? (k_lo + per) : K.kflat_steps;
+                const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + K.off_f + 8 * kq;
+                const GLOBAL_AS bf16x8 *wa = (const GLOBAL_AS bf16x8 *)K.wh + lane;
+                f32x4_t hacc[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hacc[m][i] = 0.0f;
+                if (PPG_DIRECT_ABLATE & 1) {
+                } else if (K.head_mt == 1) {
+                    // the weight fragments come from L2: six requested at once, then their six MFMAs (a dependent chain either way)
+                    for (int k0 = k_lo; k0 < k_hi; k0 += 6) {
+                        bf16x8 a[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) a[i] = wa[(size_t)((k0 + i) < k_hi ? (k0 + i) : k_lo) * 64];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i)
+                            if (k0 + i < k_hi)
+                                hacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], *(const bf16x8 *)(fb + 32 * (k0 + i)), hacc[0], 0, 0, 0);
+                    }
+                } else {
+                    for (int k0 = k_lo; k0 < k_hi; k0 += 3) {
+                        bf16x8 a[2][3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const int ks = (k0 + i) < k_hi ? (k0 + i) : k_lo;
+                            a[0][i] = wa[(size_t)ks * 64];
+                            a[1][i] = wa[((size_t)K.kflat_steps + ks) * 64];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            if (k0 + i < k_hi) {
+                                const bf16x8 b = *(const bf16x8 *)(fb + 32 * (k0 + i));
+                                hacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][i], b, hacc[0], 0, 0, 0);
+                                hacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][i], b, hacc[1], 0, 0, 0);
+                            }
+                    }
+                }
+                // D: lane (column = sample colh, rows 4 kq + i) -> red[wave][action tile][row][column]
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    if (m < K.head_mt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) red[((wave * K.head_mt + m) * 16 + 4 * kq + i) * 16 + colh] = hacc[m][i];
+            }
+            __syncthreads();
+            // ---- logits and actions: thread (sample = tid >> 4, action = tid & 15), so a sample's 16 actions sit in 16 consecutive
+            // lanes of ONE wavefront (four samples per wavefront, all four wavefronts busy): partial sums + bias, Gumbel noise, and
+            // the argmax as four xor-shuffles inside the 16-lane group (first maximum wins, like torch.argmax) ------------------
+            if (!(PPG_DIRECT_ABLATE & 2)) {
+                const int smp = tid >> 4, a16 = tid & 15;
+                const bool live = smp < ns;
+                const int s_local = s0 + (live ? smp : 0);
+                int8_t *dst = (int8_t *)(uintptr_t)tab[2 * s_local + 1];
+                uint32_t c_env = 0, c_slot = 0;   // Philox counter of this agent = (global env index, row slot), as in phase_head
+                if (K.sample) {
+                    int k = 0;
+#pragma unroll
+                    for (int q = 1; q < MAX_HANDLES; ++q)
+                        if (q < K.n_handles && (uintptr_t)dst >= (uintptr_t)K.actions[q] &&
+                            (uintptr_t)dst < (uintptr_t)K.actions[q] + (size_t)(K.env_base[q + 1] - K.env_base[q]) * (size_t)K.S) k = q;
+                    const uint32_t off = (uint32_t)((uintptr_t)dst - (uintptr_t)K.actions[k]);
+                    const uint32_t b = off / (uint32_t)K.S;
+                    c_env = (uint32_t)K.env_base[k] + b;
+                    c_slot = off - b * (uint32_t)K.S;
+                }
+                float bestv = -INFINITY;
+                int best = 0;
+                for (int m = 0; m < K.head_mt; ++m) {
+                    const int a = 16 * m + a16;
+                    float v = -INFINITY;
+                    if (a < K.n_actions) {
+                        v = K.bh[a];   // bias, then the four wavefronts' partial sums in wavefront order
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) v += red[((w * K.head_mt + m) * 16 + a16) * 16 + smp];
+                        if (K.logits && live) K.logits[(size_t)(n0 + s_local) * K.n_actions + a] = v;
+                        if (K.sample) {   // Gumbel-max: argmax(logit - log(-log u)) ~ softmax(logits); u = word (a & 3) of Philox block a >> 2
+                            uint32_t rnd[4];
+                            philox(c_env, c_slot, (uint32_t)(a >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
+                            const uint32_t r = (a & 3) == 0 ? rnd[0] : (a & 3) == 1 ? rnd[1] : (a & 3) == 2 ? rnd[2] : rnd[3];
+                            const float u = (float)(r >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
+                            v -= __logf(-__logf(u));
+                        }
+                    }
+                    if (v > bestv) { bestv = v; best = a; }
+                }
+#pragma unroll
+                for (int d = 8; d; d >>= 1) {
+                    const float ov = __shfl_xor(bestv, d, 16);
+                    const int oa = __shfl_xor(best, d, 16);
+                    if (ov > bestv || (ov == bestv && oa < best)) { bestv = ov; best = oa; }
+                }
+                if (live && a16 == 0) *dst = (int8_t)best;
+            }
+            // (no barrier here: the next conv1 reads X and writes Y; `red` is written again three barriers from now)
+        }
+    }
+}
+
+#define PPG_POLICY_DIRECT_KERNEL(name, OBS, NCH, DEEP)                                           \
+    extern "C" __global__ void __launch_bounds__(256, 2) name(const PolParams K) {               \
+        extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                      \
+        direct_main<OBS, NCH, DEEP>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);          \
+    }
+// NCH = input channel slots staged per position: 8 (R <= 8 channels-last, or any channel-first image with <= 8 channels) or 16
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_direct8_f64, 0, 8, false)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_direct8_f32, 1, 8, false)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_direct8_bf16, 2, 8, false)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_direct16_f64, 0, 16, false)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_direct16_f32, 1, 16, false)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_direct16_bf16, 2, 16, false)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_deep8_f64, 0, 8, true)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_deep8_f32, 1, 8, true)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_deep8_bf16, 2, 8, true)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_deep16_f64, 0, 16, true)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_deep16_f32, 1, 16, true)
+PPG_POLICY_DIRECT_KERNEL(ppg_policy_deep16_bf16, 2, 16, true)
+
+}  // namespace ppgpol

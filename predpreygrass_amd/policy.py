@@ -1,13 +1,18 @@
 """Policy inference next to the env: the observations never leave the GPU.
 
-The reference trains one PPO policy per species with RLlib
+The reference trains one PPO policy per species with RLlib's `DefaultPPOTorchRLModule`
 (base_environment/tune_ppo_base_environment.py:106-141: conv_filters [[16,[3,3],1],[32,[3,3],1],[64,[3,3],1]],
-fcnet_hiddens [256,256], ReLU).  `PolicyNet` is that architecture as a plain float32 `torch.nn.Module` -- the container a
-user trains / loads weights into and the reference the parity tests compare against.  `FusedPolicy` hands the weights of two
-such modules to libppg_hip.so (`ppg_policy_create`: repacked into MFMA fragment order, bf16) and `act()` launches
-`ppg_policy_act`: hand-written matrix-core kernels that read `obs_pred` / `obs_prey` where `ppg_step` wrote them and write
-one int8 action per agent row into the env's action tensor.  bf16 operands, fp32 accumulation; tolerance in
-tests/test_policy.py.
+fcnet_hiddens [256,256], ReLU).  WHAT RLLIB BUILDS FROM THAT is pinned by the checkpoint the reference tree itself holds
+(.../shared_prey/experiments/PPO_v_APPO/.../checkpoint_000099/learner_group/learner/rl_module/type_1_predator/module_state.pkl,
+ray 2.52.1; tests/golden/rllib_checkpoint/): the (C,R,R) Box is read channels-last -- a C x R image with R channels --, the CNN
+encoder is one [ZeroPad2d, Conv2d 3x3, ReLU] per conv_filters entry (`encoder.actor_encoder.net.0.cnn.{1,4,7,..}`), its output is
+permuted back to channels-last and flattened, `fcnet_hiddens` is IGNORED for image observations, and the policy head is a single
+`Linear(flat, n_actions)` (`pi.net.mlp.0`).  `PolicyNet` is that network as a plain float32 `torch.nn.Module` WITH RLLIB'S
+PARAMETER NAMES (a checkpoint's actor entries load with `load_state_dict(strict=True)`) -- the container a user loads weights
+into and the reference the parity tests compare against.  `FusedPolicy` hands the weights of two such modules to libppg_hip.so
+(`ppg_policy_create_spec`: repacked into MFMA fragment order, bf16) and `act()` launches `ppg_policy_act`: hand-written
+matrix-core kernels that read `obs_pred` / `obs_prey` where `ppg_step` wrote them and write one int8 action per agent row into
+the env's action tensor.  bf16 operands, fp32 accumulation; tolerance in tests/test_policy.py.
 """
 from __future__ import annotations
 
@@ -19,53 +24,94 @@ import torch
 from . import _abi
 
 
+class _Named(torch.nn.Module):
+    """An empty module: only there to give the parameters RLlib's key names."""
+
+
+class _TorchCNN(torch.nn.Module):
+    """ray.rllib.core.models.torch.primitives.TorchCNN as the checkpoint's keys describe it: `cnn` = Sequential of
+    (ZeroPad2d, Conv2d, ReLU) per layer -- the convolutions sit at cnn.1, cnn.4, cnn.7, ..."""
+
+    def __init__(self, cin, channels):
+        super().__init__()
+        layers = []
+        for c in channels:
+            layers += [torch.nn.ZeroPad2d(1), torch.nn.Conv2d(cin, c, 3, 1), torch.nn.ReLU()]
+            cin = c
+        self.cnn = torch.nn.Sequential(*layers)
+
+
 class PolicyNet(torch.nn.Module):
-    """conv3x3 16/32/64 "same" + ReLU -> flatten (channel-major) -> 256 -> 256 -> n_actions logits, on a (4,R,R) observation read
-    as an image in one of two ways:
+    """L x [zero-pad 1, conv3x3 stride 1, ReLU] -> flatten -> [Linear, ReLU] per hidden head layer -> Linear -> n_actions logits,
+    on a (C,R,R) observation read as an image in one of two ways:
 
-    layout "chw"  channel-first: an R x R image with 4 channels (conv1 weight [16,4,3,3], 64 R^2 flat features);
-    layout "hwc"  channels-last: a 4 x R image with R channels (conv1 weight [16,R,3,3], 64*4*R flat features).  RLlib's CNN
-                  encoder takes 3-D Box spaces as [H, W, C], so this is the reading a module trained by
-                  tune_ppo_base_environment.py:106-141 on Box(0, 100, (4,R,R)) has; its [256, 256] MLP is the policy head.
-    `forward` takes the observation rows as the env writes them, [N,4,R,R], in either layout."""
+    layout "hwc"  channels-last, RLlib's reading of a 3-D Box: a C x R image with R channels (conv1 weight [16,R,3,3]); the
+                  encoder output is flattened [row][column][channel] (flatten "nhwc").  THE DEFAULT: with conv_channels
+                  (16,32,64) and no hidden head layer this is the module tune_ppo_base_environment.py:106-141 trains.
+    layout "chw"  channel-first: an R x R image with C channels (conv1 weight [16,C,3,3]), flattened channel-major ("nchw") -- a
+                  plain PyTorch network of one's own, not what RLlib builds.
+    Parameter names are RLlib's: encoder.actor_encoder.net.0.cnn.{1+3l}.{weight,bias}, pi.net.mlp.{2l}.{weight,bias}.
+    `forward` takes the observation rows as the env writes them, [N,C,R,R], in either layout; `.conv` / `.fc` list the layers."""
 
-    def __init__(self, obs_range: int, n_actions: int = 9, layout: str = "chw"):
+    def __init__(self, obs_range: int, n_actions: int = 9, layout: str = "hwc", obs_channels: int = 4,
+                 conv_channels=(16, 32, 64), head_hiddens=(), flatten: str = None):
         super().__init__()
         if layout not in ("chw", "hwc"):
             raise ValueError("layout must be 'chw' or 'hwc'")
-        self.obs_range, self.n_actions, self.layout = int(obs_range), int(n_actions), layout
-        R = self.obs_range
-        cin, positions = (4, R * R) if layout == "chw" else (R, 4 * R)
-        self.conv = torch.nn.ModuleList([torch.nn.Conv2d(cin, 16, 3, padding=1), torch.nn.Conv2d(16, 32, 3, padding=1),
-                                         torch.nn.Conv2d(32, 64, 3, padding=1)])
-        self.fc = torch.nn.ModuleList([torch.nn.Linear(64 * positions, 256), torch.nn.Linear(256, 256),
-                                       torch.nn.Linear(256, self.n_actions)])
+        flatten = flatten or ("nhwc" if layout == "hwc" else "nchw")
+        if flatten not in ("nhwc", "nchw"):
+            raise ValueError("flatten must be 'nhwc' or 'nchw'")
+        self.obs_range, self.n_actions, self.layout, self.flatten = int(obs_range), int(n_actions), layout, flatten
+        self.obs_channels = int(obs_channels)
+        self.conv_channels, self.head_hiddens = tuple(int(c) for c in conv_channels), tuple(int(h) for h in head_hiddens)
+        R, Cn = self.obs_range, self.obs_channels
+        cin, positions = (Cn, R * R) if layout == "chw" else (R, Cn * R)
+        self.encoder = _Named()
+        self.encoder.actor_encoder = _Named()
+        self.encoder.actor_encoder.net = torch.nn.Sequential(_TorchCNN(cin, self.conv_channels))
+        dims = [self.conv_channels[-1] * positions, *self.head_hiddens, self.n_actions]
+        mlp = []
+        for l in range(len(dims) - 1):
+            mlp.append(torch.nn.Linear(dims[l], dims[l + 1]))
+            if l + 2 < len(dims):
+                mlp.append(torch.nn.ReLU())
+        self.pi = _Named()
+        self.pi.net = _Named()
+        self.pi.net.mlp = torch.nn.Sequential(*mlp)
+
+    @property
+    def conv(self):
+        return [m for m in self.encoder.actor_encoder.net[0].cnn if isinstance(m, torch.nn.Conv2d)]
+
+    @property
+    def fc(self):
+        return [m for m in self.pi.net.mlp if isinstance(m, torch.nn.Linear)]
 
     def forward(self, obs):
         x = obs.to(torch.float32)
         if self.layout == "hwc":
-            x = x.permute(0, 3, 1, 2)   # [N, H=4, W=R, C=R] -> NCHW, as RLlib's TorchCNN does with its channels-last input
-        for c in self.conv:
-            x = torch.relu(c(x))
-        x = x.flatten(1)
-        x = torch.relu(self.fc[0](x))
-        x = torch.relu(self.fc[1](x))
-        return self.fc[2](x)
+            x = x.permute(0, 3, 1, 2)   # [N, H=C, W=R, channels=R] -> NCHW, as TorchCNN.forward does with its channels-last input
+        x = self.encoder.actor_encoder.net[0].cnn(x)
+        if self.flatten == "nhwc":
+            x = x.permute(0, 2, 3, 1)   # "permute back to channels_last", then nn.Flatten
+        return self.pi.net.mlp(x.flatten(1))
 
 
-def load_rllib_state_dict(state_dict, obs_range: int = None) -> PolicyNet:
+def load_rllib_state_dict(state_dict, obs_range: int = None, obs_channels: int = None) -> PolicyNet:
     """A `PolicyNet` holding the policy (actor) network of an RLlib PPO RLModule state dict -- what
     `RLModule.from_checkpoint(...)` holds in evaluate_ppo_from_checkpoint_debug.py:129 and greedy actions are taken from at its
-    lines 69-96 (`module.get_state()` / `module.state_dict()`, tensors or numpy arrays).
+    lines 69-96 (`module.get_state()` / the unpickled `module_state.pkl` of a checkpoint; tensors or numpy arrays).
 
     Parameter discovery is by ROLE, because the key names depend on the RLlib version and on `vf_share_layers`:
       conv layers  = the 4-D weights (with their biases) whose key contains "encoder" and not "critic" / "vf", in key order
-                     (e.g. encoder.actor_encoder.net.0.cnn.{1,4,7}.weight, or encoder.encoder... with a shared encoder);
-      head layers  = the 2-D weights whose key starts with "pi." (e.g. pi.net.mlp.{0,2,4}.weight).
-    Shapes are checked strictly: three 3x3 convolutions C -> 16 -> 32 -> 64, then Linear(flat -> 256), (256 -> 256),
-    (256 -> n_actions).  conv1's input channels decide the layout: 4 = channel-first ("chw"), R = channels-last ("hwc", RLlib's
-    own reading of a (4,R,R) Box; R is then also read off the weight).  With R == 4 the two are indistinguishable by shape and
-    `obs_range` plus the flat size decide.  Anything else raises ValueError naming the keys and shapes found."""
+                     (encoder.actor_encoder.net.0.cnn.{1,4,7,...}.weight, or encoder.encoder... with a shared encoder);
+      head layers  = the 2-D weights whose key starts with "pi." (pi.net.mlp.0.weight alone in what RLlib builds by default;
+                     pi.net.mlp.{0,2,..} with `head_fcnet_hiddens`).
+    The ARCHITECTURE IS TAKEN FROM THE SHAPES: 1-6 convolutions 3x3 (up to 16 / 32 / 64 / 64 .. channels), 0-2 hidden head layers
+    (up to 256 features).  conv1's input channels and the head's input size decide the reading of the (C,R,R) Box: channels-last
+    ("hwc", RLlib: conv1 takes R channels, flat = C * R * cout) or channel-first ("chw": conv1 takes C channels, flat = R * R *
+    cout); where both fit, `obs_range` / `obs_channels` decide and channels-last wins otherwise.  Anything else raises ValueError
+    naming the keys and shapes found."""
     def arr(v):
         return v.detach().cpu().to(torch.float32) if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v), dtype=torch.float32)
     sd = {k: arr(v) for k, v in state_dict.items() if hasattr(v, "shape")}
@@ -75,13 +121,14 @@ def load_rllib_state_dict(state_dict, obs_range: int = None) -> PolicyNet:
         kl = k.lower()
         return "encoder" in kl and "critic" not in kl and ".vf" not in kl and not kl.startswith("vf")
     conv_w = [k for k, v in sd.items() if v.dim() == 4 and is_actor_encoder(k)]
-    if not conv_w:   # a bare state dict of the network itself (e.g. a PolicyNet's own)
+    if not conv_w:   # a bare state dict of the network itself
         conv_w = [k for k, v in sd.items() if v.dim() == 4]
     head_w = [k for k, v in sd.items() if v.dim() == 2 and k.lower().startswith("pi.")]
     if not head_w:
         head_w = [k for k, v in sd.items() if v.dim() == 2 and "critic" not in k.lower() and not k.lower().startswith("vf")]
-    if len(conv_w) != 3 or len(head_w) != 3:
-        raise ValueError(f"expected 3 convolution and 3 linear weights of the policy network, found {len(conv_w)} / {len(head_w)}: {listing}")
+    if not 1 <= len(conv_w) <= _abi.POLICY_MAX_CONV or not 1 <= len(head_w) <= _abi.POLICY_MAX_FC:
+        raise ValueError(f"expected 1-{_abi.POLICY_MAX_CONV} convolution and 1-{_abi.POLICY_MAX_FC} linear weights of the policy "
+                         f"network, found {len(conv_w)} / {len(head_w)}: {listing}")
 
     def bias_of(k):
         kb = k[: -len("weight")] + "bias" if k.endswith("weight") else None
@@ -90,30 +137,52 @@ def load_rllib_state_dict(state_dict, obs_range: int = None) -> PolicyNet:
         return sd[kb]
     cw, hw = [sd[k] for k in conv_w], [sd[k] for k in head_w]
     cin = int(cw[0].shape[1])
-    want_conv = [(16, cin, 3, 3), (32, 16, 3, 3), (64, 32, 3, 3)]
-    if [tuple(w.shape) for w in cw] != want_conv:
-        raise ValueError(f"convolutions {[tuple(w.shape) for w in cw]} are not 3x3 {cin} -> 16 -> 32 -> 64 "
-                         "(tune_ppo_base_environment.py:112-116)")
-    flat, n_actions = int(hw[0].shape[1]), int(hw[2].shape[0])
-    if tuple(hw[0].shape) != (256, flat) or tuple(hw[1].shape) != (256, 256) or tuple(hw[2].shape) != (n_actions, 256):
-        raise ValueError(f"policy head {[tuple(w.shape) for w in hw]} is not Linear(flat, 256), (256, 256), (256, n_actions)")
-    layouts = []
-    if cin == 4 and flat % 64 == 0 and int(round((flat // 64) ** 0.5)) ** 2 == flat // 64:
-        layouts.append(("chw", int(round((flat // 64) ** 0.5))))
-    if flat == 64 * 4 * cin:
-        layouts.append(("hwc", cin))
+    chans, prev = [], cin
+    for l, w in enumerate(cw):
+        if tuple(w.shape[2:]) != (3, 3) or int(w.shape[1]) != prev:
+            raise ValueError(f"convolutions {[tuple(w.shape) for w in cw]} are not 3x3 layers feeding each other "
+                             "(tune_ppo_base_environment.py:112-116)")
+        prev = int(w.shape[0])
+        if prev > (16, 32, 64)[min(l, 2)]:
+            raise ValueError(f"convolution {l + 1} has {prev} output channels: the kernels take up to 16 / 32 / 64 / 64 ...")
+        chans.append(prev)
+    flat, n_actions = int(hw[0].shape[1]), int(hw[-1].shape[0])
+    hidden, prev = [], flat
+    for l, w in enumerate(hw):
+        if int(w.shape[1]) != prev:
+            raise ValueError(f"policy head {[tuple(w.shape) for w in hw]} is not a chain of Linear layers")
+        prev = int(w.shape[0])
+        if l + 1 < len(hw):
+            if prev > 256:
+                raise ValueError(f"policy head {[tuple(w.shape) for w in hw]}: hidden layers of up to 256 features")
+            hidden.append(prev)
+    if hidden and len(cw) != 3:
+        raise ValueError(f"a policy head with hidden layers needs exactly three convolutions, found {len(cw)}")
+    if flat % chans[-1]:
+        raise ValueError(f"the head takes {flat} features, not a multiple of the last convolution's {chans[-1]} channels")
+    positions = flat // chans[-1]
+    layouts = []   # (layout, R, C)
+    if positions % cin == 0 and 1 <= positions // cin <= 8:
+        layouts.append(("hwc", cin, positions // cin))
+    r = int(round(positions ** 0.5))
+    if r * r == positions and 1 <= cin <= 8:
+        layouts.append(("chw", r, cin))
     if obs_range is not None:
-        layouts = [(l, r) for l, r in layouts if r == int(obs_range)]
+        layouts = [t for t in layouts if t[1] == int(obs_range)]
+    if obs_channels is not None:
+        layouts = [t for t in layouts if t[2] == int(obs_channels)]
     if not layouts:
-        raise ValueError(f"conv1 has {cin} input channels and the head takes {flat} features: neither 64 R^2 with 4 channels "
-                         f"(channel-first) nor 64*4*R with R channels (channels-last)"
-                         + (f" for obs_range {obs_range}" if obs_range is not None else ""))
-    layout, R = layouts[-1] if cin != 4 else layouts[0]
-    net = PolicyNet(R, n_actions, layout)
+        raise ValueError(f"conv1 has {cin} input channels and the head takes {flat} = {positions} x {chans[-1]} features: neither "
+                         f"C x R positions with R channels (channels-last) nor R x R positions with C channels (channel-first)"
+                         + (f" for obs_range {obs_range}" if obs_range is not None else "")
+                         + (f" for obs_channels {obs_channels}" if obs_channels is not None else ""))
+    layout, R, Cn = layouts[0]
+    net = PolicyNet(R, n_actions, layout, obs_channels=Cn, conv_channels=chans, head_hiddens=hidden)
     with torch.no_grad():
-        for l in range(3):
-            net.conv[l].weight.copy_(cw[l]); net.conv[l].bias.copy_(bias_of(conv_w[l]))
-            net.fc[l].weight.copy_(hw[l]); net.fc[l].bias.copy_(bias_of(head_w[l]))
+        for l, m in enumerate(net.conv):
+            m.weight.copy_(cw[l]); m.bias.copy_(bias_of(conv_w[l]))
+        for l, m in enumerate(net.fc):
+            m.weight.copy_(hw[l]); m.bias.copy_(bias_of(head_w[l]))
     return net
 
 
@@ -138,24 +207,32 @@ class FusedPolicy:
     def _create(self, net):
         if net is None:
             return None
-        keep = []   # the host arrays must live until ppg_policy_create returns
+        keep = []   # the host arrays must live until ppg_policy_create_spec returns
 
         def host(t):
             a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
             keep.append(a)
             return a.ctypes.data
-        w = _abi.PpgPolicyWeights()
-        for l in range(3):
-            w.conv_w[l], w.conv_b[l] = host(net.conv[l].weight), host(net.conv[l].bias)
-            w.fc_w[l], w.fc_b[l] = host(net.fc[l].weight), host(net.fc[l].bias)
+        convs, fcs = net.conv, net.fc
+        if len(convs) > _abi.POLICY_MAX_CONV or len(fcs) > _abi.POLICY_MAX_FC:
+            raise ValueError(f"{len(convs)} convolutions / {len(fcs)} linear layers: the kernels take up to "
+                             f"{_abi.POLICY_MAX_CONV} / {_abi.POLICY_MAX_FC}")
+        sp = _abi.PpgPolicySpec()
+        sp.obs_channels, sp.obs_range, sp.n_actions = net.obs_channels, net.obs_range, net.n_actions
+        sp.layout = _abi.POLICY_LAYOUT_HWC if net.layout == "hwc" else _abi.POLICY_LAYOUT_CHW
+        sp.flatten = _abi.POLICY_FLATTEN_NHWC if net.flatten == "nhwc" else _abi.POLICY_FLATTEN_NCHW
+        sp.n_conv, sp.n_fc = len(convs), len(fcs)
+        for l, m in enumerate(convs):
+            sp.conv_out[l], sp.conv_w[l], sp.conv_b[l] = m.out_channels, host(m.weight), host(m.bias)
+        for l, m in enumerate(fcs):
+            sp.fc_out[l], sp.fc_w[l], sp.fc_b[l] = m.out_features, host(m.weight), host(m.bias)
         h = C.c_void_p()
-        layout = _abi.POLICY_LAYOUT_HWC if getattr(net, "layout", "chw") == "hwc" else _abi.POLICY_LAYOUT_CHW
-        rc = self._lib.ppg_policy_create_layout(self.device.index, net.obs_range, net.n_actions, layout, C.byref(w), C.byref(h))
+        rc = self._lib.ppg_policy_create_spec(self.device.index, C.byref(sp), C.byref(h))
         if rc != 0:
             msg = self._lib.ppg_policy_last_error(None).decode()
             if rc == -1:
                 raise ValueError(msg)
-            raise RuntimeError(f"ppg_policy_create failed ({rc}): {msg}")
+            raise RuntimeError(f"ppg_policy_create_spec failed ({rc}): {msg}")
         return h
 
     def macs_per_observation(self, species: int) -> int:

@@ -71,6 +71,8 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
         '         offsetof(ppg_config_gen2, mutation_rate_prey), offsetof(ppg_config_gen2, mask_observation_with_visibility));\n'
         '  printf("%zu %zu\\n", offsetof(ppg_buffers, row_lastrep), offsetof(ppg_buffers, row_info));\n'
         '  printf("%d %d\\n", PPG_ABI_VERSION, PPG_ENV_WORDS);\n'
+        '  printf("%zu %zu %zu %zu %zu\\n", sizeof(ppg_policy_spec), offsetof(ppg_policy_spec, conv_out), offsetof(ppg_policy_spec, n_fc),\n'
+        '         offsetof(ppg_policy_spec, conv_w), offsetof(ppg_policy_spec, fc_b));\n'
         '  return 0;\n}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
@@ -83,3 +85,5 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
                                 ("n_grass", "reward_predator_catch_prey", "mutation_rate_prey", "mask_observation_with_visibility")]
     assert lines[3].split() == [str(B.row_lastrep.offset), str(B.row_info.offset)]
     assert lines[4].split() == [str(_abi.ABI_VERSION), str(_abi.ENV_WORDS)]
+    PS = _abi.PpgPolicySpec
+    assert lines[5].split() == [str(ctypes.sizeof(PS))] + [str(getattr(PS, n).offset) for n in ("conv_out", "n_fc", "conv_w", "fc_b")]

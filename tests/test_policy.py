@@ -1,10 +1,16 @@
 """Policy inference next to the env (ppg_policy_*).
 
-The MFMA kernels compute in bf16 with fp32 accumulation and round activations to bf16 between the six layers; the reference is
-`PolicyNet` -- the same architecture in float32 PyTorch -- on the same weights and the same observation rows.
-TOLERANCE (stated here, checked below): |logit_hip - logit_fp32| <= 0.02 * max(1, max|logit_fp32|) for every logit, and the
-greedy action agrees wherever the fp32 margin between the best and the second-best logit exceeds twice that bound.  The
-reference's own RLlib module cannot be imported in this container: parity vs RLlib itself is unpinned."""
+WHAT IS PINNED: the architecture.  The reference tree holds one real RLlib checkpoint of its PPO setup (ray 2.52.1); its key names,
+shapes and float32 actor weights are committed under tests/golden/rllib_checkpoint/ (make_fixture.py) and `PolicyNet` -- the float32
+PyTorch restatement the kernels are compared with -- must load them with `strict=True`.  RLlib itself cannot be imported here
+(SURVEY.md 8(c)), so the FORWARD semantics (zero-pad + conv + ReLU per layer, channels-last flatten, one Linear head) are restated
+from ray/rllib/core/models/torch/{primitives,encoder}.py, not executed.
+TOLERANCE of the MFMA kernels (bf16 operands, fp32 accumulation, activations rounded to bf16 between layers), stated here and checked
+below: |logit_hip - logit_fp32| <= 0.02 * max(1, max|logit_fp32|) for every logit, and the greedy action agrees wherever the fp32
+margin between the best and the second-best logit exceeds twice that bound."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,81 +20,136 @@ from predpreygrass_amd.config import config_env
 from predpreygrass_amd.policy import PolicyNet
 
 REL_TOL = 0.02
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rllib_checkpoint")
 
 
-def make_nets(Rp=7, Rq=9, scale=3.0, seed=0, layout="chw"):
+def make_nets(Rp=7, Rq=9, scale=3.0, seed=0, **kw):
     """Default-initialised networks with the weights scaled up so that the logits are O(1) and distinct."""
     torch.manual_seed(seed)
-    nets = [PolicyNet(Rp, layout=layout), PolicyNet(Rq, layout=layout)]
+    nets = [PolicyNet(Rp, **kw), PolicyNet(Rq, **kw)]
     with torch.no_grad():
         for net in nets:
-            for m in list(net.conv) + list(net.fc):
+            for m in net.conv + net.fc:
                 m.weight.mul_(scale)
                 m.bias.uniform_(-0.2, 0.2)
     return nets
 
 
-def test_policy_net_is_the_reference_architecture():
-    """tune_ppo_base_environment.py:106-141: conv 3x3 [16, 32, 64] stride 1, fcnet_hiddens [256, 256], ReLU."""
+def test_policy_net_is_what_rllib_builds():
+    """tune_ppo_base_environment.py:106-141 -> RLlib: the (4,9,9) Box read as a 4 x 9 image with 9 channels, conv 3x3 [16, 32, 64]
+    with explicit zero padding, channels-last flatten, ONE Linear head (fcnet_hiddens is ignored for image observations)."""
     net = PolicyNet(9)
-    assert [tuple(c.weight.shape) for c in net.conv] == [(16, 4, 3, 3), (32, 16, 3, 3), (64, 32, 3, 3)]
-    assert [tuple(f.weight.shape) for f in net.fc] == [(256, 64 * 81), (256, 256), (9, 256)]
-    out = net(torch.zeros(5, 4, 9, 9, dtype=torch.float64))
+    assert list(net.state_dict()) == [f"encoder.actor_encoder.net.0.cnn.{i}.{w}" for i in (1, 4, 7) for w in ("weight", "bias")] + \
+        ["pi.net.mlp.0.weight", "pi.net.mlp.0.bias"]
+    assert [tuple(c.weight.shape) for c in net.conv] == [(16, 9, 3, 3), (32, 16, 3, 3), (64, 32, 3, 3)]
+    assert [tuple(f.weight.shape) for f in net.fc] == [(9, 64 * 4 * 9)]
+    x = torch.rand(5, 4, 9, 9, dtype=torch.float64)
+    out = net(x)
     assert out.shape == (5, 9) and out.dtype == torch.float32
+    # the forward pass, written out: [N, H=4, W=9, C=9] -> NCHW -> (pad, conv, relu) x 3 -> NHWC -> flatten -> Linear
+    y = x.float().permute(0, 3, 1, 2)
+    for c in net.conv:
+        y = torch.relu(torch.nn.functional.conv2d(torch.nn.functional.pad(y, (1, 1, 1, 1)), c.weight, c.bias))
+    assert y.shape == (5, 64, 4, 9)
+    want = torch.nn.functional.linear(y.permute(0, 2, 3, 1).reshape(5, -1), net.fc[0].weight, net.fc[0].bias)
+    assert torch.equal(out, want)
+
+
+def test_real_rllib_checkpoint_pins_the_architecture():
+    """The checkpoint in the reference tree (shared_prey PPO run, Box(5,9,9), conv_filters 16/32/64/64, fcnet_hiddens [256,256]):
+    its state holds four convolutions with conv1 taking NINE input channels (channels-last reading) and a single-Linear head
+    [9, 2880] -- no 256-wide layer anywhere.  PolicyNet takes the actor entries with strict=True, and load_rllib_state_dict
+    recovers the same network from the full state (critic and value head ignored)."""
+    from predpreygrass_amd.policy import load_rllib_state_dict
+    listing = json.load(open(os.path.join(FIXTURE, "state_listing.json")))
+    assert listing["metadata"]["ray_version"] == "2.52.1"
+    for sp in ("type_1_predator", "type_1_prey"):
+        ctor, state = listing[sp]["ctor"], listing[sp]["state"]
+        assert ctor["module_class"] == "DefaultPPOTorchRLModule" and ctor["observation_box_shape"] == [5, 9, 9]
+        assert ctor["conv_filters"] == [[16, [3, 3], 1], [32, [3, 3], 1], [64, [3, 3], 1], [64, [3, 3], 1]]
+        assert ctor["fcnet_hiddens"] == [256, 256] and "head_fcnet_hiddens" not in ctor["model_config_keys"]
+        assert state["encoder.actor_encoder.net.0.cnn.1.weight"]["shape"] == [16, 9, 3, 3]
+        assert state["pi.net.mlp.0.weight"]["shape"] == [9, 2880] and "pi.net.mlp.2.weight" not in state
+        assert not any(256 in v["shape"] for v in state.values())          # fcnet_hiddens built nothing
+    actor = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(FIXTURE, "type_1_predator_actor.npz")).items()}
+    net = PolicyNet(9, 9, "hwc", obs_channels=5, conv_channels=(16, 32, 64, 64))
+    net.load_state_dict(actor, strict=True)                                # names AND shapes
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == \
+        {k: v["shape"] for k, v in listing["type_1_predator"]["state"].items() if k in actor}
+    full = dict(actor)
+    for k, v in listing["type_1_predator"]["state"].items():
+        if k not in full:
+            full[k] = torch.randn(v["shape"])                              # critic encoder, value head, log_std constants
+    got = load_rllib_state_dict(full)
+    assert (got.layout, got.flatten, got.obs_range, got.obs_channels, got.n_actions) == ("hwc", "nhwc", 9, 5, 9)
+    assert got.conv_channels == (16, 32, 64, 64) and got.head_hiddens == ()
+    x = torch.rand(7, 5, 9, 9) * 3
+    assert torch.equal(got(x), net(x))
+    assert float(net(x).abs().max()) > 1e-3
 
 
 def rllib_style_state_dict(net, shared_encoder=False, numpy_values=False):
-    """The parameter names an RLlib PPO RLModule gives such a network (actor / critic encoder or one shared encoder: a TorchCNN is
-    ZeroPad2d, Conv2d, activation per layer, so the convolutions sit at cnn.1 / cnn.4 / cnn.7; heads are TorchMLPs), with a critic
-    next to the actor."""
-    enc = "encoder.encoder" if shared_encoder else "encoder.actor_encoder"
+    """The state of an RLlib PPO RLModule around `net`'s actor network: the critic's encoder and the value head next to it (or one
+    shared encoder, vf_share_layers), key names as in the real checkpoint."""
     sd = {}
-    for l in range(3):
-        sd[f"{enc}.net.0.cnn.{1 + 3 * l}.weight"] = net.conv[l].weight.detach().clone()
-        sd[f"{enc}.net.0.cnn.{1 + 3 * l}.bias"] = net.conv[l].bias.detach().clone()
-        if not shared_encoder:
-            sd[f"encoder.critic_encoder.net.0.cnn.{1 + 3 * l}.weight"] = torch.randn_like(net.conv[l].weight)
-            sd[f"encoder.critic_encoder.net.0.cnn.{1 + 3 * l}.bias"] = torch.randn_like(net.conv[l].bias)
-        sd[f"pi.net.mlp.{2 * l}.weight"] = net.fc[l].weight.detach().clone()
-        sd[f"pi.net.mlp.{2 * l}.bias"] = net.fc[l].bias.detach().clone()
-    flat = net.fc[0].weight.shape[1]
-    for l, shape in enumerate([(256, flat), (256, 256), (1, 256)]):
-        sd[f"vf.net.mlp.{2 * l}.weight"] = torch.randn(shape)
-        sd[f"vf.net.mlp.{2 * l}.bias"] = torch.randn(shape[0])
+    for k, v in net.state_dict().items():
+        if shared_encoder:
+            k = k.replace("encoder.actor_encoder.", "encoder.encoder.")
+        sd[k] = v.detach().clone()
+        if not shared_encoder and k.startswith("encoder.actor_encoder."):
+            sd[k.replace("actor_encoder", "critic_encoder")] = torch.randn_like(v)
+    sd["pi.log_std_clip_param_const"] = torch.zeros(1)
+    dims = [net.fc[0].in_features, *net.head_hiddens, 1]
+    for l in range(len(dims) - 1):
+        sd[f"vf.net.mlp.{2 * l}.weight"] = torch.randn(dims[l + 1], dims[l])
+        sd[f"vf.net.mlp.{2 * l}.bias"] = torch.randn(dims[l + 1])
     if numpy_values:
         sd = {k: v.numpy() for k, v in sd.items()}
     return sd
 
 
 @pytest.mark.parametrize("layout,R", [("chw", 7), ("chw", 9), ("hwc", 7), ("hwc", 9), ("hwc", 5)])
+@pytest.mark.parametrize("hiddens", [(), (256,), (256, 256), (128, 64)])
 @pytest.mark.parametrize("shared,as_numpy", [(False, False), (True, True)])
-def test_load_rllib_state_dict_recovers_the_network_in_either_layout(layout, R, shared, as_numpy):
-    """conv1 [16,4,3,3] = channel-first, [16,R,3,3] = RLlib's channels-last reading of the (4,R,R) Box; the loaded network gives the
-    same logits as the one the state dict was taken from, the critic's parameters are ignored."""
+def test_load_rllib_state_dict_takes_the_architecture_from_the_shapes(layout, R, hiddens, shared, as_numpy):
+    """conv1 [16,4,3,3] = channel-first, [16,R,3,3] = RLlib's channels-last reading of the (4,R,R) Box; 0, 1 or 2 hidden head layers
+    (head_fcnet_hiddens); the loaded network gives the same logits as the one the state dict was taken from."""
     from predpreygrass_amd.policy import load_rllib_state_dict
     torch.manual_seed(R)
-    src = PolicyNet(R, 9, layout)
+    src = PolicyNet(R, 9, layout, head_hiddens=hiddens)
     net = load_rllib_state_dict(rllib_style_state_dict(src, shared, as_numpy))
-    assert (net.layout, net.obs_range, net.n_actions) == (layout, R, 9)
+    assert (net.layout, net.obs_range, net.n_actions, net.obs_channels, net.head_hiddens) == (layout, R, 9, 4, hiddens)
     assert tuple(net.conv[0].weight.shape) == ((16, 4, 3, 3) if layout == "chw" else (16, R, 3, 3))
     assert net.fc[0].weight.shape[1] == (64 * R * R if layout == "chw" else 64 * 4 * R)
     x = torch.rand(6, 4, R, R, dtype=torch.float64)
     assert torch.equal(net(x), src(x))
-    # the channels-last network really convolves over the (4, R) plane with the last axis as channels
-    if layout == "hwc":
-        y = torch.relu(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), net.conv[0].weight, net.conv[0].bias, padding=1))
-        assert y.shape == (6, 16, 4, R)
+
+
+def test_load_rllib_state_dict_other_depths_and_channels():
+    """The second-generation tune scripts size the encoder by the window ((R - 1) // 2 layers of 16, 32, 64, 64 ..,
+    red_queen/utils/networks.py:18-25) and the walls variant can add a fifth observation channel."""
+    from predpreygrass_amd.policy import load_rllib_state_dict
+    for R, chans, C in [(5, (16, 32), 4), (9, (16, 32, 64, 64), 4), (11, (16, 32, 64, 64, 64), 5), (3, (16,), 4)]:
+        src = PolicyNet(R, 25, "hwc", obs_channels=C, conv_channels=chans)
+        net = load_rllib_state_dict(rllib_style_state_dict(src))
+        assert (net.conv_channels, net.obs_channels, net.obs_range, net.n_actions) == (chans, C, R, 25)
+        x = torch.rand(3, C, R, R)
+        assert torch.equal(net(x), src(x))
 
 
 def test_load_rllib_state_dict_fails_loudly():
     from predpreygrass_amd.policy import load_rllib_state_dict
-    good = rllib_style_state_dict(PolicyNet(7, 9, "hwc"))
+    good = rllib_style_state_dict(PolicyNet(7, 9, "hwc", head_hiddens=(256, 256)))
     for mutate, what in [
-        (lambda d: d.pop("pi.net.mlp.4.weight"), "3 linear"),                                            # a head layer missing
+        (lambda d: [d.pop(k) for k in list(d) if k.startswith("pi.net.mlp")], "linear weights"),          # no head at all
         (lambda d: d.pop("encoder.actor_encoder.net.0.cnn.4.bias"), "no bias"),
         (lambda d: d.update({"encoder.actor_encoder.net.0.cnn.4.weight": torch.zeros(32, 16, 5, 5)}), "not 3x3"),   # another filter size
         (lambda d: d.update({"pi.net.mlp.0.weight": torch.zeros(256, 64 * 4 * 7 + 64), "pi.net.mlp.0.bias": torch.zeros(256)}), "neither"),
-        (lambda d: d.update({"pi.net.mlp.2.weight": torch.zeros(128, 256), "pi.net.mlp.2.bias": torch.zeros(128)}), "policy head"),
+        (lambda d: d.update({"pi.net.mlp.2.weight": torch.zeros(128, 255), "pi.net.mlp.2.bias": torch.zeros(128)}), "chain of Linear"),
+        (lambda d: d.update({"pi.net.mlp.0.weight": torch.zeros(512, 64 * 4 * 7), "pi.net.mlp.0.bias": torch.zeros(512),
+                             "pi.net.mlp.2.weight": torch.zeros(256, 512)}), "up to 256"),
+        (lambda d: d.update({"encoder.actor_encoder.net.0.cnn.7.weight": torch.zeros(128, 32, 3, 3),
+                             "encoder.actor_encoder.net.0.cnn.7.bias": torch.zeros(128)}), "output channels"),
     ]:
         d = dict(good)
         mutate(d)
@@ -96,6 +157,11 @@ def test_load_rllib_state_dict_fails_loudly():
             load_rllib_state_dict(d)
     with pytest.raises(ValueError, match="obs_range 9"):
         load_rllib_state_dict(good, obs_range=9)     # a 7-window network for 9-window observations
+    deep = rllib_style_state_dict(PolicyNet(9, 9, "hwc", conv_channels=(16, 32, 64, 64)))
+    deep.update({"pi.net.mlp.0.weight": torch.zeros(256, 64 * 36), "pi.net.mlp.0.bias": torch.zeros(256),
+                 "pi.net.mlp.2.weight": torch.zeros(9, 256), "pi.net.mlp.2.bias": torch.zeros(9)})
+    with pytest.raises(ValueError, match="exactly three convolutions"):
+        load_rllib_state_dict(deep)
 
 
 def test_fused_policy_fails_loudly_without_a_gpu():
@@ -199,14 +265,17 @@ def test_policy_over_sub_batches_partial_tiles_and_other_window_sizes():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("Rp,Rq", [(7, 9), (5, 11), (9, 15)])
-def test_channels_last_networks_match_fp32_reference(Rp, Rq):
-    """RLlib's reading of the (4,R,R) Box -- a 4 x R image with R channels (PPG_POLICY_LAYOUT_HWC): one and two channel blocks into
-    conv1 (R <= 8 / R >= 9), loaded from an RLlib-style state dict, float64 and float32 observations, sparse and dense windows."""
+@pytest.mark.parametrize("hiddens", [(), (256,), (256, 256), (96, 160)])
+def test_rllib_networks_with_any_head_depth_match_fp32_reference(Rp, Rq, hiddens):
+    """RLlib's reading of the (4,R,R) Box -- a 4 x R image with R channels, channels-last flatten -- with the single-Linear head RLlib
+    builds by default (the all-in-LDS kernels) and with 1 or 2 hidden head layers (head_fcnet_hiddens; widths below 256 are
+    zero-padded): one and two channel blocks into conv1 (R <= 8 / R >= 9), loaded from an RLlib-style state dict, float64 and
+    float32 observations, sparse and dense windows."""
     from predpreygrass_amd.batched import BatchedPredPreyGrass
     from predpreygrass_amd.policy import FusedPolicy, load_rllib_state_dict
-    src = make_nets(Rp, Rq, seed=11, layout="hwc")
+    src = make_nets(Rp, Rq, seed=11, head_hiddens=hiddens)
     nets = [load_rllib_state_dict(rllib_style_state_dict(n)) for n in src]
-    assert [n.layout for n in nets] == ["hwc", "hwc"]
+    assert [(n.layout, n.flatten, n.head_hiddens) for n in nets] == [("hwc", "nhwc", hiddens)] * 2
     fused = FusedPolicy(nets[0], nets[1])
     cfg = {**config_env, "predator_obs_range": Rp, "prey_obs_range": Rq}
     for dt in (torch.float64, torch.float32):
@@ -216,19 +285,94 @@ def test_channels_last_networks_match_fp32_reference(Rp, Rq):
             env.step(random_actions=True, auto_reset=True)
         w1, a1 = check_against_fp32([env], nets, fused)
         w2, a2 = check_against_fp32([env], nets, fused, dense_obs=True, seed=2)
-        print(f"hwc {Rp}/{Rq} {dt}: max relative logit error {max(w1, w2):.2e}; greedy agreement {a1:.4f} / {a2:.4f}")
+        print(f"hwc {Rp}/{Rq} {hiddens} {dt}: max relative logit error {max(w1, w2):.2e}; greedy agreement {a1:.4f} / {a2:.4f}")
         assert a1 > 0.97 and a2 > 0.97
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", ["chw", "hwc"])
-def test_bfloat16_observation_rows_give_bit_identical_logits(layout):
+@pytest.mark.parametrize("kw", [dict(layout="chw", head_hiddens=(256, 256)), dict(layout="chw"), dict(layout="chw", flatten="nhwc"),
+                                dict(layout="hwc", flatten="nchw"), dict(conv_channels=(16, 32)), dict(conv_channels=(16,)),
+                                dict(conv_channels=(16, 32, 64, 64)), dict(conv_channels=(16, 32, 64, 64, 64)),
+                                dict(conv_channels=(12, 24, 40)), dict(conv_channels=(16, 32, 64), head_hiddens=(256, 256), flatten="nchw")])
+def test_other_network_shapes_match_fp32_reference(kw):
+    """Everything ppg_policy_create_spec takes: channel-first images (rounds 2-3's network: R x R image, 256/256 head, channel-major
+    flatten), either flatten order with either reading, 1 to 5 convolutions (the second-generation tune scripts use (R - 1) // 2
+    layers), channel counts that are not multiples of 8."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy
+    nets = make_nets(seed=13, **kw)
+    fused = FusedPolicy(nets[0], nets[1])
+    env = BatchedPredPreyGrass(dict(config_env), batch_size=23, device="cuda:0", seed=7)
+    env.reset()
+    for _ in range(40):
+        env.step(random_actions=True, auto_reset=True)
+    w1, a1 = check_against_fp32([env], nets, fused)
+    w2, a2 = check_against_fp32([env], nets, fused, dense_obs=True, seed=5)
+    print(f"{kw}: max relative logit error {max(w1, w2):.2e}; greedy agreement {a1:.4f} / {a2:.4f}")
+    assert a1 > 0.97 and a2 > 0.97
+
+
+@pytest.mark.gpu
+def test_real_rllib_checkpoint_weights_on_the_matrix_cores():
+    """The actor of the checkpoint the reference tree holds (Box(5,9,9), four convolutions, Linear(2880, 9)) evaluated on the
+    5-channel 9x9 observations of the walls variant with its visibility channel: the kernels' logits against the float32 module
+    holding the same real weights, on the env's own observations and on dense ones."""
+    from predpreygrass_amd.policy import FusedPolicy, load_rllib_state_dict
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+    from predpreygrass_amd.walls_occlusion import config_env_zigzag_walls
+    actor = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(FIXTURE, "type_1_predator_actor.npz")).items()}
+    net = load_rllib_state_dict(actor)
+    assert (net.obs_channels, net.obs_range, net.conv_channels, net.head_hiddens) == (5, 9, (16, 32, 64, 64), ())
+    fused = FusedPolicy(net, net)
+    cfg = {**config_env_zigzag_walls, "predator_obs_range": 9, "prey_obs_range": 9}
+    env = BatchedRedQueen(cfg, batch_size=29, device="cuda:0", walls=True, obs_dtype=torch.float32, seed=3)   # (the reference's dtype)
+    assert env.obs_channels == 5
+    env.set_walls(cfg["manual_wall_positions"])
+    env.reset()
+    for _ in range(40):
+        env.step(random_actions=True, auto_reset=True)
+    w1, a1 = check_against_fp32([env], [net, net], fused)
+    print(f"real checkpoint, env observations: max relative logit error {w1:.2e}; greedy agreement {a1:.4f}")
+    assert a1 > 0.95
+    # Dense random windows in [-1, 3) are far from anything this network was trained on, and its four trained layers amplify the
+    # rounding of bf16 operands beyond the 2 % bound (a float32 PyTorch forward pass with weights and activations rounded to
+    # bf16 the way the kernels round them is itself 3-5 % away from the float32 one).  So on these inputs the kernels are compared
+    # with THAT emulation -- same roundings, only the summation order differs -- within 0.5 % of the largest logit.
+    g = torch.Generator(device="cuda:0").manual_seed(8)
+    for t in (env.obs_pred, env.obs_prey):
+        t.copy_((torch.rand(t.shape, generator=g, device="cuda:0", dtype=torch.float32) * 4 - 1).to(t.dtype))
+    lg = fused.act(env, want_logits=True)
+    torch.cuda.synchronize()
+    mp, mq = rows_in_use(env)
+    net = net.to("cuda:0")
+
+    def bf(t):
+        return t.bfloat16().float()
+    for got, obs in ((lg[0], env.obs_pred[mp]), (lg[1], env.obs_prey[mq])):
+        with torch.no_grad():
+            y = bf(obs.float()).permute(0, 3, 1, 2)
+            for c in net.conv:
+                y = bf(torch.relu(torch.nn.functional.conv2d(torch.nn.functional.pad(y, (1, 1, 1, 1)), bf(c.weight), c.bias)))
+            emu = torch.nn.functional.linear(y.permute(0, 2, 3, 1).flatten(1), bf(net.fc[0].weight), net.fc[0].bias)
+            ref = net(obs)
+        n = obs.shape[0]
+        err_emu, err_fp32 = float((got[:n] - emu).abs().max()), float((got[:n] - ref).abs().max())
+        print(f"real checkpoint, dense windows: |hip - bf16 emulation| {err_emu:.3e}, |hip - fp32| {err_fp32:.3e}, max |logit| {float(ref.abs().max()):.2f}")
+        assert err_emu <= 0.005 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(ValueError, match="channel"):
+        from predpreygrass_amd.batched import BatchedPredPreyGrass
+        fused.act(BatchedPredPreyGrass({**config_env, "predator_obs_range": 9}, batch_size=2, device="cuda:0").reset())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(head_hiddens=(256, 256)), dict(layout="chw", head_hiddens=(256, 256))])
+def test_bfloat16_observation_rows_give_bit_identical_logits(kw):
     """obs_dtype bfloat16: ppg_step writes the rows the policy stages -- the float64 value rounded exactly as the policy kernels
     round it -- a quarter of the bytes, the SAME logits and actions bit for bit (no float64 row is written or read
     in a rollout whose policy runs next to the env)."""
     from predpreygrass_amd.batched import BatchedPredPreyGrass
     from predpreygrass_amd.policy import FusedPolicy
-    nets = make_nets(seed=21, layout=layout)
+    nets = make_nets(seed=21, **kw)
     fused = FusedPolicy(nets[0], nets[1])
     out = []
     for dt in (torch.float64, torch.bfloat16):
