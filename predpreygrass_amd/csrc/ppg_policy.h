@@ -96,7 +96,9 @@ struct PolParams {
     int32_t head_mt;              // 16-row tiles of actions: 1 or 2
     const bf16x8 *wcd[PPG_POLICY_MAX_CONV - 3];   // fragments of the convolutions behind the third (64 -> 64 channels)
     const bf16x8 *wh;             // head fragments [action tile][k-step][lane]
+    const bf16x8 *whw;            // the same of action tile 0 per wavefront: [wavefront][18][lane], zeros behind a wavefront's share of k-steps
     const float *bh;              // head bias [32]
+    float *lgs;                   // library-owned [gridDim.x][TILE][16 head_mt]: a workgroup's logits of its current tile
 #ifdef PPG_EXPERIMENTS
     unsigned long long *timeline; // diagnostic builds: [tile][64] = workgroup, hardware id, samples, 4 wall-clock stamps (10 ns units); [8 + 12 wave + i] cycles of wave in step i of the convolutions, [56 + 2 wave + i] FC1 wait / barrier cycles
 #endif
@@ -923,6 +925,7 @@ struct ppg_policy {
     ppgpol::PolParams base;
     void *dev_weights;     // one allocation: fragments + biases
     __bf16 *xg;            // scratch slots (FC chain only)
+    float *lgs;            // logits rows of the tiles in flight (direct path only)
     bool xg_is_spread;     // (from ppg_alloc_spread)
     uint32_t *plan;        // [PLAN_HDR + plan_envs] header + prefix sums, then the first env of every tile
     int32_t plan_envs;
@@ -1107,6 +1110,16 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
                     }
                 }
         for (int a = 0; a < n_actions; ++a) bias[512 + a] = sp.fc_b[0][a];
+        {   // K.whw: wavefront w owns k-steps [w per, (w + 1) per), its first 18 ride in registers (ppg_policy_direct.h)
+            const int HFR = 18, per = (ksteps + 3) / 4;
+            f[FC0 + 1].assign((size_t)4 * HFR * 64 * 8, 0);
+            for (int w = 0; w < 4; ++w)
+                for (int i = 0; i < HFR && i < per; ++i) {
+                    const int ks = w * per + i;
+                    if (ks >= ksteps) break;
+                    memcpy(&f[FC0 + 1][((size_t)w * HFR + i) * 64 * 8], &f[FC0][(size_t)ks * 64 * 8], 64 * 8 * 2);
+                }
+        }
     } else {
         // FC1: the K order is the scratch slot's [row tile of conv3][position][32 channels]; hidden widths are zero-padded to 256
         const int h1 = sp.fc_out[0], h2 = sp.n_fc == 3 ? sp.fc_out[1] : 0;
@@ -1158,7 +1171,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
     K.wc3 = (const ppgpol::bf16x8 *)(dw + off[2]);
     for (int l = 3; l < PPG_POLICY_MAX_CONV; ++l) K.wcd[l - 3] = (const ppgpol::bf16x8 *)(dw + off[l]);
     K.w1 = (const ppgpol::bf16x8 *)(dw + off[FC0]); K.w2 = (const ppgpol::bf16x8 *)(dw + off[FC0 + 1]); K.w3 = (const ppgpol::bf16x8 *)(dw + off[FC0 + 2]);
-    K.wh = K.w1;
+    K.wh = K.w1; K.whw = K.w2;
     const float *db = (const float *)(dw + off[NF]);
     K.bc1 = K.bc2 = K.bc3 = nullptr;   // (the convolutions' biases ride in their fragments)
     K.b1 = db; K.b2 = db + 256; K.b3 = db + 512; K.bh = db + 512;
@@ -1172,10 +1185,13 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         const int blk = K.Wp2 * 8, f_elems = K.kflat_steps * 32 + 8;   // (+ 8: consecutive samples' fragments fall into different banks)
         K.off_x = 0; K.off_y = 4 * blk; K.off_f = 6 * blk; K.off_d0 = K.off_f + f_elems; K.off_d1 = K.off_d0 + 8 * blk;
         K.sample_stride = K.off_f + f_elems + (sp.n_conv > 3 ? 8 * blk : 0) + (sp.n_conv > 4 ? 8 * blk : 0);
-        const int fixed = ppgpol::TILE * 16 + K.head_mt * 4096;
-        int st_max = (80 * 1024 - fixed) / (K.sample_stride * 2);
+        const int tail_slack = 18 * 32 * 2;   // bytes behind the last sample's region: the head's unconditional fragment reads end there
+        const int fixed = ppgpol::TILE * 16 + K.head_mt * 4096 + tail_slack;
+        const bool w1 = PPG_DIRECT_W1;   // one workgroup per CU with all of its LDS (ppg_policy_direct.h)
+        int st_max = ((w1 ? 160 : 80) * 1024 - fixed) / (K.sample_stride * 2);
         if (st_max > 16) st_max = 16;                // (the head's 16 sample columns)
-        while (st_max > 1 && st_max * P > 256) --st_max;   // a thread stages at most one position
+        while (st_max > 1 && st_max * P > (w1 ? 512 : 256)) --st_max;   // a thread stages at most two / one positions
+        if (w1) p->grid = prop.multiProcessorCount;
         if (st_max < 1) {
             (void)hipFree(p->dev_weights);
             delete p;
@@ -1191,6 +1207,13 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         }
         K.ST = st;
         p->lds_bytes = fixed + st * K.sample_stride * 2;
+        const size_t lgs_bytes = (size_t)p->grid * ppgpol::TILE * 16 * K.head_mt * 4;
+        if (hipMalloc((void **)&p->lgs, lgs_bytes) != hipSuccess || hipMemset(p->lgs, 0, lgs_bytes) != hipSuccess) {
+            (void)hipFree(p->dev_weights);
+            delete p;
+            return ppg_policy_fail(nullptr, PPG_EHIP, "hipMalloc of %zu bytes of scratch failed", lgs_bytes);
+        }
+        K.lgs = p->lgs;
         for (const void *fn : {(const void *)ppgpol::ppg_policy_direct8_f64, (const void *)ppgpol::ppg_policy_direct8_f32,
                                (const void *)ppgpol::ppg_policy_direct8_bf16, (const void *)ppgpol::ppg_policy_direct16_f64,
                                (const void *)ppgpol::ppg_policy_direct16_f32, (const void *)ppgpol::ppg_policy_direct16_bf16,
@@ -1246,6 +1269,7 @@ int ppg_policy_destroy(ppg_policy *p) {
     if (p->dev_weights) (void)hipFree(p->dev_weights);
     if (p->xg) { if (p->xg_is_spread) (void)ppg_free_spread(p->xg); else (void)hipFree(p->xg); }
     if (p->plan) (void)hipFree(p->plan);
+    if (p->lgs) (void)hipFree(p->lgs);
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->fork) (void)hipEventDestroy(p->fork);
     if (p->join) (void)hipEventDestroy(p->join);
@@ -1329,6 +1353,20 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
                               {ppgpol::ppg_policy_forward_hwc8_f64, ppgpol::ppg_policy_forward_hwc8_f32, ppgpol::ppg_policy_forward_hwc8_bf16},
                               {ppgpol::ppg_policy_forward_hwc16_f64, ppgpol::ppg_policy_forward_hwc16_f32, ppgpol::ppg_policy_forward_hwc16_bf16}};
     const int dt = K.obs_f32 == 2 ? 2 : K.obs_f32 ? 1 : 0;
+#ifdef PPG_DIRECT_PROFILE   // diagnostic build: per-wavefront phase cycles of launch number PPG_DIRECT_PROFILE_RUN (default 300) -> $PPG_DIRECT_PROFILE_FILE.{pred,prey}
+    static int dp_runs[2] = {0, 0};
+    static unsigned long long *dp_buf[2] = {nullptr, nullptr};
+    const char *dp_path = getenv("PPG_DIRECT_PROFILE_FILE");
+    const int dp_at = getenv("PPG_DIRECT_PROFILE_RUN") ? atoi(getenv("PPG_DIRECT_PROFILE_RUN")) : 300;
+    const size_t dp_bytes = (size_t)p->grid * 4 * 16 * 8;
+    if (p->direct && dp_path && !dp_buf[species]) {
+        PPG_POL_TRY(p, hipMalloc((void **)&dp_buf[species], dp_bytes));
+        PPG_POL_TRY(p, hipMemset(dp_buf[species], 0, dp_bytes));
+        PPG_POL_TRY(p, hipDeviceSynchronize());
+    }
+    const bool dp_now = p->direct && dp_path && ++dp_runs[species] == dp_at;
+    K.xg = dp_now ? (__bf16 *)dp_buf[species] : nullptr;
+#endif
     if (p->direct) {
         const fwd_fn dir[4][3] = {{ppgpol::ppg_policy_direct8_f64, ppgpol::ppg_policy_direct8_f32, ppgpol::ppg_policy_direct8_bf16},
                                   {ppgpol::ppg_policy_direct16_f64, ppgpol::ppg_policy_direct16_f32, ppgpol::ppg_policy_direct16_bf16},
@@ -1340,6 +1378,16 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
         hipLaunchKernelGGL(fwd[variant][dt], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     }
     PPG_POL_TRY(p, hipGetLastError());
+#ifdef PPG_DIRECT_PROFILE
+    if (dp_now) {
+        PPG_POL_TRY(p, hipDeviceSynchronize());
+        std::vector<unsigned long long> host(dp_bytes / 8);
+        PPG_POL_TRY(p, hipMemcpy(host.data(), dp_buf[species], dp_bytes, hipMemcpyDeviceToHost));
+        char name[512];
+        snprintf(name, sizeof name, "%s.%s", dp_path, species ? "prey" : "pred");
+        if (FILE *f = fopen(name, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    }
+#endif
 #ifdef PPG_EXPERIMENTS
     if (tl_now && species == 0) {   // (the predators' launch is the second of a step: both species' stamps are complete after a device sync)
         PPG_POL_TRY(p, hipDeviceSynchronize());

@@ -35,6 +35,27 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #ifndef PPG_DIRECT_ABLATE
 #define PPG_DIRECT_ABLATE 0
 #endif
+// -DPPG_DIRECT_PROFILE (tools/gpu_direct_profile.sh): cycles per phase, summed per wavefront over the launch, into K.xg (unused by the
+// direct path) as [workgroup][wavefront][16] -- 0 tile set-up, 1 conv1, 2 its barrier, 3 conv2, 4 barrier, 5 conv3 (+ deeper), 6 barrier,
+// 7 staging + head, 8 barrier, 9 logits / actions, 15 sub-groups
+// PPG_DIRECT_W1 (default 1): the direct-head kernels run ONE workgroup per CU (one wavefront per SIMD: 512 registers --
+// every weight of the network and the head's fragments resident, both of conv3's row tiles in one wavefront, 160 KB of LDS = twice the
+// samples per sub-group); 0 = two workgroups per CU with 256 registers each (conv3's row tiles split over wavefront pairs, the head's
+// fragments from L2 six at a time) -- the A/B build
+#ifndef PPG_DIRECT_W1
+#define PPG_DIRECT_W1 1
+#endif
+#ifndef PPG_DIRECT_B12
+#define PPG_DIRECT_B12 0
+#endif
+#ifndef PPG_DIRECT_B3
+#define PPG_DIRECT_B3 5
+#endif
+#ifdef PPG_DIRECT_PROFILE
+#define PPG_DP(i) do { const long long now_ = (long long)clock64(); dp_acc[i] += now_ - dp_prev; dp_prev = now_; } while (0)
+#else
+#define PPG_DP(i) do { } while (0)
+#endif
 
 // partial logits in LDS: [wavefront][action tile (head_mt of them)][action row][sample column] floats = head_mt * 4 KB
 
@@ -124,11 +145,19 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
     }
 }
 
+// DEEP = false: one to three convolutions: their weights stay in registers for the whole launch.
+// DEEP = true: more than three convolutions: every layer's weights come from L2 when the layer starts.
 template <int OBS, int NCH, bool DEEP>
 __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
+    constexpr bool W1 = PPG_DIRECT_W1, WRES = W1 && !DEEP;   // (DEEP: 512 registers too, but every layer's weights come per sub-group)
+    constexpr int MT3 = WRES ? 2 : 1;    // conv3 row tiles per wavefront
+    constexpr int NPOS = W1 ? 2 : 1;     // positions a thread stages per sub-group (ST * P <= 256 NPOS)
+    constexpr int HF = WRES ? 18 : 1;    // head fragments of this wavefront that stay in registers
     constexpr int CB1 = NCH > 8 ? 2 : 1;
+    constexpr int B12 = PPG_DIRECT_B12;   // fragments per batch in conv1 / conv2 (0 = all of a tile's at once)
     const auto &K = *Kp;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: tile loops, k-step ranges and their branches stay scalar)
     unsigned long long *tab = (unsigned long long *)lds;                    // [TILE][2]: observation row, action slot
     float *red = (float *)(lds + TILE * 16);
     __bf16 *img = (__bf16 *)(lds + TILE * 16 + K.head_mt * 4096);
@@ -137,24 +166,60 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
     const int N = (int)K.plan[0], n_full = (int)K.plan[1], ts = (int)K.plan[2];
     const int n_tiles = n_full + (N - n_full * TILE + ts - 1) / ts;
     if ((int)blockIdx.x >= n_tiles) return;
-    // weights of the first three layers: resident in registers for the whole launch (DEEP: every layer's weights come per sub-group)
+    // (A rotation of conv1's / conv2's weights and the head's fragments through the same registers -- each on its way from L2 while the
+    // other computes -- was tried: hipcc answered with 40-70 spilled registers in every formulation; profiles/r04.)
     ConvW<CB1, 1> w1c;
     ConvW<2, 1> w2c;
-    ConvW<4, 1> w3c;
+    ConvW<4, MT3> w3c;
     if (!DEEP) {
         w1c.load(K, K.wc1, lane);
         if (n_conv > 1) w2c.load(K, K.wc2, lane);
-        if (n_conv > 2) w3c.load(K, K.wc3, lane, wave >> 1);
+        if (n_conv > 2) w3c.load(K, K.wc3, lane, WRES ? 0 : wave >> 1);
     }
+    // this thread's logits: sample tid >> 4 of the sub-group, actions tid & 15 (+ 16)
+    const int smp = tid >> 4, a16 = tid & 15;
+    float bias_r[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) bias_r[m] = (16 * m + a16 < K.n_actions) ? K.bh[16 * m + a16] : 0.0f;
+    const int apad = 16 * K.head_mt;
+    float *lgs = K.lgs + (size_t)blockIdx.x * TILE * apad;    // this workgroup's logits of the current tile (global scratch, L2)
     // halo cells (and area F's slack) are zero and stay zero: only interiors are ever written
-    for (int i = tid; i < (K.ST * sample_stride) / 8; i += 256) ((bf16x8 *)img)[i] = zero8();
+    for (int i = tid; i < (K.ST * sample_stride) / 8 + 18 * 4; i += 256) ((bf16x8 *)img)[i] = zero8();   // (+ the slack behind the last region)
     if (!DEEP) {
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w1c.landed();
         if (n_conv > 1) w2c.landed();
         if (n_conv > 2) w3c.landed();
     }
+
+    // head: k-steps of this wavefront, and which of them ride in registers
+    const int kq = lane >> 4, colh = lane & 15;
+    const int per = (K.kflat_steps + 3) >> 2;
+    const int k_lo = wave * per, k_hi = (k_lo + per) < K.kflat_steps ? (k_lo + per) : K.kflat_steps;
+    const GLOBAL_AS bf16x8 *wa = (const GLOBAL_AS bf16x8 *)K.wh + lane;
+    // [k_lo, k_reg): this wavefront's first HF k-steps, fragments resident in registers -- taken from the per-wavefront table K.whw
+    // [wavefront][HF][lane], zero-filled behind the wavefront's share, so that neither the loads nor their MFMAs need a condition (a
+    // zero fragment times whatever finite bf16 values lie behind the share in LDS adds nothing)
+    const bool resident = WRES && K.head_mt == 1;
+    const int k_reg = resident ? ((k_lo + HF) < k_hi ? (k_lo + HF) : k_hi) : k_lo;
+    bf16x8 hf[HF];
+    if (WRES) {
+#pragma unroll
+        for (int i = 0; i < HF; ++i) hf[i] = ((const GLOBAL_AS bf16x8 *)K.whw)[((size_t)wave * HF + i) * 64 + lane];
+    }
+    if (WRES) {
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < HF; ++i) {   // (arrived: no wait-count bookkeeping follows these registers into the loops)
+            u32x4_t v = __builtin_bit_cast(u32x4_t, hf[i]);
+            __asm__ volatile("" : "+v"(v));
+            hf[i] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
     typedef typename ObsRaw<OBS, NCH>::type raw_t;
+#ifdef PPG_DIRECT_PROFILE
+    long long dp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dp_prev = (long long)clock64();
+#endif
     for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
         const int size = tile < n_full ? TILE : ts;
         const int n0 = tile < n_full ? tile * TILE : n_full * TILE + (tile - n_full) * ts;
@@ -176,30 +241,38 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
             tab[2 * tid + 1] = dst;
         }
         __syncthreads();
-        raw_t pre[NCH];
-        auto request = [&](int s0) {   // (a thread stages at most ONE position: ST * P <= 256, ppg_policy_create_spec)
+        raw_t pre[NPOS][NCH];
+        auto request = [&](int s0) {   // (a thread stages at most NPOS positions: ST * P <= 256 NPOS, ppg_policy_create_spec)
             const int left = nt_samples - s0, ns = left < K.ST ? left : K.ST;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) pre[c] = (raw_t)0;
-            if (tid < ns * K.P) {
-                const int s = div_small(tid, K.magic_P), p = tid - __mul24(s, K.P);
-                typedef typename ObsRaw<OBS, NCH>::elem elem_t;
-                const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
+            for (int j = 0; j < NPOS; ++j) {
+                const int idx = tid + 256 * j;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) if (c < K.cin) pre[c] = (raw_t)src[c * K.c_stride];
+                for (int c = 0; c < NCH; ++c) pre[j][c] = (raw_t)0;
+                if (idx < ns * K.P) {
+                    const int s = div_small(idx, K.magic_P), p = idx - __mul24(s, K.P);
+                    typedef typename ObsRaw<OBS, NCH>::elem elem_t;
+                    const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)(uintptr_t)tab[2 * (s0 + s)] + p * K.p_stride;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) if (c < K.cin) pre[j][c] = (raw_t)src[c * K.c_stride];
+                }
             }
         };
         auto stage = [&](int s0) {
             const int left = nt_samples - s0, ns = left < K.ST ? left : K.ST;
-            if (tid < ns * K.P) {
-                const int s = div_small(tid, K.magic_P), p = tid - __mul24(s, K.P);
-                const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
 #pragma unroll
-                for (int cb = 0; cb < CB1; ++cb) {
-                    bf16x8 v = zero8();
+            for (int j = 0; j < NPOS; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx < ns * K.P) {
+                    const int s = div_small(idx, K.magic_P), p = idx - __mul24(s, K.P);
+                    const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
 #pragma unroll
-                    for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = ObsRaw<OBS, NCH>::to_bf16(pre[8 * cb + c]);
-                    *(bf16x8 *)(img + __mul24(s, sample_stride) + K.off_x + (cb * K.Wp2 + __mul24(y + 1, K.Wp) + (x + 1)) * 8) = v;
+                    for (int cb = 0; cb < CB1; ++cb) {
+                        bf16x8 v = zero8();
+#pragma unroll
+                        for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = ObsRaw<OBS, NCH>::to_bf16(pre[j][8 * cb + c]);
+                        *(bf16x8 *)(img + __mul24(s, sample_stride) + K.off_x + (cb * K.Wp2 + __mul24(y + 1, K.Wp) + (x + 1)) * 8) = v;
+                    }
                 }
             }
         };
@@ -209,32 +282,40 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
             if (K.ST < nt_samples) request(K.ST);
         }
         __syncthreads();
+        PPG_DP(0);
         for (int s0 = 0; s0 < nt_samples; s0 += K.ST) {
             const int ns = (nt_samples - s0) < K.ST ? (nt_samples - s0) : K.ST;
             // ---- convolutions -------------------------------------------------------------------------------------------
             if (!(PPG_DIRECT_ABLATE & 8)) {
-                if (DEEP) { w1c.load(K, K.wc1, lane); __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); w1c.landed(); }
-                dconv<CB1, 1, 0>(K, w1c, img, sample_stride, K.off_x, n_conv == 1 ? K.off_f : K.off_y, K.cout_blocks[0],
+                if (DEEP) { w1c.load(K, K.wc1, lane); w1c.landed(); }
+                dconv<CB1, 1, B12>(K, w1c, img, sample_stride, K.off_x, n_conv == 1 ? K.off_f : K.off_y, K.cout_blocks[0],
                                  n_conv == 1 ? K.flat_c : 0, ns, wave, 4, lane, 0);
+                PPG_DP(1);
                 __syncthreads();
+                PPG_DP(2);
             }
             if (n_conv > 1 && !(PPG_DIRECT_ABLATE & 8)) {
-                if (DEEP) { w2c.load(K, K.wc2, lane); __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); w2c.landed(); }
-                dconv<2, 1, 0>(K, w2c, img, sample_stride, K.off_y, n_conv == 2 ? K.off_f : K.off_x, K.cout_blocks[1],
+                if (DEEP) { w2c.load(K, K.wc2, lane); w2c.landed(); }
+                dconv<2, 1, B12>(K, w2c, img, sample_stride, K.off_y, n_conv == 2 ? K.off_f : K.off_x, K.cout_blocks[1],
                                n_conv == 2 ? K.flat_c : 0, ns, wave, 4, lane, 0);
+                PPG_DP(3);
                 __syncthreads();
+                PPG_DP(4);
             }
             if (n_conv > 2 && !(PPG_DIRECT_ABLATE & 4)) {
-                if (DEEP) { w3c.load(K, K.wc3, lane, wave >> 1); __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); w3c.landed(); }
-                dconv<4, 1, 3>(K, w3c, img, sample_stride, K.off_x, n_conv == 3 ? K.off_f : K.off_d0, K.cout_blocks[2],
-                               n_conv == 3 ? K.flat_c : 0, ns, wave & 1, 2, lane, wave >> 1);
+                if (DEEP) { w3c.load(K, K.wc3, lane, wave >> 1); w3c.landed(); }
+                dconv<4, MT3, DEEP ? 3 : PPG_DIRECT_B3>(K, w3c, img, sample_stride, K.off_x, n_conv == 3 ? K.off_f : K.off_d0, K.cout_blocks[2],
+                                            n_conv == 3 ? K.flat_c : 0, ns, WRES ? wave : wave & 1, WRES ? 4 : 2, lane, WRES ? 0 : wave >> 1);
+            }
+            if (n_conv > 2 && !(PPG_DIRECT_ABLATE & 4)) {
+                PPG_DP(5);
                 __syncthreads();
+                PPG_DP(6);
             }
             if (DEEP) {
                 for (int l = 3; l < n_conv; ++l) {   // 64 -> 64 channels: D0 -> D1 -> D0 ..., the last one into F
                     ConvW<8, 1> wd;
                     wd.load(K, K.wcd[l - 3], lane, wave >> 1);
-                    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     wd.landed();
                     const int in_off = (l & 1) ? K.off_d0 : K.off_d1, mid_off = (l & 1) ? K.off_d1 : K.off_d0;
                     const bool last = l + 1 == n_conv;
@@ -249,20 +330,25 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                 if (s0 + 2 * K.ST < nt_samples) request(s0 + 2 * K.ST);
             }
             {
-                const int kq = lane >> 4, colh = lane & 15;
-                const int per = (K.kflat_steps + 3) >> 2;
-                const int k_lo = wave * per, k_hi = (k_lo + per) < K.kflat_steps ? (k_lo + per) : K.kflat_steps;
                 const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + K.off_f + 8 * kq;
-                const GLOBAL_AS bf16x8 *wa = (const GLOBAL_AS bf16x8 *)K.wh + lane;
                 f32x4_t hacc[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hacc[m][i] = 0.0f;
+                if (WRES && !(PPG_DIRECT_ABLATE & 1)) {
+                    if (resident) {
+                        bf16x8 fv[HF];
+#pragma unroll
+                        for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + 32 * (k_lo + i));
+#pragma unroll
+                        for (int i = 0; i < HF; ++i) hacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i], fv[i], hacc[0], 0, 0, 0);
+                    }
+                }
                 if (PPG_DIRECT_ABLATE & 1) {
                 } else if (K.head_mt == 1) {
-                    // the weight fragments come from L2: six requested at once, then their six MFMAs (a dependent chain either way)
-                    for (int k0 = k_lo; k0 < k_hi; k0 += 6) {
+                    // (k-steps beyond the resident fragments, or all of them: from L2, six requested at once, then their six MFMAs)
+                    for (int k0 = k_reg; k0 < k_hi; k0 += 6) {
                         bf16x8 a[6];
 #pragma unroll
                         for (int i = 0; i < 6; ++i) a[i] = wa[(size_t)((k0 + i) < k_hi ? (k0 + i) : k_lo) * 64];
@@ -296,15 +382,35 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) red[((wave * K.head_mt + m) * 16 + 4 * kq + i) * 16 + colh] = hacc[m][i];
             }
+            PPG_DP(7);
             __syncthreads();
-            // ---- logits and actions: thread (sample = tid >> 4, action = tid & 15), so a sample's 16 actions sit in 16 consecutive
-            // lanes of ONE wavefront (four samples per wavefront, all four wavefronts busy): partial sums + bias, Gumbel noise, and
-            // the argmax as four xor-shuffles inside the 16-lane group (first maximum wins, like torch.argmax) ------------------
-            if (!(PPG_DIRECT_ABLATE & 2)) {
-                const int smp = tid >> 4, a16 = tid & 15;
-                const bool live = smp < ns;
-                const int s_local = s0 + (live ? smp : 0);
-                int8_t *dst = (int8_t *)(uintptr_t)tab[2 * s_local + 1];
+            PPG_DP(8);
+            // ---- logits of the sub-group: thread (sample tid >> 4, action tid & 15): bias + the four wavefronts' partial sums in
+            // wavefront order -> this workgroup's scratch rows (the actions are chosen for the whole tile at once, below) ----
+            if (smp < ns && !(PPG_DIRECT_ABLATE & 2)) {
+                const int s_local = s0 + smp;
+                for (int m = 0; m < K.head_mt; ++m) {
+                    float v = bias_r[m];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red[((w * K.head_mt + m) * 16 + a16) * 16 + smp];
+                    lgs[s_local * apad + 16 * m + a16] = v;
+                    if (K.logits && 16 * m + a16 < K.n_actions) K.logits[(size_t)(n0 + s_local) * K.n_actions + 16 * m + a16] = v;
+                }
+            }
+            PPG_DP(9);
+#ifdef PPG_DIRECT_PROFILE
+            dp_acc[15] += 1;
+#endif
+            // (no barrier here: the next conv1 reads X and writes Y; `red` is written again three barriers from now)
+        }
+        // ---- actions of the tile: one lane per sample (argmax, or Gumbel-max with Philox keyed by (seed, env, row)) ----
+        if (!(PPG_DIRECT_ABLATE & 2)) {
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's scratch rows have been written ...
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ... and stale L1 lines of the previous tile's rows are dropped
+            if (tid < nt_samples) {
+                const float *row = lgs + tid * apad;
+                int8_t *dst = (int8_t *)(uintptr_t)tab[2 * tid + 1];
                 uint32_t c_env = 0, c_slot = 0;   // Philox counter of this agent = (global env index, row slot), as in phase_head
                 if (K.sample) {
                     int k = 0;
@@ -317,41 +423,36 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                     c_env = (uint32_t)K.env_base[k] + b;
                     c_slot = off - b * (uint32_t)K.S;
                 }
-                float bestv = -INFINITY;
+                uint32_t rnd[4] = {0, 0, 0, 0};
                 int best = 0;
-                for (int m = 0; m < K.head_mt; ++m) {
-                    const int a = 16 * m + a16;
-                    float v = -INFINITY;
-                    if (a < K.n_actions) {
-                        v = K.bh[a];   // bias, then the four wavefronts' partial sums in wavefront order
+                float bestv = -INFINITY;
+                for (int a4 = 0; a4 < K.n_actions; a4 += 4) {
+                    const f32x4_t q = *(const GLOBAL_AS f32x4_t *)(row + a4);
+                    if (K.sample) philox(c_env, c_slot, (uint32_t)(a4 >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) v += red[((w * K.head_mt + m) * 16 + a16) * 16 + smp];
-                        if (K.logits && live) K.logits[(size_t)(n0 + s_local) * K.n_actions + a] = v;
-                        if (K.sample) {   // Gumbel-max: argmax(logit - log(-log u)) ~ softmax(logits); u = word (a & 3) of Philox block a >> 2
-                            uint32_t rnd[4];
-                            philox(c_env, c_slot, (uint32_t)(a >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
-                            const uint32_t r = (a & 3) == 0 ? rnd[0] : (a & 3) == 1 ? rnd[1] : (a & 3) == 2 ? rnd[2] : rnd[3];
-                            const float u = (float)(r >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
+                    for (int i = 0; i < 4; ++i) {
+                        if (a4 + i >= K.n_actions) continue;
+                        float v = q[i];
+                        if (K.sample) {   // Gumbel-max: argmax(logit - log(-log u)) ~ softmax(logits)
+                            const float u = (float)(rnd[i] >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
                             v -= __logf(-__logf(u));
                         }
+                        if (v > bestv) { bestv = v; best = a4 + i; }
                     }
-                    if (v > bestv) { bestv = v; best = a; }
                 }
-#pragma unroll
-                for (int d = 8; d; d >>= 1) {
-                    const float ov = __shfl_xor(bestv, d, 16);
-                    const int oa = __shfl_xor(best, d, 16);
-                    if (ov > bestv || (ov == bestv && oa < best)) { bestv = ov; best = oa; }
-                }
-                if (live && a16 == 0) *dst = (int8_t)best;
+                *dst = (int8_t)best;
             }
-            // (no barrier here: the next conv1 reads X and writes Y; `red` is written again three barriers from now)
         }
+        PPG_DP(0);
     }
+#ifdef PPG_DIRECT_PROFILE
+    if (K.xg && lane == 0)
+        for (int i = 0; i < 16; ++i) ((unsigned long long *)K.xg)[((size_t)blockIdx.x * 4 + wave) * 16 + i] = (unsigned long long)dp_acc[i];
+#endif
 }
 
 #define PPG_POLICY_DIRECT_KERNEL(name, OBS, NCH, DEEP)                                           \
-    extern "C" __global__ void __launch_bounds__(256, 2) name(const PolParams K) {               \
+    extern "C" __global__ void __launch_bounds__(256, PPG_DIRECT_W1 ? 1 : 2) name(const PolParams K) { \
         extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                      \
         direct_main<OBS, NCH, DEEP>((KPtr)__builtin_amdgcn_kernarg_segment_ptr(), lds);          \
     }
