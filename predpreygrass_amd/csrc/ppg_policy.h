@@ -1186,7 +1186,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         K.off_x = 0; K.off_y = 4 * blk; K.off_f = 6 * blk; K.off_d0 = K.off_f + f_elems; K.off_d1 = K.off_d0 + 8 * blk;
         K.sample_stride = K.off_f + f_elems + (sp.n_conv > 3 ? 8 * blk : 0) + (sp.n_conv > 4 ? 8 * blk : 0);
         const int tail_slack = 18 * 32 * 2;   // bytes behind the last sample's region: the head's unconditional fragment reads end there
-        const int fixed = ppgpol::TILE * 16 + K.head_mt * 4096 + tail_slack;
+        const int fixed = ppgpol::TILE * 16 + K.head_mt * 4096 + 4096 + tail_slack;   // table, partial logits, dconv's dummy slots
         const bool w1 = PPG_DIRECT_W1;   // one workgroup per CU with all of its LDS (ppg_policy_direct.h)
         int st_max = ((w1 ? 160 : 80) * 1024 - fixed) / (K.sample_stride * 2);
         if (st_max > 16) st_max = 16;                // (the head's 16 sample columns)

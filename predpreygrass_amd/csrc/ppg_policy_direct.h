@@ -64,85 +64,103 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 //   out_blocks         real output channel blocks (of 8) of the layer
 //   flat_c             0: the output is a padded image (the next convolution's input); > 0: the output is area F,
 //                      [position][flat_c channels] (the head's input)
+//   dummy              element index (from img) of 16 bytes of LDS that belong to this lane alone: stores of lanes without a position
+//                      (the last tile's tail) or without a real channel block (conv1's upper half) go there -- no branch in the epilogue
+// ONE wavefront per SIMD runs this (PPG_DIRECT_W1), so nothing hides a stall but the code itself: the loop is software-pipelined by
+// hand -- the epilogue of tile t (accumulators -> ReLU -> bf16 -> LDS) sits between the first fragment reads of tile t + 1 and its first
+// MFMA, where it covers the LDS latency, and the positions of tile t + 1 are computed behind the MFMAs of tile t.
+struct TileCtx { int in_base, out_base; bool valid; };
+
 template <int CBIN, int MT, int BATCH, class KP>
 __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __bf16 *img, int sample_stride, int in_off, int out_off,
-                                      int out_blocks, int flat_c, int ns, int nt_first, int nt_step, int lane, int mt_base) {
+                                      int out_blocks, int flat_c, int ns, int nt_first, int nt_step, int lane, int mt_base, int dummy) {
     constexpr int KS = ConvW<CBIN, MT>::KS;
+    constexpr int NB = BATCH ? (KS + BATCH - 1) / BATCH : 1, BS = BATCH ? BATCH : KS;   // batches of fragment reads per tile
     const int h = lane >> 5, col = lane & 31;
     const int n_pos = ns * K.P;
     const int n_tiles = (n_pos + 31) / 32;
+    if (nt_first >= n_tiles) return;
     const int blk = K.Wp2 * 8;
-    const __bf16 *in = img + in_off + (CBIN > 1 ? h : 0) * blk;
+    const int in0 = in_off + (CBIN > 1 ? h : 0) * blk;
     const int pair = 2 * blk;   // distance between the channel-block pairs a k-step's two lane halves read
-    for (int nt = nt_first; nt < n_tiles; nt += nt_step) {
+    const int cb0 = 4 * mt_base + 2 * h;                  // this lane's first channel block
+    const int cb_step = flat_c ? 8 : blk;                 // elements from one channel block to the next in the output area
+    auto context = [&](int nt) -> TileCtx {
         const int n = 32 * nt + col;
-        const bool valid = n < n_pos;
-        const int nn = valid ? n : 0;
+        TileCtx c;
+        c.valid = n < n_pos;
+        const int nn = c.valid ? n : 0;
         const int s = div_small(nn, K.magic_P), p = nn - __mul24(s, K.P);
         const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
         const int pidx = __mul24(y + 1, K.Wp) + (x + 1);
-        const __bf16 *base = in + __mul24(s, sample_stride) + pidx * 8;
-        f32x16 acc[MT];
+        const int sb = __mul24(s, sample_stride);
+        c.in_base = sb + in0 + pidx * 8;
+        c.out_base = sb + out_off + (flat_c ? __mul24(p, flat_c) : pidx * 8) + __mul24(cb0, cb_step);
+        return c;
+    };
+    auto fragment = [&](const TileCtx &c, int ks) -> bf16x8 {
+        constexpr int KSB = ConvW<CBIN, MT>::KS_BIAS, HB = ConvW<CBIN, MT>::H_BIAS;
+        bf16x8 v;
+        if (ks == KSB && CBIN > 1 && HB == 0) {   // (the whole k-step is the bias block + nothing)
+            v = zero8();
+            if (h == HB) { v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
+        } else {
+            v = *(const bf16x8 *)(img + c.in_base + W.offset(K, ks, pair));
+            if (ks == KSB && h == HB) { v = zero8(); v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
+        }
+        return v;
+    };
+    auto epilogue = [&](const TileCtx &c, const f32x16 (&acc)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {   // this lane's channels 32 (mt_base + mt) + 16 h + 8 j .. + 7 = channel block cb0 + 4 mt + j
+                const bool real = c.valid && (cb0 + 4 * mt + j < out_blocks);
+                const int at = real ? c.out_base + (4 * mt + j) * cb_step : dummy;
+                *(bf16x8 *)(img + at) = relu_pack8(acc[mt], 8 * j);
+            }
+    };
+    // the MFMAs of one tile; `between` runs behind the first batch of fragment reads (the previous tile's epilogue)
+    auto tile = [&](const TileCtx &c, f32x16 (&acc)[MT], auto between) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-        auto fragment = [&](int ks) -> bf16x8 {
-            constexpr int KSB = ConvW<CBIN, MT>::KS_BIAS, HB = ConvW<CBIN, MT>::H_BIAS;
-            bf16x8 v;
-            if (ks == KSB && CBIN > 1 && HB == 0) {   // (the whole k-step is the bias block + nothing)
-                v = zero8();
-                if (h == HB) { v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
-            } else {
-                v = *(const bf16x8 *)(base + W.offset(K, ks, pair));
-                if (ks == KSB && h == HB) { v = zero8(); v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
+        bf16x8 b[2][BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i) b[0][i] = fragment(c, i);
+        __builtin_amdgcn_sched_barrier(0);   // (keep the reads together and in front: left alone, the scheduler re-pairs each with its MFMA)
+        between();
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (nb + 1 < NB) {
+#pragma unroll
+                for (int i = 0; i < BS; ++i) if ((nb + 1) * BS + i < KS) b[(nb + 1) & 1][i] = fragment(c, (nb + 1) * BS + i);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            return v;
-        };
-        if constexpr (BATCH == 0) {
-            bf16x8 b[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) b[ks] = fragment(ks);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < BS; ++i)
+                if (nb * BS + i < KS) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][ks], b[ks], acc[mt], 0, 0, 0);
-        } else {
-            constexpr int NB = (KS + BATCH - 1) / BATCH;
-            bf16x8 b[2][BATCH];
-#pragma unroll
-            for (int i = 0; i < BATCH; ++i) b[0][i] = fragment(i);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                if (nb + 1 < NB) {
-#pragma unroll
-                    for (int i = 0; i < BATCH; ++i) if ((nb + 1) * BATCH + i < KS) b[(nb + 1) & 1][i] = fragment((nb + 1) * BATCH + i);
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][nb * BS + i], b[nb & 1][i], acc[mt], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < BATCH; ++i)
-                    if (nb * BATCH + i < KS) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][nb * BATCH + i], b[nb & 1][i], acc[mt], 0, 0, 0);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
-        if (!valid) continue;
-        __bf16 *dst = img + __mul24(s, sample_stride) + out_off;
+    };
+    int nt = nt_first;
+    TileCtx cur = context(nt);
+    f32x16 acc_prev[MT];
+    tile(cur, acc_prev, [] {});
+    TileCtx prev = cur;
+    for (nt += nt_step; nt < n_tiles; nt += nt_step) {
+        cur = context(nt);
+        f32x16 acc[MT];
+        tile(cur, acc, [&] { epilogue(prev, acc_prev); });
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {   // this lane's channels 32 (mt_base + mt) + 16 h + 8 j .. + 7 = channel block cb
-                const int cb = 4 * (mt_base + mt) + 2 * h + j;
-                if (cb >= out_blocks) continue;
-                const bf16x8 v = relu_pack8(acc[mt], 8 * j);
-                if (flat_c) *(bf16x8 *)(dst + __mul24(p, flat_c) + cb * 8) = v;
-                else *(bf16x8 *)(dst + (__mul24(cb, K.Wp2) + pidx) * 8) = v;
-            }
+        for (int mt = 0; mt < MT; ++mt) acc_prev[mt] = acc[mt];
+        prev = cur;
     }
+    epilogue(prev, acc_prev);
 }
 
 // DEEP = false: one to three convolutions: their weights stay in registers for the whole launch.
@@ -160,7 +178,8 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: tile loops, k-step ranges and their branches stay scalar)
     unsigned long long *tab = (unsigned long long *)lds;                    // [TILE][2]: observation row, action slot
     float *red = (float *)(lds + TILE * 16);
-    __bf16 *img = (__bf16 *)(lds + TILE * 16 + K.head_mt * 4096);
+    __bf16 *img = (__bf16 *)(lds + TILE * 16 + K.head_mt * 4096 + 4096);
+    const int dummy = -2048 + 8 * tid;   // (element index from img: this thread's 16 bytes of the 4 KB in front of the images; dconv)
     const int sample_stride = K.sample_stride;
     const int n_conv = K.n_conv;
     const int N = (int)K.plan[0], n_full = (int)K.plan[1], ts = (int)K.plan[2];
@@ -289,7 +308,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
             if (!(PPG_DIRECT_ABLATE & 8)) {
                 if (DEEP) { w1c.load(K, K.wc1, lane); w1c.landed(); }
                 dconv<CB1, 1, B12>(K, w1c, img, sample_stride, K.off_x, n_conv == 1 ? K.off_f : K.off_y, K.cout_blocks[0],
-                                 n_conv == 1 ? K.flat_c : 0, ns, wave, 4, lane, 0);
+                                 n_conv == 1 ? K.flat_c : 0, ns, wave, 4, lane, 0, dummy);
                 PPG_DP(1);
                 __syncthreads();
                 PPG_DP(2);
@@ -297,7 +316,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
             if (n_conv > 1 && !(PPG_DIRECT_ABLATE & 8)) {
                 if (DEEP) { w2c.load(K, K.wc2, lane); w2c.landed(); }
                 dconv<2, 1, B12>(K, w2c, img, sample_stride, K.off_y, n_conv == 2 ? K.off_f : K.off_x, K.cout_blocks[1],
-                               n_conv == 2 ? K.flat_c : 0, ns, wave, 4, lane, 0);
+                               n_conv == 2 ? K.flat_c : 0, ns, wave, 4, lane, 0, dummy);
                 PPG_DP(3);
                 __syncthreads();
                 PPG_DP(4);
@@ -305,7 +324,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
             if (n_conv > 2 && !(PPG_DIRECT_ABLATE & 4)) {
                 if (DEEP) { w3c.load(K, K.wc3, lane, wave >> 1); w3c.landed(); }
                 dconv<4, MT3, DEEP ? 3 : PPG_DIRECT_B3>(K, w3c, img, sample_stride, K.off_x, n_conv == 3 ? K.off_f : K.off_d0, K.cout_blocks[2],
-                                            n_conv == 3 ? K.flat_c : 0, ns, WRES ? wave : wave & 1, WRES ? 4 : 2, lane, WRES ? 0 : wave >> 1);
+                                            n_conv == 3 ? K.flat_c : 0, ns, WRES ? wave : wave & 1, WRES ? 4 : 2, lane, WRES ? 0 : wave >> 1, dummy);
             }
             if (n_conv > 2 && !(PPG_DIRECT_ABLATE & 4)) {
                 PPG_DP(5);
@@ -320,7 +339,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                     const int in_off = (l & 1) ? K.off_d0 : K.off_d1, mid_off = (l & 1) ? K.off_d1 : K.off_d0;
                     const bool last = l + 1 == n_conv;
                     dconv<8, 1, 3>(K, wd, img, sample_stride, in_off, last ? K.off_f : mid_off, K.cout_blocks[l], last ? K.flat_c : 0,
-                                   ns, wave & 1, 2, lane, wave >> 1);
+                                   ns, wave & 1, 2, lane, wave >> 1, dummy);
                     __syncthreads();
                 }
             }
