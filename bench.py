@@ -96,8 +96,10 @@ def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
             n += env.rollout_random(seed0 + i, chunk)
         return n, time.perf_counter() - t0
 
-    # single thread first (the scalar port), then all cores (ctypes releases the GIL)
+    # single thread first (the scalar port: a third of the time), then all cores (ctypes releases the GIL)
+    full_seconds, seconds = seconds, seconds / 3.0
     n1, t1 = work(0)
+    seconds = full_seconds
     with cf.ThreadPoolExecutor(threads) as ex:
         res = list(ex.map(work, range(threads)))
     tot = sum(r[0] for r in res)
@@ -236,7 +238,8 @@ def parse_args(argv):
                          "the two policy networks of the reference's PPO setup evaluated on the matrix cores next to the env "
                          "(SURVEY 8(f) N4; no observation leaves the GPU, roofline = bf16 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0,
+                    help="cpu_baseline: wall seconds of the all-cores leg (a single-thread leg of a third of that runs first)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step).  2 vs 3 with the "
                          "cooperative kernels, us per 4096-env step in one gpurun call each: GPU in its fast state 68.3 / 71.2, 67.2 / "
@@ -475,6 +478,9 @@ def main(argv=None, backend=None):
                                        #  where they are not: on a box that hands out mostly slow ones the search goes on for a while)
                                        placement_target_us=80.0 if (args.workload == "base" and B == 4096 and args.obs_dtype == "f64"
                                                                     and args.placement_candidates > 1) else None,
+                                       # (at most ONE more than asked for: round 4's store_patterns5 runs showed that a GPU whose placements
+                                       #  all probe slow stays slow whatever is allocated, and every candidate costs 2-3 s of untimed work)
+                                       placement_max_candidates=args.placement_candidates + 1,
                                        **extra_kw,
                                        **backend.env_kwargs())
 
@@ -763,8 +769,9 @@ def main(argv=None, backend=None):
     value = n_gpus * env_steps_rank / wall
     # HBM bytes per launch from rocprofv3 PMC passes of the driver's command (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md
     # HBM section), scaled by this run's own counted bytes relative to the profiled run's (same workload, same pre-roll)
-    traffic = traffic_src = None
+    traffic = traffic_src = traffic_origin = None   # traffic_origin: "in_run" (PMC passes of THIS run) | "profiles_fallback" | None
     if pmc is not None:
+        traffic_origin = "in_run"
         scale = (run_bytes / args.steps / n_sub) / pmc["counted"]
         traffic = int(pmc["total"] * scale)
         traffic_src = (f"THIS run's box: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE passes (counters only, one child process each) of "
@@ -780,6 +787,7 @@ def main(argv=None, backend=None):
         if same:
             scale = (run_bytes / args.steps / n_sub) / prof["counted_bytes_per_launch"]
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"] * scale)
+            traffic_origin = "profiles_fallback"
             traffic_src = (f"profiles/r03/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            f"{prof['hbm_traffic_per_launch_bytes']['total_corrected']} B per launch at "
                            f"{prof['mean_agents_per_env']} agents/env, scaled x{scale:.4f} by this run's counted bytes")
@@ -800,6 +808,7 @@ def main(argv=None, backend=None):
             # design never moves; with it the figure can exceed 1 (64x64 grids), so it is a comparison number, not `frac`
             "frac_survey_formula": round(survey_bytes / args.steps / kernel_s / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "traffic_origin": traffic_origin,
             "traffic_source": traffic_src,
             "write_pattern_ceiling": "the same write pattern and launch structure with no compute (tools/store_patterns4.hip, "
                                      "profiles/r03) in plain hipMalloc memory: 61-73 us per 4096-env step depending on where the driver put "
@@ -856,6 +865,11 @@ def main(argv=None, backend=None):
                 "device_state_under_load": dev_state,
                 "obs_spread": args.obs_spread, **({"obs_spread_note": spread_note} if spread_note else {}),
                 "placement_candidates_us_per_step": None if group.placement_probe_us is None else [round(v, 1) for v in group.placement_probe_us],
+                # which placement mode this run drew (60 ms probes of each candidate buffer set; good placements of the headline workload
+                # probe at 67-79 us per step, slow ones -- and every placement on a slow GPU of the pool -- at 80-91)
+                "placement_probe_us": None if not group.placement_probe_us else {
+                    "min": round(min(group.placement_probe_us), 1), "median": round(float(np.median(group.placement_probe_us)), 1),
+                    "n": len(group.placement_probe_us)},
                 "preroll_mean_agents_per_env_by_64_step_window": [round(v, 2) for v in trace[-8:]],
                 "mean_agents_per_env": round((n_obs_pred + n_obs_prey) / env_steps_rank, 2),
                 "status_bits": status,

@@ -515,11 +515,15 @@ const char *ppg_policy_last_error(const ppg_policy *p);
  * the pages of those two tensors lie decides how fast HBM takes the step's scattered 1 KB pieces: 62-64 us per 4096-env step with
  * spread 32-64 against 62-91 us for what hipMalloc happens to return and 105-121 us for physically contiguous memory (DESIGN.md
  * section 5.0).  Costs: spread 32 at 1.8 GB takes about 2.5 s and 58 GB of transient device memory; if the device cannot hold the
- * pool the spread shrinks.  Not in the CPU test build.  ppg_free_spread gives the physical memory back and RETIRES the virtual range
+ * pool the spread shrinks, and the transient pool never takes more than half of the memory that is free when it is built.  Not in the
+ * CPU test build.  ppg_free_spread gives the physical memory back and RETIRES the virtual range
  * (a re-used range was seen to go through stale translations).  Returns PPG_OK or an error code (ppg_spread_last_error()). */
 int ppg_alloc_spread(int32_t device, uint64_t bytes, int32_t spread, uint64_t seed, void **out);
 int ppg_free_spread(void *ptr);
-const char *ppg_spread_last_error(void);
+/* what this process holds / has given up: bytes mapped now, and the virtual ranges (count, bytes) ppg_free_spread has retired.  Any
+ * pointer may be NULL. */
+int ppg_spread_stats(uint64_t *live_bytes, uint64_t *retired_ranges, uint64_t *retired_bytes);
+const char *ppg_spread_last_error(void);   /* of the calling thread */
 
 /* Sort key of the decimal string of `id` (digits d: sum (d+1)*11^(5-pos)); host helper. */
 uint32_t ppg_lexkey(uint32_t id);

@@ -146,7 +146,7 @@ POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_c
                   "ppg_policy_macs_per_observation", "ppg_policy_last_error"]
 
 
-SPREAD_SYMBOLS = ["ppg_alloc_spread", "ppg_free_spread", "ppg_spread_last_error"]   # HIP library only, like the policy symbols
+SPREAD_SYMBOLS = ["ppg_alloc_spread", "ppg_free_spread", "ppg_spread_stats", "ppg_spread_last_error"]   # HIP library only, like the policy symbols
 EXPORTED_SYMBOLS = [
     "ppg_abi_version", "ppg_create", "ppg_destroy", "ppg_get_buffers", "ppg_reset", "ppg_reset_from_state", "ppg_observe", "ppg_step", "ppg_step_many",
     "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_set_wave_plan",
@@ -210,6 +210,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
         lib.ppg_alloc_spread.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]
         lib.ppg_free_spread.restype = C.c_int
         lib.ppg_free_spread.argtypes = [C.c_void_p]
+        if hasattr(lib, "ppg_spread_stats"):
+            lib.ppg_spread_stats.restype = C.c_int
+            lib.ppg_spread_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
         lib.ppg_spread_last_error.restype = C.c_char_p
     if hasattr(lib, "ppg_policy_create"):   # (the MFMA kernels exist in the HIP library only, not in the CPU test build)
         lib.ppg_policy_create.restype = C.c_int

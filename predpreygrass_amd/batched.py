@@ -8,6 +8,7 @@ HIP kernel per call on torch's current stream.  All environment logic
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -191,9 +192,10 @@ class BatchedPredPreyGrass:
 
         holder = _Holder()
         holder.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
-        if not hasattr(self, "_spread_ptrs"):
-            self._spread_ptrs = []
-        self._spread_ptrs.append(ptr.value)
+        # THE MAPPING LIVES AS LONG AS THE MEMORY IS REFERENCED: torch keeps `holder` alive until the last tensor (or view, or
+        # tensor returned by reset_batch / step_batch) over this storage is gone, and only then are the pages unmapped -- never in
+        # close(), which a caller may well outlive with an observation tensor in hand (touching unmapped memory is a GPU fault)
+        weakref.finalize(holder, self._lib.ppg_free_spread, C.c_void_p(ptr.value))
         with torch.cuda.device(self.device):
             t = torch.as_tensor(holder, device=self.device).view(self.obs_dtype).view(shape)
             t.zero_()
@@ -219,9 +221,6 @@ class BatchedPredPreyGrass:
         h, self._handle = getattr(self, "_handle", None), None
         if h:
             self._lib.ppg_destroy(h)
-        ptrs, self._spread_ptrs = getattr(self, "_spread_ptrs", []), []
-        for p in ptrs:   # (the observation tensors of an obs_spread env are dead from here on)
-            self._lib.ppg_free_spread(C.c_void_p(p))
 
     def __del__(self):
         try:

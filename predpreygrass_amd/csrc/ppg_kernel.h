@@ -1482,6 +1482,7 @@ struct Env {
         const int total = n_live * blk;
         const size_t obase = (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;
         constexpr int U = 2;   // pieces in flight per wavefront: the three dependent LDS lookups of one hide behind the other's
+        const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
         for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
             uint32_t o[U], i0[U], i1[U];
             bool on[U];
@@ -1491,7 +1492,7 @@ struct Env {
                 on[u] = s0 < total;
                 const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
                 const uint32_t i = wv::mulhi(sc, magic), w = sc - i * (uint32_t)blk;
-                const uint32_t ent = on[u] ? list[i] : 0u;
+                const uint32_t ent = on[u] ? list[i] : safe_cell;
                 const uint2 d = *(const uint2 *)(L + w);
                 const int pc = (int)(ent & 0xFFFFu);
                 i0[u] = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)] + (d.x >> 16);

@@ -104,7 +104,7 @@ class ObservationGatherer:
             self.flags |= _abi.PACK_NO_OBS
         if mode not in ("all_gather", "gather", "all_pairs"):
             raise ValueError("mode must be 'all_gather', 'gather' or 'all_pairs'")
-        self.mode, self.dst = mode, int(dst)
+        self.mode, self.dst = mode, int(dst)   # (dst and every rank below are GROUP-relative; _global() translates for torch.distributed)
         self._handles = (C.c_void_p * len(self.envs))(*[e._handle for e in self.envs])
         if rows_per_env is None:
             rows_per_env = (min(e0.pred_capacity, 3 * max(e0.P0, 2)), min(e0.prey_capacity, 3 * max(e0.Q0, 2)))
@@ -113,6 +113,10 @@ class ObservationGatherer:
         self._set_capacity(int(self._lib.ppg_pack_bytes(e0._handle, n_max, int(n_max * rows_per_env[0]),
                                                         int(n_max * rows_per_env[1]), self.flags)), slots)
         self.last_bytes = 0
+
+    def _global(self, r):
+        """Global rank of group rank r: dist.gather(dst=...) and P2POp peers are global ranks whatever the group."""
+        return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def _max_envs(self):
         t = torch.tensor([self.n_envs], dtype=torch.int64, device=self.device)
@@ -133,11 +137,15 @@ class ObservationGatherer:
         self._slot = 0
         self._cuda = self.device.type == "cuda"
         self._done = [None] * slots
+        self._gathered = None          # (no image of the old buffers can be looked at any more)
+        self._pending_capacity = None
 
     # ------------------------------------------------------------------
     def pack(self, stream=None):
         """`ppg_pack` of the envs' last call into the next image slot; asynchronous on `stream` (default: torch's current
         stream), which must be ordered behind the envs' step.  Returns the slot index."""
+        if self._pending_capacity is not None:   # fit() decided to shrink: now that the last step's views have been consumed
+            self._set_capacity(self._pending_capacity)
         self._slot = (self._slot + 1) % len(self._local)
         buf = self._local[self._slot]
         if self._cuda and self._done[self._slot] is not None:
@@ -161,17 +169,17 @@ class ObservationGatherer:
             dist.all_gather_into_tensor(self._all[slot], self._local[slot], group=self.group)
         elif self.mode == "gather":
             if self.rank == self.dst:
-                dist.gather(self._local[slot], list(self._all[slot].view(self.world, self.capacity).unbind(0)), dst=self.dst, group=self.group)
+                dist.gather(self._local[slot], list(self._all[slot].view(self.world, self.capacity).unbind(0)), dst=self._global(self.dst), group=self.group)
             else:
-                dist.gather(self._local[slot], None, dst=self.dst, group=self.group)
+                dist.gather(self._local[slot], None, dst=self._global(self.dst), group=self.group)
         else:   # all_pairs: every image straight to every other rank, one grouped batch of point-to-point copies
             rows = self._all[slot].view(self.world, self.capacity)
             rows[self.rank].copy_(self._local[slot])
             ops = []
             for r in range(self.world):
                 if r != self.rank:
-                    ops.append(dist.P2POp(dist.isend, self._local[slot], r, group=self.group))
-                    ops.append(dist.P2POp(dist.irecv, rows[r], r, group=self.group))
+                    ops.append(dist.P2POp(dist.isend, self._local[slot], self._global(r), group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, rows[r], self._global(r), group=self.group))
             for req in (dist.batch_isend_irecv(ops) if ops else []):
                 req.wait()
         if self._cuda:   # (the calling stream waits for the collective; an event behind it marks the slot as free again)
@@ -188,6 +196,8 @@ class ObservationGatherer:
 
     def image(self, rank, slot=None):
         slot = self._gathered if slot is None else slot
+        if slot is None:
+            raise RuntimeError("no gathered image: the capacity changed (grow / fit) since the last gather()")
         if not self.holds_all:
             if rank != self.rank:
                 raise RuntimeError(f"mode 'gather': only rank {self.dst} holds the other ranks' images")
@@ -199,6 +209,8 @@ class ObservationGatherer:
         (mode "gather") the headers are exchanged with one small all-gather, so that `grow()` / `fit()` decide the same thing
         on every rank."""
         slot = self._gathered if slot is None else slot
+        if slot is None:
+            raise RuntimeError("no gathered image: the capacity changed (grow / fit) since the last gather()")
         if self.holds_all and self.mode != "gather":
             h = self._all[slot].view(self.world, self.capacity)[:, :64].cpu().numpy()
         else:
@@ -222,14 +234,15 @@ class ObservationGatherer:
     def fit(self, slot=None, margin=1.15, shrink_below=0.8):
         """Size the image from what the last step really used: capacity = max over the ranks of header.bytes_used x margin.
         Grows when an image overflowed (like `grow()`: that step has to be gathered again -> returns True) and SHRINKS when the
-        largest image fills less than `shrink_below` of the capacity (returns False: nothing to redo).  Populations drift
-        slowly, so calling this every few hundred steps keeps the wire bytes within ~15 % of the payload."""
+        largest image fills less than `shrink_below` of the capacity (returns False: nothing to redo, and the images of the last
+        gather stay readable -- the smaller buffers are only allocated by the NEXT `pack()`).  Populations drift slowly, so calling
+        this every few hundred steps keeps the wire bytes within ~15 % of the payload."""
         need = max(int(h.bytes_used) for h in self.headers(slot))
         if need > self.capacity:
             self._set_capacity(int(need * margin))
             return True
         if need * margin < shrink_below * self.capacity:
-            self._set_capacity(int(need * margin))
+            self._pending_capacity = int(need * margin)
         return False
 
     # ------------------------------------------------------------------

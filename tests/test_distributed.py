@@ -150,13 +150,56 @@ def _worker_modes(rank, world, port, tmpdir):
     slot = big.gather()
     cap0 = big.capacity
     used = max(int(h.bytes_used) for h in big.headers(slot))
-    assert not big.fit(slot) and big.capacity < cap0    # shrunk, nothing to redo
-    assert used <= big.capacity <= int(used * 1.16) + 256
-    slot = big.gather()
+    assert not big.fit(slot) and big.capacity == cap0   # nothing to redo, and nothing reallocated yet:
+    for r in range(world):                              # the images of that gather are still there to be consumed
+        assert np.array_equal(big.views(r, slot)["obs_prey"].numpy(), refs[r]["obs_prey"])
+    slot = big.gather()                                 # the NEXT pack shrinks the buffers
+    assert used <= big.capacity <= int(used * 1.16) + 256 and big.capacity < cap0
     for r in range(world):
         assert np.array_equal(big.views(r, slot)["obs_prey"].numpy(), refs[r]["obs_prey"])
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _worker_subgroup(rank, world, port, tmpdir):
+    """A gatherer on a SUB-GROUP of the job (ranks 1..world-1): its ranks, its root and its point-to-point peers are group-relative
+    and have to be translated to global ranks for torch.distributed (a hang or a wrong destination otherwise)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.config import config_env
+    from predpreygrass_amd.distributed import ObservationGatherer
+    from tests.emu_backend import library
+    members = list(range(1, world))
+    sub = dist.new_group(members)          # (every rank of the job takes part in creating it)
+    if rank in members:
+        env = BatchedPredPreyGrass(config_env, batch_size=2, _library=library(), seed=70 + 10 * rank)
+        env.reset()
+        for _ in range(12):
+            env.step(random_actions=True, auto_reset=True)
+        want = local_rows_reference(env)
+        np.savez(os.path.join(tmpdir, f"s{rank}.npz"), **{k: v.numpy() for k, v in want.items()})
+        dist.barrier(group=sub)
+        refs = [np.load(os.path.join(tmpdir, f"s{r}.npz")) for r in members]
+        for mode in ("all_gather", "all_pairs", "gather"):
+            g = ObservationGatherer(env, group=sub, mode=mode, dst=len(members) - 1)    # root = the group's LAST rank
+            assert g.world == len(members) and g.rank == rank - 1
+            slot = g.gather()
+            if g.holds_all:
+                for r in range(g.world):
+                    assert np.array_equal(g.views(r, slot)["obs_prey"].numpy(), refs[r]["obs_prey"]), (mode, rank, r)
+            else:
+                assert np.array_equal(g.views(g.rank, slot)["id_prey"].numpy(), refs[g.rank]["id_prey"])
+        dist.barrier(group=sub)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gatherer_on_a_sub_group_translates_ranks(tmp_path):
+    world = 3
+    port = 30600 + (os.getpid() * 3) % 300
+    mp.spawn(_worker_subgroup, args=(world, port, str(tmp_path)), nprocs=world, join=True)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -564,7 +564,16 @@ def test_spread_observation_tensors_change_no_result():
     cfg = {**config_env, "max_steps": 60}
     a = BatchedPredPreyGrass(cfg, batch_size=200, device="cuda:0", seed=9)
     b = BatchedPredPreyGrass(cfg, batch_size=200, device="cuda:0", seed=9, obs_spread=4)
-    assert len(b._spread_ptrs) == 2 and b.obs_prey.data_ptr() in b._spread_ptrs and b.obs_prey.data_ptr() % (2 << 20) == 0
+    import ctypes as C
+    lib = _abi.load_hip_library()
+
+    def spread_stats():
+        v = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+        assert lib.ppg_spread_stats(*[C.byref(x) for x in v]) == 0
+        return [int(x.value) for x in v]   # live bytes, retired ranges, retired bytes
+    live0, retired0, _ = spread_stats()
+    assert b.obs_prey.data_ptr() % (2 << 20) == 0 and b.obs_pred.data_ptr() % (2 << 20) == 0
+    assert spread_stats()[0] - live0 >= b.obs_prey.numel() * 8 + b.obs_pred.numel() * 8
     assert float(b.obs_prey.abs().sum()) == 0.0
     for e in (a, b):
         e.set_wave_plan(4, 0, 2)
@@ -575,8 +584,21 @@ def test_spread_observation_tensors_change_no_result():
     torch.cuda.synchronize()
     for n in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
         assert torch.equal(getattr(a, n), getattr(b, n)), n
+    # THE MAPPING FOLLOWS THE TENSORS, NOT THE ENV: an observation tensor (or a view of one) a caller still holds stays readable
+    # after close() and after the env object is gone; the pages go back when the last reference does
+    keep = b.obs_prey[:3]
+    want = keep.clone()
+    live1 = spread_stats()[0]
     b.close()
-    assert b._spread_ptrs == []
+    del b
+    import gc
+    gc.collect()
+    assert torch.equal(keep, want)
+    assert spread_stats()[0] < live1                 # obs_pred's pages are back ...
+    assert spread_stats()[1] == retired0 + 1
+    del keep
+    gc.collect()
+    assert spread_stats()[1] == retired0 + 2         # ... and now obs_prey's
     c = BatchedPredPreyGrass(cfg, batch_size=64, device="cuda:0", seed=9, obs_spread=2, obs_dtype=torch.bfloat16)
     c.reset()
     c.step(random_actions=True)
@@ -621,3 +643,7 @@ def test_spread_allocator_gives_the_memory_back():
         assert out.value not in seen
         seen.add(out.value)
         assert lib.ppg_free_spread(out) == 0
+    # what that costs: virtual address space only -- counted, so that a long-lived process can see it (2^47 bytes exist)
+    live, ranges, nbytes = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert lib.ppg_spread_stats(C.byref(live), C.byref(ranges), C.byref(nbytes)) == 0
+    assert ranges.value >= len(seen) and nbytes.value >= len(seen) * size
