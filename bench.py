@@ -725,6 +725,8 @@ def main(argv=None, backend=None):
                     "image_overflows": int(sum(h.overflow for h in hs)),
                     "wire_obs_dtype": "f32" if (wire is not None or obs_dtype == torch.float32) else "f64",
                     "what": (("one all_gather_into_tensor (RCCL) of the packed observation image per step" if mode == "all_gather" else
+                              "the all-gather of the packed observation image spelled as ONE grouped batch of point-to-point copies per step "
+                              "(every image straight to every peer: the direct algorithm on the xGMI mesh)" if mode == "all_pairs" else
                               "one gather of the packed observation image to rank 0 per step (every other rank sends once, receives nothing)") +
                              ("" if include_obs else " WITHOUT the observation sections (PPG_PACK_NO_OBS: env words, ids, rewards, flags -- "
                               "what leaves a GPU when the policy runs next to the env)") +
@@ -732,6 +734,7 @@ def main(argv=None, backend=None):
                               else ", synchronous: the next step waits for it"))}
         for name, kw in (("sync", dict(overlapped=False)), ("overlapped", dict(overlapped=True)),
                          ("obs_gather_to_root", dict(overlapped=False, mode="gather")),
+                         ("obs_all_pairs", dict(overlapped=False, mode="all_pairs")),
                          ("ids_rewards_gather", dict(overlapped=False, include_obs=False))):
             try:   # never lose the main measurement to an optional leg
                 res = leg(**kw)

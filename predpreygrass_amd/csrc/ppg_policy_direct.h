@@ -155,7 +155,8 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
     for (nt += nt_step; nt < n_tiles; nt += nt_step) {
         cur = context(nt);
         f32x16 acc[MT];
-        tile(cur, acc, [&] { epilogue(prev, acc_prev); });
+        tile(cur, acc, [&] { epilogue(prev, acc_prev); });   // (requesting tile t + 1's first fragments behind tile t's last batch as
+                                                             //  well -- a cross-tile prefetch -- measured the same: profiles/r04)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc_prev[mt] = acc[mt];
         prev = cur;
@@ -248,8 +249,13 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
             unsigned long long src = 0, dst = 0;
             if (tid < nt_samples) {
                 const uint32_t n = (uint32_t)(n0 + tid);
-                int lo = (int)K.tile_env[tile];
-                while (lo + 1 < K.n_envs && K.plan[PLAN_HDR + 1 + lo] <= n) ++lo;
+                // the last env whose prefix sum is <= n: bisection between this tile's first env and the next tile's (predator tiles span
+                // twenty envs: a forward walk is twenty dependent loads)
+                int lo = (int)K.tile_env[tile], hi = tile + 1 < n_tiles ? (int)K.tile_env[tile + 1] : K.n_envs - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (K.plan[PLAN_HDR + mid] <= n) lo = mid; else hi = mid - 1;
+                }
                 const int e = lo, row = (int)(n - K.plan[PLAN_HDR + e]);
                 const int k = handle_of(K.env_base, K.n_handles, e);
                 const int b = e - K.env_base[k];

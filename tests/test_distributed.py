@@ -262,7 +262,7 @@ def test_bench_two_ranks_dry_run_with_gather_leg(launcher):
     d = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--envs", "5", "--streams", "2",
                     "--gather-steps", "3", "--preroll-min", "64", "--preroll-max", "64"], 2, launcher=launcher)
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 5
-    for leg in ("obs_gather", "obs_gather_overlapped", "obs_gather_to_root", "ids_rewards_gather"):
+    for leg in ("obs_gather", "obs_gather_overlapped", "obs_gather_to_root", "obs_all_pairs", "ids_rewards_gather"):
         assert leg in d and "error" not in d[leg], d.get(leg)
         assert d[leg]["steps"] == 3 and d[leg]["collectives_per_step"] == 1 and d[leg]["image_overflows"] == 0
         assert d[leg]["wire_bytes_per_step_per_rank"] > 0 and len(d[leg]["image_bytes_used_last_step"]) == 2

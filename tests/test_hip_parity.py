@@ -410,6 +410,11 @@ def test_bench_rccl_gather_legs_with_one_rank():
         assert "error" not in d[leg], d[leg]
         assert d[leg]["collectives_per_step"] == 1 and d[leg]["image_overflows"] == 0
         assert d[leg]["wire_bytes_per_step_per_rank"] > 1e6
+    # the other modes on RCCL too: gather-to-root, the all-pairs spelling, the image without observations
+    for leg in ("obs_gather_to_root", "obs_all_pairs", "ids_rewards_gather"):
+        assert "error" not in d[leg], d[leg]
+        assert d[leg]["collectives_per_step"] == 1 and d[leg]["image_overflows"] == 0
+    assert d["ids_rewards_gather"]["wire_bytes_per_step_per_rank"] * 20 < d["obs_gather"]["wire_bytes_per_step_per_rank"]
 
 
 def test_snapshot_restore_on_gpu_base_and_second_generation():
@@ -562,16 +567,18 @@ def test_spread_observation_tensors_change_no_result():
     """obs_spread: the observation tensors on physical pages from ppg_alloc_spread (HIP virtual memory management) -- placement only.
     Same results as on torch's allocator, for the step kernels, the fused rollout and an env that is closed and rebuilt."""
     cfg = {**config_env, "max_steps": 60}
-    a = BatchedPredPreyGrass(cfg, batch_size=200, device="cuda:0", seed=9)
-    b = BatchedPredPreyGrass(cfg, batch_size=200, device="cuda:0", seed=9, obs_spread=4)
     import ctypes as C
+    import gc
     lib = _abi.load_hip_library()
 
     def spread_stats():
         v = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
         assert lib.ppg_spread_stats(*[C.byref(x) for x in v]) == 0
         return [int(x.value) for x in v]   # live bytes, retired ranges, retired bytes
+    gc.collect()
     live0, retired0, _ = spread_stats()
+    a = BatchedPredPreyGrass(cfg, batch_size=200, device="cuda:0", seed=9)
+    b = BatchedPredPreyGrass(cfg, batch_size=200, device="cuda:0", seed=9, obs_spread=4)
     assert b.obs_prey.data_ptr() % (2 << 20) == 0 and b.obs_pred.data_ptr() % (2 << 20) == 0
     assert spread_stats()[0] - live0 >= b.obs_prey.numel() * 8 + b.obs_pred.numel() * 8
     assert float(b.obs_prey.abs().sum()) == 0.0
@@ -590,8 +597,7 @@ def test_spread_observation_tensors_change_no_result():
     want = keep.clone()
     live1 = spread_stats()[0]
     b.close()
-    del b
-    import gc
+    del b, e          # (`e`: the loop variable above still names the env)
     gc.collect()
     assert torch.equal(keep, want)
     assert spread_stats()[0] < live1                 # obs_pred's pages are back ...
