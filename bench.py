@@ -22,7 +22,7 @@ For N>1 two extra legs measure the step followed by the ONE RCCL all-gather of t
 image that north_star specifies ("obs_gather", "obs_gather_overlapped"; bandwidth-bound on xGMI, see
 DESIGN.md).  Within one GPU the 4096 envs are stepped as --streams (default 3) independent sub-batches on
 separate HIP streams.  Their observation tensors are allocated with ppg_alloc_spread (--obs-spread, default 32: physical
-pages from a large stretch of device memory, which is what HBM wants for the step's scattered writes -- DESIGN.md 5.0), and
+pages from a large stretch of device memory, which is what HBM wants for the step's scattered writes -- profiles/EXPERIMENTS.md, round 3), and
 of --placement-candidates (default 3) such buffer sets the fastest is kept; both are allocation choices, results never depend
 on them.
 
@@ -41,7 +41,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r03", "bench_driver_summary.json")
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r04", "bench_driver_summary.json")
 
 
 def device_state():
@@ -791,7 +791,7 @@ def main(argv=None, backend=None):
             scale = (run_bytes / args.steps / n_sub) / prof["counted_bytes_per_launch"]
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"] * scale)
             traffic_origin = "profiles_fallback"
-            traffic_src = (f"profiles/r03/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+            traffic_src = (f"profiles/r04/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            f"{prof['hbm_traffic_per_launch_bytes']['total_corrected']} B per launch at "
                            f"{prof['mean_agents_per_env']} agents/env, scaled x{scale:.4f} by this run's counted bytes")
     except Exception:

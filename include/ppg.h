@@ -315,7 +315,7 @@ int ppg_step(ppg_handle *h, const int8_t *actions, uint32_t flags, void *stream)
  * On a handle whose wave plan is cooperative (a full GPU of 25x25 grids: the default) it runs the fused form of the cooperative step
  * kernel: a workgroup's envs never interact with any other workgroup's, so the workgroups simply run on from step to step at their
  * own pace -- no launch boundary at which everybody computes and nobody stores -- and ONE launch stream reaches 61 us per 4096-env
- * step where per-step launches need three sub-batches in flight for 66-71.  On other handles (small batches,
+ * step where per-step launches need three sub-batches in flight for 66-71 (profiles/EXPERIMENTS.md, round 3).  On other handles (small batches,
  * 64x64 grids) it is the round-1 one-wave-per-env loop, which is SLOWER than per-step launches and kept only as a diagnostic.  Base
  * family without the kickback / drive variants; second-generation handles (ppg_create_gen2, no walls) on a cooperative four-wave plan
  * only (PPG_EINVAL otherwise), reproduction uniforms from the device's Philox streams as in ppg_step. */
@@ -513,8 +513,8 @@ const char *ppg_policy_last_error(const ppg_policy *p);
  * memory `spread` times its size (HIP virtual memory management: spread x as many 2 MB chunks are created, a random subset is
  * mapped in random order, the rest is given back at once).  Optional -- any device pointer works as obs_pred / obs_prey -- but where
  * the pages of those two tensors lie decides how fast HBM takes the step's scattered 1 KB pieces: 62-64 us per 4096-env step with
- * spread 32-64 against 62-91 us for what hipMalloc happens to return and 105-121 us for physically contiguous memory (DESIGN.md
- * section 5.0).  Costs: spread 32 at 1.8 GB takes about 2.5 s and 58 GB of transient device memory; if the device cannot hold the
+ * spread 32-64 against 62-91 us for what hipMalloc happens to return and 105-121 us for physically contiguous memory (profiles/EXPERIMENTS.md,
+ * round 3).  Costs: spread 32 at 1.8 GB takes about 2.5 s and 58 GB of transient device memory; if the device cannot hold the
  * pool the spread shrinks, and the transient pool never takes more than half of the memory that is free when it is built.  Not in the
  * CPU test build.  ppg_free_spread gives the physical memory back and RETIRES the virtual range
  * (a re-used range was seen to go through stale translations).  Returns PPG_OK or an error code (ppg_spread_last_error()). */

@@ -50,7 +50,7 @@ class BatchedPredPreyGrass:
                  prey_capacity=128, seed=0, _library=None, obs_spread=0):
         """obs_spread = N > 1: the two observation tensors live in memory from `ppg_alloc_spread` (include/ppg.h) -- physical pages
         picked at random from a stretch of device memory N times their size, which is what HBM wants for the step's scattered writes
-        (N = 32 costs a few seconds and N x the tensors' size of transient device memory).  They stay valid
+        (profiles/EXPERIMENTS.md, round 3; N = 32 costs a few seconds and N x the tensors' size of transient device memory).  They stay valid
         until close()."""
         cfg = resolve_config(config)
         self.config = cfg

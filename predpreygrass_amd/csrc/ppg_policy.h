@@ -1414,7 +1414,10 @@ int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handle
     // The predators are few (a third of the chip's workgroup slots at 4096 envs): their launch goes to a side stream that is
     // forked from and joined back into `stream` with events, so that it fills the CUs the prey launch leaves idle.
     void *pred_stream = stream;
-    if (pred && prey) {
+    // (direct-head networks: every workgroup needs a whole CU's LDS, so the two launches cannot share CUs -- a side stream only adds two
+    //  cross-stream event waits; they run back to back on the caller's stream)
+    const bool side = pred && prey && !(pred->direct && prey->direct);
+    if (side) {
         if (!pred->side) {
             PPG_POL_TRY(pred, hipStreamCreateWithFlags(&pred->side, hipStreamNonBlocking));
             PPG_POL_TRY(pred, hipEventCreateWithFlags(&pred->fork, hipEventDisableTiming));
@@ -1432,7 +1435,7 @@ int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handle
         const int rc = ppg_policy_run(pred, 0, handles, n, actions, flags, seed, logits_pred, pred_stream);
         if (rc != PPG_OK) { memcpy(g_ppg_policy_error, pred->err, sizeof g_ppg_policy_error); return rc; }
     }
-    if (pred && prey) {
+    if (side) {
         PPG_POL_TRY(pred, hipEventRecord(pred->join, pred->side));
         PPG_POL_TRY(pred, hipStreamWaitEvent((hipStream_t)stream, pred->join, 0));
     }

@@ -1,6 +1,6 @@
 // ppg_spread.h -- device buffers whose physical pages are spread over a large stretch of device memory (include/ppg.h: ppg_alloc_spread).
 //
-// Why (profiles/r03/e_placement_experiments.txt): ppg_step writes every env's observation rows as ~2000
+// Why (profiles/EXPERIMENTS.md, round 3, profiles/r03/e_placement_experiments.txt): ppg_step writes every env's observation rows as ~2000
 // concurrent sequential streams of 1 KB pieces, one per workgroup, into slabs a few hundred KB apart.  How fast HBM takes that
 // pattern depends on the PHYSICAL pages behind the tensor: physically contiguous memory is the worst case (105-121 us per 4096-env
 // step), what hipMalloc returns draws from 62-91 us, and pages picked at random from a stretch of device memory N times the

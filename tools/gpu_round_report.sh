@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: the end-of-round evidence run.  usage: tools/gpu_round_report.sh <tag>
 set -u
-tag=${1:-r03a}
+tag=${1:-r04a}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -18,6 +18,9 @@ for w in c4 red_queen drive walls; do
 done
 python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --cpu-seconds 8 > gpurun_out/${tag}_bench_policy_rollout.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --workload policy_rollout --obs-dtype f64 --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_policy_rollout_f64.json 2>> gpurun_out/${tag}_bench.err
+for a in fc256 r3; do   # the same encoder with head_fcnet_hiddens [256, 256]; rounds 2-3's network
+  python3 bench.py --workload policy_rollout --policy-arch $a --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_policy_rollout_$a.json 2>> gpurun_out/${tag}_bench.err
+done
 python3 bench.py --envs 256 --steps 2000 --warmup 100 --no-cpu-baseline --sustained-steps 0 > gpurun_out/${tag}_bench_c2_256envs.json 2>> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_ptrace -o t -- python3 bench.py --workload policy_rollout --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_policy_under_trace.json 2> gpurun_out/${tag}_ptrace.err
 find gpurun_out/${tag}_ptrace -name '*kernel_stats.csv' -exec cp {} gpurun_out/${tag}_kernel_stats_policy.csv \;
