@@ -31,7 +31,8 @@ namespace ppgpol {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // timing-only ablation builds (tools/gpu_direct_ablate.sh; never defined in the product -- the results are then meaningless):
-// 1 no head k-loop, 2 no action selection, 4 no conv3, 8 no conv1 / conv2, 16 no observation staging
+// 1 no head k-loop, 2 no action selection, 4 no conv3, 8 no conv1 / conv2, 16 no observation staging, 32 no LDS fragment reads in the
+// convolutions, 64 no convolution epilogues
 #ifndef PPG_DIRECT_ABLATE
 #define PPG_DIRECT_ABLATE 0
 #endif
@@ -105,6 +106,10 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
             v = zero8();
             if (h == HB) { v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
         } else {
+            if (PPG_DIRECT_ABLATE & 32) {   // (timing-only build: no fragment reads)
+                v = zero8();
+                v[0] = (__bf16)(float)(c.in_base + ks);
+            } else
             v = *(const bf16x8 *)(img + c.in_base + W.offset(K, ks, pair));
             if (ks == KSB && h == HB) { v = zero8(); v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
         }
@@ -117,6 +122,9 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
             for (int j = 0; j < 2; ++j) {   // this lane's channels 32 (mt_base + mt) + 16 h + 8 j .. + 7 = channel block cb0 + 4 mt + j
                 const bool real = c.valid && (cb0 + 4 * mt + j < out_blocks);
                 const int at = real ? c.out_base + (4 * mt + j) * cb_step : dummy;
+                if (PPG_DIRECT_ABLATE & 64) {   // (timing-only build: no ReLU / pack / store -- one value kept so that the MFMAs stay)
+                    if (acc[mt][8 * j] == 123.0f) *(float *)(img + dummy) = acc[mt][8 * j];
+                } else
                 *(bf16x8 *)(img + at) = relu_pack8(acc[mt], 8 * j);
             }
     };
@@ -130,7 +138,6 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
 #pragma unroll
         for (int i = 0; i < BS; ++i) b[0][i] = fragment(c, i);
         __builtin_amdgcn_sched_barrier(0);   // (keep the reads together and in front: left alone, the scheduler re-pairs each with its MFMA)
-        between();
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             if (nb + 1 < NB) {
@@ -138,6 +145,9 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
                 for (int i = 0; i < BS; ++i) if ((nb + 1) * BS + i < KS) b[(nb + 1) & 1][i] = fragment(c, (nb + 1) * BS + i);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (nb == 0) between();   // (no fence between the previous tile's epilogue and this batch's MFMAs: the scheduler interleaves them.
+                                      //  Measured the same as the epilogue in front of the MFMAs; so did two position tiles per iteration in
+                                      //  conv1 / conv2 and a cross-tile fragment prefetch: profiles/r04/b_policy_direct_*)
 #pragma unroll
             for (int i = 0; i < BS; ++i)
                 if (nb * BS + i < KS) {
