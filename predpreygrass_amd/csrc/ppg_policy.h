@@ -125,7 +125,7 @@ __device__ __forceinline__ int handle_of(P env_base, int n_handles, int e) {
 // Exclusive prefix sums of one env_state word over the concatenated envs of all handles, and for every 128-sample tile the env
 // its first sample belongs to.  One workgroup of 1024 threads: thread t sums a contiguous run of envs, the 1024 partial sums are
 // scanned in LDS, then every thread bisects for its tiles.
-extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan(const PlanParams K) {
+__device__ __forceinline__ void plan_body(const PlanParams &K) {
     __shared__ uint32_t part[1024];
     const int t = (int)threadIdx.x;
     const int per = (K.n_envs + 1023) / 1024;
@@ -175,6 +175,11 @@ extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan(const PlanPar
         }
         K.tile_env[tile] = (uint32_t)a;
     }
+}
+extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan(const PlanParams K) { plan_body(K); }
+// both species' plans in one launch (workgroup 0: A, workgroup 1: B): one launch and one dependent-load chain less per step
+extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan2(const PlanParams A, const PlanParams B) {
+    if (blockIdx.x == 0) plan_body(A); else plan_body(B);
 }
 
 __device__ __forceinline__ bf16x8 zero8() {
@@ -1281,8 +1286,21 @@ uint64_t ppg_policy_macs_per_observation(const ppg_policy *p) { return p ? p->ma
 
 const char *ppg_policy_last_error(const ppg_policy *p) { return p ? p->err : g_ppg_policy_error; }
 
+// the plan buffer of a policy: [PLAN_HDR + envs] header + prefix sums, then the first env of every tile
+static int ppg_policy_ensure_plan(ppg_policy *p, int total, int cap) {
+    if (p->plan_envs >= total) return PPG_OK;
+    if (p->plan) (void)hipFree(p->plan);
+    p->plan = nullptr;
+    const size_t max_tiles = ((size_t)total * cap + 31) / 32 + 1;   // (tiles of 32 samples are the smallest the plan picks)
+    PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(ppgpol::PLAN_HDR + total) + max_tiles) * 4));
+    p->plan_envs = total;
+    return PPG_OK;
+}
+
+// also_plan_for: the OTHER species' policy whose plan this call's plan launch computes as well (ppg_policy_plan2); skip_plan: this
+// species' plan was computed by the other call
 static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles, int32_t n, int8_t *const *actions, uint32_t flags,
-                          uint64_t seed, float *logits, void *stream) {
+                          uint64_t seed, float *logits, void *stream, ppg_policy *also_plan_for = nullptr, bool skip_plan = false) {
     ppg_handle *h0 = handles[0];
     const int R = species ? h0->base.Rq : h0->base.Rp;
     if (R != p->R) return ppg_policy_fail(p, PPG_EINVAL, "the policy was created for %dx%d observations, the %s observe %dx%d", p->R, p->R,
@@ -1316,12 +1334,9 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     K.n_envs = L.n_envs = total;
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != p->device) PPG_POL_TRY(p, hipSetDevice(p->device));
-    if (p->plan_envs < total) {
-        if (p->plan) (void)hipFree(p->plan);
-        p->plan = nullptr;
-        const size_t max_tiles = ((size_t)total * K.cap + 31) / 32 + 1;   // (tiles of 32 samples are the smallest the plan picks)
-        PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(ppgpol::PLAN_HDR + total) + max_tiles) * 4));
-        p->plan_envs = total;
+    {
+        const int rc = ppg_policy_ensure_plan(p, total, K.cap);
+        if (rc != PPG_OK) return rc;
     }
     K.plan = L.plan = p->plan;
     K.tile_env = L.tile_env = p->plan + ppgpol::PLAN_HDR + total;
@@ -1347,7 +1362,20 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     const bool tl_now = tl_path && ++tl_runs[species] == tl_at;
     K.timeline = tl_now ? tl_buf[species] : nullptr;
 #endif
-    hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
+    if (also_plan_for) {   // the other species' plan in the same launch: same envs, its row-count word, its buffers, its grid
+        ppg_policy *o = also_plan_for;
+        const int rc = ppg_policy_ensure_plan(o, total, species ? h0->base.cap_pred : h0->base.cap_prey);
+        if (rc != PPG_OK) { memcpy(p->err, o->err, sizeof p->err); return rc; }
+        ppgpol::PlanParams L2 = L;
+        L2.word = species ? PPG_ENV_N_PRED_ROWS : PPG_ENV_N_PREY_ROWS;
+        L2.plan = o->plan;
+        L2.tile_env = o->plan + ppgpol::PLAN_HDR + total;
+        L2.slots = o->grid;
+        L2.force_ts = 0;
+        hipLaunchKernelGGL(ppgpol::ppg_policy_plan2, dim3(2), dim3(1024), 0, (hipStream_t)stream, L, L2);
+    } else if (!skip_plan) {
+        hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
+    }
     typedef void (*fwd_fn)(const ppgpol::PolParams);
     const fwd_fn fwd[3][3] = {{ppgpol::ppg_policy_forward_f64, ppgpol::ppg_policy_forward_f32, ppgpol::ppg_policy_forward_bf16},
                               {ppgpol::ppg_policy_forward_hwc8_f64, ppgpol::ppg_policy_forward_hwc8_f32, ppgpol::ppg_policy_forward_hwc8_bf16},
@@ -1427,12 +1455,13 @@ int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handle
         PPG_POL_TRY(pred, hipStreamWaitEvent(pred->side, pred->fork, 0));
         pred_stream = pred->side;
     }
+    const bool one_plan = pred && prey && !side;   // (same stream: the prey call's plan launch computes the predators' plan too)
     if (prey) {
-        const int rc = ppg_policy_run(prey, 1, handles, n, actions, flags, seed, logits_prey, stream);
+        const int rc = ppg_policy_run(prey, 1, handles, n, actions, flags, seed, logits_prey, stream, one_plan ? pred : nullptr);
         if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
     }
     if (pred) {
-        const int rc = ppg_policy_run(pred, 0, handles, n, actions, flags, seed, logits_pred, pred_stream);
+        const int rc = ppg_policy_run(pred, 0, handles, n, actions, flags, seed, logits_pred, pred_stream, nullptr, one_plan);
         if (rc != PPG_OK) { memcpy(g_ppg_policy_error, pred->err, sizeof g_ppg_policy_error); return rc; }
     }
     if (side) {
