@@ -166,10 +166,17 @@ __device__ __forceinline__ void plan_body(const PlanParams &K) {
     __syncthreads();   // (the prefix sums are re-read below by other threads of this workgroup: same CU, written through L1)
     const uint32_t tail = all - n_full * (uint32_t)TILE;
     const int n_tiles = (int)(n_full + (tail + ts - 1) / ts);
+    // exclusive prefix of thread u's run = part[u] - (its own sum) = part[u - 1]: the bisection first finds the RUN in LDS (ten steps, no
+    // memory round trip), then the env inside the run (`per` <= a handful of prefix sums from memory)
     for (int tile = t; tile < n_tiles; tile += 1024) {
         const uint32_t n = (uint32_t)tile < n_full ? (uint32_t)tile * (uint32_t)TILE : n_full * (uint32_t)TILE + ((uint32_t)tile - n_full) * ts;
-        int a = 0, b = K.n_envs - 1;
-        while (a < b) {   // the last env whose prefix sum is <= n
+        int ua = 0, ub = 1023;
+        while (ua < ub) {   // the last run whose first env's prefix sum (= the inclusive sum of the runs before it) is <= n
+            const int mid = (ua + ub + 1) >> 1;
+            if (part[mid - 1] <= n) ua = mid; else ub = mid - 1;
+        }
+        int a = ua * per < K.n_envs ? ua * per : K.n_envs - 1, b = (a + per - 1) < (K.n_envs - 1) ? (a + per - 1) : (K.n_envs - 1);
+        while (a < b) {   // the last env of that run whose prefix sum is <= n
             const int mid = (a + b + 1) >> 1;
             if (__builtin_nontemporal_load(&K.plan[PLAN_HDR + mid]) <= n) a = mid; else b = mid - 1;
         }
