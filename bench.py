@@ -618,7 +618,10 @@ def main(argv=None, backend=None):
 
     # clocks / power / temperatures WHILE the same loop runs (untimed extra steps on rank 0 for as long as one rocm-smi call takes)
     dev_state = None
-    if not dry and rank == 0 and not args.traffic_child and args.sustained_steps > 0:
+    # (never under a profiler: its preloaded library initialises the GPU in every child process, and rocm-smi is a `#!/usr/bin/env python3`
+    #  script -- an exec from a GPU-initialised process, which the GPU boxes refuse)
+    under_profiler = bool(os.environ.get("LD_PRELOAD")) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if not dry and rank == 0 and not args.traffic_child and args.sustained_steps > 0 and not under_profiler:
         import threading
         box = {}
         th = threading.Thread(target=lambda: box.update(state=device_state()))
