@@ -38,7 +38,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #endif
 // -DPPG_DIRECT_PROFILE (tools/gpu_direct_profile.sh): cycles per phase, summed per wavefront over the launch, into K.xg (unused by the
 // direct path) as [workgroup][wavefront][16] -- 0 tile set-up, 1 conv1, 2 its barrier, 3 conv2, 4 barrier, 5 conv3 (+ deeper), 6 barrier,
-// 7 staging + head, 8 barrier, 9 logits / actions, 15 sub-groups
+// 7 partial sums to LDS, 8 barrier, 9 logits, 10 staging, 11 requests of the rows two sub-groups ahead, 12 head, 15 sub-groups
 // PPG_DIRECT_W1 (default 1): the direct-head kernels run ONE workgroup per CU (one wavefront per SIMD: 512 registers --
 // every weight of the network and the head's fragments resident, both of conv3's row tiles in one wavefront, 160 KB of LDS = twice the
 // samples per sub-group); 0 = two workgroups per CU with 256 registers each (conv3's row tiles split over wavefront pairs, the head's
@@ -362,7 +362,9 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
             // ---- head: partial logits of this wavefront's share of the k-steps; the next sub-group's input goes into X meanwhile ----
             if (s0 + K.ST < nt_samples && !(PPG_DIRECT_ABLATE & 16)) {
                 stage(s0 + K.ST);
+                PPG_DP(10);
                 if (s0 + 2 * K.ST < nt_samples) request(s0 + 2 * K.ST);
+                PPG_DP(11);
             }
             {
                 const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + K.off_f + 8 * kq;
@@ -378,6 +380,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                         for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + 32 * (k_lo + i));
 #pragma unroll
                         for (int i = 0; i < HF; ++i) hacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i], fv[i], hacc[0], 0, 0, 0);
+                        // (four independent accumulator chains instead of this one: slower, 1751 vs 1225 cycles -- profiles/r04)
                     }
                 }
                 if (PPG_DIRECT_ABLATE & 1) {
@@ -410,6 +413,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                             }
                     }
                 }
+                PPG_DP(12);
                 // D: lane (column = sample colh, rows 4 kq + i) -> red[wave][action tile][row][column]
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
