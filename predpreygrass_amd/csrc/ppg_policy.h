@@ -99,6 +99,7 @@ struct PolParams {
     const bf16x8 *whw;            // the same of action tile 0 per wavefront: [wavefront][18][lane], zeros behind a wavefront's share of k-steps
     const float *bh;              // head bias [32]
     float *lgs;                   // library-owned [gridDim.x][TILE][16 head_mt]: a workgroup's logits of its current tile
+    int32_t range_tile;           // samples per tile inside a workgroup's share (PlanParams::range_tile)
 #ifdef PPG_EXPERIMENTS
     unsigned long long *timeline; // diagnostic builds: [tile][64] = workgroup, hardware id, samples, 4 wall-clock stamps (10 ns units); [8 + 12 wave + i] cycles of wave in step i of the convolutions, [56 + 2 wave + i] FC1 wait / barrier cycles
 #endif
@@ -108,6 +109,8 @@ struct PlanParams {
     int32_t n_handles, n_envs, word;   // word: PPG_ENV_N_PRED_ROWS / PPG_ENV_N_PREY_ROWS
     int32_t slots;                     // workgroups the forward launch keeps resident (its grid)
     int32_t force_ts;                  // experiments (env PPG_POLICY_TILE_PREY / _PRED): every tile 32 / 64 / 96 / 128 samples; 0 = choose
+    int32_t range_tile, range_st;      // direct-head kernels: > 0 = RANGE MODE -- every workgroup gets one contiguous share of the samples (a
+                                       // multiple of range_st = its sub-group size), cut into tiles of range_tile samples (a multiple too)
     int32_t env_base[MAX_HANDLES + 1];
     const int32_t *env_state[MAX_HANDLES];
     uint32_t *plan;
@@ -149,6 +152,35 @@ __device__ __forceinline__ void plan_body(const PlanParams &K) {
         const int k = handle_of(K.env_base, K.n_handles, e);
         K.plan[PLAN_HDR + e] = before;
         before += (uint32_t)K.env_state[k][(size_t)(e - K.env_base[k]) * PPG_ENV_WORDS + K.word];
+    }
+    if (K.range_tile > 0) {
+        // RANGE MODE: workgroup w owns samples [w S, (w + 1) S), S = the per-workgroup share rounded up to whole sub-groups, as tiles of
+        // range_tile samples -- every workgroup the same number of FULL sub-groups (whole rounds of 128-sample tiles + a short last round
+        // leave most of the chip idle in the last round and cut a two-sample sub-group off every tile: 7 % at the benchmark's 132 k prey)
+        const uint32_t st = (uint32_t)K.range_st, slots = (uint32_t)K.slots, tsz = (uint32_t)K.range_tile;
+        const uint32_t S = st * ((all + slots * st - 1u) / (slots * st));
+        const uint32_t tpw = S ? (S + tsz - 1u) / tsz : 1u;
+        if (t == 0) { K.plan[0] = all; K.plan[1] = S; K.plan[2] = tpw; }
+        __threadfence_block();
+        __syncthreads();
+        const int n_slots = (int)(slots * tpw);
+        for (int tile = t; tile < n_slots; tile += 1024) {
+            uint32_t n = ((uint32_t)tile / tpw) * S + ((uint32_t)tile % tpw) * tsz;
+            if (all == 0u) { K.tile_env[tile] = 0u; continue; }
+            if (n > all - 1u) n = all - 1u;    // (an empty tile slot: behind every sample of the tiles in front of it -- keeps the list monotone)
+            int ua = 0, ub = 1023;
+            while (ua < ub) {
+                const int mid = (ua + ub + 1) >> 1;
+                if (part[mid - 1] <= n) ua = mid; else ub = mid - 1;
+            }
+            int a = ua * per < K.n_envs ? ua * per : K.n_envs - 1, b = (a + per - 1) < (K.n_envs - 1) ? (a + per - 1) : (K.n_envs - 1);
+            while (a < b) {
+                const int mid = (a + b + 1) >> 1;
+                if (__builtin_nontemporal_load(&K.plan[PLAN_HDR + mid]) <= n) a = mid; else b = mid - 1;
+            }
+            K.tile_env[tile] = (uint32_t)a;
+        }
+        return;
     }
     // Tiles: as many whole ROUNDS of 128-sample tiles as the resident workgroups (slots) can be given (the FC1 weights are re-read
     // once per tile, so tiles are as large as the accumulators allow), then ONE last round in which the remaining samples are
@@ -1218,6 +1250,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
             if (score > best * 1.0001) { best = score; st = c; }
         }
         K.ST = st;
+        K.range_tile = st * (ppgpol::TILE / st);   // whole sub-groups per tile
         p->lds_bytes = fixed + st * K.sample_stride * 2;
         const size_t lgs_bytes = (size_t)p->grid * ppgpol::TILE * 16 * K.head_mt * 4;
         if (hipMalloc((void **)&p->lgs, lgs_bytes) != hipSuccess || hipMemset(p->lgs, 0, lgs_bytes) != hipSuccess) {
@@ -1298,7 +1331,12 @@ static int ppg_policy_ensure_plan(ppg_policy *p, int total, int cap) {
     if (p->plan_envs >= total) return PPG_OK;
     if (p->plan) (void)hipFree(p->plan);
     p->plan = nullptr;
-    const size_t max_tiles = ((size_t)total * cap + 31) / 32 + 1;   // (tiles of 32 samples are the smallest the plan picks)
+    size_t max_tiles = ((size_t)total * cap + 31) / 32 + 1;   // (tiles of 32 samples are the smallest the plan picks)
+    if (p->direct) {   // range mode: grid x tiles-per-workgroup slots, some of them empty
+        const size_t share = ((size_t)total * cap + p->grid - 1) / p->grid + (size_t)p->base.ST;
+        const size_t slots = (size_t)p->grid * ((share + p->base.range_tile - 1) / p->base.range_tile + 1);
+        if (slots > max_tiles) max_tiles = slots;
+    }
     PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(ppgpol::PLAN_HDR + total) + max_tiles) * 4));
     p->plan_envs = total;
     return PPG_OK;
@@ -1348,6 +1386,8 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     K.plan = L.plan = p->plan;
     K.tile_env = L.tile_env = p->plan + ppgpol::PLAN_HDR + total;
     L.slots = p->grid;
+    L.range_tile = p->direct ? K.range_tile : 0;
+    L.range_st = K.ST;
 #ifdef PPG_EXPERIMENTS
     if (const char *f = getenv(species ? "PPG_POLICY_TILE_PREY" : "PPG_POLICY_TILE_PRED")) {
         const int v = atoi(f);
@@ -1379,6 +1419,8 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
         L2.tile_env = o->plan + ppgpol::PLAN_HDR + total;
         L2.slots = o->grid;
         L2.force_ts = 0;
+        L2.range_tile = o->direct ? o->base.range_tile : 0;
+        L2.range_st = o->base.ST;
         hipLaunchKernelGGL(ppgpol::ppg_policy_plan2, dim3(2), dim3(1024), 0, (hipStream_t)stream, L, L2);
     } else if (!skip_plan) {
         hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);

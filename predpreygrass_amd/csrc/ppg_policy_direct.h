@@ -193,9 +193,11 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
     const int dummy = -2048 + 8 * tid;   // (element index from img: this thread's 16 bytes of the 4 KB in front of the images; dconv)
     const int sample_stride = K.sample_stride;
     const int n_conv = K.n_conv;
-    const int N = (int)K.plan[0], n_full = (int)K.plan[1], ts = (int)K.plan[2];
-    const int n_tiles = n_full + (N - n_full * TILE + ts - 1) / ts;
-    if ((int)blockIdx.x >= n_tiles) return;
+    // RANGE MODE of the plan (ppg_policy.h): this workgroup owns samples [begin, end) as tiles of K.range_tile
+    const int N = (int)K.plan[0], share = (int)K.plan[1], tpw = (int)K.plan[2];
+    const int begin = (int)blockIdx.x * share, end = (begin + share) < N ? (begin + share) : N;
+    if (begin >= end) return;
+    const int n_slots = (int)gridDim.x * tpw;
     // (A rotation of conv1's / conv2's weights and the head's fragments through the same registers -- each on its way from L2 while the
     // other computes -- was tried: hipcc answered with 40-70 spilled registers in every formulation; profiles/r04.)
     ConvW<CB1, 1> w1c;
@@ -250,10 +252,11 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
 #ifdef PPG_DIRECT_PROFILE
     long long dp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dp_prev = (long long)clock64();
 #endif
-    for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
-        const int size = tile < n_full ? TILE : ts;
-        const int n0 = tile < n_full ? tile * TILE : n_full * TILE + (tile - n_full) * ts;
-        const int nt_samples = (N - n0) < size ? (N - n0) : size;
+    for (int j = 0; j < tpw; ++j) {
+        const int tile = (int)blockIdx.x * tpw + j;
+        const int n0 = begin + j * K.range_tile;
+        if (n0 >= end) break;
+        const int nt_samples = (end - n0) < K.range_tile ? (end - n0) : K.range_tile;
         __syncthreads();   // the previous tile's last readers of the table are done
         if (tid < TILE) {  // sample -> (handle, env, row): walk forward from the tile's first env
             unsigned long long src = 0, dst = 0;
@@ -261,7 +264,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                 const uint32_t n = (uint32_t)(n0 + tid);
                 // the last env whose prefix sum is <= n: bisection between this tile's first env and the next tile's (predator tiles span
                 // twenty envs: a forward walk is twenty dependent loads)
-                int lo = (int)K.tile_env[tile], hi = tile + 1 < n_tiles ? (int)K.tile_env[tile + 1] : K.n_envs - 1;
+                int lo = (int)K.tile_env[tile], hi = tile + 1 < n_slots ? (int)K.tile_env[tile + 1] : K.n_envs - 1;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     if (K.plan[PLAN_HDR + mid] <= n) lo = mid; else hi = mid - 1;
