@@ -100,6 +100,9 @@ struct PolParams {
     const float *bh;              // head bias [32]
     float *lgs;                   // library-owned [gridDim.x][TILE][16 head_mt]: a workgroup's logits of its current tile
     int32_t range_tile;           // samples per tile inside a workgroup's share (PlanParams::range_tile)
+    // the two-role pipeline (ppg_policy_pipe.h): element offsets of the second X / F area in a sample's region; byte offsets of the
+    // partial-sum buffers (+ role B's barrier counter) and of the images in LDS
+    int32_t pipe_x1, pipe_f1, pipe_red, pipe_img;
 #ifdef PPG_EXPERIMENTS
     unsigned long long *timeline; // diagnostic builds: [tile][64] = workgroup, hardware id, samples, 4 wall-clock stamps (10 ns units); [8 + 12 wave + i] cycles of wave in step i of the convolutions, [56 + 2 wave + i] FC1 wait / barrier cycles
 #endif
@@ -955,6 +958,7 @@ PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_bf16, 2, 16)
 }  // namespace ppgpol
 
 #include "ppg_policy_direct.h"
+#include "ppg_policy_pipe.h"
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side
@@ -965,6 +969,7 @@ struct ppg_policy {
     int32_t obs_channels;  // C of the (C,R,R) rows this network reads
     int32_t direct;        // 1: no hidden head layer, ppg_policy_direct.h (2: with more than three convolutions); 0: the FC chain
     int32_t nch16;         // more than 8 input channels into conv1
+    int32_t pipe;          // direct == 1 only: the two-role pipeline kernels (ppg_policy_pipe.h), 512 threads per workgroup
     uint64_t macs;         // real multiply-accumulates per observation
     ppgpol::PolParams base;
     void *dev_weights;     // one allocation: fragments + biases
@@ -1230,6 +1235,53 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         K.off_x = 0; K.off_y = 4 * blk; K.off_f = 6 * blk; K.off_d0 = K.off_f + f_elems; K.off_d1 = K.off_d0 + 8 * blk;
         K.sample_stride = K.off_f + f_elems + (sp.n_conv > 3 ? 8 * blk : 0) + (sp.n_conv > 4 ? 8 * blk : 0);
         const int tail_slack = 18 * 32 * 2;   // bytes behind the last sample's region: the head's unconditional fragment reads end there
+#ifndef PPG_POLICY_PIPE
+#define PPG_POLICY_PIPE 1   // (0: A/B builds without the two-role pipeline)
+#endif
+        // the two-role pipeline (ppg_policy_pipe.h): three convolutions, up to 16 actions, a wavefront's quarter of the head's k-steps in 18
+        // fragments; region of a sample: X0 | X1 (4 blocks each) | Y (2 blocks) | F0 | F1
+        if (PPG_POLICY_PIPE && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18) {
+            int stride = 10 * blk + 2 * f_elems;
+            while (((stride / 2) % 64) % 8 != 4) stride += 8;   // consecutive samples 16 bytes x an odd number apart in the banks: the head's
+                                                                // sixteen sample columns read conflict-free
+            const int fixed_p = 2 * 4096 + 64 + 8192 + tail_slack;   // partial sums x 2, role B's counter, dconv's dummy slots (512 threads)
+            int st_cap = (160 * 1024 - fixed_p - 128 * 16) / (stride * 2);   // (at least 128 samples of table)
+            if (st_cap > 16) st_cap = 16;
+            while (st_cap > 1 && st_cap * P > 256) --st_cap;   // a role-B thread stages one position
+            if (st_cap >= 1 && P <= 256) {
+                int st = st_cap;
+                double best = 0.0;
+                for (int c = st_cap; c >= 1; --c) {   // the most samples per round of position tiles (four wavefronts a tile each)
+                    const int tiles = (c * P + 31) / 32, rounds = (tiles + 3) / 4;
+                    const double score = (double)c / rounds;
+                    if (score > best * 1.0001) { best = score; st = c; }
+                }
+                int cap_tab = (160 * 1024 - fixed_p - st * stride * 2) / 16;
+                if (cap_tab > 1024) cap_tab = 1024;
+                K.ST = st;
+                K.range_tile = st * (cap_tab / st);
+                K.off_x = 0; K.pipe_x1 = 4 * blk; K.off_y = 8 * blk; K.off_f = 10 * blk; K.pipe_f1 = K.off_f + f_elems;
+                K.sample_stride = stride;
+                K.pipe_red = K.range_tile * 16;
+                K.pipe_img = K.pipe_red + 2 * 4096 + 64 + 8192;
+                p->pipe = 1;
+                p->grid = prop.multiProcessorCount;
+                p->lds_bytes = K.pipe_img + st * stride * 2 + tail_slack;
+                const size_t lgs_bytes = (size_t)p->grid * K.range_tile * 16 * 4;
+                if (hipMalloc((void **)&p->lgs, lgs_bytes) != hipSuccess || hipMemset(p->lgs, 0, lgs_bytes) != hipSuccess) {
+                    (void)hipFree(p->dev_weights);
+                    delete p;
+                    return ppg_policy_fail(nullptr, PPG_EHIP, "hipMalloc of %zu bytes of scratch failed", lgs_bytes);
+                }
+                K.lgs = p->lgs;
+                for (const void *fn : {(const void *)ppgpol::ppg_policy_pipe8_f64, (const void *)ppgpol::ppg_policy_pipe8_f32,
+                                       (const void *)ppgpol::ppg_policy_pipe8_bf16, (const void *)ppgpol::ppg_policy_pipe16_f64,
+                                       (const void *)ppgpol::ppg_policy_pipe16_f32, (const void *)ppgpol::ppg_policy_pipe16_bf16})
+                    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+                *out = p;
+                return PPG_OK;
+            }
+        }
         const int fixed = ppgpol::TILE * 16 + K.head_mt * 4096 + 4096 + tail_slack;   // table, partial logits, dconv's dummy slots
         const bool w1 = PPG_DIRECT_W1;   // one workgroup per CU with all of its LDS (ppg_policy_direct.h)
         int st_max = ((w1 ? 160 : 80) * 1024 - fixed) / (K.sample_stride * 2);
@@ -1435,7 +1487,7 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     static unsigned long long *dp_buf[2] = {nullptr, nullptr};
     const char *dp_path = getenv("PPG_DIRECT_PROFILE_FILE");
     const int dp_at = getenv("PPG_DIRECT_PROFILE_RUN") ? atoi(getenv("PPG_DIRECT_PROFILE_RUN")) : 300;
-    const size_t dp_bytes = (size_t)p->grid * 4 * 16 * 8;
+    const size_t dp_bytes = (size_t)p->grid * 8 * 16 * 8;   // (the pipeline kernels have eight wavefronts, the others use the first half)
     if (p->direct && dp_path && !dp_buf[species]) {
         PPG_POL_TRY(p, hipMalloc((void **)&dp_buf[species], dp_bytes));
         PPG_POL_TRY(p, hipMemset(dp_buf[species], 0, dp_bytes));
@@ -1449,6 +1501,11 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
                                   {ppgpol::ppg_policy_direct16_f64, ppgpol::ppg_policy_direct16_f32, ppgpol::ppg_policy_direct16_bf16},
                                   {ppgpol::ppg_policy_deep8_f64, ppgpol::ppg_policy_deep8_f32, ppgpol::ppg_policy_deep8_bf16},
                                   {ppgpol::ppg_policy_deep16_f64, ppgpol::ppg_policy_deep16_f32, ppgpol::ppg_policy_deep16_bf16}};
+        const fwd_fn pipe[2][3] = {{ppgpol::ppg_policy_pipe8_f64, ppgpol::ppg_policy_pipe8_f32, ppgpol::ppg_policy_pipe8_bf16},
+                                   {ppgpol::ppg_policy_pipe16_f64, ppgpol::ppg_policy_pipe16_f32, ppgpol::ppg_policy_pipe16_bf16}};
+        if (p->pipe)
+            hipLaunchKernelGGL(pipe[p->nch16 ? 1 : 0][dt], dim3((unsigned)p->grid), dim3(512), (size_t)p->lds_bytes, (hipStream_t)stream, K);
+        else
         hipLaunchKernelGGL(dir[(p->direct == 2 ? 2 : 0) + (p->nch16 ? 1 : 0)][dt], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     } else {
         const int variant = p->layout == PPG_POLICY_LAYOUT_HWC ? (p->cin > 8 ? 2 : 1) : 0;

@@ -72,7 +72,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // MFMA, where it covers the LDS latency, and the positions of tile t + 1 are computed behind the MFMAs of tile t.
 struct TileCtx { int in_base, out_base; bool valid; };
 
-template <int CBIN, int MT, int BATCH, class KP>
+// SWP = false (ppg_policy_pipe.h, where a second wavefront on the SIMD fills the gaps): tile by tile, no second set of accumulators.
+template <int CBIN, int MT, int BATCH, bool SWP = true, class KP>
 __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __bf16 *img, int sample_stride, int in_off, int out_off,
                                       int out_blocks, int flat_c, int ns, int nt_first, int nt_step, int lane, int mt_base, int dummy) {
     constexpr int KS = ConvW<CBIN, MT>::KS;
@@ -158,6 +159,15 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
         }
     };
     int nt = nt_first;
+    if (!SWP) {
+        for (; nt < n_tiles; nt += nt_step) {
+            const TileCtx c = context(nt);
+            f32x16 acc[MT];
+            tile(c, acc, [] {});
+            epilogue(c, acc);
+        }
+        return;
+    }
     TileCtx cur = context(nt);
     f32x16 acc_prev[MT];
     tile(cur, acc_prev, [] {});
