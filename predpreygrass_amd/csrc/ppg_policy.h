@@ -103,6 +103,9 @@ struct PolParams {
     // the two-role pipeline (ppg_policy_pipe.h): element offsets of the second X / F area in a sample's region; byte offsets of the
     // partial-sum buffers (+ role B's barrier counter) and of the images in LDS
     int32_t pipe_x1, pipe_f1, pipe_red, pipe_img;
+    int32_t pipe_raw, pipe_ni;    // bfloat16 rows of a multiple of 8 bytes: byte offset of the LDS area that takes a sub-group's rows as they
+    uint32_t pipe_magic;          // lie in HBM, 8-byte loads per role-B thread and sub-group (0: one load per channel), ceil(2^32 / chunks per row),
+    int32_t pipe_slots;           // samples whose chunks the 256 role-B threads cover at once: floor(256 / chunks per row)
 #ifdef PPG_EXPERIMENTS
     unsigned long long *timeline; // diagnostic builds: [tile][64] = workgroup, hardware id, samples, 4 wall-clock stamps (10 ns units); [8 + 12 wave + i] cycles of wave in step i of the convolutions, [56 + 2 wave + i] FC1 wait / barrier cycles
 #endif
@@ -1244,8 +1247,10 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
             int stride = 10 * blk + 2 * f_elems;
             while (((stride / 2) % 64) % 8 != 4) stride += 8;   // consecutive samples 16 bytes x an odd number apart in the banks: the head's
                                                                 // sixteen sample columns read conflict-free
-            const int fixed_p = 2 * 4096 + 64 + 8192 + tail_slack;   // partial sums x 2, role B's counter, dconv's dummy slots (512 threads)
-            int st_cap = (160 * 1024 - fixed_p - 128 * 16) / (stride * 2);   // (at least 128 samples of table)
+            const int fixed_p = 2 * 4096 + 64 + 1024 + tail_slack;   // partial sums x 2, role B's counter, dconv's dummy slots (64 lanes)
+            const int row_bf16 = C * R * R * 2;   // bytes of a bfloat16 row; the area `raw` takes ST of them when they are whole 8-byte chunks
+            const bool chunks = row_bf16 % 8 == 0;
+            int st_cap = (160 * 1024 - fixed_p - 128 * 16) / (stride * 2 + (chunks ? row_bf16 : 0));   // (at least 128 samples of table)
             if (st_cap > 16) st_cap = 16;
             while (st_cap > 1 && st_cap * P > 256) --st_cap;   // a role-B thread stages one position
             if (st_cap >= 1 && P <= 256) {
@@ -1256,24 +1261,25 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
                     const double score = (double)c / rounds;
                     if (score > best * 1.0001) { best = score; st = c; }
                 }
-                int cap_tab = (160 * 1024 - fixed_p - st * stride * 2) / 16;
-                if (cap_tab > 1024) cap_tab = 1024;
+                int raw_bytes = chunks ? (st * row_bf16 + 15) / 16 * 16 : 0;
+                const int cpr = row_bf16 / 8;   // 8-byte chunks per row; the role-B threads cover floor(256 / cpr) samples per load
+                K.pipe_slots = chunks && cpr <= 256 ? 256 / cpr : 0;
+                K.pipe_ni = K.pipe_slots ? (st + K.pipe_slots - 1) / K.pipe_slots : 0;
+                if (K.pipe_ni > ppgpol::PIPE_CHUNKS) K.pipe_ni = 0;   // (that many chunk registers per thread)
+                if (!K.pipe_ni) raw_bytes = 0;
+                K.pipe_magic = K.pipe_ni ? (uint32_t)((0x100000000ull + cpr - 1) / cpr) : 0u;
+                int cap_tab = (160 * 1024 - fixed_p - raw_bytes - st * stride * 2) / 16;
+                if (cap_tab > 2048) cap_tab = 2048;
                 K.ST = st;
                 K.range_tile = st * (cap_tab / st);
                 K.off_x = 0; K.pipe_x1 = 4 * blk; K.off_y = 8 * blk; K.off_f = 10 * blk; K.pipe_f1 = K.off_f + f_elems;
                 K.sample_stride = stride;
                 K.pipe_red = K.range_tile * 16;
-                K.pipe_img = K.pipe_red + 2 * 4096 + 64 + 8192;
+                K.pipe_raw = K.pipe_red + 2 * 4096 + 64;
+                K.pipe_img = K.pipe_raw + raw_bytes + 1024;
                 p->pipe = 1;
                 p->grid = prop.multiProcessorCount;
                 p->lds_bytes = K.pipe_img + st * stride * 2 + tail_slack;
-                const size_t lgs_bytes = (size_t)p->grid * K.range_tile * 16 * 4;
-                if (hipMalloc((void **)&p->lgs, lgs_bytes) != hipSuccess || hipMemset(p->lgs, 0, lgs_bytes) != hipSuccess) {
-                    (void)hipFree(p->dev_weights);
-                    delete p;
-                    return ppg_policy_fail(nullptr, PPG_EHIP, "hipMalloc of %zu bytes of scratch failed", lgs_bytes);
-                }
-                K.lgs = p->lgs;
                 for (const void *fn : {(const void *)ppgpol::ppg_policy_pipe8_f64, (const void *)ppgpol::ppg_policy_pipe8_f32,
                                        (const void *)ppgpol::ppg_policy_pipe8_bf16, (const void *)ppgpol::ppg_policy_pipe16_f64,
                                        (const void *)ppgpol::ppg_policy_pipe16_f32, (const void *)ppgpol::ppg_policy_pipe16_bf16})

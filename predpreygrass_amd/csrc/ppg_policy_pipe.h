@@ -30,6 +30,25 @@ __device__ __forceinline__ void pipe_bsync(uint32_t *ctr, uint32_t target, int l
     __asm__ volatile("" ::: "memory");
 }
 
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int PIPE_CHUNKS = 3;   // 8-byte chunks of observation rows a role-B thread fetches per sub-group (ppg_policy_create_spec: pipe_ni)
+
+// Handle of global env e WITHOUT a per-lane index into the parameter block (K.obs[k] with k in a vector register is a vector load
+// from the kernarg segment: a memory round trip in front of every address that depends on it): the handles' base pointers are read as
+// scalars and picked by comparison.  Returns the env's index inside its handle.
+template <class KP, class Bases, class PtrT>
+__device__ __forceinline__ int pipe_pick_handle(const KP &K, const Bases &bases, int e, PtrT &base) {
+    base = bases[0];
+    int eb = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_HANDLES; ++q) {
+        const bool in = q < K.n_handles && e >= K.env_base[q];
+        base = in ? bases[q] : base;
+        eb = in ? K.env_base[q] : eb;
+    }
+    return e - eb;
+}
+
 template <int OBS, int NCH>
 __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
     constexpr int CB1 = NCH > 8 ? 2 : 1, HF = 18;
@@ -38,18 +57,17 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool role_b = wave >= 4;
     const int bw = wave & 3;
-    unsigned long long *tab = (unsigned long long *)lds;                    // [range_tile][2]: observation row, action slot
+    unsigned long long *tab = (unsigned long long *)lds;                    // [range_tile][2]: observation row; global env index | row << 32
     float *red = (float *)(lds + K.pipe_red);                               // [2][wavefront][16 actions][16 samples]
     uint32_t *ctr = (uint32_t *)(lds + K.pipe_red + 8192);
     __bf16 *img = (__bf16 *)(lds + K.pipe_img);
-    const int dummy = -4096 + 8 * tid;   // (element index from img: this thread's 16 bytes of the 8 KB in front of the images; dconv)
+    const int dummy = -512 + 8 * lane;   // (element index from img: this lane's 16 bytes of the 1 KB in front of the images; dconv.  Shared
+                                         //  by the wavefronts: what lands there is never read)
     const int sample_stride = K.sample_stride;
     const int N = (int)K.plan[0], share = (int)K.plan[1], tpw = (int)K.plan[2];
     const int begin = (int)blockIdx.x * share, end = (begin + share) < N ? (begin + share) : N;
     if (begin >= end) return;
     const int n_slots = (int)gridDim.x * tpw;
-    const int apad = 16;
-    float *lgs = K.lgs + (size_t)blockIdx.x * K.range_tile * apad;
     for (int i = tid; i < (K.ST * sample_stride) / 8 + 18 * 4; i += 512) ((bf16x8 *)img)[i] = zero8();
     if (tid == 0) *ctr = 0u;
     typedef typename ObsRaw<OBS, NCH>::type raw_t;
@@ -71,7 +89,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
     const int per = (K.kflat_steps + 3) >> 2, k_lo = bw * per;
     const int smp = btid >> 4, a16 = btid & 15;
 
-    // the tile's sample table: sample -> (observation row, action slot), bisection over the envs' prefix sums
+    // the tile's sample table: sample -> (observation row; global env index, row), bisection over the envs' prefix sums
     auto build_table = [&](int tile, int n0, int nt_samples) {
         __syncthreads();   // the previous tile's last readers of the table are done (and the zero fill has landed)
         for (int i = tid; i < nt_samples; i += 512) {
@@ -82,60 +100,21 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 if (K.plan[PLAN_HDR + mid] <= n) lo = mid; else hi = mid - 1;
             }
             const int e = lo, row = (int)(n - K.plan[PLAN_HDR + e]);
-            const int k = handle_of(K.env_base, K.n_handles, e);
-            const int b = e - K.env_base[k];
-            tab[2 * i] = (unsigned long long)(uintptr_t)(K.obs[k] + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS == 2 ? 2 : OBS == 1 ? 4 : 8));
-            tab[2 * i + 1] = (unsigned long long)(uintptr_t)(K.actions[k] + (size_t)b * K.S + K.slot0 + row);
+            const unsigned char *base;
+            const int b = pipe_pick_handle(K, K.obs, e, base);
+            tab[2 * i] = (unsigned long long)(uintptr_t)(base + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS == 2 ? 2 : OBS == 1 ? 4 : 8));
+            tab[2 * i + 1] = (unsigned long long)(uint32_t)e | ((unsigned long long)(uint32_t)row << 32);
         }
         __syncthreads();
-    };
-    // the tile's actions: one lane per sample (argmax, or Gumbel-max with Philox keyed by (seed, env, row))
-    auto select_actions = [&](int nt_samples) {
-        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's scratch rows have been written ...
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ... and stale L1 lines of the previous tile's rows are dropped
-        for (int i = tid; i < nt_samples; i += 512) {
-            const float *row = lgs + i * apad;
-            int8_t *dst = (int8_t *)(uintptr_t)tab[2 * i + 1];
-            uint32_t c_env = 0, c_slot = 0;   // Philox counter of this agent = (global env index, row slot), as in phase_head
-            if (K.sample) {
-                int k = 0;
-#pragma unroll
-                for (int q = 1; q < MAX_HANDLES; ++q)
-                    if (q < K.n_handles && (uintptr_t)dst >= (uintptr_t)K.actions[q] &&
-                        (uintptr_t)dst < (uintptr_t)K.actions[q] + (size_t)(K.env_base[q + 1] - K.env_base[q]) * (size_t)K.S) k = q;
-                const uint32_t off = (uint32_t)((uintptr_t)dst - (uintptr_t)K.actions[k]);
-                const uint32_t b = off / (uint32_t)K.S;
-                c_env = (uint32_t)K.env_base[k] + b;
-                c_slot = off - b * (uint32_t)K.S;
-            }
-            uint32_t rnd[4] = {0, 0, 0, 0};
-            int best = 0;
-            float bestv = -INFINITY;
-            for (int a4 = 0; a4 < K.n_actions; a4 += 4) {
-                const f32x4_t q = *(const GLOBAL_AS f32x4_t *)(row + a4);
-                if (K.sample) philox(c_env, c_slot, (uint32_t)(a4 >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    if (a4 + i4 >= K.n_actions) continue;
-                    float v = q[i4];
-                    if (K.sample) {   // Gumbel-max: argmax(logit - log(-log u)) ~ softmax(logits)
-                        const float u = (float)(rnd[i4] >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
-                        v -= __logf(-__logf(u));
-                    }
-                    if (v > bestv) { bestv = v; best = a4 + i4; }
-                }
-            }
-            *dst = (int8_t)best;
-        }
     };
 
     // The two roles are two separate loops (not two branches inside one): inside one loop the register allocator would have to keep BOTH
     // roles' weights alive.  Both execute the same sequence of workgroup barriers.
     if (!role_b) {
-        // ================= role A: conv3 =================
+        // ================= role A: conv3; logits and actions of the sub-group two iterations back =================
         ConvW<4, 2> w3c;
         w3c.load(K, K.wc3, lane, 0);
+        const float bias_r = (a16 < K.n_actions) ? K.bh[a16] : 0.0f;
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w3c.landed();
         for (int j = 0; j < tpw; ++j) {
@@ -147,6 +126,50 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
             build_table(tile, n0, nt_samples);
             PPG_DP(0);
             for (int it = -1; it <= G + 1; ++it) {
+                if (it >= 2 && 4 * wave < nt_samples - (it - 2) * K.ST) {   // (this wavefront's four samples: 4 wave .. 4 wave + 3)
+                    // thread (sample smp, action a16) of sub-group it - 2: bias + the four partial sums in wavefront order = the logit; then
+                    // the sixteen lanes of a sample pick the action: argmax, or Gumbel-max with Philox keyed by (seed, env, row slot) as in
+                    // phase_head -- the first maximum wins, as in a loop over the actions
+                    const int g = it - 2, left = nt_samples - g * K.ST, ns = left < K.ST ? left : K.ST;
+                    const float *rd = red + (g & 1) * 1024;
+                    float v = bias_r;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += rd[(w * 16 + a16) * 16 + smp];
+                    const int s_local = g * K.ST + (smp < ns ? smp : 0);
+                    const unsigned long long er = tab[2 * s_local + 1];
+                    const uint32_t e = (uint32_t)er, row = (uint32_t)(er >> 32);
+                    if (K.logits && smp < ns && a16 < K.n_actions) K.logits[(size_t)(n0 + s_local) * K.n_actions + a16] = v;
+                    if (K.sample) {
+                        uint32_t rnd[4];
+                        philox(e, (uint32_t)K.slot0 + row, (uint32_t)(a16 >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
+                        const uint32_t r = (a16 & 3) == 0 ? rnd[0] : (a16 & 3) == 1 ? rnd[1] : (a16 & 3) == 2 ? rnd[2] : rnd[3];
+                        const float u = (float)(r >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
+                        v -= __logf(-__logf(u));
+                    }
+                    if (a16 >= K.n_actions) v = -INFINITY;
+                    int best = a16;
+                    // all-reduce over the sample's sixteen lanes on the DPP cross-lane paths: partners lane ^ 1, lane ^ 2, then 7 - lane and
+                    // 15 - lane (every lane of the row ends with the same maximum)
+#define PPG_PIPE_ARGMAX_STEP(CTRL)                                                                                   \
+                    {                                                                                                \
+                        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false)); \
+                        const int ob = __builtin_amdgcn_update_dpp(0, best, CTRL, 0xF, 0xF, false);                  \
+                        const bool take = ov > v || (!(v > ov) && ob < best);                                        \
+                        v = take ? ov : v;                                                                           \
+                        best = take ? ob : best;                                                                     \
+                    }
+                    PPG_PIPE_ARGMAX_STEP(0xB1)    // quad_perm [1, 0, 3, 2]
+                    PPG_PIPE_ARGMAX_STEP(0x4E)    // quad_perm [2, 3, 0, 1]
+                    PPG_PIPE_ARGMAX_STEP(0x141)   // row_half_mirror
+                    PPG_PIPE_ARGMAX_STEP(0x140)   // row_mirror
+#undef PPG_PIPE_ARGMAX_STEP
+                    if (a16 == 0 && smp < ns) {
+                        int8_t *base;
+                        const int b = pipe_pick_handle(K, K.actions, (int)e, base);
+                        base[(size_t)b * K.S + K.slot0 + row] = (int8_t)best;
+                    }
+                }
+                PPG_DP(3);
                 if (it >= 0 && it < G) {
                     const int left = nt_samples - it * K.ST, ns = left < K.ST ? left : K.ST;
                     dconv<4, 2, PPG_DIRECT_B3, false>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
@@ -156,13 +179,11 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 __syncthreads();
                 PPG_DP(2);
             }
-            select_actions(nt_samples);
-            PPG_DP(14);
         }
         dp_dump();
         return;
     }
-    // ================= role B: rows -> X, conv1, conv2; head; logits =================
+    // ================= role B: rows -> X, conv1, conv2; head =================
     // Role B is the longer chain, and its MFMAs are few and dependent: with equal priorities the SIMD serves role A's dense MFMA stream
     // first and the head's 18 MFMAs take as long as the whole of conv3 (profiles/r04) -- B goes first whenever it has something to issue.
     __builtin_amdgcn_s_setprio(3);
@@ -173,7 +194,6 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
     w2c.load(K, K.wc2, lane);
 #pragma unroll
     for (int i = 0; i < HF; ++i) hf[i] = ((const GLOBAL_AS bf16x8 *)K.whw)[((size_t)bw * HF + i) * 64 + lane];
-    const float bias_r = (a16 < K.n_actions) ? K.bh[a16] : 0.0f;
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     w1c.landed();
     w2c.landed();
@@ -184,6 +204,25 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
         hf[i] = __builtin_bit_cast(bf16x8, v);
     }
     uint32_t b_target = 0;
+    // bfloat16 rows whose size is a multiple of 8 bytes (K.pipe_ni > 0) come in as they lie in HBM: ALIGNED 8-byte chunks, consecutive
+    // lanes consecutive chunks (two or three loads per thread and sub-group), parked in the LDS area `raw` one iteration later and picked
+    // apart by the position threads from there.  One 2-byte load per channel and position -- 64 scattered lanes per instruction, nine
+    // instructions per wavefront -- kept the texture addresser busy for 1500 cycles per sub-group; so did unaligned 16-byte loads.
+    const bool row_chunks = OBS == 2 && K.pipe_ni > 0;
+    unsigned char *raw = lds + K.pipe_raw;
+    auto row_of = [&](int s_tile) -> const GLOBAL_AS unsigned char * { return (const GLOBAL_AS unsigned char *)(uintptr_t)tab[2 * s_tile]; };
+    // a thread's place in the sub-group never changes: the position it stages, and (row chunks) chunk ch_w of the samples ch_q,
+    // ch_q + K.pipe_slots, ...: consecutive lanes consecutive chunks of one row
+    const int st_s = div_small(btid, K.magic_P), st_p = btid - __mul24(st_s, K.P);
+    const int st_y = div_small(st_p, K.magic_R), st_x = st_p - __mul24(st_y, K.IW);
+    const int st_img = __mul24(st_s, sample_stride) + (__mul24(st_y + 1, K.Wp) + (st_x + 1)) * 8;
+    const int st_raw = __mul24(st_s, K.obs_elems) + st_p * K.p_stride;
+    const int cpr = K.obs_elems >> 2;   // 8-byte chunks per bfloat16 row
+    const int ch_q = row_chunks ? (int)__umulhi((uint32_t)btid, K.pipe_magic) : 0, ch_w = btid - ch_q * cpr;
+    // (the tile loop exists twice, with and without row chunks: a run-time switch inside the loop would put the chunk registers into
+    //  merges with undefined values -- register copies behind the loads, i.e. waits)
+    auto b_tiles = [&](auto ch_tag) {
+    constexpr bool CH = decltype(ch_tag)::value;
     for (int j = 0; j < tpw; ++j) {
         const int tile = (int)blockIdx.x * tpw + j;
         const int n0 = begin + j * K.range_tile;
@@ -193,13 +232,31 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
         build_table(tile, n0, nt_samples);
         auto group_ns = [&](int g) { const int left = nt_samples - g * K.ST; return left < K.ST ? left : K.ST; };
         raw_t pre[NCH];
+        u32x2_t chunk[PIPE_CHUNKS];
+        auto fetch = [&](int g) {   // row chunks: chunk ch_w of this thread's samples of sub-group g -> registers
+            // (every load unconditional, the sample clamped: a load under a condition is merged with its default value by a register
+            //  copy right behind it -- a wait for the whole memory round trip, 1500-3700 cycles per sub-group: profiles/r04)
+            const int last = group_ns(g) - 1;
+#pragma unroll
+            for (int k = 0; k < PIPE_CHUNKS; ++k) {
+                const int s0 = ch_q + K.pipe_slots * k, s = s0 < last ? s0 : last;
+                chunk[k] = *(const GLOBAL_AS u32x2_t *)(row_of(g * K.ST + s) + 8 * ch_w);
+            }
+        };
+        auto park = [&](int g, bool valid) {    // ... -> `raw` (behind conv1 and conv2: the loads have had that long to land)
+            const int ns = valid && ch_q < K.pipe_slots ? group_ns(g) : 0;
+#pragma unroll
+            for (int k = 0; k < PIPE_CHUNKS; ++k) {
+                const int s = ch_q + K.pipe_slots * k;
+                if (s < ns) ((u32x2_t *)raw)[s * cpr + ch_w] = chunk[k];
+            }
+        };
         auto request = [&](int g) {   // (a B thread stages one position: ST * P <= 256, ppg_policy_create_spec)
             const int ns = group_ns(g);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) pre[c] = (raw_t)0;
             if (btid < ns * K.P) {
-                const int s = div_small(btid, K.magic_P), p = btid - __mul24(s, K.P);
-                const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)(uintptr_t)tab[2 * (g * K.ST + s)] + p * K.p_stride;
+                const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)row_of(g * K.ST + st_s) + st_p * K.p_stride;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) if (c < K.cin) pre[c] = (raw_t)src[c * K.c_stride];
             }
@@ -207,33 +264,30 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
         auto stage = [&](int g) {
             const int ns = group_ns(g);
             if (btid < ns * K.P) {
-                const int s = div_small(btid, K.magic_P), p = btid - __mul24(s, K.P);
-                const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
+                if constexpr (CH) {
+                    const uint16_t *rh = (const uint16_t *)raw + st_raw;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) pre[c] = (c < K.cin) ? (raw_t)rh[c * K.c_stride] : (raw_t)0;
+                }
 #pragma unroll
                 for (int cb = 0; cb < CB1; ++cb) {
                     bf16x8 v = zero8();
 #pragma unroll
                     for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = ObsRaw<OBS, NCH>::to_bf16(pre[8 * cb + c]);
-                    *(bf16x8 *)(img + __mul24(s, sample_stride) + ((g & 1) ? K.pipe_x1 : 0) + (cb * K.Wp2 + __mul24(y + 1, K.Wp) + (x + 1)) * 8) = v;
+                    *(bf16x8 *)(img + st_img + ((g & 1) ? K.pipe_x1 : 0) + cb * K.Wp2 * 8) = v;
                 }
             }
         };
-        request(0);
+        if constexpr (CH) {   // sub-group 0's rows are in `raw` before any B wavefront stages a position
+            fetch(0);
+            park(0, true);
+            b_target += 4;
+            pipe_bsync(ctr, b_target, lane);
+        } else {
+            request(0);
+        }
         PPG_DP(0);
         for (int it = -1; it <= G + 1; ++it) {
-            if (it >= 2 && it - 2 < G) {   // logits of sub-group it - 2: bias + the four partial sums in wavefront order
-                const int g = it - 2, ns = group_ns(g);
-                if (smp < ns) {
-                    const float *rd = red + (g & 1) * 1024;
-                    float v = bias_r;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) v += rd[(w * 16 + a16) * 16 + smp];
-                    const int s_local = g * K.ST + smp;
-                    lgs[s_local * apad + a16] = v;
-                    if (K.logits && a16 < K.n_actions) K.logits[(size_t)(n0 + s_local) * K.n_actions + a16] = v;
-                }
-            }
-            PPG_DP(3);
             if (it >= 1 && it - 1 < G) {   // head of sub-group it - 1: this wavefront's k-steps
                 const int g = it - 1, ns = group_ns(g);
                 const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + ((g & 1) ? K.pipe_f1 : K.off_f) + 8 * kq;
@@ -253,7 +307,9 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
             if (it + 1 < G) {   // sub-group it + 1: rows -> X, conv1, conv2
                 const int g = it + 1, ns = group_ns(g), xo = (g & 1) ? K.pipe_x1 : 0;
                 stage(g);
-                if (g + 1 < G) request(g + 1);
+                PPG_DP(11);
+                if constexpr (CH) fetch(g + 1 < G ? g + 1 : g);   // (unconditional, like the loads in it; the last one is not parked)
+                else if (g + 1 < G) request(g + 1);
                 PPG_DP(5);
                 b_target += 4;
                 pipe_bsync(ctr, b_target, lane);
@@ -265,6 +321,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 PPG_DP(8);
                 dconv<2, 1, PPG_DIRECT_B12>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy);
                 PPG_DP(9);
+                if constexpr (CH) park(g + 1, g + 1 < G);   // (every B wavefront has staged sub-group g out of `raw`: two private barriers ago)
             }
             __syncthreads();
             PPG_DP(10);
@@ -272,9 +329,9 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
             dp_acc[15] += 1;
 #endif
         }
-        select_actions(nt_samples);
-        PPG_DP(14);
     }
+    };
+    if (row_chunks) b_tiles(std::true_type{}); else b_tiles(std::false_type{});
     dp_dump();
 }
 
