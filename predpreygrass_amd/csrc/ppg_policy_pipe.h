@@ -19,6 +19,13 @@
 // drains once per launch.  Same arithmetic in the same order as ppg_policy_direct.h: the logits are bit-identical.
 #pragma once
 
+// Fragment reads per batch in role A's conv3.  LDS serves requests in arrival order, whatever the priority of the wavefront: five
+// 1 KB reads per role-A wavefront queued at once stand in front of every LDS access of role B's chain (its table reads alone took
+// 1000 cycles per sub-group); batches of 5 / 4 / 3 / 2: 0.362 / 0.356 / 0.350 / 0.347 ms per 4096-env step on one GPU (profiles/r04)
+#ifndef PPG_PIPE_B3
+#define PPG_PIPE_B3 2
+#endif
+
 namespace ppgpol {
 
 // role B's private barrier: the `target`-th arrival releases the four wavefronts (monotonic counter, never reset)
@@ -172,7 +179,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 PPG_DP(3);
                 if (it >= 0 && it < G) {
                     const int left = nt_samples - it * K.ST, ns = left < K.ST ? left : K.ST;
-                    dconv<4, 2, PPG_DIRECT_B3, false>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
+                    dconv<4, 2, PPG_PIPE_B3, false>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
                                                       K.cout_blocks[2], K.flat_c, ns, wave, 4, lane, 0, dummy);
                 }
                 PPG_DP(1);
