@@ -26,6 +26,13 @@
 #define PPG_PIPE_B3 2
 #endif
 
+#ifndef PPG_PIPE_SLEEP
+#define PPG_PIPE_SLEEP 1    // s_sleep argument between two polls of role B's private barrier
+#endif
+#ifndef PPG_PIPE_PRIO_B
+#define PPG_PIPE_PRIO_B 3   // s_setprio of role B's wavefronts (role A: 0)
+#endif
+
 namespace ppgpol {
 
 // role B's private barrier: the `target`-th arrival releases the four wavefronts (monotonic counter, never reset)
@@ -33,7 +40,7 @@ __device__ __forceinline__ void pipe_bsync(uint32_t *ctr, uint32_t target, int l
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's LDS writes have landed (LDS serves a wavefront in order)
     if (lane == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(PPG_PIPE_SLEEP);
     __asm__ volatile("" ::: "memory");
 }
 
@@ -193,7 +200,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
     // ================= role B: rows -> X, conv1, conv2; head =================
     // Role B is the longer chain, and its MFMAs are few and dependent: with equal priorities the SIMD serves role A's dense MFMA stream
     // first and the head's 18 MFMAs take as long as the whole of conv3 (profiles/r04) -- B goes first whenever it has something to issue.
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(PPG_PIPE_PRIO_B);
     ConvW<CB1, 1> w1c;
     ConvW<2, 1> w2c;
     bf16x8 hf[HF];

@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: the end-of-round evidence run.  usage: tools/gpu_round_report.sh <tag>
 set -u
-tag=${1:-r04a}
+tag=${1:-r04b}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -25,6 +25,30 @@ python3 bench.py --envs 256 --steps 2000 --warmup 100 --no-cpu-baseline --sustai
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_ptrace -o t -- python3 bench.py --workload policy_rollout --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_policy_under_trace.json 2> gpurun_out/${tag}_ptrace.err
 find gpurun_out/${tag}_ptrace -name '*kernel_stats.csv' -exec cp {} gpurun_out/${tag}_kernel_stats_policy.csv \;
 rm -rf gpurun_out/${tag}_ptrace
+# MFMA-busy share of the policy kernels (counters in runs of their own, two at a time) and package power / clocks during a policy run
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE SQ_WAVES"; do
+  i=$((i + 1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/${tag}_ppmc$i -o t -- python3 bench.py --workload policy_rollout --steps 12 --warmup 3 --no-cpu-baseline --no-measure-traffic > /dev/null 2> gpurun_out/${tag}_ppmc$i.err
+done
+python3 - ${tag} <<'PY' > gpurun_out/${tag}_policy_pmc.txt 2>&1
+import csv, glob, sys, collections
+tag = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"gpurun_out/{tag}_ppmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if "ppg_policy" in k:
+            acc[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in sorted(acc.items()):
+    print(k, "  ".join(f"{c} {sum(v) / len(v):.4g} (n={len(v)})" for c, v in sorted(cs.items())))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "SQ_BUSY_CU_CYCLES" in cs:
+        m, b = (sum(cs[c]) / len(cs[c]) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"))
+        print(f"   MFMA busy cycles / (4 x CU busy cycles) = {m / (4 * b):.3f}   (MFMA_BUSY is summed over the SIMDs: MI355X_MICROARCH.md)")
+PY
+rm -rf gpurun_out/${tag}_ppmc*
+bash tools/gpu_power_probe.sh ${tag} policy_rollout 3000 > /dev/null 2>&1
+cat gpurun_out/${tag}_policy_pmc.txt
 cat gpurun_out/${tag}_pytest.log
 for f in gpurun_out/${tag}_bench_*.json gpurun_out/${tag}_bench.json; do python3 - "$f" <<'PY'
 import json, sys
