@@ -379,7 +379,7 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
             },
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": ("ppg_policy_direct{8,16}_" if args.policy_arch == "rllib" else "ppg_policy_forward_") + args.obs_dtype,
+                         "kernel": ("ppg_policy_pipe{8,16}_" if args.policy_arch == "rllib" else "ppg_policy_forward_") + args.obs_dtype,
                          "policy_arch": args.policy_arch,
                          "macs_per_observation": [fused.macs_per_observation(0), fused.macs_per_observation(1)],
                          "kernel_ms": round(pol_ms / args.steps, 5),

@@ -13,6 +13,7 @@ python3 tools/ab_plans.py --streams 3 --rounds 5 coop42:4,0,2 pair:2,0,0 2>&1 | 
 python3 tools/ab_plans.py --workload red_queen --streams 3 --rounds 5 coop42:4,0,2 w2:4,72,0 2>&1 | grep -v amdgpu.ids >> gpurun_out/${tag}_ab_plans.txt
 ./tools/store_patterns4.bin 4096 36 300 0 2,4,18 1,2,9 2>&1 | grep "streams" >> gpurun_out/${tag}_bare_pattern.txt
 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${tag}_pytest.log
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 >> gpurun_out/${tag}_pytest.log
 for w in c4 red_queen drive walls; do
   python3 bench.py --workload $w --steps 1000 --warmup 100 --sustained-steps 0 > gpurun_out/${tag}_bench_$w.json 2>> gpurun_out/${tag}_bench.err
 done
