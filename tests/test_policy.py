@@ -396,6 +396,58 @@ def test_bfloat16_observation_rows_give_bit_identical_logits(kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Rp,Rq", [(5, 11), (9, 15), (3, 13)])
+def test_bfloat16_rows_of_other_windows_through_the_pipeline_kernels(Rp, Rq):
+    """The two-role pipeline kernels fetch bfloat16 rows as aligned 8-byte chunks through LDS when a sub-group's rows fit three chunks
+    per thread (5x5: ten samples per load; 11x11 / 13x13: two / one), and with one load per channel otherwise (15x15; 3x3: too many
+    samples per load for the table's padding): both against the fp32 module on the same rows, sparse and dense windows -- and the
+    float64 rows of the same state give the same logits bit for bit."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy
+    nets = make_nets(Rp, Rq, seed=31)
+    fused = FusedPolicy(nets[0], nets[1])
+    cfg = {**config_env, "predator_obs_range": Rp, "prey_obs_range": Rq}
+    logits = []
+    for dt in (torch.bfloat16, torch.float64):
+        env = BatchedPredPreyGrass(cfg, batch_size=150, device="cuda:0", obs_dtype=dt, seed=8)
+        env.reset()
+        for _ in range(40):
+            env.step(random_actions=True, auto_reset=True)
+        lg = fused.act(env, want_logits=True)
+        torch.cuda.synchronize()
+        logits.append((lg[0].clone(), lg[1].clone()))
+        if dt == torch.bfloat16:
+            w1, a1 = check_against_fp32([env], nets, fused)
+            w2, a2 = check_against_fp32([env], nets, fused, dense_obs=True, seed=5)
+            assert a1 > 0.97 and a2 > 0.97
+    assert torch.equal(logits[0][0], logits[1][0]) and torch.equal(logits[0][1], logits[1][1])
+
+
+@pytest.mark.gpu
+def test_a_workgroups_share_larger_than_its_sample_table():
+    """6500 envs: ~200 k prey rows on 256 workgroups = shares of ~800 samples, more than the pipeline kernels' LDS table holds (693 at
+    9x9) -- every workgroup walks two tiles (the pipeline drains and refills); and 3 envs: most workgroups get nothing."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy
+    nets = make_nets(seed=41)
+    fused = FusedPolicy(nets[0], nets[1])
+    for batch, steps in ((6500, 500), (3, 30)):   # (500 steps: the prey have grown from 10 to ~32 per env)
+        env = BatchedPredPreyGrass(dict(config_env), batch_size=batch, device="cuda:0", obs_dtype=torch.bfloat16, seed=12)
+        env.reset()
+        for _ in range(steps):
+            env.step(random_actions=True, auto_reset=True)
+        n_prey = int(env.env_state[:, _abi.ENV_N_PREY_ROWS].sum())
+        assert (n_prey > 256 * 700) == (batch == 6500)
+        w, a = check_against_fp32([env], nets, fused)
+        assert a > 0.97
+        fused.act(env, sample=True, seed=3)
+        env.step(env.actions, auto_reset=True)
+        torch.cuda.synchronize()
+        assert (env.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()
+        del env
+
+
+@pytest.mark.gpu
 def test_sampled_actions_do_not_depend_on_where_they_are_written():
     """PPG_POLICY_SAMPLE is keyed by (seed, env, row): the same seed gives the same actions in another tensor, in another
     process, on another rank; split into sub-batches the envs keep their draws."""
