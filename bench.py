@@ -228,7 +228,7 @@ def parse_args(argv):
     ap.add_argument("--obs-dtype", choices=["f64", "f32", "bf16"], default=None,
                     help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen, bf16 -- the "
                          "compact rows the policy kernels stage without conversion -- for policy_rollout)")
-    ap.add_argument("--policy-arch", choices=["rllib", "fc256", "r3"], default="rllib",
+    ap.add_argument("--policy-arch", choices=["rllib", "fc256", "r3", "depth"], default="rllib",
                     help="policy_rollout: the network (rllib = what RLlib builds from the reference's model_config)")
     ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls", "policy_rollout"], default="base",
                     help="base: BASELINE.json configs[2] (the headline); c4: configs[3] (64x64 grid, 16 predators / 32 prey, "
@@ -317,14 +317,19 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
     # --policy-arch rllib (default): what RLlib builds from tune_ppo_base_environment.py:106-141 -- channels-last reading, conv 3x3
     # 16/32/64, ONE Linear head (tests/golden/rllib_checkpoint/); fc256: the same encoder with head_fcnet_hiddens [256, 256];
     # r3: rounds 2-3's network (channel-first image, 256/256 head, channel-major flatten)
-    arch_kw = {"rllib": dict(), "fc256": dict(head_hiddens=(256, 256)), "r3": dict(layout="chw", head_hiddens=(256, 256))}[args.policy_arch]
-    nets = [PolicyNet(env.Rp, **arch_kw), PolicyNet(env.Rq, **arch_kw)]
+    arch_kw = {"rllib": dict(), "fc256": dict(head_hiddens=(256, 256)), "r3": dict(layout="chw", head_hiddens=(256, 256)), "depth": dict()}[args.policy_arch]
+    if args.policy_arch == "depth":   # the newer tune scripts' rule (utils/networks.py: build_module_spec): (R - 1) // 2 convolutions of 16, 32, 64, 64 ...
+        depth = lambda R: tuple(([16, 32, 64] + [64] * 8)[:(R - 1) // 2])
+        nets = [PolicyNet(env.Rp, conv_channels=depth(env.Rp)), PolicyNet(env.Rq, conv_channels=depth(env.Rq))]
+    else:
+        nets = [PolicyNet(env.Rp, **arch_kw), PolicyNet(env.Rq, **arch_kw)]
     fused = FusedPolicy(nets[0], nets[1], device=device)
     arch_text = {"rllib": "channels-last 4 x R image with R channels, conv 3x3 16/32/64, flatten, ONE Linear(flat, 9) head: what RLlib's "
                           "DefaultPPOTorchRLModule builds from that model_config (fcnet_hiddens is ignored for image observations; pinned by the "
                           "reference tree's own checkpoint, tests/golden/rllib_checkpoint/)",
                  "fc256": "channels-last conv 3x3 16/32/64 + head_fcnet_hiddens [256, 256] + Linear(256, 9)",
-                 "r3": "rounds 2-3's reading: channel-first R x R image, conv 3x3 16/32/64 + FC 256/256/9"}[args.policy_arch]
+                 "r3": "rounds 2-3's reading: channel-first R x R image, conv 3x3 16/32/64 + FC 256/256/9",
+                 "depth": "channels-last, (R - 1) // 2 convolutions 16/32/64/64.. (the newer tune scripts' build_module_spec), ONE Linear head"}[args.policy_arch]
     env.reset()
     t_step = [0]
 
@@ -379,7 +384,7 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
             },
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": ("ppg_policy_pipe{8,16}_" if args.policy_arch == "rllib" else "ppg_policy_forward_") + args.obs_dtype,
+                         "kernel": {"rllib": "ppg_policy_pipe{8,16}_", "depth": "ppg_policy_pipe8_ (predators) + ppg_policy_deep16_ (prey) "}.get(args.policy_arch, "ppg_policy_forward_") + args.obs_dtype,
                          "policy_arch": args.policy_arch,
                          "macs_per_observation": [fused.macs_per_observation(0), fused.macs_per_observation(1)],
                          "kernel_ms": round(pol_ms / args.steps, 5),

@@ -19,7 +19,7 @@ for w in c4 red_queen drive walls; do
 done
 python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --cpu-seconds 8 > gpurun_out/${tag}_bench_policy_rollout.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --workload policy_rollout --obs-dtype f64 --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_policy_rollout_f64.json 2>> gpurun_out/${tag}_bench.err
-for a in fc256 r3; do   # the same encoder with head_fcnet_hiddens [256, 256]; rounds 2-3's network
+for a in fc256 r3 depth; do   # the same encoder with head_fcnet_hiddens [256, 256]; rounds 2-3's network; (R - 1) // 2 convolutions
   python3 bench.py --workload policy_rollout --policy-arch $a --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_policy_rollout_$a.json 2>> gpurun_out/${tag}_bench.err
 done
 python3 bench.py --envs 256 --steps 2000 --warmup 100 --no-cpu-baseline --sustained-steps 0 > gpurun_out/${tag}_bench_c2_256envs.json 2>> gpurun_out/${tag}_bench.err
