@@ -1247,7 +1247,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
             int stride = 10 * blk + 2 * f_elems;
             while (((stride / 2) % 64) % 8 != 4) stride += 8;   // consecutive samples 16 bytes x an odd number apart in the banks: the head's
                                                                 // sixteen sample columns read conflict-free
-            const int fixed_p = 2 * 4096 + 64 + 1024 + tail_slack;   // partial sums x 2, role B's counter, dconv's dummy slots (64 lanes)
+            const int fixed_p = 2 * 4096 + 64 + 2048 + 1024 + tail_slack;   // partial sums x 2, role B's counter, Gumbel noise x 2, dconv's dummy slots (64 lanes)
             const int row_bf16 = C * R * R * 2;   // bytes of a bfloat16 row; the area `raw` takes ST of them when they are whole 8-byte chunks
             const bool chunks = row_bf16 % 8 == 0;
             int st_cap = (160 * 1024 - fixed_p - 128 * 16) / (stride * 2 + (chunks ? row_bf16 : 0));   // (at least 128 samples of table)
@@ -1275,7 +1275,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
                 K.off_x = 0; K.pipe_x1 = 4 * blk; K.off_y = 8 * blk; K.off_f = 10 * blk; K.pipe_f1 = K.off_f + f_elems;
                 K.sample_stride = stride;
                 K.pipe_red = K.range_tile * 16;
-                K.pipe_raw = K.pipe_red + 2 * 4096 + 64;
+                K.pipe_raw = K.pipe_red + 2 * 4096 + 64 + 2048;
                 K.pipe_img = K.pipe_raw + raw_bytes + 1024;
                 p->pipe = 1;
                 p->grid = prop.multiProcessorCount;

@@ -35,13 +35,21 @@
 
 namespace ppgpol {
 
-// role B's private barrier: the `target`-th arrival releases the four wavefronts (monotonic counter, never reset)
-__device__ __forceinline__ void pipe_bsync(uint32_t *ctr, uint32_t target, int lane) {
-    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's LDS writes have landed (LDS serves a wavefront in order)
+// Role B's private barrier, in two halves: a wavefront ARRIVES (its LDS writes have landed, the counter goes up) and WAITS for the
+// `target`-th arrival later -- with work that does not depend on the other wavefronts in between, the wait finds the counter there.
+// Monotonic counter, never reset.
+__device__ __forceinline__ void pipe_arrive(uint32_t *ctr, int lane) {
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LDS serves a wavefront in order)
     if (lane == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pipe_wait(uint32_t *ctr, uint32_t target) {
     while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
         __builtin_amdgcn_s_sleep(PPG_PIPE_SLEEP);
     __asm__ volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pipe_bsync(uint32_t *ctr, uint32_t target, int lane) {
+    pipe_arrive(ctr, lane);
+    pipe_wait(ctr, target);
 }
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -74,6 +82,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
     unsigned long long *tab = (unsigned long long *)lds;                    // [range_tile][2]: observation row; global env index | row << 32
     float *red = (float *)(lds + K.pipe_red);                               // [2][wavefront][16 actions][16 samples]
     uint32_t *ctr = (uint32_t *)(lds + K.pipe_red + 8192);
+    float *noise = (float *)(lds + K.pipe_red + 8192 + 64);                 // [2][16 samples][16 actions]: Gumbel noise of two sub-groups
     __bf16 *img = (__bf16 *)(lds + K.pipe_img);
     const int dummy = -512 + 8 * lane;   // (element index from img: this lane's 16 bytes of the 1 KB in front of the images; dconv.  Shared
                                          //  by the wavefronts: what lands there is never read)
@@ -140,10 +149,10 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
             build_table(tile, n0, nt_samples);
             PPG_DP(0);
             for (int it = -1; it <= G + 1; ++it) {
-                if (it >= 2 && 4 * wave < nt_samples - (it - 2) * K.ST) {   // (this wavefront's four samples: 4 wave .. 4 wave + 3)
+                if (it >= 2 && 4 * wave < K.ST && 4 * wave < nt_samples - (it - 2) * K.ST) {   // (this wavefront's four samples: 4 wave .. 4 wave + 3)
                     // thread (sample smp, action a16) of sub-group it - 2: bias + the four partial sums in wavefront order = the logit; then
-                    // the sixteen lanes of a sample pick the action: argmax, or Gumbel-max with Philox keyed by (seed, env, row slot) as in
-                    // phase_head -- the first maximum wins, as in a loop over the actions
+                    // the sixteen lanes of a sample pick the action: argmax, or Gumbel-max -- the first maximum wins, as in a loop over the
+                    // actions.  The Gumbel noise was computed one iteration ago by ANOTHER wavefront (below) and waits in LDS.
                     const int g = it - 2, left = nt_samples - g * K.ST, ns = left < K.ST ? left : K.ST;
                     const float *rd = red + (g & 1) * 1024;
                     float v = bias_r;
@@ -153,13 +162,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                     const unsigned long long er = tab[2 * s_local + 1];
                     const uint32_t e = (uint32_t)er, row = (uint32_t)(er >> 32);
                     if (K.logits && smp < ns && a16 < K.n_actions) K.logits[(size_t)(n0 + s_local) * K.n_actions + a16] = v;
-                    if (K.sample) {
-                        uint32_t rnd[4];
-                        philox(e, (uint32_t)K.slot0 + row, (uint32_t)(a16 >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
-                        const uint32_t r = (a16 & 3) == 0 ? rnd[0] : (a16 & 3) == 1 ? rnd[1] : (a16 & 3) == 2 ? rnd[2] : rnd[3];
-                        const float u = (float)(r >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
-                        v -= __logf(-__logf(u));
-                    }
+                    if (K.sample) v += noise[(g & 1) * 256 + btid];
                     if (a16 >= K.n_actions) v = -INFINITY;
                     int best = a16;
                     // all-reduce over the sample's sixteen lanes on the DPP cross-lane paths: partners lane ^ 1, lane ^ 2, then 7 - lane and
@@ -190,6 +193,23 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                                                       K.cout_blocks[2], K.flat_c, ns, wave, 4, lane, 0, dummy);
                 }
                 PPG_DP(1);
+                // Gumbel noise of sub-group it - 1 (needed in the next iteration): -log(-log u), u from Philox keyed by (seed, env, row
+                // slot, action) as in phase_head.  Sample s is served by wavefront (s / 4 + 2) & 3: with 7 samples per sub-group the
+                // wavefronts 2, 3 -- which have no sample to pick actions for and would wait at the barrier -- do all of it.
+                if (K.sample && it >= 1 && it - 1 < G) {
+                    const int g = it - 1, left = nt_samples - g * K.ST, ns = left < K.ST ? left : K.ST;
+                    const int s0 = 4 * ((wave + 2) & 3);
+                    if (s0 < ns) {
+                        const int sm = s0 + (lane >> 4);
+                        const unsigned long long er = tab[2 * (g * K.ST + (sm < ns ? sm : 0)) + 1];
+                        uint32_t rnd[4];
+                        philox((uint32_t)er, (uint32_t)K.slot0 + (uint32_t)(er >> 32), (uint32_t)(a16 >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
+                        const uint32_t r = (a16 & 3) == 0 ? rnd[0] : (a16 & 3) == 1 ? rnd[1] : (a16 & 3) == 2 ? rnd[2] : rnd[3];
+                        const float u = (float)(r >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
+                        noise[(g & 1) * 256 + sm * 16 + a16] = -__logf(-__logf(u));
+                    }
+                }
+                PPG_DP(5);
                 __syncthreads();
                 PPG_DP(2);
             }
@@ -302,6 +322,15 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
         }
         PPG_DP(0);
         for (int it = -1; it <= G + 1; ++it) {
+            // order inside the iteration: stage -> ARRIVE -> head (needs nothing of the other B wavefronts) -> WAIT -> conv1 -> ARRIVE -> row
+            // fetch -> WAIT -> conv2: the waits of the two private barriers find most arrivals done
+            const bool more = it + 1 < G;   // sub-group it + 1: rows -> X, conv1, conv2
+            if (more) {
+                stage(it + 1);
+                b_target += 4;
+                pipe_arrive(ctr, lane);
+            }
+            PPG_DP(11);
             if (it >= 1 && it - 1 < G) {   // head of sub-group it - 1: this wavefront's k-steps
                 const int g = it - 1, ns = group_ns(g);
                 const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + ((g & 1) ? K.pipe_f1 : K.off_f) + 8 * kq;
@@ -318,20 +347,18 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 for (int i = 0; i < 4; ++i) wr[(bw * 16 + 4 * kq + i) * 16 + colh] = hacc[i];
             }
             PPG_DP(4);
-            if (it + 1 < G) {   // sub-group it + 1: rows -> X, conv1, conv2
+            if (more) {
                 const int g = it + 1, ns = group_ns(g), xo = (g & 1) ? K.pipe_x1 : 0;
-                stage(g);
-                PPG_DP(11);
-                if constexpr (CH) fetch(g + 1 < G ? g + 1 : g);   // (unconditional, like the loads in it; the last one is not parked)
-                else if (g + 1 < G) request(g + 1);
-                PPG_DP(5);
-                b_target += 4;
-                pipe_bsync(ctr, b_target, lane);
+                pipe_wait(ctr, b_target);
                 PPG_DP(6);
                 dconv<CB1, 1, PPG_DIRECT_B12>(K, w1c, img, sample_stride, xo, K.off_y, K.cout_blocks[0], 0, ns, bw, 4, lane, 0, dummy);
                 PPG_DP(7);
                 b_target += 4;
-                pipe_bsync(ctr, b_target, lane);
+                pipe_arrive(ctr, lane);
+                if constexpr (CH) fetch(g + 1 < G ? g + 1 : g);   // (unconditional, like the loads in it; the last one is not parked)
+                else if (g + 1 < G) request(g + 1);
+                PPG_DP(5);
+                pipe_wait(ctr, b_target);
                 PPG_DP(8);
                 dconv<2, 1, PPG_DIRECT_B12>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy);
                 PPG_DP(9);

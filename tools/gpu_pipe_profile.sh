@@ -9,7 +9,7 @@ export PPG_HIP_LIB=$PWD/predpreygrass_amd/csrc/libppg_hip_dprof.so PPG_DIRECT_PR
 python3 bench.py --workload policy_rollout --steps 20 --warmup 10 --no-cpu-baseline "$@" > gpurun_out/${tag}_dprof.json 2> gpurun_out/${tag}_dprof.err
 python3 - <<PY | tee gpurun_out/${tag}_pipe_profile.txt
 import numpy as np, json
-names = {0: "table", 1: "conv3", 2: "barrier wait", 3: "logits+actions", 4: "head", 5: "request", 11: "stage", 6: "private barrier 1", 7: "conv1", 8: "private barrier 2",
+names = {0: "table", 1: "conv3", 2: "barrier wait", 3: "logits+actions", 4: "head", 5: "noise (A) / request (B)", 11: "stage", 6: "private barrier 1", 7: "conv1", 8: "private barrier 2",
          9: "conv2", 10: "barrier wait", 14: "actions"}
 print(json.loads(open("gpurun_out/${tag}_dprof.json").readlines()[-1])["roofline"])
 for sp in ("prey", "pred"):
@@ -17,7 +17,7 @@ for sp in ("prey", "pred"):
     a = a[a[:, 4, 15] > 0]
     its = a[:, 4, 15].mean()
     print(f"== {sp}: {len(a)} workgroups, iterations per workgroup {its:.1f}")
-    for role, waves, keys in (("A", range(0, 4), (0, 3, 1, 2)), ("B", range(4, 8), (0, 4, 11, 5, 6, 7, 8, 9, 10))):
+    for role, waves, keys in (("A", range(0, 4), (0, 3, 1, 5, 2)), ("B", range(4, 8), (0, 4, 11, 5, 6, 7, 8, 9, 10))):
         tot = a[:, waves, :15].sum(axis=2)
         print(f"  role {role}: cycles per wavefront {tot.mean():.0f} (clock64 ticks); per iteration: " +
               "  ".join(f"{names[k]} {a[:, waves, k].mean() / its:.0f}" for k in keys))
