@@ -26,6 +26,12 @@
 #define PPG_PIPE_B3 2
 #endif
 
+#ifndef PPG_PIPE_B12
+#define PPG_PIPE_B12 0      // fragment reads per batch in role B's conv1 / conv2 (0 = a tile's ten at once)
+#endif
+#ifndef PPG_PIPE_SWP_B
+#define PPG_PIPE_SWP_B true   // role B's convolution loops software-pipelined (the epilogue of tile t behind the reads of tile t + 1)
+#endif
 #ifndef PPG_PIPE_SLEEP
 #define PPG_PIPE_SLEEP 1    // s_sleep argument between two polls of role B's private barrier
 #endif
@@ -351,7 +357,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 const int g = it + 1, ns = group_ns(g), xo = (g & 1) ? K.pipe_x1 : 0;
                 pipe_wait(ctr, b_target);
                 PPG_DP(6);
-                dconv<CB1, 1, PPG_DIRECT_B12>(K, w1c, img, sample_stride, xo, K.off_y, K.cout_blocks[0], 0, ns, bw, 4, lane, 0, dummy);
+                dconv<CB1, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B>(K, w1c, img, sample_stride, xo, K.off_y, K.cout_blocks[0], 0, ns, bw, 4, lane, 0, dummy);
                 PPG_DP(7);
                 b_target += 4;
                 pipe_arrive(ctr, lane);
@@ -360,7 +366,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 PPG_DP(5);
                 pipe_wait(ctr, b_target);
                 PPG_DP(8);
-                dconv<2, 1, PPG_DIRECT_B12>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy);
+                dconv<2, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy);
                 PPG_DP(9);
                 if constexpr (CH) park(g + 1, g + 1 < G);   // (every B wavefront has staged sub-group g out of `raw`: two private barriers ago)
             }
