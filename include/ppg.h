@@ -508,6 +508,16 @@ int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handle
 /* multiply-accumulates one observation costs in this network (for FLOP accounting: 2 flops each) */
 uint64_t ppg_policy_macs_per_observation(const ppg_policy *p);
 const char *ppg_policy_last_error(const ppg_policy *p);
+/* Which kernels ppg_policy_create_spec would pick for this network and how they lay out a CU's 160 KB of LDS -- computed without a
+ * device and without the weights (the pointers of `spec` are not read); for tests and for sizing.  Fills up to n of:
+ *   out[0] kernel family: 0 FC chain (hidden head layers), 1 one-role direct-head kernels, 2 the same for more than three
+ *          convolutions, 3 the two-role pipeline (three convolutions, <= 16 actions)
+ *   out[1] samples per sub-group   out[2] dynamic LDS bytes per workgroup   out[3] threads per workgroup
+ *   family 3 only: out[4] samples a workgroup's table holds, out[5] bytes of a sample's region, out[6] 8-byte row chunks a thread
+ *   fetches per sub-group (0: one load per channel), out[7] samples covered per chunk load, out[8..10] byte offsets of the
+ *   partial-sum area, the row area and the images, out[11] bytes of the row area
+ * Returns PPG_EINVAL for a spec ppg_policy_create_spec would reject on its shape. */
+int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n);
 
 /* A device buffer for the caller-owned observation tensors whose physical pages are picked at random from a stretch of device
  * memory `spread` times its size (HIP virtual memory management: spread x as many 2 MB chunks are created, a random subset is

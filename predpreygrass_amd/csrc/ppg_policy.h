@@ -1078,6 +1078,63 @@ int ppg_policy_create(int32_t device, int32_t obs_range, int32_t n_actions, cons
     return ppg_policy_create_layout(device, obs_range, n_actions, PPG_POLICY_LAYOUT_CHW, w, out);
 }
 
+int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n);
+int ppg_policy_destroy(ppg_policy *p);
+// ppg_policy_describe restates the kernel choice and the layout without a device: a policy is only handed out if the two agree
+static int ppg_policy_matches_description(ppg_policy *p, const ppg_policy_spec *spec) {
+    int32_t d[4] = {-1, -1, -1, -1};
+    const int family = p->pipe ? 3 : p->direct;
+    if (ppg_policy_describe(spec, d, 4) != PPG_OK || d[0] != family || d[1] != p->base.ST || d[2] != p->lds_bytes || d[3] != (p->pipe ? 512 : 256))
+        return ppg_policy_fail(nullptr, PPG_EHIP, "internal: ppg_policy_describe says family %d, %d samples per sub-group, %d bytes of LDS; built %d, %d, %d",
+                               d[0], d[1], d[2], family, p->base.ST, p->lds_bytes);
+    return PPG_OK;
+}
+
+#ifndef PPG_POLICY_PIPE
+#define PPG_POLICY_PIPE 1   // (0: A/B builds without the two-role pipeline)
+#endif
+// LDS layout of the two-role pipeline kernels (ppg_policy_pipe.h) for rows of C x R x R elements read as P positions; blk = elements of
+// one channel block of a sample's padded image, f_elems = elements of an area F.  Device-free (ppg_policy_describe, CPU tests).
+static bool ppg_pipe_layout(int C, int R, int P, int blk, int f_elems, int tail_slack, ppgpol::PolParams &K, int *lds_bytes) {
+    int stride = 10 * blk + 2 * f_elems;
+    while (((stride / 2) % 64) % 8 != 4) stride += 8;   // consecutive samples 16 bytes x an odd number apart in the banks: the head's
+                                                        // sixteen sample columns read conflict-free
+    const int fixed_p = 2 * 4096 + 64 + 2048 + 1024 + tail_slack;   // partial sums x 2, role B's counter, Gumbel noise x 2, dconv's dummy slots (64 lanes)
+    const int row_bf16 = C * R * R * 2;   // bytes of a bfloat16 row; the area `raw` takes ST of them when they are whole 8-byte chunks
+    const bool chunks = row_bf16 % 8 == 0;
+    int st_cap = (160 * 1024 - fixed_p - 128 * 16) / (stride * 2 + (chunks ? row_bf16 : 0));   // (at least 128 samples of table)
+    if (st_cap > 16) st_cap = 16;
+    while (st_cap > 1 && st_cap * P > 256) --st_cap;   // a role-B thread stages one position
+    if (st_cap < 1 || P > 256) return false;
+    {
+        int st = st_cap;
+        double best = 0.0;
+        for (int c = st_cap; c >= 1; --c) {   // the most samples per round of position tiles (four wavefronts a tile each)
+            const int tiles = (c * P + 31) / 32, rounds = (tiles + 3) / 4;
+            const double score = (double)c / rounds;
+            if (score > best * 1.0001) { best = score; st = c; }
+        }
+        int raw_bytes = chunks ? (st * row_bf16 + 15) / 16 * 16 : 0;
+        const int cpr = row_bf16 / 8;   // 8-byte chunks per row; the role-B threads cover floor(256 / cpr) samples per load
+        K.pipe_slots = chunks && cpr <= 256 ? 256 / cpr : 0;
+        K.pipe_ni = K.pipe_slots ? (st + K.pipe_slots - 1) / K.pipe_slots : 0;
+        if (K.pipe_ni > ppgpol::PIPE_CHUNKS) K.pipe_ni = 0;   // (that many chunk registers per thread)
+        if (!K.pipe_ni) raw_bytes = 0;
+        K.pipe_magic = K.pipe_ni ? (uint32_t)((0x100000000ull + cpr - 1) / cpr) : 0u;
+        int cap_tab = (160 * 1024 - fixed_p - raw_bytes - st * stride * 2) / 16;
+        if (cap_tab > 2048) cap_tab = 2048;
+        K.ST = st;
+        K.range_tile = st * (cap_tab / st);
+        K.off_x = 0; K.pipe_x1 = 4 * blk; K.off_y = 8 * blk; K.off_f = 10 * blk; K.pipe_f1 = K.off_f + f_elems;
+        K.sample_stride = stride;
+        K.pipe_red = K.range_tile * 16;
+        K.pipe_raw = K.pipe_red + 2 * 4096 + 64 + 2048;
+        K.pipe_img = K.pipe_raw + raw_bytes + 1024;
+        *lds_bytes = K.pipe_img + st * stride * 2 + tail_slack;
+    }
+    return true;
+}
+
 int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_policy **out) {
     if (!spec || !out) return ppg_policy_fail(nullptr, PPG_EINVAL, "null argument");
     const ppg_policy_spec &sp = *spec;
@@ -1238,52 +1295,19 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         K.off_x = 0; K.off_y = 4 * blk; K.off_f = 6 * blk; K.off_d0 = K.off_f + f_elems; K.off_d1 = K.off_d0 + 8 * blk;
         K.sample_stride = K.off_f + f_elems + (sp.n_conv > 3 ? 8 * blk : 0) + (sp.n_conv > 4 ? 8 * blk : 0);
         const int tail_slack = 18 * 32 * 2;   // bytes behind the last sample's region: the head's unconditional fragment reads end there
-#ifndef PPG_POLICY_PIPE
-#define PPG_POLICY_PIPE 1   // (0: A/B builds without the two-role pipeline)
-#endif
         // the two-role pipeline (ppg_policy_pipe.h): three convolutions, up to 16 actions, a wavefront's quarter of the head's k-steps in 18
         // fragments; region of a sample: X0 | X1 (4 blocks each) | Y (2 blocks) | F0 | F1
         if (PPG_POLICY_PIPE && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18) {
-            int stride = 10 * blk + 2 * f_elems;
-            while (((stride / 2) % 64) % 8 != 4) stride += 8;   // consecutive samples 16 bytes x an odd number apart in the banks: the head's
-                                                                // sixteen sample columns read conflict-free
-            const int fixed_p = 2 * 4096 + 64 + 2048 + 1024 + tail_slack;   // partial sums x 2, role B's counter, Gumbel noise x 2, dconv's dummy slots (64 lanes)
-            const int row_bf16 = C * R * R * 2;   // bytes of a bfloat16 row; the area `raw` takes ST of them when they are whole 8-byte chunks
-            const bool chunks = row_bf16 % 8 == 0;
-            int st_cap = (160 * 1024 - fixed_p - 128 * 16) / (stride * 2 + (chunks ? row_bf16 : 0));   // (at least 128 samples of table)
-            if (st_cap > 16) st_cap = 16;
-            while (st_cap > 1 && st_cap * P > 256) --st_cap;   // a role-B thread stages one position
-            if (st_cap >= 1 && P <= 256) {
-                int st = st_cap;
-                double best = 0.0;
-                for (int c = st_cap; c >= 1; --c) {   // the most samples per round of position tiles (four wavefronts a tile each)
-                    const int tiles = (c * P + 31) / 32, rounds = (tiles + 3) / 4;
-                    const double score = (double)c / rounds;
-                    if (score > best * 1.0001) { best = score; st = c; }
-                }
-                int raw_bytes = chunks ? (st * row_bf16 + 15) / 16 * 16 : 0;
-                const int cpr = row_bf16 / 8;   // 8-byte chunks per row; the role-B threads cover floor(256 / cpr) samples per load
-                K.pipe_slots = chunks && cpr <= 256 ? 256 / cpr : 0;
-                K.pipe_ni = K.pipe_slots ? (st + K.pipe_slots - 1) / K.pipe_slots : 0;
-                if (K.pipe_ni > ppgpol::PIPE_CHUNKS) K.pipe_ni = 0;   // (that many chunk registers per thread)
-                if (!K.pipe_ni) raw_bytes = 0;
-                K.pipe_magic = K.pipe_ni ? (uint32_t)((0x100000000ull + cpr - 1) / cpr) : 0u;
-                int cap_tab = (160 * 1024 - fixed_p - raw_bytes - st * stride * 2) / 16;
-                if (cap_tab > 2048) cap_tab = 2048;
-                K.ST = st;
-                K.range_tile = st * (cap_tab / st);
-                K.off_x = 0; K.pipe_x1 = 4 * blk; K.off_y = 8 * blk; K.off_f = 10 * blk; K.pipe_f1 = K.off_f + f_elems;
-                K.sample_stride = stride;
-                K.pipe_red = K.range_tile * 16;
-                K.pipe_raw = K.pipe_red + 2 * 4096 + 64 + 2048;
-                K.pipe_img = K.pipe_raw + raw_bytes + 1024;
+            int pipe_lds = 0;
+            if (ppg_pipe_layout(C, R, P, blk, f_elems, tail_slack, K, &pipe_lds)) {
                 p->pipe = 1;
                 p->grid = prop.multiProcessorCount;
-                p->lds_bytes = K.pipe_img + st * stride * 2 + tail_slack;
+                p->lds_bytes = pipe_lds;
                 for (const void *fn : {(const void *)ppgpol::ppg_policy_pipe8_f64, (const void *)ppgpol::ppg_policy_pipe8_f32,
                                        (const void *)ppgpol::ppg_policy_pipe8_bf16, (const void *)ppgpol::ppg_policy_pipe16_f64,
                                        (const void *)ppgpol::ppg_policy_pipe16_f32, (const void *)ppgpol::ppg_policy_pipe16_bf16})
                     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+                if (ppg_policy_matches_description(p, spec) != PPG_OK) { (void)ppg_policy_destroy(p); return PPG_EHIP; }
                 *out = p;
                 return PPG_OK;
             }
@@ -1324,6 +1348,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
                                (const void *)ppgpol::ppg_policy_deep8_bf16, (const void *)ppgpol::ppg_policy_deep16_f64,
                                (const void *)ppgpol::ppg_policy_deep16_f32, (const void *)ppgpol::ppg_policy_deep16_bf16})
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+        if (ppg_policy_matches_description(p, spec) != PPG_OK) { (void)ppg_policy_destroy(p); return PPG_EHIP; }
         *out = p;
         return PPG_OK;
     }
@@ -1363,7 +1388,61 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
                            (const void *)ppgpol::ppg_policy_forward_hwc16_f64, (const void *)ppgpol::ppg_policy_forward_hwc16_f32,
                            (const void *)ppgpol::ppg_policy_forward_hwc16_bf16})
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
+    if (ppg_policy_matches_description(p, spec) != PPG_OK) { (void)ppg_policy_destroy(p); return PPG_EHIP; }
     *out = p;
+    return PPG_OK;
+}
+
+int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n) {
+    if (!spec || !out || n < 1) return PPG_EINVAL;
+    const ppg_policy_spec &sp = *spec;
+    const int R = sp.obs_range, C = sp.obs_channels;
+    if ((sp.layout != PPG_POLICY_LAYOUT_CHW && sp.layout != PPG_POLICY_LAYOUT_HWC) || R < 1 || R > 15 || C < 1 || C > 8 || sp.n_actions < 1 ||
+        sp.n_actions > 32 || sp.n_conv < 1 || sp.n_conv > PPG_POLICY_MAX_CONV || sp.n_fc < 1 || sp.n_fc > PPG_POLICY_MAX_FC)
+        return PPG_EINVAL;
+    const int hwc = sp.layout == PPG_POLICY_LAYOUT_HWC;
+    const int IH = hwc ? C : R, IW = R, P = IH * IW;
+    int32_t v[12] = {0, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (sp.n_fc > 1) {   // FC chain: tile table + max(images of ST samples, H, FC1 staging); two workgroups per CU
+        const int per_sample = 6 * (IH + 2) * (IW + 2) * 8 * 2;
+        int st = (78 * 1024 - ppgpol::TILE * 16) / per_sample;
+        st = st < 1 ? 1 : st > 16 ? 16 : st;
+        while (st > 1 && st * P > 512) --st;
+        int overlay = st * per_sample;
+        if (ppgpol::TILE * ppgpol::HSTRIDE * 2 > overlay) overlay = ppgpol::TILE * ppgpol::HSTRIDE * 2;
+        if (3 * ppgpol::FC1_BUF > overlay) overlay = 3 * ppgpol::FC1_BUF;
+        v[1] = st; v[2] = ppgpol::TILE * 16 + overlay;
+    } else {
+        ppgpol::PolParams K;
+        memset(&K, 0, sizeof K);
+        const int cout_last_blocks = (sp.conv_out[sp.n_conv - 1] + 7) / 8;
+        K.flat_c = 8 * cout_last_blocks; K.kflat_steps = (P * K.flat_c + 31) / 32; K.head_mt = (sp.n_actions + 15) / 16;
+        K.Wp = IW + 1; K.Wp2 = (IH + 2) * (IW + 1) + 1;
+        const int blk = K.Wp2 * 8, f_elems = K.kflat_steps * 32 + 8, tail_slack = 18 * 32 * 2;
+        int lds = 0;
+        if (PPG_POLICY_PIPE && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18 &&
+            ppg_pipe_layout(C, R, P, blk, f_elems, tail_slack, K, &lds)) {
+            v[0] = 3; v[1] = K.ST; v[2] = lds; v[3] = 512; v[4] = K.range_tile; v[5] = K.sample_stride * 2; v[6] = K.pipe_ni; v[7] = K.pipe_slots;
+            v[8] = K.pipe_red; v[9] = K.pipe_raw; v[10] = K.pipe_img; v[11] = K.pipe_img - 1024 - K.pipe_raw;
+        } else {
+            const int stride = 6 * blk + f_elems + (sp.n_conv > 3 ? 8 * blk : 0) + (sp.n_conv > 4 ? 8 * blk : 0);
+            const int fixed = ppgpol::TILE * 16 + K.head_mt * 4096 + 4096 + tail_slack;
+            const bool w1 = PPG_DIRECT_W1;
+            int st_max = ((w1 ? 160 : 80) * 1024 - fixed) / (stride * 2);
+            if (st_max > 16) st_max = 16;
+            while (st_max > 1 && st_max * P > (w1 ? 512 : 256)) --st_max;
+            if (st_max < 1) return PPG_EINVAL;
+            int st = st_max;
+            double best = 0.0;
+            for (int c = st_max; c >= 1; --c) {
+                const int tiles = (c * P + 31) / 32, rounds = (tiles + 3) / 4;
+                const double score = (double)c / rounds;
+                if (score > best * 1.0001) { best = score; st = c; }
+            }
+            v[0] = sp.n_conv > 3 ? 2 : 1; v[1] = st; v[2] = fixed + st * stride * 2;
+        }
+    }
+    for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
     return PPG_OK;
 }
 

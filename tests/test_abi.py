@@ -87,3 +87,59 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     assert lines[4].split() == [str(_abi.ABI_VERSION), str(_abi.ENV_WORDS)]
     PS = _abi.PpgPolicySpec
     assert lines[5].split() == [str(ctypes.sizeof(PS))] + [str(getattr(PS, n).offset) for n in ("conv_out", "n_fc", "conv_w", "fc_b")]
+
+
+def test_policy_kernel_choice_and_lds_layout_for_every_shape(hip_lib_path):
+    """ppg_policy_describe (host arithmetic only, no device): for every observation shape and network depth ppg_policy_create_spec
+    accepts, the kernels' LDS layout fits a CU (160 KB), a sub-group fits the staging threads, and the two-role pipeline's areas
+    (table, partial sums, row area, images) follow each other without overlap."""
+    from predpreygrass_amd import _abi
+    lib = _abi.bind(ctypes.CDLL(hip_lib_path))
+    LDS = 160 * 1024
+    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    for layout in (_abi.POLICY_LAYOUT_CHW, _abi.POLICY_LAYOUT_HWC):
+        for C in range(4, 9):
+            for R in range(1, 16):
+                for n_conv in range(1, 7):
+                    for n_fc, n_actions in ((1, 5), (1, 9), (1, 16), (1, 17), (1, 25), (2, 9), (3, 9)):
+                        if n_fc > 1 and n_conv != 3:
+                            continue
+                        sp = _abi.PpgPolicySpec()
+                        sp.obs_channels, sp.obs_range, sp.n_actions, sp.layout, sp.flatten = C, R, n_actions, layout, _abi.POLICY_FLATTEN_NHWC
+                        sp.n_conv, sp.n_fc = n_conv, n_fc
+                        for l, c in enumerate(([16, 32, 64] + [64] * 3)[:n_conv]):
+                            sp.conv_out[l] = c
+                        for l in range(n_fc):
+                            sp.fc_out[l] = 256 if l + 1 < n_fc else n_actions
+                        out = (ctypes.c_int32 * 12)()
+                        rc = lib.ppg_policy_describe(ctypes.byref(sp), out, 12)
+                        P = (C if layout == _abi.POLICY_LAYOUT_HWC else R) * R
+                        if rc != 0:
+                            assert n_fc == 1 and P * 64 * 6 * 2 > 100 * 1024, (layout, C, R, n_conv, n_fc, n_actions)   # only images too large for one sample
+                            continue
+                        fam, st, lds, threads = out[0], out[1], out[2], out[3]
+                        seen[fam] += 1
+                        assert 1 <= st <= 16 and 0 < lds <= LDS, (fam, st, lds, C, R, n_conv)
+                        assert fam == (0 if n_fc > 1 else 2 if n_conv > 3 else fam) or fam in (1, 3)
+                        if fam == 3:
+                            assert n_conv == 3 and n_actions <= 16 and threads == 512
+                            table, region, ni, slots, red, raw, img, raw_bytes = out[4:12]
+                            assert st * P <= 256 and table >= 100 and table % st == 0 and region % 16 == 0
+                            assert red == table * 16 and raw == red + 2 * 4096 + 64 + 2048 and img == raw + raw_bytes + 1024
+                            assert img + st * region + 18 * 32 * 2 == lds
+                            row = C * R * R * 2
+                            if ni:
+                                assert row % 8 == 0 and 1 <= ni <= 3 and slots * (row // 8) <= 256 and slots * ni >= st and raw_bytes >= st * row
+                            else:
+                                assert raw_bytes == 0
+                        else:
+                            assert threads == 256 and st * P <= 512
+    assert seen[0] > 0 and seen[1] > 0 and seen[2] > 0 and seen[3] > 100
+    # the reference's shapes: 7x7 predators, 9x9 prey, three convolutions, nine actions -> the pipeline with 9 / 7 samples per sub-group
+    for R, st in ((7, 9), (9, 7)):
+        sp = _abi.PpgPolicySpec()
+        sp.obs_channels, sp.obs_range, sp.n_actions, sp.layout, sp.flatten, sp.n_conv, sp.n_fc = 4, R, 9, _abi.POLICY_LAYOUT_HWC, _abi.POLICY_FLATTEN_NHWC, 3, 1
+        sp.conv_out[0], sp.conv_out[1], sp.conv_out[2], sp.fc_out[0] = 16, 32, 64, 9
+        out = (ctypes.c_int32 * 12)()
+        assert lib.ppg_policy_describe(ctypes.byref(sp), out, 12) == 0
+        assert (out[0], out[1], out[3]) == (3, st, 512) and out[4] >= 518 and out[6] > 0
