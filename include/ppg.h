@@ -516,7 +516,8 @@ const char *ppg_policy_last_error(const ppg_policy *p);
  *   family 3 only: out[4] samples a workgroup's table holds, out[5] bytes of a sample's region, out[6] 8-byte row chunks a thread
  *   fetches per sub-group (0: one load per channel), out[7] samples covered per chunk load, out[8..10] byte offsets of the
  *   partial-sum area, the row area and the images, out[11] bytes of the row area
- * Returns PPG_EINVAL for a spec ppg_policy_create_spec would reject on its shape. */
+ * Returns PPG_EINVAL for a spec ppg_policy_create_spec would reject on its shape.  (Diagnostic: with the environment variable
+ * PPG_POLICY_PIPE=0 set when a policy is created, a network of family 3 gets the kernels of family 1 -- same logits, bit for bit.) */
 int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n);
 
 /* A device buffer for the caller-owned observation tensors whose physical pages are picked at random from a stretch of device

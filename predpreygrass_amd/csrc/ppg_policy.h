@@ -1093,6 +1093,12 @@ static int ppg_policy_matches_description(ppg_policy *p, const ppg_policy_spec *
 #ifndef PPG_POLICY_PIPE
 #define PPG_POLICY_PIPE 1   // (0: A/B builds without the two-role pipeline)
 #endif
+// diagnostic switch: environment variable PPG_POLICY_PIPE=0 at creation time sends a network the pipeline would take to the one-role
+// direct-head kernels instead (tests compare the two bit for bit)
+static bool ppg_pipe_enabled() {
+    const char *e = getenv("PPG_POLICY_PIPE");
+    return PPG_POLICY_PIPE && !(e && e[0] == '0' && e[1] == 0);
+}
 // LDS layout of the two-role pipeline kernels (ppg_policy_pipe.h) for rows of C x R x R elements read as P positions; blk = elements of
 // one channel block of a sample's padded image, f_elems = elements of an area F.  Device-free (ppg_policy_describe, CPU tests).
 static bool ppg_pipe_layout(int C, int R, int P, int blk, int f_elems, int tail_slack, ppgpol::PolParams &K, int *lds_bytes) {
@@ -1297,7 +1303,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         const int tail_slack = 18 * 32 * 2;   // bytes behind the last sample's region: the head's unconditional fragment reads end there
         // the two-role pipeline (ppg_policy_pipe.h): three convolutions, up to 16 actions, a wavefront's quarter of the head's k-steps in 18
         // fragments; region of a sample: X0 | X1 (4 blocks each) | Y (2 blocks) | F0 | F1
-        if (PPG_POLICY_PIPE && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18) {
+        if (ppg_pipe_enabled() && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18) {
             int pipe_lds = 0;
             if (ppg_pipe_layout(C, R, P, blk, f_elems, tail_slack, K, &pipe_lds)) {
                 p->pipe = 1;
@@ -1420,7 +1426,7 @@ int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n) {
         K.Wp = IW + 1; K.Wp2 = (IH + 2) * (IW + 1) + 1;
         const int blk = K.Wp2 * 8, f_elems = K.kflat_steps * 32 + 8, tail_slack = 18 * 32 * 2;
         int lds = 0;
-        if (PPG_POLICY_PIPE && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18 &&
+        if (ppg_pipe_enabled() && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18 &&
             ppg_pipe_layout(C, R, P, blk, f_elems, tail_slack, K, &lds)) {
             v[0] = 3; v[1] = K.ST; v[2] = lds; v[3] = 512; v[4] = K.range_tile; v[5] = K.sample_stride * 2; v[6] = K.pipe_ni; v[7] = K.pipe_slots;
             v[8] = K.pipe_red; v[9] = K.pipe_raw; v[10] = K.pipe_img; v[11] = K.pipe_img - 1024 - K.pipe_raw;

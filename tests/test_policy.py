@@ -424,6 +424,32 @@ def test_bfloat16_rows_of_other_windows_through_the_pipeline_kernels(Rp, Rq):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float64])
+def test_pipeline_and_one_role_kernels_give_the_same_logits_bit_for_bit(dt, monkeypatch):
+    """The two-role pipeline kernels (ppg_policy_pipe.h) do the arithmetic of the one-role direct-head kernels in the same order:
+    PPG_POLICY_PIPE=0 at creation time selects the latter for the same network -- identical logits, greedy AND sampled actions."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy
+    nets = make_nets(seed=51)
+    env = BatchedPredPreyGrass(dict(config_env), batch_size=700, device="cuda:0", obs_dtype=dt, seed=14)
+    env.reset()
+    for _ in range(60):
+        env.step(random_actions=True, auto_reset=True)
+    out = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("PPG_POLICY_PIPE", pipe)
+        fused = FusedPolicy(nets[0], nets[1])
+        lg = fused.act(env, want_logits=True)
+        greedy = env.actions.clone()
+        fused.act(env, sample=True, seed=77)
+        torch.cuda.synchronize()
+        out.append((lg[0].clone(), lg[1].clone(), greedy, env.actions.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert bool(out[0][1].abs().sum() > 0) and not torch.equal(out[0][2], out[0][3])
+
+
+@pytest.mark.gpu
 def test_a_workgroups_share_larger_than_its_sample_table():
     """6500 envs: ~200 k prey rows on 256 workgroups = shares of ~800 samples, more than the pipeline kernels' LDS table holds (693 at
     9x9) -- every workgroup walks two tiles (the pipeline drains and refills); and 3 envs: most workgroups get nothing."""
