@@ -350,10 +350,11 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the timed region: exactly --steps steps, NO events inside (an event record between two kernels of a stream costs ~5 us of idle
+    # GPU on each side of the policy call: rocprofv3 timestamps, profiles/r04/v_policy_rollout_step_timeline.txt)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(evs[k])
+        one_step()
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
@@ -362,11 +363,20 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
         t = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    pol_ms = sum(a.elapsed_time(b) for a, b in evs)
     es = env.env_state.cpu().numpy().astype("int64")
     n_pred, n_prey = int(es[:, _abi.ENV_OBS_PRED].sum()), int(es[:, _abi.ENV_OBS_PREY].sum())
+    # second leg (untimed for `value`): the policy kernels' own time, HIP events around every policy call of up to 100 more steps
+    ev_steps = min(args.steps, 100)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ev_steps)]
+    for k in range(ev_steps):
+        one_step(evs[k])
+    torch.cuda.synchronize(device)
+    pol_ms = sum(a.elapsed_time(b) for a, b in evs) / ev_steps * args.steps   # (scaled to the timed region's step count)
+    es2 = env.env_state.cpu().numpy().astype("int64")
+    ev_pred, ev_prey = int(es2[:, _abi.ENV_OBS_PRED].sum()) - n_pred, int(es2[:, _abi.ENV_OBS_PREY].sum()) - n_prey
     flops = 2.0 * (n_pred * fused.macs_per_observation(0) + n_prey * fused.macs_per_observation(1))
-    achieved = flops / (pol_ms * 1e-3) / 1e12
+    ev_flops = 2.0 * (ev_pred * fused.macs_per_observation(0) + ev_prey * fused.macs_per_observation(1))
+    achieved = ev_flops / (pol_ms / args.steps * ev_steps * 1e-3) / 1e12
     if rank == 0:
         out = {
             "metric": "env-steps/sec at 4096x(25x25) grids, 1/2/4/8 MI355X; % HBM roofline",
