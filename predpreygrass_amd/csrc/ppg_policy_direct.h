@@ -70,10 +70,23 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // ONE wavefront per SIMD runs this (PPG_DIRECT_W1), so nothing hides a stall but the code itself: the loop is software-pipelined by
 // hand -- the epilogue of tile t (accumulators -> ReLU -> bf16 -> LDS) sits between the first fragment reads of tile t + 1 and its first
 // MFMA, where it covers the LDS latency, and the positions of tile t + 1 are computed behind the MFMAs of tile t.
-struct TileCtx { int in_base, out_base; bool valid; };
+struct TileCtx { int in_base, out_base, swz; bool valid; };
+
+// Area F is [position][flat_c channels] -- RLlib's flatten order.  With 64 channels a position is 128 bytes = ALL the banks of a wide
+// store's lane group: conv3's epilogue stores 16 bytes per lane, one POSITION per lane, so the eight lanes of a group hit the same four
+// banks (8-way conflicts; 61 % of the pipeline kernels' LDS cycles were bank conflicts, 78 % of the epilogues': profiles/r04).  The
+// 16-byte chunk c of position p therefore lives at chunk c ^ (p & 7) of its row (F_SWIZZLE): no padding, every group conflict-free.
+// The head reads k-step k (32 features = chunks 4 (k & 1) .. + 3 of position k >> 1) through the same permutation.
+template <class KP>
+__device__ __forceinline__ int f_koff(const KP &K, int k, int kq) {   // element offset of lane quarter kq's 16 bytes of k-step k
+    if (K.flat_c != 64) return 32 * k + 8 * kq;
+    const int q = k >> 1;
+    return q * 64 + (((4 * (k & 1) + kq) ^ (q & 7)) << 3);
+}
 
 // SWP = false (ppg_policy_pipe.h, where a second wavefront on the SIMD fills the gaps): tile by tile, no second set of accumulators.
-template <int CBIN, int MT, int BATCH, bool SWP = true, class KP>
+// F64 = true: the output is an area F of 64 channels per position (F_SWIZZLE above; the caller checks K.flat_c == 64).
+template <int CBIN, int MT, int BATCH, bool SWP = true, bool F64 = false, class KP>
 __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __bf16 *img, int sample_stride, int in_off, int out_off,
                                       int out_blocks, int flat_c, int ns, int nt_first, int nt_step, int lane, int mt_base, int dummy) {
     constexpr int KS = ConvW<CBIN, MT>::KS;
@@ -97,7 +110,8 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
         const int pidx = __mul24(y + 1, K.Wp) + (x + 1);
         const int sb = __mul24(s, sample_stride);
         c.in_base = sb + in0 + pidx * 8;
-        c.out_base = sb + out_off + (flat_c ? __mul24(p, flat_c) : pidx * 8) + __mul24(cb0, cb_step);
+        c.out_base = sb + out_off + (flat_c ? __mul24(p, flat_c) : pidx * 8) + (F64 ? 0 : __mul24(cb0, cb_step));
+        c.swz = F64 ? (p & 7) : 0;
         return c;
     };
     auto fragment = [&](const TileCtx &c, int ks) -> bf16x8 {
@@ -122,7 +136,7 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
 #pragma unroll
             for (int j = 0; j < 2; ++j) {   // this lane's channels 32 (mt_base + mt) + 16 h + 8 j .. + 7 = channel block cb0 + 4 mt + j
                 const bool real = c.valid && (cb0 + 4 * mt + j < out_blocks);
-                const int at = real ? c.out_base + (4 * mt + j) * cb_step : dummy;
+                const int at = !real ? dummy : F64 ? c.out_base + (((cb0 + 4 * mt + j) ^ c.swz) << 3) : c.out_base + (4 * mt + j) * cb_step;
                 if (PPG_DIRECT_ABLATE & 64) {   // (timing-only build: no ReLU / pack / store -- one value kept so that the MFMAs stay)
                     if (acc[mt][8 * j] == 123.0f) *(float *)(img + dummy) = acc[mt][8 * j];
                 } else
@@ -352,6 +366,10 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
             }
             if (n_conv > 2 && !(PPG_DIRECT_ABLATE & 4)) {
                 if (DEEP) { w3c.load(K, K.wc3, lane, wave >> 1); w3c.landed(); }
+                if (n_conv == 3 && K.flat_c == 64)
+                    dconv<4, MT3, DEEP ? 3 : PPG_DIRECT_B3, true, true>(K, w3c, img, sample_stride, K.off_x, K.off_f, K.cout_blocks[2], 64, ns,
+                                                                    WRES ? wave : wave & 1, WRES ? 4 : 2, lane, WRES ? 0 : wave >> 1, dummy);
+                else
                 dconv<4, MT3, DEEP ? 3 : PPG_DIRECT_B3>(K, w3c, img, sample_stride, K.off_x, n_conv == 3 ? K.off_f : K.off_d0, K.cout_blocks[2],
                                             n_conv == 3 ? K.flat_c : 0, ns, WRES ? wave : wave & 1, WRES ? 4 : 2, lane, WRES ? 0 : wave >> 1, dummy);
             }
@@ -367,6 +385,9 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                     wd.landed();
                     const int in_off = (l & 1) ? K.off_d0 : K.off_d1, mid_off = (l & 1) ? K.off_d1 : K.off_d0;
                     const bool last = l + 1 == n_conv;
+                    if (last && K.flat_c == 64)
+                        dconv<8, 1, 3, true, true>(K, wd, img, sample_stride, in_off, K.off_f, K.cout_blocks[l], 64, ns, wave & 1, 2, lane, wave >> 1, dummy);
+                    else
                     dconv<8, 1, 3>(K, wd, img, sample_stride, in_off, last ? K.off_f : mid_off, K.cout_blocks[l], last ? K.flat_c : 0,
                                    ns, wave & 1, 2, lane, wave >> 1, dummy);
                     __syncthreads();
@@ -380,7 +401,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                 PPG_DP(11);
             }
             {
-                const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + K.off_f + 8 * kq;
+                const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + K.off_f;
                 f32x4_t hacc[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -390,7 +411,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
                     if (resident) {
                         bf16x8 fv[HF];
 #pragma unroll
-                        for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + 32 * (k_lo + i));
+                        for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + f_koff(K, k_lo + i, kq));
 #pragma unroll
                         for (int i = 0; i < HF; ++i) hacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i], fv[i], hacc[0], 0, 0, 0);
                         // (four independent accumulator chains instead of this one: slower, 1751 vs 1225 cycles -- profiles/r04)
@@ -406,7 +427,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
 #pragma unroll
                         for (int i = 0; i < 6; ++i)
                             if (k0 + i < k_hi)
-                                hacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], *(const bf16x8 *)(fb + 32 * (k0 + i)), hacc[0], 0, 0, 0);
+                                hacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], *(const bf16x8 *)(fb + f_koff(K, k0 + i, kq)), hacc[0], 0, 0, 0);
                     }
                 } else {
                     for (int k0 = k_lo; k0 < k_hi; k0 += 3) {
@@ -420,7 +441,7 @@ __device__ __forceinline__ void direct_main(KPtr Kp, unsigned char *lds) {
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
                             if (k0 + i < k_hi) {
-                                const bf16x8 b = *(const bf16x8 *)(fb + 32 * (k0 + i));
+                                const bf16x8 b = *(const bf16x8 *)(fb + f_koff(K, k0 + i, kq));
                                 hacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][i], b, hacc[0], 0, 0, 0);
                                 hacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][i], b, hacc[1], 0, 0, 0);
                             }

@@ -195,6 +195,10 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 PPG_DP(3);
                 if (it >= 0 && it < G) {
                     const int left = nt_samples - it * K.ST, ns = left < K.ST ? left : K.ST;
+                    if (K.flat_c == 64)
+                        dconv<4, 2, PPG_PIPE_B3, false, true>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
+                                                              K.cout_blocks[2], 64, ns, wave, 4, lane, 0, dummy);
+                    else
                     dconv<4, 2, PPG_PIPE_B3, false>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
                                                       K.cout_blocks[2], K.flat_c, ns, wave, 4, lane, 0, dummy);
                 }
@@ -339,13 +343,13 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
             PPG_DP(11);
             if (it >= 1 && it - 1 < G) {   // head of sub-group it - 1: this wavefront's k-steps
                 const int g = it - 1, ns = group_ns(g);
-                const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + ((g & 1) ? K.pipe_f1 : K.off_f) + 8 * kq;
+                const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + ((g & 1) ? K.pipe_f1 : K.off_f);
                 f32x4_t hacc;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hacc[i] = 0.0f;
                 bf16x8 fv[HF];
 #pragma unroll
-                for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + 32 * (k_lo + i));
+                for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + f_koff(K, k_lo + i, kq));
 #pragma unroll
                 for (int i = 0; i < HF; ++i) hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i], fv[i], hacc, 0, 0, 0);
                 float *wr = red + (g & 1) * 1024;
