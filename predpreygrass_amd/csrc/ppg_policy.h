@@ -134,16 +134,20 @@ __device__ __forceinline__ int handle_of(P env_base, int n_handles, int e) {
 // Exclusive prefix sums of one env_state word over the concatenated envs of all handles, and for every 128-sample tile the env
 // its first sample belongs to.  One workgroup of 1024 threads: thread t sums a contiguous run of envs, the 1024 partial sums are
 // scanned in LDS, then every thread bisects for its tiles.
+// LDS_SUMS = false (ppg_policy_plan_small, the FC-chain policies): the per-env sums go through memory only and the kernel needs 4 KB of
+// LDS -- those policies' forward kernels fill every CU to within 4 KB (two workgroups of 78 KB), and the OTHER species' plan runs on
+// a side stream beside them: with 36 KB it found no CU to run on until a forward workgroup finished (fc256: 0.80 -> 0.89 ms per step).
+template <bool LDS_SUMS>
 __device__ __forceinline__ void plan_body(const PlanParams &K) {
     __shared__ uint32_t part[1024];
     // Up to PLAN_LDS_ENVS envs the per-env prefix sums stay in LDS as well and a thread keeps its run's counts in registers: ONE trip to
     // memory per launch (the counts) instead of four dependent ones (counts, counts again, two bisection steps over the sums just
     // written) -- the plan is a 1024-thread chain in front of every policy step (14 -> 9 us at 4096 envs).
     constexpr int PLAN_LDS_ENVS = 8192, PLAN_RUN = PLAN_LDS_ENVS / 1024;
-    __shared__ uint32_t env_pre[PLAN_LDS_ENVS];
+    __shared__ uint32_t env_pre[LDS_SUMS ? PLAN_LDS_ENVS : 1];
     const int t = (int)threadIdx.x;
     const int per = (K.n_envs + 1023) / 1024;
-    const bool in_lds = K.n_envs <= PLAN_LDS_ENVS;
+    const bool in_lds = LDS_SUMS && K.n_envs <= PLAN_LDS_ENVS;
     const int lo = t * per < K.n_envs ? t * per : K.n_envs, hi = (lo + per) < K.n_envs ? (lo + per) : K.n_envs;
     // (the handle's env_state pointer by scalar comparisons: indexed with a per-lane handle number it is a vector load from the
     //  parameter block, one more dependent trip)
@@ -256,10 +260,11 @@ __device__ __forceinline__ void plan_body(const PlanParams &K) {
         K.tile_env[tile] = (uint32_t)a;
     }
 }
-extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan(const PlanParams K) { plan_body(K); }
+extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan(const PlanParams K) { plan_body<true>(K); }
+extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan_small(const PlanParams K) { plan_body<false>(K); }
 // both species' plans in one launch (workgroup 0: A, workgroup 1: B): one launch and one dependent-load chain less per step
 extern "C" __global__ void __launch_bounds__(1024) ppg_policy_plan2(const PlanParams A, const PlanParams B) {
-    if (blockIdx.x == 0) plan_body(A); else plan_body(B);
+    if (blockIdx.x == 0) plan_body<true>(A); else plan_body<true>(B);
 }
 
 __device__ __forceinline__ bf16x8 zero8() {
@@ -1601,7 +1606,7 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
         L2.range_st = o->base.ST;
         hipLaunchKernelGGL(ppgpol::ppg_policy_plan2, dim3(2), dim3(1024), 0, (hipStream_t)stream, L, L2);
     } else if (!skip_plan) {
-        hipLaunchKernelGGL(ppgpol::ppg_policy_plan, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
+        hipLaunchKernelGGL(p->direct ? ppgpol::ppg_policy_plan : ppgpol::ppg_policy_plan_small, dim3(1), dim3(1024), 0, (hipStream_t)stream, L);
     }
     typedef void (*fwd_fn)(const ppgpol::PolParams);
     const fwd_fn fwd[3][3] = {{ppgpol::ppg_policy_forward_f64, ppgpol::ppg_policy_forward_f32, ppgpol::ppg_policy_forward_bf16},
