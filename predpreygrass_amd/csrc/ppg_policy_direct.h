@@ -60,6 +60,22 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // partial logits in LDS: [wavefront][action tile (head_mt of them)][action row][sample column] floats = head_mt * 4 KB
 
+// The two words per tile dconv() takes as `pre` (positions beyond the ST * P of a full sub-group look at position 0 of sample 0: their
+// results are never stored).
+template <class KP>
+__device__ __forceinline__ void dconv_cells(const KP &K, int sample_stride, int nt_first, int nt_step, int lane, int (&pre)[4]) {
+    const int col = lane & 31, n_full = K.ST * K.P;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * (nt_first + t * nt_step) + col, nn = n < n_full ? n : 0;
+        const int s = div_small(nn, K.magic_P), p = nn - __mul24(s, K.P);
+        const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
+        const int sb = __mul24(s, sample_stride);
+        pre[2 * t] = sb + (__mul24(y + 1, K.Wp) + (x + 1)) * 8;
+        pre[2 * t + 1] = (sb + p * 64) | (p & 7);
+    }
+}
+
 // One convolution layer of the direct path over the `ns` samples of a sub-group, this wavefront's share of the 32-position tiles.
 //   in_off / out_off   element offsets of the input / output area inside a sample's LDS region (blocks of an area are contiguous)
 //   out_blocks         real output channel blocks (of 8) of the layer
@@ -86,9 +102,13 @@ __device__ __forceinline__ int f_koff(const KP &K, int k, int kq) {   // element
 
 // SWP = false (ppg_policy_pipe.h, where a second wavefront on the SIMD fills the gaps): tile by tile, no second set of accumulators.
 // F64 = true: the output is an area F of 64 channels per position (F_SWIZZLE above; the caller checks K.flat_c == 64).
+// pre: nullptr, or this lane's two precomputed words per tile of this wavefront (tile t = nt_first + t nt_step, t < 2; ppg_policy_pipe.h,
+// where a wavefront's tiles are the same positions in every sub-group): pre[2 t] = sample base + 8 x padded position (the element of its
+// cell in channel block 0 of area 0), pre[2 t + 1] = (sample base + 64 x position) | (position & 7) -- dconv_cells() below.
 template <int CBIN, int MT, int BATCH, bool SWP = true, bool F64 = false, class KP>
 __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __bf16 *img, int sample_stride, int in_off, int out_off,
-                                      int out_blocks, int flat_c, int ns, int nt_first, int nt_step, int lane, int mt_base, int dummy) {
+                                      int out_blocks, int flat_c, int ns, int nt_first, int nt_step, int lane, int mt_base, int dummy,
+                                      const int *pre = nullptr) {
     constexpr int KS = ConvW<CBIN, MT>::KS;
     constexpr int NB = BATCH ? (KS + BATCH - 1) / BATCH : 1, BS = BATCH ? BATCH : KS;   // batches of fragment reads per tile
     const int h = lane >> 5, col = lane & 31;
@@ -104,6 +124,14 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
         const int n = 32 * nt + col;
         TileCtx c;
         c.valid = n < n_pos;
+        if (pre) {   // (compile-time after inlining: the caller passes an array or nothing)
+            const int t = nt == nt_first ? 0 : 1;
+            const int cell = t ? pre[2] : pre[0], fp = t ? pre[3] : pre[1];
+            c.in_base = cell + in0;
+            c.out_base = F64 ? (fp & ~7) + out_off : cell + out_off + __mul24(cb0, cb_step);
+            c.swz = F64 ? (fp & 7) : 0;
+            return c;
+        }
         const int nn = c.valid ? n : 0;
         const int s = div_small(nn, K.magic_P), p = nn - __mul24(s, K.P);
         const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);

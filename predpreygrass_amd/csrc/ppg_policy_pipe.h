@@ -146,6 +146,8 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
         const float bias_r = (a16 < K.n_actions) ? K.bh[a16] : 0.0f;
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w3c.landed();
+        int cells[4];   // this wavefront's two position tiles are the same positions in every sub-group: their LDS offsets once per launch
+        dconv_cells(K, sample_stride, wave, 4, lane, cells);
         for (int j = 0; j < tpw; ++j) {
             const int tile = (int)blockIdx.x * tpw + j;
             const int n0 = begin + j * K.range_tile;
@@ -197,7 +199,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                     const int left = nt_samples - it * K.ST, ns = left < K.ST ? left : K.ST;
                     if (K.flat_c == 64)
                         dconv<4, 2, PPG_PIPE_B3, false, true>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
-                                                              K.cout_blocks[2], 64, ns, wave, 4, lane, 0, dummy);
+                                                              K.cout_blocks[2], 64, ns, wave, 4, lane, 0, dummy, cells);
                     else
                     dconv<4, 2, PPG_PIPE_B3, false>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
                                                       K.cout_blocks[2], K.flat_c, ns, wave, 4, lane, 0, dummy);
@@ -248,6 +250,8 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
         hf[i] = __builtin_bit_cast(bf16x8, v);
     }
     uint32_t b_target = 0;
+    int cells[4];   // (as in role A: the positions of this wavefront's two tiles, once per launch)
+    dconv_cells(K, sample_stride, bw, 4, lane, cells);
     // bfloat16 rows whose size is a multiple of 8 bytes (K.pipe_ni > 0) come in as they lie in HBM: ALIGNED 8-byte chunks, consecutive
     // lanes consecutive chunks (two or three loads per thread and sub-group), parked in the LDS area `raw` one iteration later and picked
     // apart by the position threads from there.  One 2-byte load per channel and position -- 64 scattered lanes per instruction, nine
@@ -361,7 +365,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 const int g = it + 1, ns = group_ns(g), xo = (g & 1) ? K.pipe_x1 : 0;
                 pipe_wait(ctr, b_target);
                 PPG_DP(6);
-                dconv<CB1, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B>(K, w1c, img, sample_stride, xo, K.off_y, K.cout_blocks[0], 0, ns, bw, 4, lane, 0, dummy);
+                dconv<CB1, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B>(K, w1c, img, sample_stride, xo, K.off_y, K.cout_blocks[0], 0, ns, bw, 4, lane, 0, dummy, cells);
                 PPG_DP(7);
                 b_target += 4;
                 pipe_arrive(ctr, lane);
@@ -370,7 +374,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
                 PPG_DP(5);
                 pipe_wait(ctr, b_target);
                 PPG_DP(8);
-                dconv<2, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy);
+                dconv<2, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy, cells);
                 PPG_DP(9);
                 if constexpr (CH) park(g + 1, g + 1 < G);   // (every B wavefront has staged sub-group g out of `raw`: two private barriers ago)
             }
