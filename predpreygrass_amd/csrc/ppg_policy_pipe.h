@@ -21,9 +21,10 @@
 
 // Fragment reads per batch in role A's conv3.  LDS serves requests in arrival order, whatever the priority of the wavefront: five
 // 1 KB reads per role-A wavefront queued at once stand in front of every LDS access of role B's chain (its table reads alone took
-// 1000 cycles per sub-group); batches of 5 / 4 / 3 / 2: 0.362 / 0.356 / 0.350 / 0.347 ms per 4096-env step on one GPU (profiles/r04)
+// 1000 cycles per sub-group); batches of 5 / 4 / 3 / 2: 0.362 / 0.356 / 0.350 / 0.347 ms per 4096-env step on one GPU; with area F swizzled and the LDS less crowded,
+// batches of 3 / 2 / 1: 0.340 / 0.321 / 0.314 (profiles/r04)
 #ifndef PPG_PIPE_B3
-#define PPG_PIPE_B3 2
+#define PPG_PIPE_B3 1
 #endif
 
 #ifndef PPG_PIPE_B12
