@@ -28,7 +28,8 @@
 #endif
 
 #ifndef PPG_PIPE_B12
-#define PPG_PIPE_B12 0      // fragment reads per batch in role B's conv1 / conv2 (0 = a tile's ten at once)
+#define PPG_PIPE_B12 2      // fragment reads per batch in role B's conv1 / conv2 (0 = a tile's ten at once): 0 / 5 / 4 / 3 / 2 / 1:
+                            // 0.3118 / 0.3129 / 0.3077 / 0.3027 / 0.3007 / 0.3058 ms per step on one GPU (profiles/r04)
 #endif
 #ifndef PPG_PIPE_SWP_B
 #define PPG_PIPE_SWP_B true   // role B's convolution loops software-pipelined (the epilogue of tile t behind the reads of tile t + 1)
