@@ -46,13 +46,19 @@ PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r04", "bench_driver_summary.js
 
 def device_state():
     """Clocks, package power and temperatures as `rocm-smi` reports them right now (one subprocess, ~0.3 s): printed next to the numbers so
-    that a slow run can be told from a hot or throttled GPU.  None if the tool is missing."""
+    that a slow run can be told from a hot or throttled GPU.  If the tool cannot be run or says nothing the record holds the REASON
+    (`unavailable`) instead of silently being null (the driver's round-4 record was)."""
     import re
+    import shutil
     import subprocess
+    exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if exe is None:
+        return {"unavailable": "rocm-smi is neither on PATH nor under /opt/rocm/bin"}
     try:
-        out = subprocess.run(["rocm-smi", "--showtemp", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
-    except Exception:
-        return None
+        res = subprocess.run([exe, "--showtemp", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20)
+        out = res.stdout
+    except Exception as exc:
+        return {"unavailable": f"{exe}: {type(exc).__name__}: {str(exc)[:160]}"}
     state = {}
     try:   # which GPU of the node this is: the placements a process draws were seen to differ from GPU to GPU
         import torch
@@ -71,7 +77,10 @@ def device_state():
             state[key.split()[0] + "_MHz"] = int(mm.group(1)) if mm else val
         elif "Power" in key:
             state["power_W"] = val
-    return state or None
+    if not any(k != "gpu_uuid" for k in state):
+        state["unavailable"] = (f"{exe} exited with {res.returncode} and printed no GPU[0] lines; stderr: {res.stderr.strip()[:200]!r}; "
+                                f"stdout starts {out.strip()[:120]!r}")
+    return state
 
 
 def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
@@ -157,6 +166,35 @@ class HipBackend:
         return torch.cuda.stream(stream)
 
 
+def gpu_uuid(device, dry=False):
+    if dry:
+        return "cpu-dry-run"
+    try:
+        import torch
+        return str(torch.cuda.get_device_properties(device).uuid)
+    except Exception as exc:
+        return f"unavailable ({type(exc).__name__})"
+
+
+def gather_per_rank(dist, world, mine):
+    """Every rank's record on every rank (one small object all-gather, outside every timed region)."""
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
+
+
+def per_rank_summary(per_rank, n_gpus, envs_per_gpu):
+    """What the N-GPU line would be if every rank ran at the MEDIAN rank's pace: the distance between this and `value` is the
+    slowest GPU's doing, not the code's."""
+    if not per_rank:
+        return {}
+    ms = sorted(r["ms_per_step"] for r in per_rank)
+    med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+    return {"per_rank": per_rank,
+            "value_if_every_rank_were_median": round(n_gpus * envs_per_gpu / (med * 1e-3), 1),
+            "slowest_over_median_rank": round(ms[-1] / med, 4)}
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` with no launcher around it: start N ranks (one per GPU) with torch.distributed.run as
     CHILD processes.  Nothing in this parent has touched the GPU (torch is not even imported yet), so no process that has
@@ -230,13 +268,15 @@ def parse_args(argv):
                          "compact rows the policy kernels stage without conversion -- for policy_rollout)")
     ap.add_argument("--policy-arch", choices=["rllib", "fc256", "r3", "depth"], default="rllib",
                     help="policy_rollout: the network (rllib = what RLlib builds from the reference's model_config)")
-    ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls", "policy_rollout"], default="base",
+    ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls", "policy_rollout", "dict_api"], default="base",
                     help="base: BASELINE.json configs[2] (the headline); c4: configs[3] (64x64 grid, 16 predators / 32 prey, "
                          "7x7 windows); red_queen: the second-generation env (SURVEY 8(f) N2) with its reference config; "
                          "drive: the drive-conditioned variant of the default config; walls: the walls variant with the "
                          "reference's zigzag layout and every line-of-sight option on; policy_rollout: the headline envs driven by "
                          "the two policy networks of the reference's PPO setup evaluated on the matrix cores next to the env "
-                         "(SURVEY 8(f) N4; no observation leaves the GPU, roofline = bf16 MFMA)")
+                         "(SURVEY 8(f) N4; no observation leaves the GPU, roofline = bf16 MFMA); dict_api: the drop-in classes an existing "
+                         "script imports -- PredPreyGrass(config).step(action_dict) for one env and VectorPredPreyGrass(64) -- driven from "
+                         "the host like the reference's random_policy.py, every call crossing PCIe both ways (calls/s; latency-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0,
                     help="cpu_baseline: wall seconds of the all-cores leg (a single-thread leg of a third of that runs first)")
@@ -289,6 +329,105 @@ def parse_args(argv):
     ap.add_argument("--gather-wire", choices=["f32", "native"], default="native",
                     help="observation dtype on the wire in the gather legs (f32 halves the bytes of float64 observations)")
     return ap.parse_args(argv)
+
+
+def dict_api(args, backend, device):
+    """`--workload dict_api`: what a script gets that only changes its import (BASE:219,473; one env per runner, TUNE:179-185).
+    Leg 1: `PredPreyGrass(config)` -- reset(seed), then step(action_dict) with host-side random actions for every live agent (the protocol
+    of random_policy.py / SURVEY Appendix B), reset again when the episode ends.  Leg 2: `VectorPredPreyGrass(64)`, one action dict per
+    env, auto-reset.  Leg 3 (comparison): leg 1's loop with the data movement of rounds 1-4 -- one host->device copy of the actions, ten
+    `.cpu()` copies of the tables and two of the observation slabs per call -- behind the same dict assembly."""
+    import numpy as np
+    import torch
+    from predpreygrass_amd import _abi
+    from predpreygrass_amd.config import config_env
+    from predpreygrass_amd.env import PredPreyGrass, VectorPredPreyGrass
+    dry = backend.dry
+    kw = backend.env_kwargs()
+    lib_kw = {"_library": kw["_library"]} if "_library" in kw else {}
+    cfg = dict(config_env)
+    rng = np.random.default_rng(args.seed)
+    seconds = 0.3 if dry else max(2.0, min(args.cpu_seconds, 6.0))
+
+    def drive_one(env, step_fn, budget):
+        obs, _ = env.reset(seed=args.seed)
+        live = list(obs)
+        n, agents, t0 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            actions = {a: int(v) for a, v in zip(live, rng.integers(0, 9, len(live)))}
+            o, r, te, tr, _ = step_fn(env, actions)
+            n += 1
+            agents += len(o)
+            live = [a for a in o if not te.get(a, False)]
+            if te["__all__"] or tr["__all__"]:
+                obs, _ = env.reset(seed=args.seed + n)
+                live = list(obs)
+        return n / (time.perf_counter() - t0), agents / max(n, 1)
+
+    def legacy_step(env, action_dict):   # rounds 1-4: thirteen synchronous copies per call
+        b, i = env._b, env._i
+        rk, in_order = env._stage(action_dict)
+        b.actions[i].copy_(torch.from_numpy(np.array(b.stage_actions(i))))
+        b.step() if in_order else b.step(act_rank=rk[None].to(b.device))
+        t = b.host_tables(i)
+        es = t["env_state"][0]
+        nP, nQ = max(int(es[_abi.ENV_N_PRED_ROWS]), 1), max(int(es[_abi.ENV_N_PREY_ROWS]), 1)
+        obs = ({i: b.obs_pred[i, :nP].cpu().numpy()}, {i: b.obs_prey[i, :nQ].cpu().numpy()})
+        t["row_info"] = np.zeros((1, b.S), dtype=np.uint8)
+        return env._collect(False, {k: np.concatenate([v] * (i + 1)) for k, v in t.items()} if i else t, obs)
+
+    one = PredPreyGrass(cfg, device=None if dry else device, **lib_kw)
+    drive_one(one, lambda e, a: e.step(a), seconds / 4)   # warm-up
+    rate_one, agents_one = drive_one(one, lambda e, a: e.step(a), seconds)
+    rate_legacy, _ = drive_one(one, legacy_step, seconds / 2)
+    nv = 4 if dry else 64
+    vec = VectorPredPreyGrass(cfg, num_envs=nv, device=None if dry else device, seed=args.seed, auto_reset=True, **lib_kw)
+    res = vec.reset(seed=args.seed)
+    lives = [list(o) for o, _ in res]
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        acts = [{a: int(v) for a, v in zip(lv, rng.integers(0, 9, len(lv)))} for lv in lives]
+        out = vec.step(acts)
+        lives = [[a for a in o if not te.get(a, False)] for o, r, te, tr, info in out]
+        n += 1
+    rate_vec = n * nv / (time.perf_counter() - t0)
+    value = rate_vec
+    us_one = 1e6 / rate_one
+    # algorithmic bytes that cross PCIe per call of leg 1: the observation blocks in use + the env's state record + the action row
+    bytes_call = agents_one * (0.15 * 4 * 49 * 8 + 0.85 * 4 * 81 * 8) + 9000 + one._b.S
+    out = {
+        "metric": "env-steps/sec at 4096x(25x25) grids, 1/2/4/8 MI355X; % HBM roofline",
+        "value": round(value, 1), "unit": "env-steps/s", "n_gpus": 1, "steps": n, "warmup": 0,
+        "ms_per_step": round(1e3 / (rate_vec / nv), 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic" if not dry else "DRY RUN ON CPU (emulated kernel) -- not a measurement",
+        "config": {
+            "workload": ("DICT API, NOT the BASELINE.json headline config: the reference's own interface (BASE:219,473) driven from the host -- "
+                         f"`value` = VectorPredPreyGrass({nv}).step(list of action dicts) with auto-reset, default config, host-side random actions for "
+                         "every live agent; every call = one host->device copy of the actions, one kernel launch, one gather launch, ONE device->host "
+                         "copy (ppg_fetch), the reference's dicts rebuilt in Python"),
+            "single_env": {"calls_per_s": round(rate_one, 1), "us_per_call": round(us_one, 1), "mean_agents_per_call": round(agents_one, 1),
+                           "what": "PredPreyGrass(config).reset(seed) / .step(action_dict), one env (what one RLlib env runner holds, TUNE:179-185)"},
+            "single_env_rounds_1_to_4_data_movement": {"calls_per_s": round(rate_legacy, 1), "us_per_call": round(1e6 / rate_legacy, 1),
+                                                       "what": "the same loop with thirteen synchronous copies per call (ten table .cpu(), two observation slabs, one action row)"},
+            "speedup_vs_rounds_1_to_4": round(rate_one / rate_legacy, 2),
+            "vector_env": {"envs": nv, "env_steps_per_s": round(rate_vec, 1), "calls_per_s": round(rate_vec / nv, 1)},
+            "reference_python_fixed": "reference Python step(): 45 env-steps/s (default config) / 441 (C1) on 1 core, ~400 on 8 cores (BASELINE.md section 2)",
+        },
+        "roofline": {"bound": "hbm", "achieved": round(bytes_call * rate_one / 1e9, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(bytes_call * rate_one / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                     "note": "a latency-bound path by construction (one env per call, PCIe round trip + Python dict assembly per call): the fraction "
+                             "of the HBM peak is printed for the contract's sake and says nothing here; the HBM-bound figure is the default workload's"},
+    }
+    if not args.no_cpu_baseline and not dry:
+        from oracle.ppg_oracle import OracleEnv
+        env = OracleEnv(cfg)
+        t0, steps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < min(args.cpu_seconds, 4.0):
+            steps += env.rollout_random(args.seed, 2000)
+        out["cpu_baseline"] = {"value": round(steps / (time.perf_counter() - t0), 1), "unit": "env-steps/s", "cores": 1, "kind": "port",
+                               "sample": "oracle/ppg_oracle.c, one env on one host thread, default config, random actions + auto-reset "
+                                         "(no Python dicts: the C restatement's own loop)"}
+    print(json.dumps(out), flush=True)
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
@@ -359,7 +498,9 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
     if distributed:
         dist.barrier()
     wall = time.perf_counter() - t0
+    per_rank = None
     if distributed:
+        per_rank = gather_per_rank(dist, n_gpus, {"rank": rank, "ms_per_step": round(wall / args.steps * 1e3, 5), "gpu_uuid": gpu_uuid(device)})
         t = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -402,6 +543,7 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
                          "note": "flops = 2 x multiply-accumulates of the network's layers (no padding counted) x observations evaluated; "
                                  "kernel_ms = both species' forward launches + their plan launches per step (HIP events on the stream)"},
         }
+        out.update(per_rank_summary(per_rank, n_gpus, B))
         if not args.no_cpu_baseline and n_gpus == 1:
             n_threads = min(os.cpu_count() or 1, 32)   # (more threads than that make these small convolutions slower, not faster)
             torch.set_num_threads(n_threads)
@@ -463,6 +605,10 @@ def main(argv=None, backend=None):
 
     if args.workload == "policy_rollout":
         return policy_rollout(args, backend, device, distributed, rank, n_gpus)
+    if args.workload == "dict_api":
+        if distributed:
+            raise SystemExit("bench.py: --workload dict_api is a one-process leg")
+        return dict_api(args, backend, device)
     rq = args.workload in ("red_queen", "walls")
     extra_kw = {}
     if args.obs_dtype is None:
@@ -600,7 +746,15 @@ def main(argv=None, backend=None):
     wall = time.perf_counter() - t0
     # mean launch-to-launch time of the step kernel on each stream (the n_sub streams run concurrently)
     dev_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / len(ev0)
+    per_rank = None
     if distributed:
+        # `value` is set by the SLOWEST rank (max over ranks, below) -- and the GPUs of this pool differ by up to 25 % on this kernel with
+        # identical clocks (profiles/r04/t_driver_command_on_eighteen_fresh_boxes.txt).  Every rank's own numbers travel with the line so
+        # that a slow GPU can be told from a scaling problem.
+        per_rank = gather_per_rank(dist, world, {
+            "rank": rank, "ms_per_step": round(wall / args.steps * 1e3, 5), "kernel_ms": round(dev_ms / args.steps, 5),
+            "placement_probe_us_min": None if not group.placement_probe_us else round(min(group.placement_probe_us), 1),
+            "gpu_uuid": gpu_uuid(device, dry)})
         t = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -632,7 +786,9 @@ def main(argv=None, backend=None):
                      "ms_per_step": ts / args.sustained_steps * 1e3}
 
     # clocks / power / temperatures WHILE the same loop runs (untimed extra steps on rank 0 for as long as one rocm-smi call takes)
-    dev_state = None
+    dev_state = {"unavailable": "not sampled: " + ("dry run" if dry else "not rank 0" if rank != 0 else "PMC child run" if args.traffic_child
+                                                   else "--sustained-steps 0" if args.sustained_steps <= 0 else "a profiler is attached "
+                                                   "(LD_PRELOAD / ROCP* in the environment: rocm-smi would be an exec from a GPU-initialised process)")}
     # (never under a profiler: its preloaded library initialises the GPU in every child process, and rocm-smi is a `#!/usr/bin/env python3`
     #  script -- an exec from a GPU-initialised process, which the GPU boxes refuse)
     under_profiler = bool(os.environ.get("LD_PRELOAD")) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
@@ -646,7 +802,7 @@ def main(argv=None, backend=None):
                 one_step()
             backend.synchronize(device)
         th.join()
-        dev_state = box.get("state")
+        dev_state = box.get("state") or {"unavailable": "the sampling thread returned nothing"}
 
     # ---- third leg: the FUSED rollout -- ppg_rollout(n): n transitions per launch, the device-side random policy, observations
     # written every step exactly as above (bit-identical to n ppg_step calls; tests).  Reported next to `value`, never as `value`:
@@ -732,11 +888,13 @@ def main(argv=None, backend=None):
             backend.synchronize(device)
             dist.barrier()
             tg = time.perf_counter() - tg
+            leg_ranks = gather_per_rank(dist, world, {"rank": rank, "ms_per_step": round(tg / args.gather_steps * 1e3, 4)})
             t = torch.tensor([tg], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             hs = g.headers()
             return {"value": round(n_gpus * B * args.gather_steps / float(t.item()), 1), "unit": "env-steps/s",
                     "steps": args.gather_steps, "ms_per_step": round(float(t.item()) / args.gather_steps * 1e3, 4),
+                    "per_rank_ms_per_step": [r["ms_per_step"] for r in leg_ranks],
                     "collectives_per_step": 1,
                     "wire_bytes_per_step_per_rank": int(g.capacity),
                     "image_bytes_used_last_step": [int(h.bytes_used) for h in hs],
@@ -900,6 +1058,7 @@ def main(argv=None, backend=None):
             },
             "roofline": roof,
         }
+        out.update(per_rank_summary(per_rank, n_gpus, B))
         if fused is not None:
             out["fused_rollout"] = fused
         if gather_info is not None:

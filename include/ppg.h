@@ -426,6 +426,36 @@ uint64_t ppg_pack_bytes(const ppg_handle *h, int32_t n_envs, int64_t n_pred_rows
 /* asynchronous on `stream`, which the caller has ordered behind the handles' last step (two small launches) */
 int ppg_pack(ppg_handle *const *handles, int32_t n, void *out, uint64_t capacity, uint32_t flags, void *stream);
 
+/* ---- host view of the last call (what PredPreyGrass.step() hands back, BASE:219,456-473) -------------------------
+ * The reference's step() returns Python dicts of one env; the dict classes of this library rebuild them from the row
+ * tables and the observation rows IN USE.  ppg_fetch brings exactly that to the host in ONE image -- one gather launch
+ * into a library-owned staging buffer, one asynchronous copy into `host` (pinned memory keeps it asynchronous), one
+ * stream synchronisation -- for the envs [env0, env0 + n_envs) of a handle:
+ *   ppg_fetch_header | n_envs x record | observation sections, env by env
+ * record (record_bytes each) = the env's slice of every state tensor in the order of the state image (ppg_export_state):
+ *   row_xy u16[S] | row_energy f64[S] | row_id i32[S] | row_key i32[S] | row_cumrew f64[S] | row_flags u8[S] |
+ *   row_reward f64[S] | row_parent i32[S] | env_state i32[PPG_ENV_WORDS] | env_seed u64 | grass_xy u16[NG] |
+ *   grass_energy f64[NG] | second generation: row_lastrep i32[S] | walls: row_info u8[S], wall_bits u32[n_wall_words]
+ * each slice padded to 8 bytes, the record to 16.  Observation section of an env = its predator blocks in use
+ * (env word PPG_ENV_N_PRED_ROWS of them, blk_pred_bytes each), padded to 16 bytes, then its prey blocks likewise, in the
+ * handle's observation dtype.  If the image does not fit `capacity`, header.overflow = 1, bytes_used = the size it needs
+ * and only header + records are valid.  Synchronous: the image is complete when the call returns. */
+#define PPG_FETCH_MAGIC 0x46475050u /* "PPGF" */
+#define PPG_FETCH_VERSION 1u
+typedef struct ppg_fetch_header {
+    uint32_t magic, version;
+    uint32_t env0, n_envs;
+    uint32_t record_bytes;
+    uint32_t blk_pred_bytes, blk_prey_bytes;
+    uint32_t overflow;
+    uint64_t bytes_used, capacity;
+    uint32_t reserved[4];
+} ppg_fetch_header;                /* 64 bytes */
+
+/* size of an image of n_envs envs with the given row totals (upper bound: every run of blocks padded to 16 bytes) */
+uint64_t ppg_fetch_bytes(const ppg_handle *h, int32_t n_envs, int64_t n_pred_rows, int64_t n_prey_rows);
+int ppg_fetch(ppg_handle *h, int32_t env0, int32_t n_envs, void *host, uint64_t capacity, void *stream);
+
 /* ---- policy inference next to the env (base_environment/tune_ppo_base_environment.py:106-141) ----------
  * The reference trains two PPO policies (predator_policy / prey_policy) with RLlib's DefaultPPOTorchRLModule and
  * model_config {conv_filters [[16,[3,3],1],[32,[3,3],1],[64,[3,3],1]], fcnet_hiddens [256,256], fcnet_activation relu}.

@@ -88,6 +88,14 @@ class PpgConfigGen2(C.Structure):
 PACK_MAGIC, PACK_VERSION, PACK_F32, PACK_MAX_HANDLES = 0x4B475050, 1, 0x1, 8
 PACK_NO_OBS = 0x2
 STATE_MAGIC, STATE_VERSION = 0x53475050, 1
+FETCH_MAGIC, FETCH_VERSION = 0x46475050, 1
+
+
+class PpgFetchHeader(C.Structure):
+    """include/ppg.h: struct ppg_fetch_header (64 bytes, little endian)."""
+    _fields_ = [(n, C.c_uint32) for n in ("magic", "version", "env0", "n_envs", "record_bytes", "blk_pred_bytes", "blk_prey_bytes",
+                                          "overflow")] + [("bytes_used", C.c_uint64), ("capacity", C.c_uint64),
+                                                          ("reserved", C.c_uint32 * 4)]
 
 
 class PpgPackHeader(C.Structure):
@@ -152,6 +160,7 @@ EXPORTED_SYMBOLS = [
     "ppg_rollout", "ppg_step_ordered", "ppg_create_gen2", "ppg_step_uniforms", "ppg_set_envs_in_flight", "ppg_set_wave_plan",
     "ppg_get_wave_plan", "ppg_rebalance",
     "ppg_export_grid", "ppg_walls_changed", "ppg_state_bytes", "ppg_export_state", "ppg_import_state", "ppg_pack_bytes", "ppg_pack",
+    "ppg_fetch_bytes", "ppg_fetch",
     "ppg_lexkey", "ppg_lds_bytes", "ppg_step_kernel_name", "ppg_last_error",
 ] + POLICY_SYMBOLS + SPREAD_SYMBOLS
 
@@ -205,6 +214,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.ppg_pack_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_uint32]
     lib.ppg_pack.restype = C.c_int
     lib.ppg_pack.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    lib.ppg_fetch_bytes.restype = C.c_uint64
+    lib.ppg_fetch_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64]
+    lib.ppg_fetch.restype = C.c_int
+    lib.ppg_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p]
     if hasattr(lib, "ppg_alloc_spread"):
         lib.ppg_alloc_spread.restype = C.c_int
         lib.ppg_alloc_spread.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]

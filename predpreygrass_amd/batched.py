@@ -400,7 +400,86 @@ class BatchedPredPreyGrass:
         return self
 
     # ------------------------------------------------------------------
-    # host views (one device->host copy each; used by the dict API and by tests)
+    # the dict classes' host traffic: ONE copy each way per call (`ppg_fetch`, include/ppg.h)
+    def _fetch_fields(self):
+        """(name, numpy dtype, elements) of an env's record in a fetch image: the state image's field order (include/ppg.h)."""
+        S, NG = self.S, self.grass_capacity
+        f = [("row_xy", "<i2", S), ("row_energy", "<f8", S), ("row_id", "<i4", S), ("row_key", "<i4", S), ("row_cumrew", "<f8", S),
+             ("row_flags", "u1", S), ("row_reward", "<f8", S), ("row_parent", "<i4", S), ("env_state", "<i4", _abi.ENV_WORDS),
+             ("env_seed", "<i8", 1), ("grass_xy", "<i2", NG), ("grass_energy", "<f8", NG)]
+        if hasattr(self, "walls"):   # BatchedRedQueen (ppg_create_gen2)
+            f.append(("row_lastrep", "<i4", S))
+            if self.walls:
+                f += [("row_info", "u1", S), ("wall_bits", "<i4", int(self.wall_bits.shape[1]))]
+        return f
+
+    def _host_buffer(self, nbytes, dtype=torch.uint8):
+        """Host memory the library copies into / out of: pinned on a GPU (the copy is then asynchronous), plain for the CPU test build."""
+        if self.device.type == "cuda":
+            return torch.empty((nbytes,), dtype=dtype).pin_memory()
+        return torch.empty((nbytes,), dtype=dtype)
+
+    def fetch(self, env0=0, n=None):
+        """What the last call returned for envs [env0, env0 + n), on the host after ONE gather launch, ONE device->host copy and ONE
+        stream synchronisation (`ppg_fetch`): (tables, obs_pred, obs_prey) -- tables[name] is the [n, ...] slice of every state tensor
+        (a copy), obs_pred[i] / obs_prey[i] the observation blocks IN USE of env env0 + i as arrays [rows, C, R, R] (views into the
+        staging buffer: valid until the next fetch)."""
+        if self.obs_dtype not in (torch.float64, torch.float32):
+            raise RuntimeError("fetch() hands observations to numpy: float64 or float32 rows")
+        n = self.batch_size - env0 if n is None else int(n)
+        if getattr(self, "_fetch_host", None) is None:
+            guess = int(self._lib.ppg_fetch_bytes(self._handle, n, n * min(self.pred_capacity, 24), n * min(self.prey_capacity, 96)))
+            self._fetch_host = self._host_buffer(guess)
+        for _ in range(3):
+            cap = self._fetch_host.numel()
+            rc = self._lib.ppg_fetch(self._handle, int(env0), n, C.c_void_p(self._fetch_host.data_ptr()), cap, self._stream())
+            if rc == -1 and cap < int(self._lib.ppg_fetch_bytes(self._handle, n, 0, 0)):   # (more envs than the buffer was sized for)
+                self._fetch_host = self._host_buffer(int(self._lib.ppg_fetch_bytes(self._handle, n, n * 24, n * 96)))
+                continue
+            self._check(rc, "ppg_fetch")
+            buf = self._fetch_host.numpy()
+            H = _abi.PpgFetchHeader.from_buffer(buf[:64])
+            if H.magic != _abi.FETCH_MAGIC or H.version != _abi.FETCH_VERSION:
+                raise RuntimeError("ppg_fetch returned an image of another version")
+            if not H.overflow:
+                break
+            self._fetch_host = self._host_buffer(int(H.bytes_used) * 3 // 2)
+        else:
+            raise RuntimeError("ppg_fetch: the image keeps overflowing")
+        rec_bytes, bp, bq = int(H.record_bytes), int(H.blk_pred_bytes), int(H.blk_prey_bytes)
+        rec = np.array(buf[64:64 + n * rec_bytes]).reshape(n, rec_bytes)   # (a copy: the tables outlive the staging buffer's next use)
+        tables, off = {}, 0
+        for name, dt, count in self._fetch_fields():
+            nb = np.dtype(dt).itemsize * count
+            tables[name] = rec[:, off:off + nb].view(dt)
+            off += (nb + 7) // 8 * 8
+        if "row_info" not in tables:
+            tables["row_info"] = np.zeros((n, self.S), dtype=np.uint8)
+        es = tables["env_state"]
+        npred, nprey = es[:, _abi.ENV_N_PRED_ROWS].astype(np.int64), es[:, _abi.ENV_N_PREY_ROWS].astype(np.int64)
+        sec_p, sec_q = (npred * bp + 15) // 16 * 16, (nprey * bq + 15) // 16 * 16
+        start = 64 + n * rec_bytes + np.concatenate([[0], np.cumsum(sec_p + sec_q)[:-1]])
+        odt = np.float64 if self.obs_dtype == torch.float64 else np.float32
+        pshape, qshape = tuple(self.obs_pred.shape[2:]), tuple(self.obs_prey.shape[2:])
+        obs_p = [buf[int(o):int(o) + int(k) * bp].view(odt).reshape((int(k),) + pshape) for o, k in zip(start, npred)]
+        obs_q = [buf[int(o):int(o) + int(k) * bq].view(odt).reshape((int(k),) + qshape) for o, k in zip(start + sec_p, nprey)]
+        return tables, obs_p, obs_q
+
+    def stage_actions(self, env=None):
+        """The pinned host mirror of the action tensor (int8 numpy [B,S]) and its upload: fill `stage_actions()` rows, then
+        `upload_actions()` -- ONE asynchronous host->device copy for all envs."""
+        if getattr(self, "_act_host", None) is None:
+            self._act_host = self._host_buffer(self.batch_size * self.S, torch.int8).view(self.batch_size, self.S)
+            self._act_host.fill_(_abi.ACTION_NONE)
+        a = self._act_host.numpy()
+        return a if env is None else a[env]
+
+    def upload_actions(self):
+        self.actions.copy_(self._act_host, non_blocking=True)
+        return self
+
+    # ------------------------------------------------------------------
+    # host views (one device->host copy each; used by tests and by white-box state surgery)
     def host_tables(self, b=None):
         """Small per-env tables copied to the host as numpy arrays."""
         sl = slice(None) if b is None else slice(b, b + 1)

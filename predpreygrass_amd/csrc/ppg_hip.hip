@@ -130,7 +130,12 @@ static void backend_release(ppg_handle *h) {
     h->coop_tab_dev = nullptr;
     if (h->order_dev) (void)hipFree(h->order_dev);
     h->order_dev = nullptr;
+    if (h->fetch_dev) (void)hipFree(h->fetch_dev);
+    h->fetch_dev = nullptr;
+    h->fetch_cap = 0;
 }
+
+static void backend_free(ppg_handle *, void *p) { (void)hipFree(p); }
 
 // order[] = the envs sorted by descending key (rows weighted by observation size): a counting sort in ONE workgroup, O(B) for any
 // batch size.  Keys are small (<= 64 * 8 + 256 * 8), so the histogram lives in LDS; envs with equal keys land in arbitrary order
@@ -188,6 +193,20 @@ static int backend_pack(ppg_handle *h, const ppg::PackParams &K, void *stream) {
     if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(ppg_pack_scan, dim3(1), dim3(64), 0, (hipStream_t)stream, K);
     hipLaunchKernelGGL(ppg_pack_rows, dim3((unsigned)K.n_envs), dim3(64), 0, (hipStream_t)stream, K);
+    PPG_HIP_TRY(h, hipGetLastError());
+    return PPG_OK;
+}
+
+// ---- ppg_fetch: the host view of a run of envs (ppg_fetch.h) ------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) ppg_fetch_rows(const ppg::FetchParams K) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[1024];
+    ppg::fetch_main(*PPG_KERNARG_PTR(ppg::FetchParams, K), lds);
+}
+
+static int backend_fetch(ppg_handle *h, const ppg::FetchParams &K, void *stream) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(ppg_fetch_rows, dim3((unsigned)K.n_envs), dim3(64), 0, (hipStream_t)stream, K);
     PPG_HIP_TRY(h, hipGetLastError());
     return PPG_OK;
 }

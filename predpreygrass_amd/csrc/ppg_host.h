@@ -18,6 +18,7 @@
 
 #include "ppg_kernel.h"
 #include "ppg_pack.h"
+#include "ppg_fetch.h"
 
 // How a handle's step is scheduled (never what it computes): wavefronts per workgroup, the row count from which helper wavefronts
 // stay, and -- cooperative kernels -- how many envs share a workgroup (0 = one env per workgroup, the ppg[w]_step kernels).
@@ -34,6 +35,9 @@ struct ppg_handle {
     int32_t envs_in_flight;  // scheduling hint (ppg_set_envs_in_flight); 0 = the handle's own batch
     int32_t *order_dev;      // library-owned [batch]: env order of ppg_rebalance (NULL until first used)
     uint32_t *vis_dev;       // library-owned [batch, G*G, vis_words]: line-of-sight masks of the walls variant (ppg_walls_changed)
+    unsigned char *fetch_dev;   // library-owned staging buffer of ppg_fetch (NULL until first used)
+    uint64_t fetch_cap;         // its size
+    uint64_t fetch_hint;        // bytes the next ppg_fetch copies in its first (usually only) transfer
     ppg_config cfg;
     ppg_config_gen2 cfg2;
     int32_t gen2;  // created by ppg_create_gen2
@@ -437,6 +441,9 @@ static int backend_alloc(ppg_handle *h, void **out, size_t bytes);   // device m
 static int backend_sync(ppg_handle *h, void *stream);
 // the two launches of ppg_pack (ppg_pack.h)
 static int backend_pack(ppg_handle *h, const ppg::PackParams &K, void *stream);
+// the launch of ppg_fetch (ppg_fetch.h), and the release of a buffer from backend_alloc
+static int backend_fetch(ppg_handle *h, const ppg::FetchParams &K, void *stream);
+static void backend_free(ppg_handle *h, void *p);
 
 // The state tensors of one env, in image order (include/ppg.h: ppg_state_header): pointer, bytes per env.
 struct ppg_state_field { void *base; size_t bytes; };
@@ -475,6 +482,7 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     h->envs_in_flight = 0;
     h->order_dev = nullptr;
     h->vis_dev = nullptr;
+    h->fetch_dev = nullptr; h->fetch_cap = 0; h->fetch_hint = 0;
     h->drive = (cfg && (cfg->n_drive[0] > 0 || cfg->n_drive[1] > 0)) ? 1 : 0;
     int rc = cfg2 ? ppg_validate_and_layout_gen2(h) : ppg_validate_and_layout(h);
     if (rc == PPG_OK) ppg_coop_layout(h);
@@ -865,6 +873,71 @@ int ppg_pack(ppg_handle *const *handles, int32_t n, void *out, uint64_t capacity
     if (capacity < fixed) return ppg_fail(h0, PPG_EINVAL, "capacity %llu is below the fixed part of the image (%llu bytes for %d envs)",
                                           (unsigned long long)capacity, (unsigned long long)fixed, total);
     return backend_pack(h0, K, stream);
+}
+
+static void ppg_fetch_geometry(const ppg_handle *h, uint32_t &rec, uint32_t &bp, uint32_t &bq) {
+    ppg_state_field f[16];
+    const int n = ppg_state_fields(h, f);
+    uint64_t r = 0;
+    for (int i = 0; i < n; ++i) r += (f[i].bytes + 7) / 8 * 8;
+    rec = (uint32_t)((r + 15) / 16 * 16);
+    int blk_p, blk_q, se, de;
+    ppg_pack_geometry(h, 0, blk_p, blk_q, se, de);
+    bp = (uint32_t)(blk_p * se); bq = (uint32_t)(blk_q * se);
+}
+
+uint64_t ppg_fetch_bytes(const ppg_handle *h, int32_t n_envs, int64_t n_pred_rows, int64_t n_prey_rows) {
+    if (!h || n_envs < 0 || n_pred_rows < 0 || n_prey_rows < 0) return 0;
+    uint32_t rec, bp, bq;
+    ppg_fetch_geometry(h, rec, bp, bq);
+    return sizeof(ppg_fetch_header) + (uint64_t)n_envs * rec + (uint64_t)n_pred_rows * bp + (uint64_t)n_prey_rows * bq + (uint64_t)n_envs * 32;
+}
+
+int ppg_fetch(ppg_handle *h, int32_t env0, int32_t n_envs, void *host, uint64_t capacity, void *stream) {
+    if (!h) return PPG_EINVAL;
+    if (!host || ((uintptr_t)host & 15u)) return ppg_fail(h, PPG_EINVAL, "host must be a 16-byte aligned host pointer");
+    if (env0 < 0 || n_envs < 1 || env0 + n_envs > h->batch) return ppg_fail(h, PPG_EINVAL, "envs [%d, %d) not in 0..%d", env0, env0 + n_envs, h->batch);
+    ppg::FetchParams K;
+    memset(&K, 0, sizeof K);
+    ppg_fetch_geometry(h, K.record_bytes, K.blk_pred_bytes, K.blk_prey_bytes);
+    const uint64_t fixed = sizeof(ppg_fetch_header) + (uint64_t)n_envs * K.record_bytes;
+    if (capacity < fixed) return ppg_fail(h, PPG_EINVAL, "capacity %llu is below the fixed part of the image (%llu bytes for %d envs)",
+                                          (unsigned long long)capacity, (unsigned long long)fixed, n_envs);
+    ppg_state_field f[16];
+    K.n_fields = ppg_state_fields(h, f);
+    for (int i = 0; i < K.n_fields; ++i) { K.field[i] = (const unsigned char *)f[i].base; K.field_bytes[i] = (uint32_t)f[i].bytes; }
+    K.env0 = env0; K.n_envs = n_envs;
+    K.env_state = h->bufs.env_state;
+    K.obs_pred = (const unsigned char *)h->bufs.obs_pred; K.obs_prey = (const unsigned char *)h->bufs.obs_prey;
+    K.cap_pred = h->base.cap_pred; K.cap_prey = h->base.cap_prey;
+    K.capacity = capacity;
+    if (h->fetch_cap < capacity) {   // the staging buffer grows with the largest image asked for
+        if (h->fetch_dev) { const int rc = backend_sync(h, stream); if (rc != PPG_OK) return rc; backend_free(h, h->fetch_dev); }
+        h->fetch_dev = nullptr; h->fetch_cap = 0;
+        const int rc = backend_alloc(h, (void **)&h->fetch_dev, (size_t)capacity);
+        if (rc != PPG_OK) return rc;
+        h->fetch_cap = capacity;
+    }
+    K.out = h->fetch_dev;
+    int rc = backend_fetch(h, K, stream);
+    if (rc != PPG_OK) return rc;
+    // ONE transfer in the common case: as many bytes as the last image took plus a margin (births add rows); the header then says
+    // whether a second transfer has to bring the rest
+    uint64_t first = h->fetch_hint ? h->fetch_hint : capacity;
+    if (first < fixed) first = fixed;
+    if (first > capacity) first = capacity;
+    rc = backend_copy(h, host, h->fetch_dev, (size_t)first, false, stream);
+    if (rc == PPG_OK) rc = backend_sync(h, stream);
+    if (rc != PPG_OK) return rc;
+    const ppg_fetch_header *H = (const ppg_fetch_header *)host;
+    if (H->magic != PPG_FETCH_MAGIC) return ppg_fail(h, PPG_EHIP, "ppg_fetch: the image has no header (magic 0x%x)", H->magic);
+    if (!H->overflow && H->bytes_used > first) {
+        rc = backend_copy(h, (unsigned char *)host + first, h->fetch_dev + first, (size_t)(H->bytes_used - first), false, stream);
+        if (rc == PPG_OK) rc = backend_sync(h, stream);
+        if (rc != PPG_OK) return rc;
+    }
+    h->fetch_hint = H->bytes_used + H->bytes_used / 4 + 4096;
+    return PPG_OK;
 }
 
 #ifdef PPG_PROFILE_PHASES

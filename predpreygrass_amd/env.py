@@ -143,7 +143,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
         batch's action tensor.  Returns (ranks uint8 [S], dict order == row order)."""
         b, i = self._b, self._i
         where = {name: (ty, row) for name, ty, row, _, te, _ in self._records if not te}
-        a = torch.full((b.S,), _abi.ACTION_NONE, dtype=torch.int8)
+        a = b.stage_actions(i)     # this env's row of the pinned host mirror of the action tensor
+        a[:] = _abi.ACTION_NONE
         rk = torch.zeros((b.S,), dtype=torch.uint8)
         last = {PREDATOR: -1, PREY: -1}
         count = {PREDATOR: 0, PREY: 0}
@@ -165,7 +166,6 @@ class PredPreyGrass(_MultiAgentEnvBase):
             if row < last[ty]:
                 in_row_order = False
             last[ty] = row
-        b.actions[i].copy_(a)
         return rk, in_row_order
 
     def step(self, action_dict):
@@ -174,6 +174,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
         if b.batch_size != 1:
             raise RuntimeError("step() of a view into a shared batch: use VectorPredPreyGrass.step")
         rk, in_row_order = self._stage(action_dict)
+        b.upload_actions()   # one host->device copy; the step and the fetch behind it are ordered on the same stream
         if in_row_order:
             b.step()
         else:
@@ -186,7 +187,12 @@ class PredPreyGrass(_MultiAgentEnvBase):
     # ------------------------------------------------------------------
     def _collect(self, after_reset, tables=None, obs=None):
         b, i = self._b, self._i
-        t = b.host_tables(i) if tables is None else {k: v[i:i + 1] for k, v in tables.items()}
+        if tables is None:   # ONE device->host copy: this env's tables and its observation rows in use (ppg_fetch)
+            t, fp, fq = b.fetch(i, 1)
+            op, oq = fp[0], fq[0]
+        else:
+            t = {k: v[i:i + 1] for k, v in tables.items()}
+            op, oq = obs[0][i], obs[1][i]
         self._tables = t
         es = t["env_state"][0]
         status = int(es[_abi.ENV_STATUS])
@@ -195,13 +201,6 @@ class PredPreyGrass(_MultiAgentEnvBase):
         if status & _abi.STATUS_FAILED_SPAWN:
             raise TypeError("no free cell for a newborn (the reference fails at predpreygrass_rllib_env.py:401-405)")
         recs = b.records(0, t)
-        if obs is None:  # copy only the rows in use (a (4,R,R) float64 block is 1.5-2.6 KB; the tables hold 64 + 128)
-            nP = max(int(es[_abi.ENV_N_PRED_ROWS]), 1)
-            nQ = max(int(es[_abi.ENV_N_PREY_ROWS]), 1)
-            op = b.obs_pred[i, :nP].cpu().numpy()
-            oq = b.obs_prey[i, :nQ].cpu().numpy()
-        else:
-            op, oq = obs[0][i], obs[1][i]
         obs, rew, term, trunc = {}, {}, {}, {}
         for name, ty, row, r, te, tr in recs:
             obs[name] = (op if ty == PREDATOR else oq)[row].astype(np.float64)
@@ -416,10 +415,8 @@ class VectorPredPreyGrass:
 
     def _collect_all(self, after_reset):
         b = self.batch
-        tables = b.host_tables()
-        nP = int(tables["env_state"][:, _abi.ENV_N_PRED_ROWS].max())
-        nQ = int(tables["env_state"][:, _abi.ENV_N_PREY_ROWS].max())
-        obs = (b.obs_pred[:, :max(nP, 1)].cpu().numpy(), b.obs_prey[:, :max(nQ, 1)].cpu().numpy())
+        tables, obs_p, obs_q = b.fetch()   # every env's tables and observation rows in use: ONE device->host copy
+        obs = (obs_p, obs_q)
         out = []
         for i, e in enumerate(self.envs):
             was_reset = bool(int(tables["env_state"][i][_abi.ENV_FLAGS]) & _abi.ENVF_WAS_RESET)
@@ -448,11 +445,12 @@ class VectorPredPreyGrass:
         for i, (e, ad) in enumerate(zip(self.envs, action_dicts)):
             done = bool(int(e._tables["env_state"][0][_abi.ENV_FLAGS]) & _abi.ENVF_DONE)
             if self.auto_reset and done:
-                b.actions[i].fill_(_abi.ACTION_NONE)  # ignored: this call resets the env
+                b.stage_actions(i)[:] = _abi.ACTION_NONE  # ignored: this call resets the env
                 continue
             rk, in_order = e._stage(ad)
             ranks[i] = rk
             all_in_order = all_in_order and in_order
+        b.upload_actions()   # ONE host->device copy for all envs
         if all_in_order:
             b.step(auto_reset=self.auto_reset)
         else:

@@ -416,7 +416,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
         """RQ:197-299."""
         b = self._b
         where = {name: (sp, row) for name, sp, row, _, te, _ in self._records if not te}
-        a = torch.full((b.S,), _abi.ACTION_NONE, dtype=torch.int8)
+        a = b.stage_actions(0)     # the pinned host mirror of the action tensor
+        a[:] = _abi.ACTION_NONE
         rk = torch.zeros((b.S,), dtype=torch.uint8)
         last, count, in_order = [-1, -1], [0, 0], True
         truncated_call = self.current_step >= self.max_steps
@@ -437,7 +438,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
             # the reference itself fails for a live agent without an action (KeyError in its per-step bookkeeping, RQ:279)
             missing = [n for n in where if n not in action_dict]
             raise KeyError(missing[0])
-        b.actions[0].copy_(a)
+        b.upload_actions()
         # the uniforms self.rng.random() would hand out (RQ:701,708): at most two per live agent; the stream is then
         # advanced by exactly the number the step consumed
         state = self.rng.bit_generator.state
@@ -454,7 +455,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
     # ------------------------------------------------------------------
     def _collect(self, after_reset):
         b = self._b
-        t = b.host_tables(0)
+        t, fp, fq = b.fetch(0, 1)   # ONE device->host copy: the tables and the observation rows in use (ppg_fetch)
         self._tables = t
         es = t["env_state"][0]
         status = int(es[_abi.ENV_STATUS])
@@ -463,9 +464,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
         if status & _abi.STATUS_FAILED_SPAWN:
             raise TypeError("no free cell for a newborn (the reference fails at RQ:751-760)")
         recs = b.records(0, t)
-        nP, nQ = max(int(es[_abi.ENV_N_PRED_ROWS]), 1), max(int(es[_abi.ENV_N_PREY_ROWS]), 1)
-        op = b.obs_pred[0, :nP].cpu().numpy()
-        oq = b.obs_prey[0, :nQ].cpu().numpy()
+        op, oq = fp[0], fq[0]
         obs, rew, term, trunc = {}, {}, {}, {}
         for name, sp, row, r, te, tr in recs:
             obs[name] = (oq if sp else op)[row].astype(np.float32)

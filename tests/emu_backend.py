@@ -15,7 +15,8 @@ _KERNEL_SOURCES = [
     os.path.join(ROOT, "include", "ppg.h"),
 ]
 _SOURCES = _KERNEL_SOURCES + [os.path.join(EMU_DIR, "ppg_emu.cpp"), os.path.join(ROOT, "predpreygrass_amd", "csrc", "ppg_host.h"),
-                              os.path.join(ROOT, "predpreygrass_amd", "csrc", "ppg_pack.h")]
+                              os.path.join(ROOT, "predpreygrass_amd", "csrc", "ppg_pack.h"),
+                              os.path.join(ROOT, "predpreygrass_amd", "csrc", "ppg_fetch.h")]
 _lib = None
 
 
@@ -23,18 +24,27 @@ def _stale(out, sources):
     return not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in sources)
 
 
+def asan_runtime():
+    """Path of gcc's libasan.so: an AddressSanitizer build can only be loaded into a process that has it preloaded (LD_PRELOAD)."""
+    return subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+
+
 def build(sanitize=False):
-    """libppg_emu.so (libppg_emu_ubsan.so): the dispatch / C-ABI unit and twelve kernel units (family x prey registers), compiled
-    in parallel (one translation unit took six minutes under UBSan)."""
-    out = EMU_LIB if not sanitize else EMU_LIB.replace(".so", "_ubsan.so")
+    """libppg_emu.so (libppg_emu_ubsan.so / libppg_emu_asan.so): the dispatch / C-ABI unit and twelve kernel units (family x prey
+    registers), compiled in parallel (one translation unit took six minutes under UBSan).  sanitize: False, True (= "undefined") or
+    "address" -- the AddressSanitizer build also poisons the bytes behind a workgroup's LDS (wave_emu.h), so that an out-of-bounds
+    LDS READ traps too (round 3's advisor found one that UBSan cannot see)."""
+    asan = sanitize == "address"
+    out = EMU_LIB if not sanitize else EMU_LIB.replace(".so", "_asan.so" if asan else "_ubsan.so")
     if not _stale(out, _SOURCES):
         return out
     from concurrent.futures import ThreadPoolExecutor
-    tag = f"{'ubsan' if sanitize else 'emu'}.{os.getpid()}"   # concurrent builders (multi-process tests) never share a file
+    tag = f"{'asan' if asan else 'ubsan' if sanitize else 'emu'}.{os.getpid()}"   # concurrent builders (multi-process tests) never share a file
     objdir = os.path.join(EMU_DIR, "_obj")
     os.makedirs(objdir, exist_ok=True)
     flags = ["-std=c++17", "-ffp-contract=off", "-fno-omit-frame-pointer", "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-fPIC"]
-    flags += ["-O1", "-fsanitize=undefined", "-fno-sanitize-recover=undefined"] if sanitize else ["-O2", "-g"]
+    san_link = ["-fsanitize=address"] if asan else ["-fsanitize=undefined"] if sanitize else []
+    flags += ["-O1", "-g", "-fsanitize=address"] if asan else ["-O1", "-fsanitize=undefined", "-fno-sanitize-recover=undefined"] if sanitize else ["-O2", "-g"]
     units = [("ppg_emu.cpp", [], "main")] + [("ppg_emu_part.cpp", [f"-DPPG_EMU_FAMILY={f}", f"-DPPG_EMU_NQ={q}"], f"f{f}_q{q}")
                                             for f in (0, 1, 2, 3) for q in (4, 2, 1)]
     cmds = [(["g++", *flags, *defs, "-c", "-o", os.path.join(objdir, f"{name}.{tag}.o"), os.path.join(EMU_DIR, src)])
@@ -45,7 +55,7 @@ def build(sanitize=False):
             for r in pool.map(lambda c: subprocess.run(c), cmds):
                 r.check_returncode()
         tmp = f"{out}.{os.getpid()}.tmp"
-        subprocess.run(["g++", "-shared", "-o", tmp, *objs] + (["-fsanitize=undefined"] if sanitize else []), check=True)
+        subprocess.run(["g++", "-shared", "-o", tmp, *objs] + san_link, check=True)
         os.replace(tmp, out)
     finally:
         for o in objs:
@@ -57,8 +67,9 @@ def build(sanitize=False):
 def library(sanitize=False):
     global _lib
     from predpreygrass_amd import _abi
-    if sanitize:  # UBSan build: traps (aborts the process) on signed overflow, bad shifts, misaligned access ...
-        return _abi.bind(ctypes.CDLL(build(sanitize=True)))
+    if sanitize:  # UBSan build: traps (aborts the process) on signed overflow, bad shifts, misaligned access ...; "address": ASan (the
+        # process must have been started with LD_PRELOAD=asan_runtime())
+        return _abi.bind(ctypes.CDLL(build(sanitize=sanitize)))
     if _lib is None:
         _lib = _abi.bind(ctypes.CDLL(build()))
     return _lib

@@ -73,6 +73,8 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
         '  printf("%d %d\\n", PPG_ABI_VERSION, PPG_ENV_WORDS);\n'
         '  printf("%zu %zu %zu %zu %zu\\n", sizeof(ppg_policy_spec), offsetof(ppg_policy_spec, conv_out), offsetof(ppg_policy_spec, n_fc),\n'
         '         offsetof(ppg_policy_spec, conv_w), offsetof(ppg_policy_spec, fc_b));\n'
+        '  printf("%zu %zu %zu %zu\\n", sizeof(ppg_fetch_header), offsetof(ppg_fetch_header, record_bytes), offsetof(ppg_fetch_header, overflow),\n'
+        '         offsetof(ppg_fetch_header, bytes_used));\n'
         '  return 0;\n}\n')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
@@ -87,6 +89,9 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     assert lines[4].split() == [str(_abi.ABI_VERSION), str(_abi.ENV_WORDS)]
     PS = _abi.PpgPolicySpec
     assert lines[5].split() == [str(ctypes.sizeof(PS))] + [str(getattr(PS, n).offset) for n in ("conv_out", "n_fc", "conv_w", "fc_b")]
+    FH = _abi.PpgFetchHeader
+    assert lines[6].split() == [str(ctypes.sizeof(FH))] + [str(getattr(FH, n).offset) for n in ("record_bytes", "overflow", "bytes_used")]
+    assert ctypes.sizeof(FH) == 64
 
 
 def test_policy_kernel_choice_and_lds_layout_for_every_shape(hip_lib_path):

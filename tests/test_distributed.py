@@ -269,6 +269,14 @@ def test_bench_two_ranks_dry_run_with_gather_leg(launcher):
     # the image without observations is two orders of magnitude smaller; images are sized from what a step really used
     assert d["ids_rewards_gather"]["wire_bytes_per_step_per_rank"] * 20 < d["obs_gather"]["wire_bytes_per_step_per_rank"]
     assert d["obs_gather"]["wire_bytes_per_step_per_rank"] < 1.25 * max(d["obs_gather"]["image_bytes_used_last_step"]) + 512
+    # the N-GPU line explains itself: every rank's own pace and GPU next to the max-over-ranks `value`
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    for r in d["per_rank"]:
+        assert set(r) >= {"ms_per_step", "kernel_ms", "placement_probe_us_min", "gpu_uuid"} and r["ms_per_step"] > 0
+    assert d["ms_per_step"] >= max(r["ms_per_step"] for r in d["per_rank"]) * 0.999   # (`value` is the slowest rank's)
+    assert d["value_if_every_rank_were_median"] >= d["value"] * 0.999 and d["slowest_over_median_rank"] >= 1.0
+    for leg in ("obs_gather", "obs_all_pairs", "ids_rewards_gather"):
+        assert len(d[leg]["per_rank_ms_per_step"]) == 2
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

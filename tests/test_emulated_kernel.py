@@ -123,6 +123,56 @@ def test_kernel_source_is_clean_under_ubsan():
     assert out.returncode == 0 and "UBSAN-CLEAN" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
+def test_kernel_source_is_clean_under_address_sanitizer():
+    """The kernel source built with -fsanitize=address (CPU wave-emulator build), the bytes behind every workgroup's LDS poisoned
+    (wave_emu.h): out-of-bounds reads and writes of LDS, of the "device" tensors (torch's CPU allocations, intercepted through the
+    preloaded runtime) and of the host code's own buffers abort the process.  Single-wave, multi-wave and cooperative kernels, the
+    second generation, the pack and fetch launches."""
+    import subprocess, sys, os
+    from tests.emu_backend import asan_runtime, build
+    rt = asan_runtime()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("gcc has no libasan.so here")
+    build(sanitize="address")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "from tests.emu_backend import library\n"
+        "from tests.parity_utils import replay_golden_cases, rollout_vs_oracle\n"
+        "from predpreygrass_amd.batched import BatchedPredPreyGrass\n"
+        "from predpreygrass_amd.config import config_env\n"
+        "from oracle.ppg_oracle import OracleEnv\n"
+        "lib = library(sanitize='address')\n"
+        "mk = lambda cfg, B: BatchedPredPreyGrass(cfg, batch_size=B, _library=lib)\n"
+        "replay_golden_cases(mk, ['dense_seed0'], config_env)\n"
+        "replay_golden_cases(mk, ['c4_seed0'], config_env)\n"
+        "cfg = {**config_env, 'grid_size': 5, 'n_initial_active_predator': 5, 'n_initial_active_prey': 9,\n"
+        "       'initial_num_grass': 8, 'predator_obs_range': 3, 'prey_obs_range': 5, 'max_steps': 60,\n"
+        "       'energy_gain_per_step_grass': 0.5}\n"
+        "rollout_vs_oracle(mk(cfg, 3), lambda: OracleEnv(cfg), seed0=9, n_calls=100)\n"
+        "for w in ('4', '8'):\n"
+        "    os.environ['PPG_EMU_WAVES'] = w\n"
+        "    replay_golden_cases(mk, ['default_seed0'], config_env, max_calls=60)\n"
+        "    rollout_vs_oracle(mk(cfg, 2), lambda: OracleEnv(cfg), seed0=10, n_calls=60)\n"
+        "os.environ.pop('PPG_EMU_WAVES')\n"
+        "def coop(c, B):\n"                       # the cooperative kernels: 1 KB pieces through the padded maps
+        "    e = mk(c, B); e.set_wave_plan(4, 0, 2); return e\n"
+        "replay_golden_cases(coop, ['default_seed0'], config_env, max_calls=60)\n"
+        "cfg7 = {**config_env, 'grid_size': 9, 'predator_obs_range': 13, 'prey_obs_range': 15, 'initial_num_grass': 20, 'max_steps': 40}\n"
+        "rollout_vs_oracle(coop(cfg7, 3), lambda: OracleEnv(cfg7), seed0=4, n_calls=50)\n"
+        "e = mk(config_env, 3); e.reset(seed=1)\n"
+        "for _ in range(5):\n"
+        "    e.step(random_actions=True, auto_reset=True); e.fetch(); e.fetch(1, 1)\n"
+        "from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base\n"
+        "from oracle.rq_oracle import RQOracleEnv\n"
+        "from tests.parity_utils_rq import rollout_vs_oracle as rq_rollout\n"
+        "rq_rollout(BatchedRedQueen(config_env_base, batch_size=2, _library=lib), lambda: RQOracleEnv(config_env_base), seed0=3, n_calls=40)\n"
+        "print('ASAN-CLEAN')\n" % root)
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", PYTHONMALLOC="malloc")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800, env=env)
+    assert out.returncode == 0 and "ASAN-CLEAN" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
 def _state(env):
     names = ["row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "grass_xy",
              "grass_energy", "obs_pred", "obs_prey"]

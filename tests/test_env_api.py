@@ -385,3 +385,35 @@ def test_reset_batch_step_batch_views_agree_with_the_records():
             seen_dead += int(term[b].sum())
             assert abs(float(rew[b][live[b]].sum()) - sum(r[3] for r in recs)) < 1e-9
     assert seen_dead > 0
+
+
+def test_fetch_image_equals_the_tensors_it_gathers():
+    """ppg_fetch (the dict classes' one device->host copy): records = every state tensor's slice, observation sections = the
+    blocks in use; any run of envs; an image that outgrows the staging buffer is fetched again into a larger one."""
+    import torch
+    from predpreygrass_amd import _abi
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
+    for make in (lambda: BatchedPredPreyGrass(dict(config_env), batch_size=5, _library=library()),
+                 lambda: BatchedRedQueen(dict(config_env_base), batch_size=3, _library=library()),
+                 lambda: BatchedRedQueen(dict(config_env_base, include_visibility_channel=True), batch_size=3, walls=True, _library=library())):
+        env = make()
+        env.reset(seed=5)
+        for call in range(12):
+            env.step(random_actions=True, auto_reset=True)
+            for env0, n in ((0, None), (1, 2), (env.batch_size - 1, 1)):
+                if call == 3:
+                    env._fetch_host = env._host_buffer(int(env._lib.ppg_fetch_bytes(env._handle, env.batch_size, 0, 0)))   # fixed part only: overflows
+                tables, obs_p, obs_q = env.fetch(env0, n)
+                n_ = env.batch_size - env0 if n is None else n
+                for name, _, _ in env._fetch_fields():
+                    want = getattr(env, name)[env0:env0 + n_].numpy().reshape(n_, -1)
+                    assert np.array_equal(tables[name].reshape(n_, -1).view(want.dtype), want), name
+                for i in range(n_):
+                    es = env.env_state[env0 + i]
+                    nP, nQ = int(es[_abi.ENV_N_PRED_ROWS]), int(es[_abi.ENV_N_PREY_ROWS])
+                    assert obs_p[i].shape[0] == nP and obs_q[i].shape[0] == nQ
+                    assert np.array_equal(obs_p[i], env.obs_pred[env0 + i, :nP].numpy())
+                    assert np.array_equal(obs_q[i], env.obs_prey[env0 + i, :nQ].numpy())
+        rc = env._lib.ppg_fetch(env._handle, 0, env.batch_size + 1, env._fetch_host.data_ptr(), env._fetch_host.numel(), None)
+        assert rc == -1 and b"not in 0.." in env._lib.ppg_last_error(env._handle)

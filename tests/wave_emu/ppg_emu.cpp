@@ -72,7 +72,11 @@ static void backend_release(ppg_handle *h) {
     h->coop_tab_dev = nullptr;
     free(h->order_dev);
     h->order_dev = nullptr;
+    free(h->fetch_dev);
+    h->fetch_dev = nullptr;
+    h->fetch_cap = 0;
 }
+static void backend_free(ppg_handle *, void *p) { free(p); }
 static int backend_rebalance(ppg_handle *h, int wp, int wq, void *) {
     if (!h->order_dev) h->order_dev = (int32_t *)malloc((size_t)h->batch * sizeof(int32_t));
     const int32_t *es = h->bufs.env_state;
@@ -113,6 +117,11 @@ static void pack_rows_entry(void *arg) { ppg::pack_rows_main(*(const ppg::PackPa
 static int backend_pack(ppg_handle *, const ppg::PackParams &K, void *) {
     wv::run_block(pack_scan_entry, (void *)&K, 0, 512, 1);
     for (int e = 0; e < K.n_envs; ++e) wv::run_block(pack_rows_entry, (void *)&K, e, 16, 1);
+    return PPG_OK;
+}
+static void fetch_entry(void *arg) { ppg::fetch_main(*(const ppg::FetchParams *)arg, wv::emu().lds); }
+static int backend_fetch(ppg_handle *, const ppg::FetchParams &K, void *) {
+    for (int e = 0; e < K.n_envs; ++e) wv::run_block(fetch_entry, (void *)&K, e, 1024, 1);
     return PPG_OK;
 }
 static int backend_copy(ppg_handle *, void *dst, const void *src, size_t bytes, bool, void *) {

@@ -19,6 +19,16 @@
 #include <string.h>
 
 #define PPG_WAVE_EMU 1
+// AddressSanitizer build (tests/emu_backend.py: build(sanitize="address")): the bytes behind a workgroup's LDS are POISONED, so a
+// read past the allocation traps as well (the 0x5C pattern below only catches writes, and only after the fact)
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#define PPG_EMU_POISON(p, n) __asan_poison_memory_region((p), (n))
+#define PPG_EMU_UNPOISON(p, n) __asan_unpoison_memory_region((p), (n))
+#else
+#define PPG_EMU_POISON(p, n) do { } while (0)
+#define PPG_EMU_UNPOISON(p, n) do { } while (0)
+#endif
 #define PPG_DEVICE static inline
 #define PPG_MEMBER inline
 #define PPG_HOST_DEVICE static inline
@@ -90,6 +100,7 @@ inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_by
     if (nwaves < 1 || nwaves > MAXW) { fprintf(stderr, "wave_emu: %d waves per workgroup\n", nwaves); abort(); }
     if (!e.stacks) e.stacks = (unsigned char *)aligned_alloc(64, STACK_BYTES * NF);  // (untouched pages stay virtual)
     constexpr size_t REDZONE = 4096;   // behind the workgroup's LDS: a write there is a kernel writing past its allocation
+    if (e.lds) PPG_EMU_UNPOISON(e.lds, e.lds_bytes);
     if (e.lds_bytes < lds_bytes + REDZONE) {
         free(e.lds);
         e.lds = (unsigned char *)aligned_alloc(64, (lds_bytes + REDZONE + 63) / 64 * 64);
@@ -98,6 +109,7 @@ inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_by
     // LDS content is undefined at launch on hardware: poison it.
     memset(e.lds, 0xA5, lds_bytes);
     memset(e.lds + lds_bytes, 0x5C, REDZONE);
+    PPG_EMU_POISON(e.lds + lds_bytes, e.lds_bytes - lds_bytes);
     e.entry = entry;
     e.arg = arg;
     e.block = block;
@@ -153,6 +165,7 @@ inline void run_block(void (*entry)(void *), void *arg, int block, size_t lds_by
         }
         e.n_collectives++;
     }
+    PPG_EMU_UNPOISON(e.lds + lds_bytes, e.lds_bytes - lds_bytes);
     for (size_t i = 0; i < REDZONE; ++i)
         if (e.lds[lds_bytes + i] != 0x5C) {
             fprintf(stderr, "wave_emu: block %d wrote %zu bytes past its %zu bytes of LDS\n", block, i + 1, lds_bytes);
