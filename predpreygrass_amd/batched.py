@@ -448,21 +448,25 @@ class BatchedPredPreyGrass:
             raise RuntimeError("ppg_fetch: the image keeps overflowing")
         rec_bytes, bp, bq = int(H.record_bytes), int(H.blk_pred_bytes), int(H.blk_prey_bytes)
         rec = np.array(buf[64:64 + n * rec_bytes]).reshape(n, rec_bytes)   # (a copy: the tables outlive the staging buffer's next use)
-        tables, off = {}, 0
-        for name, dt, count in self._fetch_fields():
-            nb = np.dtype(dt).itemsize * count
-            tables[name] = rec[:, off:off + nb].view(dt)
-            off += (nb + 7) // 8 * 8
+        if getattr(self, "_fetch_layout", None) is None:   # (name, dtype, byte offset, bytes) of every field of a record, once
+            lay, off = [], 0
+            for name, dt, count in self._fetch_fields():
+                nb = np.dtype(dt).itemsize * count
+                lay.append((name, dt, off, nb))
+                off += (nb + 7) // 8 * 8
+            self._fetch_layout = lay
+        tables = {name: rec[:, off:off + nb].view(dt) for name, dt, off, nb in self._fetch_layout}
         if "row_info" not in tables:
             tables["row_info"] = np.zeros((n, self.S), dtype=np.uint8)
         es = tables["env_state"]
-        npred, nprey = es[:, _abi.ENV_N_PRED_ROWS].astype(np.int64), es[:, _abi.ENV_N_PREY_ROWS].astype(np.int64)
-        sec_p, sec_q = (npred * bp + 15) // 16 * 16, (nprey * bq + 15) // 16 * 16
-        start = 64 + n * rec_bytes + np.concatenate([[0], np.cumsum(sec_p + sec_q)[:-1]])
         odt = np.float64 if self.obs_dtype == torch.float64 else np.float32
         pshape, qshape = tuple(self.obs_pred.shape[2:]), tuple(self.obs_prey.shape[2:])
-        obs_p = [buf[int(o):int(o) + int(k) * bp].view(odt).reshape((int(k),) + pshape) for o, k in zip(start, npred)]
-        obs_q = [buf[int(o):int(o) + int(k) * bq].view(odt).reshape((int(k),) + qshape) for o, k in zip(start + sec_p, nprey)]
+        obs_p, obs_q, o = [], [], 64 + n * rec_bytes
+        for kp, kq in zip(es[:, _abi.ENV_N_PRED_ROWS].tolist(), es[:, _abi.ENV_N_PREY_ROWS].tolist()):
+            obs_p.append(buf[o:o + kp * bp].view(odt).reshape((kp,) + pshape))
+            o += (kp * bp + 15) // 16 * 16
+            obs_q.append(buf[o:o + kq * bq].view(odt).reshape((kq,) + qshape))
+            o += (kq * bq + 15) // 16 * 16
         return tables, obs_p, obs_q
 
     def stage_actions(self, env=None):
@@ -493,16 +497,16 @@ class BatchedPredPreyGrass:
         predator survivors, prey survivors, predator newborns, prey newborns."""
         t = tables if tables is not None else self.host_tables(b)
         i = 0 if tables is None else b
-        es = t["env_state"][i]
-        nP, nQ = int(es[_abi.ENV_N_PRED_ROWS]), int(es[_abi.ENV_N_PREY_ROWS])
-        newP, newQ = int(es[_abi.ENV_N_PRED_NEW]), int(es[_abi.ENV_N_PREY_NEW])
+        es = t["env_state"][i].tolist()
+        nP, nQ = es[_abi.ENV_N_PRED_ROWS], es[_abi.ENV_N_PREY_ROWS]
+        newP, newQ = es[_abi.ENV_N_PRED_NEW], es[_abi.ENV_N_PREY_NEW]
         cp = self.pred_capacity
-        order = [(PREDATOR, r) for r in range(nP - newP)] + [(PREY, r) for r in range(nQ - newQ)] + \
-                [(PREDATOR, r) for r in range(nP - newP, nP)] + [(PREY, r) for r in range(nQ - newQ, nQ)]
+        # (whole rows as Python lists once: indexing numpy scalars one by one costs more than the rest of the dict assembly)
+        ids, fls, rws = t["row_id"][i].tolist(), t["row_flags"][i].tolist(), t["row_reward"][i].tolist()
         out = []
-        for ty, r in order:
-            s = r if ty == PREDATOR else cp + r
-            fl = int(t["row_flags"][i, s])
-            out.append((agent_name(ty, t["row_id"][i, s]), ty, r, float(t["row_reward"][i, s]),
-                        bool(fl & _abi.ROW_DIED), bool(fl & _abi.ROW_TRUNC)))
+        for ty, lo, hi in ((PREDATOR, 0, nP - newP), (PREY, 0, nQ - newQ), (PREDATOR, nP - newP, nP), (PREY, nQ - newQ, nQ)):
+            base, fmt = (0, "predator_%d") if ty == PREDATOR else (cp, "prey_%d")
+            for r in range(lo, hi):
+                fl = fls[base + r]
+                out.append((fmt % ids[base + r], ty, r, rws[base + r], bool(fl & _abi.ROW_DIED), bool(fl & _abi.ROW_TRUNC)))
         return out

@@ -1021,6 +1021,7 @@ struct ppg_policy {
     bool xg_is_spread;     // (from ppg_alloc_spread)
     uint32_t *plan;        // [PLAN_HDR + plan_envs] header + prefix sums, then the first env of every tile
     int32_t plan_envs;
+    size_t plan_words;     // words the buffer was allocated with (it depends on the species' row capacity too)
     int32_t grid;
     int32_t lds_bytes;
     hipStream_t side;      // ppg_policy_act with both species: the predators' launch runs beside the prey's (fork / join by events)
@@ -1181,9 +1182,9 @@ static bool ppg_pipe_layout(int C, int R, int P, int blk, int f_elems, int tail_
     return true;
 }
 
-int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_policy **out) {
-    if (!spec || !out) return ppg_policy_fail(nullptr, PPG_EINVAL, "null argument");
-    const ppg_policy_spec &sp = *spec;
+// The shape rules of ppg_policy_create_spec, device-free: shared with ppg_policy_describe so that the description of a network exists
+// exactly when the network can be created.  need_weights: also require the weight pointers.
+static int ppg_policy_check_spec(const ppg_policy_spec &sp, bool need_weights) {
     const int layout = sp.layout, R = sp.obs_range, n_actions = sp.n_actions, C = sp.obs_channels;
     if (layout != PPG_POLICY_LAYOUT_CHW && layout != PPG_POLICY_LAYOUT_HWC) return ppg_policy_fail(nullptr, PPG_EINVAL, "unknown layout %d", layout);
     if (sp.flatten != PPG_POLICY_FLATTEN_NCHW && sp.flatten != PPG_POLICY_FLATTEN_NHWC) return ppg_policy_fail(nullptr, PPG_EINVAL, "unknown flatten order %d", sp.flatten);
@@ -1196,21 +1197,33 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         const int lim = l == 0 ? 16 : l == 1 ? 32 : 64;
         if (sp.conv_out[l] < 1 || sp.conv_out[l] > lim)
             return ppg_policy_fail(nullptr, PPG_EINVAL, "convolution %d has %d output channels: the kernels take up to 16 / 32 / 64 / 64 ...", l + 1, sp.conv_out[l]);
-        if (!sp.conv_w[l] || !sp.conv_b[l]) return ppg_policy_fail(nullptr, PPG_EINVAL, "a convolution weight pointer is NULL");
+        if (need_weights && (!sp.conv_w[l] || !sp.conv_b[l])) return ppg_policy_fail(nullptr, PPG_EINVAL, "a convolution weight pointer is NULL");
     }
     for (int l = 0; l < sp.n_fc; ++l) {
-        if (!sp.fc_w[l] || !sp.fc_b[l]) return ppg_policy_fail(nullptr, PPG_EINVAL, "a linear weight pointer is NULL");
+        if (need_weights && (!sp.fc_w[l] || !sp.fc_b[l])) return ppg_policy_fail(nullptr, PPG_EINVAL, "a linear weight pointer is NULL");
         if (l + 1 < sp.n_fc && (sp.fc_out[l] < 1 || sp.fc_out[l] > 256))
             return ppg_policy_fail(nullptr, PPG_EINVAL, "hidden head layer %d has %d features: the kernels take up to 256", l + 1, sp.fc_out[l]);
     }
     if (sp.fc_out[sp.n_fc - 1] != n_actions) return ppg_policy_fail(nullptr, PPG_EINVAL, "the last linear layer has %d outputs, n_actions is %d", sp.fc_out[sp.n_fc - 1], n_actions);
     if (sp.n_fc > 1 && sp.n_conv != 3) return ppg_policy_fail(nullptr, PPG_EINVAL, "a head with hidden layers needs exactly three convolutions (found %d)", sp.n_conv);
+    if (sp.n_fc > 1 && layout != PPG_POLICY_LAYOUT_HWC && C != 4)
+        return ppg_policy_fail(nullptr, PPG_EINVAL, "channel-first networks with hidden head layers read 4-channel rows (found %d)", C);
+    return PPG_OK;
+}
+
+int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_policy **out) {
+    if (!spec || !out) return ppg_policy_fail(nullptr, PPG_EINVAL, "null argument");
+    const ppg_policy_spec &sp = *spec;
+    const int layout = sp.layout, R = sp.obs_range, n_actions = sp.n_actions, C = sp.obs_channels;
+    {
+        const int rc = ppg_policy_check_spec(sp, true);
+        if (rc != PPG_OK) return rc;
+    }
     // the image the convolutions run on: R x R with C channels, or (channels-last) C x R with R channels
     const int hwc = layout == PPG_POLICY_LAYOUT_HWC;
     const int IH = hwc ? C : R, IW = R, CIN = hwc ? R : C, CB1 = CIN > 8 ? 2 : 1;
     const int P = IH * IW;
     const bool direct = sp.n_fc == 1;
-    if (!direct && !hwc && C != 4) return ppg_policy_fail(nullptr, PPG_EINVAL, "channel-first networks with hidden head layers read 4-channel rows (found %d)", C);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return ppg_policy_fail(nullptr, PPG_ENODEV, "device %d not available", device);
     hipDeviceProp_t prop;
@@ -1349,10 +1362,6 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
                 p->pipe = 1;
                 p->grid = prop.multiProcessorCount;
                 p->lds_bytes = pipe_lds;
-                for (const void *fn : {(const void *)ppgpol::ppg_policy_pipe8_f64, (const void *)ppgpol::ppg_policy_pipe8_f32,
-                                       (const void *)ppgpol::ppg_policy_pipe8_bf16, (const void *)ppgpol::ppg_policy_pipe16_f64,
-                                       (const void *)ppgpol::ppg_policy_pipe16_f32, (const void *)ppgpol::ppg_policy_pipe16_bf16})
-                    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
                 if (ppg_policy_matches_description(p, spec) != PPG_OK) { (void)ppg_policy_destroy(p); return PPG_EHIP; }
                 *out = p;
                 return PPG_OK;
@@ -1387,13 +1396,6 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
             return ppg_policy_fail(nullptr, PPG_EHIP, "hipMalloc of %zu bytes of scratch failed", lgs_bytes);
         }
         K.lgs = p->lgs;
-        for (const void *fn : {(const void *)ppgpol::ppg_policy_direct8_f64, (const void *)ppgpol::ppg_policy_direct8_f32,
-                               (const void *)ppgpol::ppg_policy_direct8_bf16, (const void *)ppgpol::ppg_policy_direct16_f64,
-                               (const void *)ppgpol::ppg_policy_direct16_f32, (const void *)ppgpol::ppg_policy_direct16_bf16,
-                               (const void *)ppgpol::ppg_policy_deep8_f64, (const void *)ppgpol::ppg_policy_deep8_f32,
-                               (const void *)ppgpol::ppg_policy_deep8_bf16, (const void *)ppgpol::ppg_policy_deep16_f64,
-                               (const void *)ppgpol::ppg_policy_deep16_f32, (const void *)ppgpol::ppg_policy_deep16_bf16})
-            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
         if (ppg_policy_matches_description(p, spec) != PPG_OK) { (void)ppg_policy_destroy(p); return PPG_EHIP; }
         *out = p;
         return PPG_OK;
@@ -1427,13 +1429,6 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         return ppg_policy_fail(nullptr, PPG_EHIP, "hipMalloc of %zu bytes of scratch failed", xg_bytes);
     }
     K.xg = p->xg;
-    for (const void *fn : {(const void *)ppgpol::ppg_policy_forward_f64, (const void *)ppgpol::ppg_policy_forward_f32,
-                           (const void *)ppgpol::ppg_policy_forward_bf16,
-                           (const void *)ppgpol::ppg_policy_forward_hwc8_f64, (const void *)ppgpol::ppg_policy_forward_hwc8_f32,
-                           (const void *)ppgpol::ppg_policy_forward_hwc8_bf16,
-                           (const void *)ppgpol::ppg_policy_forward_hwc16_f64, (const void *)ppgpol::ppg_policy_forward_hwc16_f32,
-                           (const void *)ppgpol::ppg_policy_forward_hwc16_bf16})
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, p->lds_bytes);
     if (ppg_policy_matches_description(p, spec) != PPG_OK) { (void)ppg_policy_destroy(p); return PPG_EHIP; }
     *out = p;
     return PPG_OK;
@@ -1443,9 +1438,7 @@ int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n) {
     if (!spec || !out || n < 1) return PPG_EINVAL;
     const ppg_policy_spec &sp = *spec;
     const int R = sp.obs_range, C = sp.obs_channels;
-    if ((sp.layout != PPG_POLICY_LAYOUT_CHW && sp.layout != PPG_POLICY_LAYOUT_HWC) || R < 1 || R > 15 || C < 1 || C > 8 || sp.n_actions < 1 ||
-        sp.n_actions > 32 || sp.n_conv < 1 || sp.n_conv > PPG_POLICY_MAX_CONV || sp.n_fc < 1 || sp.n_fc > PPG_POLICY_MAX_FC)
-        return PPG_EINVAL;
+    if (ppg_policy_check_spec(sp, false) != PPG_OK) return PPG_EINVAL;
     const int hwc = sp.layout == PPG_POLICY_LAYOUT_HWC;
     const int IH = hwc ? C : R, IW = R, P = IH * IW;
     int32_t v[12] = {0, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1511,38 +1504,60 @@ const char *ppg_policy_last_error(const ppg_policy *p) { return p ? p->err : g_p
 
 // the plan buffer of a policy: [PLAN_HDR + envs] header + prefix sums, then the first env of every tile
 static int ppg_policy_ensure_plan(ppg_policy *p, int total, int cap) {
-    if (p->plan_envs >= total) return PPG_OK;
-    if (p->plan) (void)hipFree(p->plan);
-    p->plan = nullptr;
     size_t max_tiles = ((size_t)total * cap + 31) / 32 + 1;   // (tiles of 32 samples are the smallest the plan picks)
     if (p->direct) {   // range mode: grid x tiles-per-workgroup slots, some of them empty
         const size_t share = ((size_t)total * cap + p->grid - 1) / p->grid + (size_t)p->base.ST;
         const size_t slots = (size_t)p->grid * ((share + p->base.range_tile - 1) / p->base.range_tile + 1);
         if (slots > max_tiles) max_tiles = slots;
     }
-    PPG_POL_TRY(p, hipMalloc((void **)&p->plan, ((size_t)(ppgpol::PLAN_HDR + total) + max_tiles) * 4));
+    // the tile list starts right behind the prefix sums of `total` envs: a buffer is reused only for the same env count and at most
+    // the tile slots it was sized for (handles with the same env count but a larger row capacity need more slots: ADVICE r4)
+    const size_t words = (size_t)(ppgpol::PLAN_HDR + total) + max_tiles;
+    if (p->plan && p->plan_envs == total && p->plan_words >= words) return PPG_OK;
+    if (p->plan) (void)hipFree(p->plan);
+    p->plan = nullptr;
+    p->plan_envs = 0; p->plan_words = 0;
+    PPG_POL_TRY(p, hipMalloc((void **)&p->plan, words * 4));
     p->plan_envs = total;
+    p->plan_words = words;
     return PPG_OK;
 }
 
-// also_plan_for: the OTHER species' policy whose plan this call's plan launch computes as well (ppg_policy_plan2); skip_plan: this
-// species' plan was computed by the other call
-static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles, int32_t n, int8_t *const *actions, uint32_t flags,
-                          uint64_t seed, float *logits, void *stream, ppg_policy *also_plan_for = nullptr, bool skip_plan = false) {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the process-global kernel symbol, not of a policy: two live policies that
+// share a kernel (say two pipe8 policies with different windows) need different amounts.  A running maximum per kernel is kept and raised
+// right before the launch that needs more; the return code is checked.
+static int ppg_policy_reserve_lds(ppg_policy *p, const void *fn, int bytes) {
+    static const void *fns[256];   // (kernel, device): the attribute belongs to the code object loaded on a device
+    static int devs[256], have[256];
+    static int n_fns = 0;
+    int i = 0;
+    while (i < n_fns && !(fns[i] == fn && devs[i] == p->device)) ++i;
+    if (i == n_fns) {
+        if (n_fns == 256) return ppg_policy_fail(p, PPG_EHIP, "internal: more than 256 (policy kernel, device) pairs");
+        fns[n_fns] = fn; devs[n_fns] = p->device; have[n_fns] = 0; ++n_fns;
+    }
+    if (have[i] >= bytes) return PPG_OK;
+    PPG_POL_TRY(p, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have[i] = bytes;
+    return PPG_OK;
+}
+
+// The per-call part of a species' parameter block: what the handles, the action tensors and the flags decide (no plan, no launch).
+static int ppg_policy_fill(ppg_policy *p, int species, ppg_handle *const *handles, int32_t n, int8_t *const *actions, uint32_t flags,
+                           uint64_t seed, float *logits, ppgpol::PolParams &K, ppgpol::PlanParams &L, int &total) {
     ppg_handle *h0 = handles[0];
     const int R = species ? h0->base.Rq : h0->base.Rp;
     if (R != p->R) return ppg_policy_fail(p, PPG_EINVAL, "the policy was created for %dx%d observations, the %s observe %dx%d", p->R, p->R,
                                           species ? "prey" : "predators", R, R);
     if (p->n_actions != 9 && !h0->gen2) return ppg_policy_fail(p, PPG_EINVAL, "the base env has 9 actions, the policy %d", p->n_actions);
-    ppgpol::PolParams K = p->base;
-    ppgpol::PlanParams L;
+    K = p->base;
     memset(&L, 0, sizeof L);
     K.species = species; K.obs_f32 = h0->base.obs_f32; K.sample = (flags & PPG_POLICY_SAMPLE) ? 1 : 0;
     K.seed_lo = (uint32_t)seed ^ (species ? 0x9E3779B9u : 0u); K.seed_hi = (uint32_t)(seed >> 32);
     K.S = h0->base.S; K.cap = species ? h0->base.cap_prey : h0->base.cap_pred; K.slot0 = species ? h0->base.cap_pred : 0;
     K.n_handles = n; L.n_handles = n;
     L.word = species ? PPG_ENV_N_PREY_ROWS : PPG_ENV_N_PRED_ROWS;
-    int total = 0;
+    total = 0;
     for (int k = 0; k < n; ++k) {
         const ppg_handle *h = handles[k];
         if (!h) return ppg_policy_fail(p, PPG_EINVAL, "handle %d is NULL", k);
@@ -1560,8 +1575,24 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     }
     for (int k = n; k <= ppgpol::MAX_HANDLES; ++k) K.env_base[k] = L.env_base[k] = total;
     K.n_envs = L.n_envs = total;
+    K.logits = logits;
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != p->device) PPG_POL_TRY(p, hipSetDevice(p->device));
+    return PPG_OK;
+}
+
+// also_plan_for: the OTHER species' policy whose plan this call's plan launch computes as well (ppg_policy_plan2); skip_plan: this
+// species' plan was computed by the other call
+static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles, int32_t n, int8_t *const *actions, uint32_t flags,
+                          uint64_t seed, float *logits, void *stream, ppg_policy *also_plan_for = nullptr, bool skip_plan = false) {
+    ppg_handle *h0 = handles[0];
+    ppgpol::PolParams K;
+    ppgpol::PlanParams L;
+    int total = 0;
+    {
+        const int rc = ppg_policy_fill(p, species, handles, n, actions, flags, seed, logits, K, L, total);
+        if (rc != PPG_OK) return rc;
+    }
     {
         const int rc = ppg_policy_ensure_plan(p, total, K.cap);
         if (rc != PPG_OK) return rc;
@@ -1577,7 +1608,6 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
         if (v == 32 || v == 64 || v == 96 || v == 128) L.force_ts = v;
     }
 #endif
-    K.logits = logits;
 #ifdef PPG_EXPERIMENTS   // PPG_POLICY_TIMELINE=<file prefix>: per-tile phase stamps of launch number PPG_POLICY_TIMELINE_RUN (default 300) of each species
     static int tl_runs[2] = {0, 0};
     static unsigned long long *tl_buf[2] = {nullptr, nullptr};
@@ -1634,12 +1664,14 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
                                   {ppgpol::ppg_policy_deep16_f64, ppgpol::ppg_policy_deep16_f32, ppgpol::ppg_policy_deep16_bf16}};
         const fwd_fn pipe[2][3] = {{ppgpol::ppg_policy_pipe8_f64, ppgpol::ppg_policy_pipe8_f32, ppgpol::ppg_policy_pipe8_bf16},
                                    {ppgpol::ppg_policy_pipe16_f64, ppgpol::ppg_policy_pipe16_f32, ppgpol::ppg_policy_pipe16_bf16}};
-        if (p->pipe)
-            hipLaunchKernelGGL(pipe[p->nch16 ? 1 : 0][dt], dim3((unsigned)p->grid), dim3(512), (size_t)p->lds_bytes, (hipStream_t)stream, K);
-        else
-        hipLaunchKernelGGL(dir[(p->direct == 2 ? 2 : 0) + (p->nch16 ? 1 : 0)][dt], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
+        const fwd_fn fn = p->pipe ? pipe[p->nch16 ? 1 : 0][dt] : dir[(p->direct == 2 ? 2 : 0) + (p->nch16 ? 1 : 0)][dt];
+        const int rc = ppg_policy_reserve_lds(p, (const void *)fn, p->lds_bytes);
+        if (rc != PPG_OK) return rc;
+        hipLaunchKernelGGL(fn, dim3((unsigned)p->grid), dim3(p->pipe ? 512 : 256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     } else {
         const int variant = p->layout == PPG_POLICY_LAYOUT_HWC ? (p->cin > 8 ? 2 : 1) : 0;
+        const int rc = ppg_policy_reserve_lds(p, (const void *)fwd[variant][dt], p->lds_bytes);
+        if (rc != PPG_OK) return rc;
         hipLaunchKernelGGL(fwd[variant][dt], dim3((unsigned)p->grid), dim3(256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
     }
     PPG_POL_TRY(p, hipGetLastError());
@@ -1669,12 +1701,86 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
     return PPG_OK;
 }
 
+// diagnostic switch: environment variable PPG_POLICY_FUSED=0 sends a call with both species' pipeline policies through the two
+// forward launches + plan launch of rounds 2-4 instead of the one fused launch (tests compare the two bit for bit)
+static bool ppg_fused_enabled() {
+    const char *e = getenv("PPG_POLICY_FUSED");
+    return !(e && e[0] == '0' && e[1] == 0);
+}
+static int ppg_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return (e && atoi(e) > 0) ? atoi(e) : dflt;
+}
+
+// Both species' pipeline policies in ONE launch and no plan launch (ppg_policy_pipe.h: fused_main).  Returns 1 if this call cannot
+// take that path (the caller then runs the separate launches), PPG_OK after the launch, or an error.
+static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handles, int32_t n, int8_t *const *actions,
+                                uint32_t flags, uint64_t seed, float *logits_pred, float *logits_prey, void *stream) {
+    ppgpol::PolParams2 K2;
+    ppgpol::PlanParams L;
+    int total_q = 0, total_p = 0;
+    int rc = ppg_policy_fill(prey, 1, handles, n, actions, flags, seed, logits_prey, K2.q, L, total_q);
+    if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
+    rc = ppg_policy_fill(pred, 0, handles, n, actions, flags, seed, logits_pred, K2.p, L, total_p);
+    if (rc != PPG_OK) { memcpy(g_ppg_policy_error, pred->err, sizeof g_ppg_policy_error); return rc; }
+    const int lds = prey->lds_bytes > pred->lds_bytes ? prey->lds_bytes : pred->lds_bytes;
+    const int img = K2.q.pipe_img > K2.p.pipe_img ? K2.q.pipe_img : K2.p.pipe_img;
+    K2.scratch_off = (img + 15) / 16 * 16;
+    if (total_q > ppgpol::FUSED_MAX_ENVS || K2.scratch_off + ppgpol::FUSED_PART_WORDS * 4 + 8 * total_q > lds) return 1;
+    K2.q.plan = K2.p.plan = nullptr; K2.q.tile_env = K2.p.tile_env = nullptr;
+    // cycles per pipeline iteration of either network (measured on the reference's shapes, profiles/r04-r05; PPG_POLICY_ITER_Q / _P:
+    // experiments): only their RATIO matters -- it decides how many workgroups serve which species
+    K2.iter_q = ppg_env_int("PPG_POLICY_ITER_Q", 7500);
+    K2.iter_p = ppg_env_int("PPG_POLICY_ITER_P", 6500);
+    typedef void (*fused_fn)(const ppgpol::PolParams2);
+    const fused_fn fn[2][2][3] = {
+        {{ppgpol::ppg_policy_pipe2_8_8_f64, ppgpol::ppg_policy_pipe2_8_8_f32, ppgpol::ppg_policy_pipe2_8_8_bf16},
+         {ppgpol::ppg_policy_pipe2_8_16_f64, ppgpol::ppg_policy_pipe2_8_16_f32, ppgpol::ppg_policy_pipe2_8_16_bf16}},
+        {{ppgpol::ppg_policy_pipe2_16_8_f64, ppgpol::ppg_policy_pipe2_16_8_f32, ppgpol::ppg_policy_pipe2_16_8_bf16},
+         {ppgpol::ppg_policy_pipe2_16_16_f64, ppgpol::ppg_policy_pipe2_16_16_f32, ppgpol::ppg_policy_pipe2_16_16_bf16}}};
+    const int dt = K2.q.obs_f32 == 2 ? 2 : K2.q.obs_f32 ? 1 : 0;
+    const fused_fn f = fn[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt];
+#ifdef PPG_DIRECT_PROFILE   // diagnostic build: per-wavefront phase cycles of launch number PPG_DIRECT_PROFILE_RUN (default 300) -> $PPG_DIRECT_PROFILE_FILE.fused
+    static int dp_runs = 0;
+    static unsigned long long *dp_buf = nullptr;
+    const char *dp_path = getenv("PPG_DIRECT_PROFILE_FILE");
+    const int dp_at = getenv("PPG_DIRECT_PROFILE_RUN") ? atoi(getenv("PPG_DIRECT_PROFILE_RUN")) : 300;
+    const size_t dp_bytes = (size_t)prey->grid * 8 * 16 * 8;
+    if (dp_path && !dp_buf) {
+        PPG_POL_TRY(prey, hipMalloc((void **)&dp_buf, dp_bytes));
+        PPG_POL_TRY(prey, hipMemset(dp_buf, 0, dp_bytes));
+        PPG_POL_TRY(prey, hipDeviceSynchronize());
+    }
+    const bool dp_now = dp_path && ++dp_runs == dp_at;
+    K2.q.xg = K2.p.xg = dp_now ? (__bf16 *)dp_buf : nullptr;
+#endif
+    rc = ppg_policy_reserve_lds(prey, (const void *)f, lds);
+    if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
+    hipLaunchKernelGGL(f, dim3((unsigned)prey->grid), dim3(512), (size_t)lds, (hipStream_t)stream, K2);
+    PPG_POL_TRY(prey, hipGetLastError());
+#ifdef PPG_DIRECT_PROFILE
+    if (dp_now) {
+        PPG_POL_TRY(prey, hipDeviceSynchronize());
+        std::vector<unsigned long long> host(dp_bytes / 8);
+        PPG_POL_TRY(prey, hipMemcpy(host.data(), dp_buf, dp_bytes, hipMemcpyDeviceToHost));
+        char name[512];
+        snprintf(name, sizeof name, "%s.fused", dp_path);
+        if (FILE *fo = fopen(name, "wb")) { fwrite(host.data(), 8, host.size(), fo); fclose(fo); }
+    }
+#endif
+    return PPG_OK;
+}
+
 int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handles, int32_t n, int8_t *const *actions,
                    uint32_t flags, uint64_t seed, float *logits_pred, float *logits_prey, void *stream) {
     ppg_policy *any = pred ? pred : prey;
     if (!any) return PPG_EINVAL;
     if (!handles || !actions || n < 1 || n > ppgpol::MAX_HANDLES || !handles[0]) return ppg_policy_fail(any, PPG_EINVAL, "bad handle list");
     if (flags & ~PPG_POLICY_SAMPLE) return ppg_policy_fail(any, PPG_EINVAL, "unknown policy flags 0x%x", flags);
+    if (pred && prey && pred->pipe && prey->pipe && pred->device == prey->device && pred->grid == prey->grid && ppg_fused_enabled()) {
+        const int rc = ppg_policy_run_fused(pred, prey, handles, n, actions, flags, seed, logits_pred, logits_prey, stream);
+        if (rc != 1) return rc;
+    }
     // (a failure is also reported through ppg_policy_last_error(NULL), whichever of the two policies it came from)
     // The predators are few (a third of the chip's workgroup slots at 4096 envs): their launch goes to a side stream that is
     // forked from and joined back into `stream` with events, so that it fills the CUs the prey launch leaves idle.

@@ -79,10 +79,79 @@ __device__ __forceinline__ int pipe_pick_handle(const KP &K, const Bases &bases,
     return e - eb;
 }
 
-template <int OBS, int NCH>
-__device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
+// The fused launch's plan, computed by every workgroup for itself (no plan launch, no trip through memory): exclusive prefix sums of the
+// envs' predator / prey row counts (env words 0, 1: one 8-byte load per env) over the concatenated envs of all handles, in LDS:
+// scratch = [512 threads][2] partial sums | pre_pred[n_envs] | pre_prey[n_envs].  512 threads; ends with a workgroup barrier.
+constexpr int FUSED_PART_WORDS = 1024, FUSED_MAX_ENVS = 8192, FUSED_RUN = FUSED_MAX_ENVS / 512;
+// FAST = true: the launch's prologue -- a thread's loads all in flight at once (16 register pairs).  FAST = false: the same sums once
+// more in front of a later tile of a long share, inside the pipeline's roles whose weights fill the register file: one env at a time.
+template <bool FAST, class KP>
+__device__ __forceinline__ void fused_prefix_sums(const KP &K, uint32_t *scratch, int tid, uint32_t &tot_pred, uint32_t &tot_prey) {
+    static_assert(PPG_ENV_N_PRED_ROWS == 0 && PPG_ENV_N_PREY_ROWS == 1, "the two row counts are one 8-byte load");
+    const int per = (K.n_envs + 511) / 512;
+    const int lo = tid * per < K.n_envs ? tid * per : K.n_envs, hi = (lo + per) < K.n_envs ? (lo + per) : K.n_envs;
+    auto count_of = [&](int e) -> u32x2_t {
+        const int32_t *base;
+        const int b = pipe_pick_handle(K, K.env_state, e, base);
+        return *(const GLOBAL_AS u32x2_t *)(base + (size_t)b * PPG_ENV_WORDS);
+    };
+    u32x2_t cnt[FAST ? FUSED_RUN : 1];
+    uint32_t sp = 0, sq = 0;
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < FUSED_RUN; ++i)   // (unconditional loads of a clamped env: see pipe_main's fetch)
+            cnt[i] = count_of((lo + i) < K.n_envs ? (lo + i) : K.n_envs - 1);
+#pragma unroll
+        for (int i = 0; i < FUSED_RUN; ++i)
+            if (i < per && lo + i < hi) { sp += cnt[i][0]; sq += cnt[i][1]; }
+    } else {
+#pragma nounroll
+        for (int e = lo; e < hi; ++e) { const u32x2_t c = count_of(e); sp += c[0]; sq += c[1]; }
+    }
+    u32x2_t *part = (u32x2_t *)scratch;
+    u32x2_t mine = {sp, sq};
+    part[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 512; d <<= 1) {   // inclusive Hillis-Steele scan of the pairs
+        u32x2_t v = {0u, 0u};
+        if (tid >= d) v = part[tid - d];
+        __syncthreads();
+        mine[0] += v[0]; mine[1] += v[1];
+        part[tid] = mine;
+        __syncthreads();
+    }
+    uint32_t bp = mine[0] - sp, bq = mine[1] - sq;
+    uint32_t *pre_pred = scratch + FUSED_PART_WORDS, *pre_prey = pre_pred + K.n_envs;
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < FUSED_RUN; ++i)
+            if (i < per && lo + i < hi) {
+                pre_pred[lo + i] = bp; pre_prey[lo + i] = bq;
+                bp += cnt[i][0]; bq += cnt[i][1];
+            }
+    } else {
+#pragma nounroll
+        for (int e = lo; e < hi; ++e) {
+            const u32x2_t c = count_of(e);
+            pre_pred[e] = bp; pre_prey[e] = bq;
+            bp += c[0]; bq += c[1];
+        }
+    }
+    const u32x2_t all = part[511];
+    tot_pred = (uint32_t)__builtin_amdgcn_readfirstlane((int)all[0]);
+    tot_prey = (uint32_t)__builtin_amdgcn_readfirstlane((int)all[1]);
+    __syncthreads();
+}
+
+// FUSED = false: one launch per species, the plan (totals, shares, first env of every tile) comes from ppg_policy_plan[2] in memory.
+// FUSED = true (ppg_policy_pipe2_*, below): BOTH species in one launch and no plan launch -- the caller (fused_main) has computed the
+// envs' exclusive prefix sums of this species' row counts into LDS (`pre`, n_envs words behind the image area's start) and hands this
+// workgroup its place `wg` among the `n_wgs` workgroups that serve the species and the species' total `N_`.
+template <int OBS, int NCH, bool FUSED = false>
+__device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 0, int n_wgs = 0, int N_ = 0, uint32_t *scratch = nullptr) {
     constexpr int CB1 = NCH > 8 ? 2 : 1, HF = 18;
     const auto &K = *Kp;
+    const uint32_t *pre = FUSED ? scratch + FUSED_PART_WORDS + (K.species ? K.n_envs : 0) : nullptr;
     const int tid = (int)threadIdx.x, lane = tid & 63, btid = tid & 255;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool role_b = wave >= 4;
@@ -95,12 +164,28 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
     const int dummy = -512 + 8 * lane;   // (element index from img: this lane's 16 bytes of the 1 KB in front of the images; dconv.  Shared
                                          //  by the wavefronts: what lands there is never read)
     const int sample_stride = K.sample_stride;
-    const int N = (int)K.plan[0], share = (int)K.plan[1], tpw = (int)K.plan[2];
-    const int begin = (int)blockIdx.x * share, end = (begin + share) < N ? (begin + share) : N;
+    int N, share, tpw;
+    if (FUSED) {   // every workgroup of the species the same number of whole sub-groups (the plan kernel's range mode)
+        N = N_;
+        const int sg = (N + K.ST - 1) / K.ST;
+        // (integer divisions run on the vector unit: their results are pinned back into scalar registers -- the plan's words came from
+        //  scalar loads, and everything derived from them is loop control)
+        share = __builtin_amdgcn_readfirstlane(K.ST * ((sg + n_wgs - 1) / n_wgs));
+        tpw = __builtin_amdgcn_readfirstlane(share ? (share + K.range_tile - 1) / K.range_tile : 1);
+    } else {
+        N = (int)K.plan[0]; share = (int)K.plan[1]; tpw = (int)K.plan[2];
+        wg = (int)blockIdx.x;
+    }
+    const int begin = wg * share, end = (begin + share) < N ? (begin + share) : N;
     if (begin >= end) return;
     const int n_slots = (int)gridDim.x * tpw;
-    for (int i = tid; i < (K.ST * sample_stride) / 8 + 18 * 4; i += 512) ((bf16x8 *)img)[i] = zero8();
-    if (tid == 0) *ctr = 0u;
+    auto zero_images = [&] {
+        for (int i = tid; i < (K.ST * sample_stride) / 8 + 18 * 4; i += 512) ((bf16x8 *)img)[i] = zero8();
+    };
+    if (!FUSED) {
+        zero_images();
+        if (tid == 0) *ctr = 0u;
+    }
     typedef typename ObsRaw<OBS, NCH>::type raw_t;
     typedef typename ObsRaw<OBS, NCH>::elem elem_t;
     // -DPPG_DIRECT_PROFILE: cycles per phase and wavefront -> K.xg [workgroup][8][16].  Role A: 0 table, 1 conv3, 2 waiting at the barrier,
@@ -123,20 +208,31 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds) {
     // the tile's sample table: sample -> (observation row; global env index, row), bisection over the envs' prefix sums
     auto build_table = [&](int tile, int n0, int nt_samples) {
         __syncthreads();   // the previous tile's last readers of the table are done (and the zero fill has landed)
+        if (FUSED && n0 != begin) {   // a later tile of a long share: the images have overwritten the prefix sums -- once more
+            uint32_t tp, tq;
+            fused_prefix_sums<false>(K, scratch, tid, tp, tq);
+        }
         for (int i = tid; i < nt_samples; i += 512) {
             const uint32_t n = (uint32_t)(n0 + i);
-            int lo = (int)K.tile_env[tile], hi = tile + 1 < n_slots ? (int)K.tile_env[tile + 1] : K.n_envs - 1;
+            int lo, hi;
+            if (FUSED) { lo = 0; hi = K.n_envs - 1; }
+            else { lo = (int)K.tile_env[tile]; hi = tile + 1 < n_slots ? (int)K.tile_env[tile + 1] : K.n_envs - 1; }
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if (K.plan[PLAN_HDR + mid] <= n) lo = mid; else hi = mid - 1;
+                if ((FUSED ? pre[mid] : K.plan[PLAN_HDR + mid]) <= n) lo = mid; else hi = mid - 1;
             }
-            const int e = lo, row = (int)(n - K.plan[PLAN_HDR + e]);
+            const int e = lo, row = (int)(n - (FUSED ? pre[e] : K.plan[PLAN_HDR + e]));
             const unsigned char *base;
             const int b = pipe_pick_handle(K, K.obs, e, base);
             tab[2 * i] = (unsigned long long)(uintptr_t)(base + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS == 2 ? 2 : OBS == 1 ? 4 : 8));
             tab[2 * i + 1] = (unsigned long long)(uint32_t)e | ((unsigned long long)(uint32_t)row << 32);
         }
         __syncthreads();
+        if (FUSED) {   // the prefix sums lived in the image area: only now can the halo cells be zeroed
+            zero_images();
+            if (tid == 0 && n0 == begin) *ctr = 0u;
+            __syncthreads();
+        }
     };
 
     // The two roles are two separate loops (not two branches inside one): inside one loop the register allocator would have to keep BOTH
@@ -403,5 +499,83 @@ PPG_POLICY_PIPE_KERNEL(ppg_policy_pipe8_bf16, 2, 8)
 PPG_POLICY_PIPE_KERNEL(ppg_policy_pipe16_f64, 0, 16)
 PPG_POLICY_PIPE_KERNEL(ppg_policy_pipe16_f32, 1, 16)
 PPG_POLICY_PIPE_KERNEL(ppg_policy_pipe16_bf16, 2, 16)
+
+// ---- BOTH species in ONE launch, no plan launch (round 5) ----------------------------------------------------------------------
+// Rounds 2-4: a plan launch (one workgroup, 11 us), the prey's forward launch, the predators' forward launch -- the last one short
+// (ten pipeline iterations per workgroup at the benchmark, i.e. a third of its time filling and draining, matrix pipes busy 35 %) and
+// serialised behind the first, whose workgroups need a CU's whole LDS.  Here every workgroup computes the plan for itself (the envs' row
+// counts are 8 bytes per env: fused_prefix_sums), and the launch's workgroups are DIVIDED between the species in proportion to their
+// work: n_q workgroups run the prey network on all prey rows, the others the predators' network on all predator rows -- each pipeline
+// fills and drains once, over six times as many iterations for the predators, and nothing waits for a launch boundary.
+struct PolParams2 {
+    PolParams q, p;            // prey, predators (same envs, handles and action tensors)
+    int32_t iter_q, iter_p;    // cycles of one pipeline iteration (a sub-group of ST samples) of either network: the split's weights
+    int32_t scratch_off;       // byte offset of the prologue's LDS scratch: behind BOTH species' fixed areas (max of their pipe_img)
+};
+typedef const __attribute__((address_space(4))) PolParams2 *K2Ptr;
+
+template <int OBS, int NCHQ, int NCHP>
+__device__ __forceinline__ void fused_main(K2Ptr K2, unsigned char *lds) {
+    const int tid = (int)threadIdx.x;
+    uint32_t *scratch = (uint32_t *)(lds + K2->scratch_off);
+    uint32_t n_pred, n_prey;
+    fused_prefix_sums<true>(K2->q, scratch, tid, n_pred, n_prey);
+    const int G = (int)gridDim.x;
+    const int sgq = ((int)n_prey + K2->q.ST - 1) / K2->q.ST, sgp = ((int)n_pred + K2->p.ST - 1) / K2->p.ST;   // sub-groups of either species
+    if (sgq == 0 && sgp == 0) return;
+    int n_q;
+    if (sgp == 0) n_q = G;
+    else if (sgq == 0) n_q = 0;
+    else if (G < 2) n_q = G;   // (one workgroup: the prey only -- never the case on a GPU)
+    else {
+        // the split that finishes first: a workgroup's time = (its sub-groups + the pipeline's three fill / drain iterations) x the
+        // species' cycles per iteration; the real-valued optimum, then the integers around it (scalar arithmetic, every thread the same)
+        const float wq = (float)sgq * (float)K2->iter_q, wp = (float)sgp * (float)K2->iter_p;
+        int guess = (int)((float)G * wq / (wq + wp) + 0.5f);
+        int best = 1;
+        long long best_t = 0x7FFFFFFFFFFFFFFFll;
+        for (int d = -3; d <= 3; ++d) {
+            int n = guess + d;
+            n = n < 1 ? 1 : n > G - 1 ? G - 1 : n;
+            const long long tq = (long long)((sgq + n - 1) / n + 3) * K2->iter_q, tp = (long long)((sgp + (G - n) - 1) / (G - n) + 3) * K2->iter_p;
+            const long long t = tq > tp ? tq : tp;
+            if (t < best_t) { best_t = t; best = n; }
+        }
+        n_q = best;
+    }
+    n_q = __builtin_amdgcn_readfirstlane(n_q);
+    const int wg = (int)blockIdx.x;
+    // (each species' parameter block through an address the optimiser cannot see through: known to be kernel arguments, the scalar loads
+    //  of BOTH blocks' fields are hoisted into this function's entry and kept -- 228 spilled scalar registers, their reloads in the
+    //  head's and the convolutions' loops)
+    if (wg < n_q) {
+        uintptr_t kp = (uintptr_t)&K2->q;
+        __asm__ volatile("" : "+s"(kp));
+        pipe_main<OBS, NCHQ, true>((KPtr)kp, lds, wg, n_q, (int)n_prey, scratch);
+    } else {
+        uintptr_t kp = (uintptr_t)&K2->p;
+        __asm__ volatile("" : "+s"(kp));
+        pipe_main<OBS, NCHP, true>((KPtr)kp, lds, wg - n_q, G - n_q, (int)n_pred, scratch);
+    }
+}
+
+#define PPG_POLICY_PIPE2_KERNEL(name, OBS, NCHQ, NCHP)                                           \
+    extern "C" __global__ void __launch_bounds__(512, 1) name(const PolParams2 K) {              \
+        extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                      \
+        fused_main<OBS, NCHQ, NCHP>((K2Ptr)__builtin_amdgcn_kernarg_segment_ptr(), lds);         \
+    }
+// name: ppg_policy_pipe2_<prey channel slots>_<predator channel slots>_<row dtype>
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_8_bf16, 2, 16, 8)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_8_f32, 1, 16, 8)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_8_f64, 0, 16, 8)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_8_bf16, 2, 8, 8)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_8_f32, 1, 8, 8)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_8_f64, 0, 8, 8)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_16_bf16, 2, 16, 16)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_16_f32, 1, 16, 16)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_16_f64, 0, 16, 16)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_bf16, 2, 8, 16)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_f32, 1, 8, 16)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_f64, 0, 8, 16)
 
 }  // namespace ppgpol

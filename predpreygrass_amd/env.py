@@ -110,7 +110,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
         self.agents_just_ate = set()
         self.current_step = 0
         self._records = []
-        self._insertion_order = []
+        self._where = {}
+        self._insertion_order = {}   # agent ids in the order the reference's dicts first saw them (an insertion-ordered set)
         self._tables = None
 
     # ------------------------------------------------------------------
@@ -134,7 +135,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
             p, q, g = placement
             b.set_placement(np.asarray(p).reshape(1, -1, 2), np.asarray(q).reshape(1, -1, 2), np.asarray(g).reshape(1, -1, 2))
         self.cumulative_rewards = {}
-        self._insertion_order = []
+        self._insertion_order = {}
         obs = self._collect(after_reset=True)[0]
         return obs, {}
 
@@ -142,30 +143,40 @@ class PredPreyGrass(_MultiAgentEnvBase):
         """Validate an action dict like the reference would and write it into this env's row of the
         batch's action tensor.  Returns (ranks uint8 [S], dict order == row order)."""
         b, i = self._b, self._i
-        where = {name: (ty, row) for name, ty, row, _, te, _ in self._records if not te}
+        where = self._where   # name -> (type, row) of the agents alive after the last call (_collect)
         a = b.stage_actions(i)     # this env's row of the pinned host mirror of the action tensor
         a[:] = _abi.ACTION_NONE
-        rk = torch.zeros((b.S,), dtype=torch.uint8)
-        last = {PREDATOR: -1, PREY: -1}
-        count = {PREDATOR: 0, PREY: 0}
+        last = [-1, -1]
+        slots, acts = [], []
         in_row_order = True
         truncated_call = self.current_step >= self.max_steps
+        cp = b.pred_capacity
         for name, act in action_dict.items():
-            if name not in where:
+            tr = where.get(name)
+            if tr is None:
                 if truncated_call:
                     continue  # the reference returns before touching action_dict (:228-238)
                 raise KeyError(name)  # dead / unknown agent: predpreygrass_rllib_env.py:246/249
             act = int(act)
             if not 0 <= act <= 8:
                 raise KeyError(act)  # action_to_move_tuple[action], predpreygrass_rllib_env.py:502
-            ty, row = where[name]
-            s = row if ty == PREDATOR else b.pred_capacity + row
-            a[s] = act
-            rk[s] = count[ty]
-            count[ty] += 1
+            ty, row = tr
+            slots.append(row if ty == PREDATOR else cp + row)
+            acts.append(act)
             if row < last[ty]:
                 in_row_order = False
             last[ty] = row
+        if slots:
+            a[slots] = acts
+        rk = None
+        if not in_row_order:   # position of each acting row within its type's action sequence (ppg_step_ordered)
+            ranks = np.zeros((b.S,), dtype=np.uint8)
+            count = [0, 0]
+            for s_ in slots:
+                ty = PREDATOR if s_ < cp else PREY
+                ranks[s_] = count[ty]
+                count[ty] += 1
+            rk = torch.from_numpy(ranks)
         return rk, in_row_order
 
     def step(self, action_dict):
@@ -200,27 +211,41 @@ class PredPreyGrass(_MultiAgentEnvBase):
             raise RuntimeError("agent row capacity exceeded: construct the env with a larger prey_capacity")
         if status & _abi.STATUS_FAILED_SPAWN:
             raise TypeError("no free cell for a newborn (the reference fails at predpreygrass_rllib_env.py:401-405)")
-        recs = b.records(0, t)
         obs, rew, term, trunc = {}, {}, {}, {}
-        for name, ty, row, r, te, tr in recs:
-            obs[name] = (op if ty == PREDATOR else oq)[row].astype(np.float64)
-            rew[name], term[name], trunc[name] = r, te, tr
-        fl = int(es[_abi.ENV_FLAGS])
+        # one float64 copy of each species' blocks in use (the fetch buffer is reused by the next call); the dict entries are its rows
+        ops = (np.array(op, dtype=np.float64), np.array(oq, dtype=np.float64))
+        cp = b.pred_capacity
+        es = es.tolist()
+        nP, nQ, newP, newQ = es[_abi.ENV_N_PRED_ROWS], es[_abi.ENV_N_PREY_ROWS], es[_abi.ENV_N_PRED_NEW], es[_abi.ENV_N_PREY_NEW]
+        ids, fls, rws, cum = (t[k][0].tolist() for k in ("row_id", "row_flags", "row_reward", "row_cumrew"))
+        order, cumulative, ate, where, recs = self._insertion_order, self.cumulative_rewards, set(), {}, []
+        DIED, TRUNC, ATE = _abi.ROW_DIED, _abi.ROW_TRUNC, _abi.ROW_ATE
+        # the reference's dict order (BatchedPredPreyGrass.records): predator survivors, prey survivors, predator newborns, prey newborns
+        for ty, lo, hi in ((PREDATOR, 0, nP - newP), (PREY, 0, nQ - newQ), (PREDATOR, nP - newP, nP), (PREY, nQ - newQ, nQ)):
+            base, fmt, rows = (0, "predator_%d", ops[0]) if ty == PREDATOR else (cp, "prey_%d", ops[1])
+            for row in range(lo, hi):
+                s = base + row
+                name, fl, r = fmt % ids[s], fls[s], rws[s]
+                te, tr = bool(fl & DIED), bool(fl & TRUNC)
+                recs.append((name, ty, row, r, te, tr))
+                obs[name] = rows[row]
+                rew[name], term[name], trunc[name] = r, te, tr
+                cumulative[name] = cum[s]
+                order.setdefault(name)
+                if fl & ATE:
+                    ate.add(name)
+                if not te:
+                    where[name] = (ty, row)
+        fl = es[_abi.ENV_FLAGS]
         was_trunc_call = bool(fl & _abi.ENVF_TRUNC_ALL)
         self._records = recs
-        self.current_step = int(es[_abi.ENV_STEP])
-        self.current_num_predators = int(es[_abi.ENV_N_PRED_ALIVE])
-        self.current_num_prey = int(es[_abi.ENV_N_PREY_ALIVE])
-        self._next_predator_idx = int(es[_abi.ENV_NEXT_PRED_ID])
-        self._next_prey_idx = int(es[_abi.ENV_NEXT_PREY_ID])
-        cp = b.pred_capacity
-        for name, ty, row, *_ in recs:
-            s = row if ty == PREDATOR else cp + row
-            self.cumulative_rewards[name] = float(t["row_cumrew"][0][s])
-            if name not in self._insertion_order:
-                self._insertion_order.append(name)
-        self.agents_just_ate = {name for name, ty, row, *_ in recs
-                                if t["row_flags"][0][row if ty == PREDATOR else cp + row] & _abi.ROW_ATE}
+        self._where = where
+        self.current_step = es[_abi.ENV_STEP]
+        self.current_num_predators = es[_abi.ENV_N_PRED_ALIVE]
+        self.current_num_prey = es[_abi.ENV_N_PREY_ALIVE]
+        self._next_predator_idx = es[_abi.ENV_NEXT_PRED_ID]
+        self._next_prey_idx = es[_abi.ENV_NEXT_PREY_ID]
+        self.agents_just_ate = ate
         names = [r[0] for r in recs]
         # self.agents: reset leaves it in creation order (:143); every full step ends with .sort() (:468);
         # the truncation call returns before the sort but the list is already sorted by then.
@@ -345,7 +370,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
         b, i = self._b, self._i
         b.import_state(snapshot["_device_state"], i)
         self.cumulative_rewards = dict(snapshot["cumulative_rewards"])
-        self._insertion_order = list(snapshot["_insertion_order"])
+        self._insertion_order = dict.fromkeys(snapshot["_insertion_order"])
         b.observe()
         saved_agents = list(snapshot["agents"])
         self._collect(after_reset=False)
@@ -421,7 +446,7 @@ class VectorPredPreyGrass:
         for i, e in enumerate(self.envs):
             was_reset = bool(int(tables["env_state"][i][_abi.ENV_FLAGS]) & _abi.ENVF_WAS_RESET)
             if was_reset and not after_reset:
-                e.cumulative_rewards, e._insertion_order = {}, []
+                e.cumulative_rewards, e._insertion_order = {}, {}
                 o, _ = e._collect(True, tables, obs)
                 out.append((o, {a: 0.0 for a in o}, {**{a: False for a in o}, "__all__": False},
                             {**{a: False for a in o}, "__all__": False}, {"reset": True}))
@@ -433,7 +458,7 @@ class VectorPredPreyGrass:
         """Device-side placement for every env (env i uses Philox key seed + i); returns [(obs, {}), ...]."""
         self.batch.reset(seed=seed)
         for e in self.envs:
-            e.cumulative_rewards, e._insertion_order = {}, []
+            e.cumulative_rewards, e._insertion_order = {}, {}
         return self._collect_all(after_reset=True)
 
     def step(self, action_dicts):
@@ -448,7 +473,8 @@ class VectorPredPreyGrass:
                 b.stage_actions(i)[:] = _abi.ACTION_NONE  # ignored: this call resets the env
                 continue
             rk, in_order = e._stage(ad)
-            ranks[i] = rk
+            if rk is not None:
+                ranks[i] = rk
             all_in_order = all_in_order and in_order
         b.upload_actions()   # ONE host->device copy for all envs
         if all_in_order:

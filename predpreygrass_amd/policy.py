@@ -103,7 +103,8 @@ def load_rllib_state_dict(state_dict, obs_range: int = None, obs_channels: int =
     lines 69-96 (`module.get_state()` / the unpickled `module_state.pkl` of a checkpoint; tensors or numpy arrays).
 
     Parameter discovery is by ROLE, because the key names depend on the RLlib version and on `vf_share_layers`:
-      conv layers  = the 4-D weights (with their biases) whose key contains "encoder" and not "critic" / "vf", in key order
+      conv layers  = the 4-D weights (with their biases) whose key contains "encoder" and not "critic" / "vf", in the natural
+                     (numeric) order of their keys
                      (encoder.actor_encoder.net.0.cnn.{1,4,7,...}.weight, or encoder.encoder... with a shared encoder);
       head layers  = the 2-D weights whose key starts with "pi." (pi.net.mlp.0.weight alone in what RLlib builds by default;
                      pi.net.mlp.{0,2,..} with `head_fcnet_hiddens`).
@@ -126,6 +127,13 @@ def load_rllib_state_dict(state_dict, obs_range: int = None, obs_channels: int =
     head_w = [k for k, v in sd.items() if v.dim() == 2 and k.lower().startswith("pi.")]
     if not head_w:
         head_w = [k for k, v in sd.items() if v.dim() == 2 and "critic" not in k.lower() and not k.lower().startswith("vf")]
+    # layer order = the NUMERIC layer indices in the keys (cnn.1, cnn.4, cnn.7, cnn.10), not the dict's order: a state dict that has
+    # been sorted or re-serialised lists cnn.1, cnn.10, cnn.4, cnn.7 (tests/golden/rllib_checkpoint/state_listing.json)
+    def natural(k):
+        import re
+        return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", k)]
+    conv_w.sort(key=natural)
+    head_w.sort(key=natural)
     if not 1 <= len(conv_w) <= _abi.POLICY_MAX_CONV or not 1 <= len(head_w) <= _abi.POLICY_MAX_FC:
         raise ValueError(f"expected 1-{_abi.POLICY_MAX_CONV} convolution and 1-{_abi.POLICY_MAX_FC} linear weights of the policy "
                          f"network, found {len(conv_w)} / {len(head_w)}: {listing}")

@@ -119,6 +119,9 @@ def test_policy_kernel_choice_and_lds_layout_for_every_shape(hip_lib_path):
                         out = (ctypes.c_int32 * 12)()
                         rc = lib.ppg_policy_describe(ctypes.byref(sp), out, 12)
                         P = (C if layout == _abi.POLICY_LAYOUT_HWC else R) * R
+                        if n_fc > 1 and layout == _abi.POLICY_LAYOUT_CHW and C != 4:
+                            assert rc != 0   # (ppg_policy_create_spec refuses it: the description does too)
+                            continue
                         if rc != 0:
                             assert n_fc == 1 and P * 64 * 6 * 2 > 100 * 1024, (layout, C, R, n_conv, n_fc, n_actions)   # only images too large for one sample
                             continue
@@ -140,6 +143,22 @@ def test_policy_kernel_choice_and_lds_layout_for_every_shape(hip_lib_path):
                         else:
                             assert threads == 256 and st * P <= 512
     assert seen[0] > 0 and seen[1] > 0 and seen[2] > 0 and seen[3] > 100
+    # a description exists exactly for the networks ppg_policy_create_spec can build: the same shape rules refuse the rest
+    def spec(**kw):
+        sp = _abi.PpgPolicySpec()
+        sp.obs_channels, sp.obs_range, sp.n_actions, sp.layout, sp.flatten, sp.n_conv, sp.n_fc = 4, 9, 9, _abi.POLICY_LAYOUT_HWC, _abi.POLICY_FLATTEN_NHWC, 3, 1
+        sp.conv_out[0], sp.conv_out[1], sp.conv_out[2], sp.fc_out[0] = 16, 32, 64, 9
+        for k, v in kw.items():
+            if isinstance(v, tuple):
+                getattr(sp, k)[v[0]] = v[1]
+            else:
+                setattr(sp, k, v)
+        return sp
+    out = (ctypes.c_int32 * 12)()
+    assert lib.ppg_policy_describe(ctypes.byref(spec()), out, 12) == 0
+    for bad in (dict(conv_out=(0, 17)), dict(conv_out=(2, 65)), dict(conv_out=(1, 0)), dict(fc_out=(0, 8)), dict(flatten=7), dict(layout=3),
+                dict(n_fc=2, fc_out=(0, 300)), dict(n_fc=2, n_conv=2, fc_out=(1, 9)), dict(n_actions=33, fc_out=(0, 33)), dict(obs_range=16)):
+        assert lib.ppg_policy_describe(ctypes.byref(spec(**bad)), out, 12) == -1, bad
     # the reference's shapes: 7x7 predators, 9x9 prey, three convolutions, nine actions -> the pipeline with 9 / 7 samples per sub-group
     for R, st in ((7, 9), (9, 7)):
         sp = _abi.PpgPolicySpec()

@@ -86,6 +86,11 @@ def test_real_rllib_checkpoint_pins_the_architecture():
     x = torch.rand(7, 5, 9, 9) * 3
     assert torch.equal(got(x), net(x))
     assert float(net(x).abs().max()) > 1e-3
+    # a state dict in SORTED key order (cnn.1, cnn.10, cnn.4, cnn.7 -- what a re-serialised checkpoint or the listing itself holds):
+    # the layers are taken in the numeric order of their indices
+    resorted = {k: full[k] for k in sorted(full)}
+    assert [k for k in resorted if "actor_encoder" in k and k.endswith("weight")][1].endswith("cnn.10.weight")
+    assert torch.equal(load_rllib_state_dict(resorted)(x), net(x))
 
 
 def rllib_style_state_dict(net, shared_encoder=False, numpy_values=False):
@@ -447,6 +452,76 @@ def test_pipeline_and_one_role_kernels_give_the_same_logits_bit_for_bit(dt, monk
     for a, b in zip(*out):
         assert torch.equal(a, b)
     assert bool(out[0][1].abs().sum() > 0) and not torch.equal(out[0][2], out[0][3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,steps,dt", [(4096, 150, torch.bfloat16), (700, 60, torch.float64), (700, 60, torch.float32),
+                                            (6500, 500, torch.bfloat16), (3, 30, torch.bfloat16), (1, 5, torch.bfloat16)])
+def test_one_fused_launch_gives_what_the_separate_launches_give(batch, steps, dt, monkeypatch):
+    """Round 5: ppg_policy_act with both species = ONE launch (ppg_policy_pipe2_*: the plan computed by every workgroup for itself, the
+    launch's workgroups divided between the species).  PPG_POLICY_FUSED=0 sends the same call through the plan launch + two forward
+    launches of rounds 2-4: identical logits, greedy AND sampled actions -- at the benchmark's size, with float64 / float32 rows, with
+    shares longer than a workgroup's table (6500 envs: several tiles per workgroup), with fewer rows than workgroups, with one env."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy
+    nets = make_nets(seed=52)
+    env = BatchedPredPreyGrass(dict(config_env), batch_size=batch, device="cuda:0", obs_dtype=dt, seed=15)
+    env.reset()
+    for _ in range(steps):
+        env.step(random_actions=True, auto_reset=True)
+    fused = FusedPolicy(nets[0], nets[1])
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PPG_POLICY_FUSED", mode)
+        env.actions.fill_(_abi.ACTION_NONE)
+        lg = fused.act(env, want_logits=True)
+        greedy = env.actions.clone()
+        fused.act(env, sample=True, seed=78)
+        torch.cuda.synchronize()
+        out.append((lg[0].clone(), lg[1].clone(), greedy, env.actions.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert bool(out[0][1].abs().sum() > 0) and (batch < 10 or not torch.equal(out[0][2], out[0][3]))
+    env.step(env.actions, auto_reset=True)
+    torch.cuda.synchronize()
+    assert (env.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()
+
+
+@pytest.mark.gpu
+def test_fused_launch_over_several_sub_batches_and_an_extinct_species(monkeypatch):
+    """The fused launch over three handles (the envs of a GPU as sub-batches), and with one species extinct everywhere (every
+    workgroup then serves the other one)."""
+    from predpreygrass_amd.policy import FusedPolicy
+    from predpreygrass_amd.subbatch import SubBatchedPredPreyGrass
+    nets = make_nets(seed=53)
+    group = SubBatchedPredPreyGrass(dict(config_env), batch_size=900, n_sub=3, device="cuda:0", obs_dtype=torch.bfloat16, seed=3)
+    group.reset()
+    for _ in range(80):
+        group.step(random_actions=True, auto_reset=True)
+    group.synchronize()
+    fused = FusedPolicy(nets[0], nets[1])
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PPG_POLICY_FUSED", mode)
+        lg = fused.act(group.subs, want_logits=True)
+        torch.cuda.synchronize()
+        res.append((lg[0].clone(), lg[1].clone(), torch.cat([e.actions for e in group.subs]).clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    cfg = dict(config_env, n_initial_active_predator=0)
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    env = BatchedPredPreyGrass(cfg, batch_size=300, device="cuda:0", obs_dtype=torch.bfloat16, seed=4)
+    env.reset()
+    env.step(random_actions=True)
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PPG_POLICY_FUSED", mode)
+        lg = fused.act(env, want_logits=True)
+        torch.cuda.synchronize()
+        res.append((lg[0].clone(), lg[1].clone(), env.actions.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][0].abs().sum()) == 0.0 and float(res[0][1].abs().sum()) > 0.0   # (no predator row anywhere)
 
 
 @pytest.mark.gpu
