@@ -295,7 +295,12 @@ struct Env {
     // cumulative_rewards rides through the step in registers (fetched with the rows, permuted with them).  The other kernels read
     // it back from HBM at the row's start-of-step slot when the rewards are assembled, to save two registers per row register --
     // but that is a second dependent memory round trip per call, and under a saturated memory system a round trip is 5-10 k cycles.
-    static constexpr bool CARRY_CUM = COOP;
+    // Round 5: the multi-wave kernels of the base family too (BASELINE configs 2 and 4: ppgw16_step / ppgwp_step) -- their phase profiles
+    // (profiles/r05) show the "store" phase, i.e. this read-back, at 16-18 % of a wavefront's transition.
+#ifndef PPG_CARRY_CUM_MULTIWAVE
+#define PPG_CARRY_CUM_MULTIWAVE 1
+#endif
+    static constexpr bool CARRY_CUM = COOP || (PPG_CARRY_CUM_MULTIWAVE && NW > 1 && !GEN2 && !WALLS && !DRIVE && !KICK && NQ <= 2);
     template <bool B8, class Dummy = void> struct MapElem { typedef uint16_t type; };
     template <class Dummy> struct MapElem<true, Dummy> { typedef uint8_t type; };
     typedef typename MapElem<MAP8>::type map_t;

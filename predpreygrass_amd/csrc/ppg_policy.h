@@ -1022,6 +1022,7 @@ struct ppg_policy {
     uint32_t *plan;        // [PLAN_HDR + plan_envs] header + prefix sums, then the first env of every tile
     int32_t plan_envs;
     size_t plan_words;     // words the buffer was allocated with (it depends on the species' row capacity too)
+    uint32_t *pre_g;       // the fused launch's prefix sums in memory (PolParams2::pre_g), [2][FUSED_MAX_ENVS]; owned by the prey's policy
     int32_t grid;
     int32_t lds_bytes;
     hipStream_t side;      // ppg_policy_act with both species: the predators' launch runs beside the prey's (fork / join by events)
@@ -1490,6 +1491,7 @@ int ppg_policy_destroy(ppg_policy *p) {
     if (p->dev_weights) (void)hipFree(p->dev_weights);
     if (p->xg) { if (p->xg_is_spread) (void)ppg_free_spread(p->xg); else (void)hipFree(p->xg); }
     if (p->plan) (void)hipFree(p->plan);
+    if (p->pre_g) (void)hipFree(p->pre_g);
     if (p->lgs) (void)hipFree(p->lgs);
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->fork) (void)hipEventDestroy(p->fork);
@@ -1522,6 +1524,30 @@ static int ppg_policy_ensure_plan(ppg_policy *p, int total, int cap) {
     p->plan_words = words;
     return PPG_OK;
 }
+
+#ifdef PPG_PIPE_DEBUG
+// diagnostic build: status words the pipeline kernels' bounded waits report into; checked (with a device synchronisation) after every
+// launch.  PPG_PIPE_DEBUG_INJECT=1 (tests): pretend a report, to exercise the path that turns it into an error.
+static uint32_t *g_pipe_status_host = nullptr;
+static int ppg_pipe_debug_arm(ppg_policy *p) {
+    if (!g_pipe_status_host) {
+        PPG_POL_TRY(p, hipMalloc((void **)&g_pipe_status_host, 32));
+        PPG_POL_TRY(p, hipMemcpyToSymbol(HIP_SYMBOL(ppgpol::g_pipe_status), &g_pipe_status_host, sizeof(uint32_t *)));
+    }
+    PPG_POL_TRY(p, hipMemset(g_pipe_status_host, 0, 32));
+    return PPG_OK;
+}
+static int ppg_pipe_debug_check(ppg_policy *p) {
+    uint32_t st[8];
+    PPG_POL_TRY(p, hipDeviceSynchronize());
+    PPG_POL_TRY(p, hipMemcpy(st, g_pipe_status_host, 32, hipMemcpyDeviceToHost));
+    if (getenv("PPG_PIPE_DEBUG_INJECT")) { st[0] = 1; st[1] = 7; st[2] = 5; st[3] = 11; st[4] = 12; }
+    if (st[0])
+        return ppg_policy_fail(p, PPG_EHIP, "pipeline barrier: %u wavefront(s) gave up waiting; first: workgroup %u wavefront %u saw counter %u, wanted %u",
+                               st[0], st[1], st[2], st[3], st[4]);
+    return PPG_OK;
+}
+#endif
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the process-global kernel symbol, not of a policy: two live policies that
 // share a kernel (say two pipe8 policies with different windows) need different amounts.  A running maximum per kernel is kept and raised
@@ -1665,9 +1691,18 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
         const fwd_fn pipe[2][3] = {{ppgpol::ppg_policy_pipe8_f64, ppgpol::ppg_policy_pipe8_f32, ppgpol::ppg_policy_pipe8_bf16},
                                    {ppgpol::ppg_policy_pipe16_f64, ppgpol::ppg_policy_pipe16_f32, ppgpol::ppg_policy_pipe16_bf16}};
         const fwd_fn fn = p->pipe ? pipe[p->nch16 ? 1 : 0][dt] : dir[(p->direct == 2 ? 2 : 0) + (p->nch16 ? 1 : 0)][dt];
-        const int rc = ppg_policy_reserve_lds(p, (const void *)fn, p->lds_bytes);
+        int rc = ppg_policy_reserve_lds(p, (const void *)fn, p->lds_bytes);
         if (rc != PPG_OK) return rc;
+#ifdef PPG_PIPE_DEBUG
+        rc = ppg_pipe_debug_arm(p);
+        if (rc != PPG_OK) return rc;
+#endif
         hipLaunchKernelGGL(fn, dim3((unsigned)p->grid), dim3(p->pipe ? 512 : 256), (size_t)p->lds_bytes, (hipStream_t)stream, K);
+#ifdef PPG_PIPE_DEBUG
+        PPG_POL_TRY(p, hipGetLastError());
+        rc = ppg_pipe_debug_check(p);
+        if (rc != PPG_OK) return rc;
+#endif
     } else {
         const int variant = p->layout == PPG_POLICY_LAYOUT_HWC ? (p->cin > 8 ? 2 : 1) : 0;
         const int rc = ppg_policy_reserve_lds(p, (const void *)fwd[variant][dt], p->lds_bytes);
@@ -1707,6 +1742,7 @@ static bool ppg_fused_enabled() {
     const char *e = getenv("PPG_POLICY_FUSED");
     return !(e && e[0] == '0' && e[1] == 0);
 }
+
 static int ppg_env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return (e && atoi(e) > 0) ? atoi(e) : dflt;
@@ -1728,10 +1764,12 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
     K2.scratch_off = (img + 15) / 16 * 16;
     if (total_q > ppgpol::FUSED_MAX_ENVS || K2.scratch_off + ppgpol::FUSED_PART_WORDS * 4 + 8 * total_q > lds) return 1;
     K2.q.plan = K2.p.plan = nullptr; K2.q.tile_env = K2.p.tile_env = nullptr;
+    if (!prey->pre_g) PPG_POL_TRY(prey, hipMalloc((void **)&prey->pre_g, (size_t)2 * ppgpol::FUSED_MAX_ENVS * 4));
+    K2.pre_g = prey->pre_g;
     // cycles per pipeline iteration of either network (measured on the reference's shapes, profiles/r04-r05; PPG_POLICY_ITER_Q / _P:
     // experiments): only their RATIO matters -- it decides how many workgroups serve which species
     K2.iter_q = ppg_env_int("PPG_POLICY_ITER_Q", 7500);
-    K2.iter_p = ppg_env_int("PPG_POLICY_ITER_P", 6500);
+    K2.iter_p = ppg_env_int("PPG_POLICY_ITER_P", 5500);
     typedef void (*fused_fn)(const ppgpol::PolParams2);
     const fused_fn fn[2][2][3] = {
         {{ppgpol::ppg_policy_pipe2_8_8_f64, ppgpol::ppg_policy_pipe2_8_8_f32, ppgpol::ppg_policy_pipe2_8_8_bf16},
@@ -1756,8 +1794,16 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
 #endif
     rc = ppg_policy_reserve_lds(prey, (const void *)f, lds);
     if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
+#ifdef PPG_PIPE_DEBUG
+    rc = ppg_pipe_debug_arm(prey);
+    if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
+#endif
     hipLaunchKernelGGL(f, dim3((unsigned)prey->grid), dim3(512), (size_t)lds, (hipStream_t)stream, K2);
     PPG_POL_TRY(prey, hipGetLastError());
+#ifdef PPG_PIPE_DEBUG
+    rc = ppg_pipe_debug_check(prey);
+    if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
+#endif
 #ifdef PPG_DIRECT_PROFILE
     if (dp_now) {
         PPG_POL_TRY(prey, hipDeviceSynchronize());

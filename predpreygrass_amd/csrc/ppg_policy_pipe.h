@@ -50,9 +50,31 @@ __device__ __forceinline__ void pipe_arrive(uint32_t *ctr, int lane) {
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LDS serves a wavefront in order)
     if (lane == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// -DPPG_PIPE_DEBUG (tools/build_pipe_debug.sh -> tools/_build/libppg_hip_pipedbg.so; never the product): the wait gives up after
+// PPG_PIPE_DEBUG_POLLS polls and reports (workgroup, wavefront, counter, target) through the policy's status words, which
+// ppg_policy_act reads back after every launch of that build -- a lost arrival is an error message instead of a hung GPU.
+#ifndef PPG_PIPE_DEBUG_POLLS
+#define PPG_PIPE_DEBUG_POLLS 2000000
+#endif
+#ifdef PPG_PIPE_DEBUG
+__device__ uint32_t *g_pipe_status;   // set per launch by the host side (hipMemcpyToSymbol): [0] count, [1..4] the first report
+#endif
 __device__ __forceinline__ void pipe_wait(uint32_t *ctr, uint32_t target) {
-    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+#ifdef PPG_PIPE_DEBUG
+    int polls = 0;
+#endif
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) {
         __builtin_amdgcn_s_sleep(PPG_PIPE_SLEEP);
+#ifdef PPG_PIPE_DEBUG
+        if (++polls > PPG_PIPE_DEBUG_POLLS) {
+            if ((threadIdx.x & 63u) == 0 && g_pipe_status && atomicAdd(&g_pipe_status[0], 1u) == 0u) {
+                g_pipe_status[1] = blockIdx.x; g_pipe_status[2] = threadIdx.x >> 6;
+                g_pipe_status[3] = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); g_pipe_status[4] = target;
+            }
+            break;
+        }
+#endif
+    }
     __asm__ volatile("" ::: "memory");
 }
 __device__ __forceinline__ void pipe_bsync(uint32_t *ctr, uint32_t target, int lane) {
@@ -83,9 +105,7 @@ __device__ __forceinline__ int pipe_pick_handle(const KP &K, const Bases &bases,
 // envs' predator / prey row counts (env words 0, 1: one 8-byte load per env) over the concatenated envs of all handles, in LDS:
 // scratch = [512 threads][2] partial sums | pre_pred[n_envs] | pre_prey[n_envs].  512 threads; ends with a workgroup barrier.
 constexpr int FUSED_PART_WORDS = 1024, FUSED_MAX_ENVS = 8192, FUSED_RUN = FUSED_MAX_ENVS / 512;
-// FAST = true: the launch's prologue -- a thread's loads all in flight at once (16 register pairs).  FAST = false: the same sums once
-// more in front of a later tile of a long share, inside the pipeline's roles whose weights fill the register file: one env at a time.
-template <bool FAST, class KP>
+template <class KP>
 __device__ __forceinline__ void fused_prefix_sums(const KP &K, uint32_t *scratch, int tid, uint32_t &tot_pred, uint32_t &tot_prey) {
     static_assert(PPG_ENV_N_PRED_ROWS == 0 && PPG_ENV_N_PREY_ROWS == 1, "the two row counts are one 8-byte load");
     const int per = (K.n_envs + 511) / 512;
@@ -95,51 +115,42 @@ __device__ __forceinline__ void fused_prefix_sums(const KP &K, uint32_t *scratch
         const int b = pipe_pick_handle(K, K.env_state, e, base);
         return *(const GLOBAL_AS u32x2_t *)(base + (size_t)b * PPG_ENV_WORDS);
     };
-    u32x2_t cnt[FAST ? FUSED_RUN : 1];
+    u32x2_t cnt[FUSED_RUN];
     uint32_t sp = 0, sq = 0;
-    if (FAST) {
 #pragma unroll
-        for (int i = 0; i < FUSED_RUN; ++i)   // (unconditional loads of a clamped env: see pipe_main's fetch)
-            cnt[i] = count_of((lo + i) < K.n_envs ? (lo + i) : K.n_envs - 1);
+    for (int i = 0; i < FUSED_RUN; ++i)   // (unconditional loads of a clamped env, all in flight at once: see pipe_main's fetch)
+        cnt[i] = count_of((lo + i) < K.n_envs ? (lo + i) : K.n_envs - 1);
 #pragma unroll
-        for (int i = 0; i < FUSED_RUN; ++i)
-            if (i < per && lo + i < hi) { sp += cnt[i][0]; sq += cnt[i][1]; }
-    } else {
-#pragma nounroll
-        for (int e = lo; e < hi; ++e) { const u32x2_t c = count_of(e); sp += c[0]; sq += c[1]; }
+    for (int i = 0; i < FUSED_RUN; ++i)
+        if (i < per && lo + i < hi) { sp += cnt[i][0]; sq += cnt[i][1]; }
+    // inclusive scan over the 512 threads: inside a wavefront on the cross-lane paths, the eight wavefronts' totals through LDS --
+    // two barriers (a Hillis-Steele scan over 512 LDS words took eighteen, in front of every workgroup's first sample)
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t ip = sp, iq = sq;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t vp = (uint32_t)__shfl_up((int)ip, d, 64), vq = (uint32_t)__shfl_up((int)iq, d, 64);
+        if (lane >= d) { ip += vp; iq += vq; }
     }
-    u32x2_t *part = (u32x2_t *)scratch;
-    u32x2_t mine = {sp, sq};
-    part[tid] = mine;
+    u32x2_t *part = (u32x2_t *)scratch;   // [8] wavefront totals
+    if (lane == 63) { const u32x2_t t = {ip, iq}; part[wave] = t; }
     __syncthreads();
-    for (int d = 1; d < 512; d <<= 1) {   // inclusive Hillis-Steele scan of the pairs
-        u32x2_t v = {0u, 0u};
-        if (tid >= d) v = part[tid - d];
-        __syncthreads();
-        mine[0] += v[0]; mine[1] += v[1];
-        part[tid] = mine;
-        __syncthreads();
-    }
-    uint32_t bp = mine[0] - sp, bq = mine[1] - sq;
-    uint32_t *pre_pred = scratch + FUSED_PART_WORDS, *pre_prey = pre_pred + K.n_envs;
-    if (FAST) {
+    uint32_t bp = ip - sp, bq = iq - sq, allp = 0, allq = 0;
 #pragma unroll
-        for (int i = 0; i < FUSED_RUN; ++i)
-            if (i < per && lo + i < hi) {
-                pre_pred[lo + i] = bp; pre_prey[lo + i] = bq;
-                bp += cnt[i][0]; bq += cnt[i][1];
-            }
-    } else {
-#pragma nounroll
-        for (int e = lo; e < hi; ++e) {
-            const u32x2_t c = count_of(e);
-            pre_pred[e] = bp; pre_prey[e] = bq;
-            bp += c[0]; bq += c[1];
-        }
+    for (int w = 0; w < 8; ++w) {
+        const u32x2_t t = part[w];
+        if (w < wave) { bp += t[0]; bq += t[1]; }
+        allp += t[0]; allq += t[1];
     }
-    const u32x2_t all = part[511];
-    tot_pred = (uint32_t)__builtin_amdgcn_readfirstlane((int)all[0]);
-    tot_prey = (uint32_t)__builtin_amdgcn_readfirstlane((int)all[1]);
+    uint32_t *pre_pred = scratch + FUSED_PART_WORDS, *pre_prey = pre_pred + K.n_envs;
+#pragma unroll
+    for (int i = 0; i < FUSED_RUN; ++i)
+        if (i < per && lo + i < hi) {
+            pre_pred[lo + i] = bp; pre_prey[lo + i] = bq;
+            bp += cnt[i][0]; bq += cnt[i][1];
+        }
+    tot_pred = (uint32_t)__builtin_amdgcn_readfirstlane((int)allp);
+    tot_prey = (uint32_t)__builtin_amdgcn_readfirstlane((int)allq);
     __syncthreads();
 }
 
@@ -148,7 +159,8 @@ __device__ __forceinline__ void fused_prefix_sums(const KP &K, uint32_t *scratch
 // envs' exclusive prefix sums of this species' row counts into LDS (`pre`, n_envs words behind the image area's start) and hands this
 // workgroup its place `wg` among the `n_wgs` workgroups that serve the species and the species' total `N_`.
 template <int OBS, int NCH, bool FUSED = false>
-__device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 0, int n_wgs = 0, int N_ = 0, uint32_t *scratch = nullptr) {
+__device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 0, int n_wgs = 0, int N_ = 0, uint32_t *scratch = nullptr,
+                                          const uint32_t *pre_g = nullptr) {
     constexpr int CB1 = NCH > 8 ? 2 : 1, HF = 18;
     const auto &K = *Kp;
     const uint32_t *pre = FUSED ? scratch + FUSED_PART_WORDS + (K.species ? K.n_envs : 0) : nullptr;
@@ -208,10 +220,6 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
     // the tile's sample table: sample -> (observation row; global env index, row), bisection over the envs' prefix sums
     auto build_table = [&](int tile, int n0, int nt_samples) {
         __syncthreads();   // the previous tile's last readers of the table are done (and the zero fill has landed)
-        if (FUSED && n0 != begin) {   // a later tile of a long share: the images have overwritten the prefix sums -- once more
-            uint32_t tp, tq;
-            fused_prefix_sums<false>(K, scratch, tid, tp, tq);
-        }
         for (int i = tid; i < nt_samples; i += 512) {
             const uint32_t n = (uint32_t)(n0 + i);
             int lo, hi;
@@ -219,9 +227,13 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
             else { lo = (int)K.tile_env[tile]; hi = tile + 1 < n_slots ? (int)K.tile_env[tile + 1] : K.n_envs - 1; }
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if ((FUSED ? pre[mid] : K.plan[PLAN_HDR + mid]) <= n) lo = mid; else hi = mid - 1;
+                // (FUSED: the first tile's prefix sums are in LDS; the images have overwritten them by the time a long share's later
+                //  tiles come -- those read the copy this workgroup put into memory, fused_main)
+                const uint32_t at = !FUSED ? K.plan[PLAN_HDR + mid] : n0 == begin ? pre[mid] : __builtin_nontemporal_load(&pre_g[mid]);
+                if (at <= n) lo = mid; else hi = mid - 1;
             }
-            const int e = lo, row = (int)(n - (FUSED ? pre[e] : K.plan[PLAN_HDR + e]));
+            const int e = lo;
+            const int row = (int)(n - (!FUSED ? K.plan[PLAN_HDR + e] : n0 == begin ? pre[e] : __builtin_nontemporal_load(&pre_g[e])));
             const unsigned char *base;
             const int b = pipe_pick_handle(K, K.obs, e, base);
             tab[2 * i] = (unsigned long long)(uintptr_t)(base + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS == 2 ? 2 : OBS == 1 ? 4 : 8));
@@ -511,6 +523,7 @@ struct PolParams2 {
     PolParams q, p;            // prey, predators (same envs, handles and action tensors)
     int32_t iter_q, iter_p;    // cycles of one pipeline iteration (a sub-group of ST samples) of either network: the split's weights
     int32_t scratch_off;       // byte offset of the prologue's LDS scratch: behind BOTH species' fixed areas (max of their pipe_img)
+    uint32_t *pre_g;           // library-owned [2][n_envs]: the prefix sums (predators, prey) for workgroups whose share is several tiles
 };
 typedef const __attribute__((address_space(4))) PolParams2 *K2Ptr;
 
@@ -519,7 +532,7 @@ __device__ __forceinline__ void fused_main(K2Ptr K2, unsigned char *lds) {
     const int tid = (int)threadIdx.x;
     uint32_t *scratch = (uint32_t *)(lds + K2->scratch_off);
     uint32_t n_pred, n_prey;
-    fused_prefix_sums<true>(K2->q, scratch, tid, n_pred, n_prey);
+    fused_prefix_sums(K2->q, scratch, tid, n_pred, n_prey);
     const int G = (int)gridDim.x;
     const int sgq = ((int)n_prey + K2->q.ST - 1) / K2->q.ST, sgp = ((int)n_pred + K2->p.ST - 1) / K2->p.ST;   // sub-groups of either species
     if (sgq == 0 && sgp == 0) return;
@@ -545,17 +558,31 @@ __device__ __forceinline__ void fused_main(K2Ptr K2, unsigned char *lds) {
     }
     n_q = __builtin_amdgcn_readfirstlane(n_q);
     const int wg = (int)blockIdx.x;
+    {   // A share longer than the workgroup's sample table comes as several tiles, and the first tile's images overwrite the prefix sums
+        // in LDS: such a workgroup puts them into memory first (K2->pre_g: every workgroup would write the SAME words there; it reads back
+        // its own stores) and bisects there for its later tiles -- twelve dependent L2 reads per sample instead of LDS reads.
+        const bool is_q = wg < n_q;
+        const int st = is_q ? K2->q.ST : K2->p.ST, rt = is_q ? K2->q.range_tile : K2->p.range_tile, n_w = is_q ? n_q : G - n_q;
+        const int sg = is_q ? sgq : sgp;
+        const int share = __builtin_amdgcn_readfirstlane(st * ((sg + n_w - 1) / n_w));
+        if (share > rt) {
+            const uint32_t *src = scratch + FUSED_PART_WORDS;
+            for (int i = tid; i < 2 * K2->q.n_envs; i += 512) K2->pre_g[i] = src[i];
+            __threadfence();
+            __syncthreads();
+        }
+    }
     // (each species' parameter block through an address the optimiser cannot see through: known to be kernel arguments, the scalar loads
     //  of BOTH blocks' fields are hoisted into this function's entry and kept -- 228 spilled scalar registers, their reloads in the
     //  head's and the convolutions' loops)
     if (wg < n_q) {
         uintptr_t kp = (uintptr_t)&K2->q;
         __asm__ volatile("" : "+s"(kp));
-        pipe_main<OBS, NCHQ, true>((KPtr)kp, lds, wg, n_q, (int)n_prey, scratch);
+        pipe_main<OBS, NCHQ, true>((KPtr)kp, lds, wg, n_q, (int)n_prey, scratch, K2->pre_g + K2->q.n_envs);
     } else {
         uintptr_t kp = (uintptr_t)&K2->p;
         __asm__ volatile("" : "+s"(kp));
-        pipe_main<OBS, NCHP, true>((KPtr)kp, lds, wg - n_q, G - n_q, (int)n_pred, scratch);
+        pipe_main<OBS, NCHP, true>((KPtr)kp, lds, wg - n_q, G - n_q, (int)n_pred, scratch, K2->pre_g);
     }
 }
 

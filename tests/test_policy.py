@@ -618,3 +618,47 @@ def test_policy_closes_the_loop_for_a_whole_rollout():
     es = env.env_state.cpu().numpy()
     assert (es[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()
     assert (es[:, _abi.ENV_CALLS] == 200).all()
+
+
+@pytest.mark.gpu
+def test_pipeline_barrier_status_stays_clean_over_a_rollout():
+    """The pipeline kernels' private barrier is a spin on an LDS counter (ppg_policy_pipe.h: pipe_wait) -- correct while all eight
+    wavefronts are resident, a silent hang otherwise.  The -DPPG_PIPE_DEBUG build (tools/build_pipe_debug.sh) bounds the spin and reports
+    through status words that ppg_policy_act checks after every launch: over a closed-loop rollout (fused launch and separate launches,
+    shares of one and of several tiles) no wait ever gives up; and a report, when there is one, surfaces as an error."""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_build", "libppg_hip_pipedbg.so")
+    if not os.path.exists(lib):
+        pytest.skip("tools/_build/libppg_hip_pipedbg.so has not been built (tools/build_pipe_debug.sh)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from predpreygrass_amd import _abi\n"
+        "from predpreygrass_amd.batched import BatchedPredPreyGrass\n"
+        "from predpreygrass_amd.config import config_env\n"
+        "from predpreygrass_amd.policy import FusedPolicy, PolicyNet\n"
+        "torch.manual_seed(7)\n"
+        "nets = [PolicyNet(7), PolicyNet(9)]\n"
+        "fused = FusedPolicy(nets[0], nets[1])\n"
+        "for batch, steps, mode in ((512, 120, '1'), (512, 40, '0'), (6500, 12, '1')):\n"
+        "    os.environ['PPG_POLICY_FUSED'] = mode\n"
+        "    env = BatchedPredPreyGrass(dict(config_env), batch_size=batch, device='cuda:0', obs_dtype=torch.bfloat16, seed=2)\n"
+        "    env.reset()\n"
+        "    if batch > 1000:\n"
+        "        for _ in range(400): env.step(random_actions=True, auto_reset=True)\n"
+        "    for t in range(steps):\n"
+        "        fused.act(env, sample=True, seed=t)\n"
+        "        env.step(env.actions, auto_reset=True)\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert (env.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()\n"
+        "os.environ['PPG_PIPE_DEBUG_INJECT'] = '1'\n"
+        "try:\n"
+        "    fused.act(env, sample=True, seed=1)\n"
+        "    print('NO ERROR')\n"
+        "except RuntimeError as exc:\n"
+        "    assert 'gave up waiting' in str(exc), exc\n"
+        "    print('PIPE-STATUS-CLEAN')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, PPG_HIP_LIB=lib))
+    assert out.returncode == 0 and "PIPE-STATUS-CLEAN" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
