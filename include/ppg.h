@@ -549,6 +549,16 @@ const char *ppg_policy_last_error(const ppg_policy *p);
  * Returns PPG_EINVAL for a spec ppg_policy_create_spec would reject on its shape.  (Diagnostic: with the environment variable
  * PPG_POLICY_PIPE=0 set when a policy is created, a network of family 3 gets the kernels of family 1 -- same logits, bit for bit.) */
 int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n);
+/* The weight fragments ppg_policy_create_spec uploads for one layer, in MFMA operand order, as bfloat16 bit patterns -- computed
+ * without a device, so that the repacking (which lane holds which weight of which k-step) can be checked on the CPU against a plain
+ * convolution before a kernel ever runs (tests/test_policy.py).  what: 0 .. n_conv - 1 = that convolution for
+ * v_mfma_f32_32x32x16_bf16, [row tile][k-step][lane][8]; PPG_POLICY_PACK_CONV1X = the first convolution as the two-role pipeline
+ * takes it (v_mfma_f32_16x16x32_bf16, [kernel row][lane][8]; up to nine input channels); PPG_POLICY_PACK_HEAD = the single Linear head
+ * of a network without hidden head layers (v_mfma_f32_16x16x32_bf16, [action tile][k-step][lane][8]).  *n_words = words the layer
+ * takes; out == NULL or capacity too small: only the size is reported (PPG_OK). */
+#define PPG_POLICY_PACK_CONV1X 100
+#define PPG_POLICY_PACK_HEAD 200
+int ppg_policy_pack(const ppg_policy_spec *spec, int32_t what, uint16_t *out, uint64_t capacity, uint64_t *n_words);
 
 /* A device buffer for the caller-owned observation tensors whose physical pages are picked at random from a stretch of device
  * memory `spread` times its size (HIP virtual memory management: spread x as many 2 MB chunks are created, a random subset is

@@ -151,7 +151,8 @@ POLICY_ARGMAX, POLICY_SAMPLE = 0x0, 0x1
 POLICY_LAYOUT_CHW, POLICY_LAYOUT_HWC = 0, 1
 POLICY_FLATTEN_NCHW, POLICY_FLATTEN_NHWC = 0, 1
 POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_create_spec", "ppg_policy_destroy", "ppg_policy_act",
-                  "ppg_policy_macs_per_observation", "ppg_policy_last_error", "ppg_policy_describe"]
+                  "ppg_policy_macs_per_observation", "ppg_policy_last_error", "ppg_policy_describe", "ppg_policy_pack"]
+POLICY_PACK_CONV1X, POLICY_PACK_HEAD = 100, 200
 
 
 SPREAD_SYMBOLS = ["ppg_alloc_spread", "ppg_free_spread", "ppg_spread_stats", "ppg_spread_last_error"]   # HIP library only, like the policy symbols
@@ -241,6 +242,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
                                        C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ppg_policy_describe.restype = C.c_int
         lib.ppg_policy_describe.argtypes = [C.POINTER(PpgPolicySpec), C.POINTER(C.c_int32), C.c_int32]
+        lib.ppg_policy_pack.restype = C.c_int
+        lib.ppg_policy_pack.argtypes = [C.POINTER(PpgPolicySpec), C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         lib.ppg_policy_macs_per_observation.restype = C.c_uint64
         lib.ppg_policy_macs_per_observation.argtypes = [C.c_void_p]
         lib.ppg_policy_last_error.restype = C.c_char_p

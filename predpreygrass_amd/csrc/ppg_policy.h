@@ -106,6 +106,8 @@ struct PolParams {
     int32_t pipe_raw, pipe_ni;    // bfloat16 rows of a multiple of 8 bytes: byte offset of the LDS area that takes a sub-group's rows as they
     uint32_t pipe_magic;          // lie in HBM, 8-byte loads per role-B thread and sub-group (0: one load per channel), ceil(2^32 / chunks per row),
     int32_t pipe_slots;           // samples whose chunks the 256 role-B threads cover at once: floor(256 / chunks per row)
+    const bf16x8 *wc1x;           // conv1 of the pipeline as three 16x16x32 fragments [ky][lane][8] (ppg_policy_pipe.h: Conv1X); its bias [16]
+    const float *bc1x;
 #ifdef PPG_EXPERIMENTS
     unsigned long long *timeline; // diagnostic builds: [tile][64] = workgroup, hardware id, samples, 4 wall-clock stamps (10 ns units); [8 + 12 wave + i] cycles of wave in step i of the convolutions, [56 + 2 wave + i] FC1 wait / barrier cycles
 #endif
@@ -1085,6 +1087,23 @@ static void ppg_pack_conv(const float *w, const float *bias, int cout, int cin, 
             }
 }
 
+// conv1 of the pipeline kernels as fragments of v_mfma_f32_16x16x32_bf16 (ppg_policy_pipe.h: Conv1X), [ky][lane][8]: lane (r = lane &
+// 15 = output channel, kq = lane >> 4) holds for kernel row ky -- kq < 3: the eight input channels 0-7 at tap (ky, kx = kq); kq = 3: the
+// ninth input channel at the taps kx = 0, 1, 2 (elements 0-2; the rest zero).  cin <= 9.
+static void ppg_pack_conv1x(const float *w, int cout, int cin, std::vector<uint16_t> &out) {
+    out.assign((size_t)3 * 64 * 8, 0);
+    for (int ky = 0; ky < 3; ++ky)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int co = lane & 15, kq = lane >> 4;
+            if (co >= cout) continue;
+            uint16_t *dst = &out[((size_t)ky * 64 + lane) * 8];
+            for (int j = 0; j < 8; ++j) {
+                const int ci = kq < 3 ? j : 8, kx = kq < 3 ? kq : j;
+                if (ci < cin && kx < 3) dst[j] = ppg_bf16_bits(w[((size_t)co * cin + ci) * 9 + ky * 3 + kx]);
+            }
+        }
+}
+
 // A Linear layer -> fragments [ks][mt][lane][8] of the 32x32x16 MFMA: lane holds output feature o = 32 mt + row feature(lane & 31) and
 // inputs k = 16 ks + 8 h + j; `value(o, k)` returns the weight (0 for padding)
 template <class Value>
@@ -1097,6 +1116,25 @@ static void ppg_pack_fc(int K, int mt_n, Value value, std::vector<uint16_t> &out
                 const int r = lane & 31, h = lane >> 5, o = 32 * mt + ppg_row_feature(r);
                 for (int j = 0; j < 8; ++j)
                     out[(((size_t)ks * mt_n + mt) * 64 + lane) * 8 + j] = ppg_bf16_bits(value(o, 16 * ks + 8 * h + j));
+            }
+}
+
+// the single Linear head of a network without hidden head layers -> fragments of v_mfma_f32_16x16x32_bf16, [action tile][k-step][lane][8]:
+// lane holds action 16 tile + (lane & 15) and the features of area F's elements 32 ks + 8 (lane >> 4) + j; F is [position][flat_c
+// channels] (flat_c = the last convolution's channels padded to blocks of 8); `nhwc`: which feature (channel c, position q) is
+static void ppg_pack_head(const float *hw, int n_actions, int P, int cout_last, bool nhwc, std::vector<uint16_t> &out) {
+    const int flat_c = (cout_last + 7) / 8 * 8, ksteps = (P * flat_c + 31) / 32, head_mt = (n_actions + 15) / 16, flat = P * cout_last;
+    out.assign((size_t)head_mt * ksteps * 64 * 8, 0);
+    for (int mt = 0; mt < head_mt; ++mt)
+        for (int ks = 0; ks < ksteps; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int a = 16 * mt + (lane & 15);
+                if (a >= n_actions) continue;
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 32 * ks + 8 * (lane >> 4) + j, q = e / flat_c, c = e % flat_c;
+                    const int ft = (q < P && c < cout_last) ? (nhwc ? q * cout_last + c : c * P + q) : -1;
+                    if (ft >= 0) out[(((size_t)mt * ksteps + ks) * 64 + lane) * 8 + j] = ppg_bf16_bits(hw[(size_t)a * flat + ft]);
+                }
             }
 }
 
@@ -1250,8 +1288,8 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
     // feature index of (channel c, position q) behind the flatten, or -1 for a padding channel
     const int flatten = sp.flatten;
     auto feature = [=](int c, int q) { return c >= cout_last ? -1 : flatten == PPG_POLICY_FLATTEN_NHWC ? q * cout_last + c : c * P + q; };
-    std::vector<uint16_t> f[PPG_POLICY_MAX_CONV + 3];   // conv layers, then up to three linear layers
-    std::vector<float> bias(256 + 256 + 32, 0.0f);      // FC chain: b1, b2, b3; direct: head bias at [512]
+    std::vector<uint16_t> f[PPG_POLICY_MAX_CONV + 4];   // conv layers, then up to three linear layers, then conv1 in the pipeline's form
+    std::vector<float> bias(256 + 256 + 32 + 16, 0.0f); // FC chain: b1, b2, b3; direct: head bias at [512]; the pipeline's conv1 bias at [544]
     int ci = CIN;
     for (int l = 0; l < sp.n_conv; ++l) {
         ppg_pack_conv(sp.conv_w[l], sp.conv_b[l], sp.conv_out[l], ci, l == 0 ? CB1 : l == 1 ? 2 : l == 2 ? 4 : 8, l < 2 ? 1 : 2, f[l]);
@@ -1265,19 +1303,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         // features of area F's elements 32 ks + 8 (lane >> 4) + j; F is [position][flat_c channels]
         const int flat_c = 8 * K.cout_blocks[sp.n_conv - 1], ksteps = (P * flat_c + 31) / 32, head_mt = (n_actions + 15) / 16;
         K.flat_c = flat_c; K.kflat_steps = ksteps; K.head_mt = head_mt;
-        f[FC0].assign((size_t)head_mt * ksteps * 64 * 8, 0);
-        const float *hw = sp.fc_w[0];
-        for (int mt = 0; mt < head_mt; ++mt)
-            for (int ks = 0; ks < ksteps; ++ks)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int a = 16 * mt + (lane & 15);
-                    if (a >= n_actions) continue;
-                    for (int j = 0; j < 8; ++j) {
-                        const int e = 32 * ks + 8 * (lane >> 4) + j, q = e / flat_c, c = e % flat_c;
-                        const int ft = q < P ? feature(c, q) : -1;
-                        if (ft >= 0) f[FC0][(((size_t)mt * ksteps + ks) * 64 + lane) * 8 + j] = ppg_bf16_bits(hw[(size_t)a * flat + ft]);
-                    }
-                }
+        ppg_pack_head(sp.fc_w[0], n_actions, P, cout_last, flatten == PPG_POLICY_FLATTEN_NHWC, f[FC0]);
         for (int a = 0; a < n_actions; ++a) bias[512 + a] = sp.fc_b[0][a];
         {   // K.whw: wavefront w owns k-steps [w per, (w + 1) per), its first 18 ride in registers (ppg_policy_direct.h)
             const int HFR = 18, per = (ksteps + 3) / 4;
@@ -1308,7 +1334,11 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         for (int i = 0; i < n_actions; ++i) bias[512 + i] = sp.fc_b[sp.n_fc - 1][i];
         K.n_hidden = sp.n_fc - 1;
     }
-    const int NF = PPG_POLICY_MAX_CONV + 3;
+    if (CIN <= 9) {
+        ppg_pack_conv1x(sp.conv_w[0], sp.conv_out[0], CIN, f[PPG_POLICY_MAX_CONV + 3]);
+        for (int c = 0; c < sp.conv_out[0] && c < 16; ++c) bias[544 + c] = sp.conv_b[0][c];
+    }
+    const int NF = PPG_POLICY_MAX_CONV + 4;
     size_t off[NF + 1], total = 0;
     for (int l = 0; l < NF; ++l) { off[l] = total; total += (f[l].size() * 2 + 255) / 256 * 256; }
     off[NF] = total; total += bias.size() * 4;
@@ -1344,6 +1374,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
     const float *db = (const float *)(dw + off[NF]);
     K.bc1 = K.bc2 = K.bc3 = nullptr;   // (the convolutions' biases ride in their fragments)
     K.b1 = db; K.b2 = db + 256; K.b3 = db + 512; K.bh = db + 512;
+    K.wc1x = (const ppgpol::bf16x8 *)(dw + off[PPG_POLICY_MAX_CONV + 3]); K.bc1x = db + 544;
     p->grid = 2 * prop.multiProcessorCount;
 #ifdef PPG_EXPERIMENTS
     if (const char *g = getenv("PPG_POLICY_GRID")) p->grid = atoi(g) > 0 ? atoi(g) : p->grid;   // resident workgroups
@@ -1357,7 +1388,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         const int tail_slack = 18 * 32 * 2;   // bytes behind the last sample's region: the head's unconditional fragment reads end there
         // the two-role pipeline (ppg_policy_pipe.h): three convolutions, up to 16 actions, a wavefront's quarter of the head's k-steps in 18
         // fragments; region of a sample: X0 | X1 (4 blocks each) | Y (2 blocks) | F0 | F1
-        if (ppg_pipe_enabled() && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18) {
+        if (ppg_pipe_enabled() && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18 && CIN <= 9) {   // (CIN: Conv1X)
             int pipe_lds = 0;
             if (ppg_pipe_layout(C, R, P, blk, f_elems, tail_slack, K, &pipe_lds)) {
                 p->pipe = 1;
@@ -1435,6 +1466,33 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
     return PPG_OK;
 }
 
+int ppg_policy_pack(const ppg_policy_spec *spec, int32_t what, uint16_t *out, uint64_t capacity, uint64_t *n_words) {
+    if (!spec || !n_words) return ppg_policy_fail(nullptr, PPG_EINVAL, "null argument");
+    const ppg_policy_spec &sp = *spec;
+    const int rc = ppg_policy_check_spec(sp, true);
+    if (rc != PPG_OK) return rc;
+    const int hwc = sp.layout == PPG_POLICY_LAYOUT_HWC;
+    const int IH = hwc ? sp.obs_channels : sp.obs_range, IW = sp.obs_range, CIN = hwc ? sp.obs_range : sp.obs_channels, P = IH * IW;
+    std::vector<uint16_t> f;
+    if (what >= 0 && what < sp.n_conv) {
+        int ci = CIN;
+        for (int l = 0; l < what; ++l) ci = sp.conv_out[l];
+        ppg_pack_conv(sp.conv_w[what], sp.conv_b[what], sp.conv_out[what], ci, what == 0 ? (CIN > 8 ? 2 : 1) : what == 1 ? 2 : what == 2 ? 4 : 8,
+                      what < 2 ? 1 : 2, f);
+    } else if (what == PPG_POLICY_PACK_CONV1X) {
+        if (CIN > 9) return ppg_policy_fail(nullptr, PPG_EINVAL, "the pipeline's first convolution takes up to nine input channels (found %d)", CIN);
+        ppg_pack_conv1x(sp.conv_w[0], sp.conv_out[0], CIN, f);
+    } else if (what == PPG_POLICY_PACK_HEAD) {
+        if (sp.n_fc != 1) return ppg_policy_fail(nullptr, PPG_EINVAL, "PPG_POLICY_PACK_HEAD: the network has hidden head layers");
+        ppg_pack_head(sp.fc_w[0], sp.n_actions, P, sp.conv_out[sp.n_conv - 1], sp.flatten == PPG_POLICY_FLATTEN_NHWC, f);
+    } else {
+        return ppg_policy_fail(nullptr, PPG_EINVAL, "ppg_policy_pack: unknown layer %d", what);
+    }
+    *n_words = f.size();
+    if (out && capacity >= f.size()) memcpy(out, f.data(), f.size() * 2);
+    return PPG_OK;
+}
+
 int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n) {
     if (!spec || !out || n < 1) return PPG_EINVAL;
     const ppg_policy_spec &sp = *spec;
@@ -1460,7 +1518,7 @@ int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n) {
         K.Wp = IW + 1; K.Wp2 = (IH + 2) * (IW + 1) + 1;
         const int blk = K.Wp2 * 8, f_elems = K.kflat_steps * 32 + 8, tail_slack = 18 * 32 * 2;
         int lds = 0;
-        if (ppg_pipe_enabled() && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18 &&
+        if (ppg_pipe_enabled() && sp.n_conv == 3 && K.head_mt == 1 && (K.kflat_steps + 3) / 4 <= 18 && (hwc ? R : C) <= 9 &&
             ppg_pipe_layout(C, R, P, blk, f_elems, tail_slack, K, &lds)) {
             v[0] = 3; v[1] = K.ST; v[2] = lds; v[3] = 512; v[4] = K.range_tile; v[5] = K.sample_stride * 2; v[6] = K.pipe_ni; v[7] = K.pipe_slots;
             v[8] = K.pipe_red; v[9] = K.pipe_raw; v[10] = K.pipe_img; v[11] = K.pipe_img - 1024 - K.pipe_raw;
@@ -1769,7 +1827,7 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
     // cycles per pipeline iteration of either network (measured on the reference's shapes, profiles/r04-r05; PPG_POLICY_ITER_Q / _P:
     // experiments): only their RATIO matters -- it decides how many workgroups serve which species
     K2.iter_q = ppg_env_int("PPG_POLICY_ITER_Q", 7500);
-    K2.iter_p = ppg_env_int("PPG_POLICY_ITER_P", 5500);
+    K2.iter_p = ppg_env_int("PPG_POLICY_ITER_P", 8500);
     typedef void (*fused_fn)(const ppgpol::PolParams2);
     const fused_fn fn[2][2][3] = {
         {{ppgpol::ppg_policy_pipe2_8_8_f64, ppgpol::ppg_policy_pipe2_8_8_f32, ppgpol::ppg_policy_pipe2_8_8_bf16},

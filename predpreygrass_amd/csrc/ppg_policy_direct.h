@@ -105,7 +105,10 @@ __device__ __forceinline__ int f_koff(const KP &K, int k, int kq) {   // element
 // pre: nullptr, or this lane's two precomputed words per tile of this wavefront (tile t = nt_first + t nt_step, t < 2; ppg_policy_pipe.h,
 // where a wavefront's tiles are the same positions in every sub-group): pre[2 t] = sample base + 8 x padded position (the element of its
 // cell in channel block 0 of area 0), pre[2 t + 1] = (sample base + 64 x position) | (position & 7) -- dconv_cells() below.
-template <int CBIN, int MT, int BATCH, bool SWP = true, bool F64 = false, class KP>
+// DEPTH: batches of fragment reads in flight ahead of the batch the MFMAs consume (1: the read of batch n + 1 is issued before the MFMAs of
+// batch n -- with one-fragment batches the next fragment has 64 cycles of MFMA to arrive, less than an LDS round trip under load: the
+// convolution then runs at the LDS latency, not at the matrix pipe's pace; 2-3: a rolling window, still ONE read issued at a time).
+template <int CBIN, int MT, int BATCH, bool SWP = true, bool F64 = false, int DEPTH = 1, class KP>
 __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __bf16 *img, int sample_stride, int in_off, int out_off,
                                       int out_blocks, int flat_c, int ns, int nt_first, int nt_step, int lane, int mt_base, int dummy,
                                       const int *pre = nullptr) {
@@ -177,15 +180,18 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-        bf16x8 b[2][BS];
+        constexpr int NSLOT = DEPTH + 1;
+        bf16x8 b[NSLOT][BS];
 #pragma unroll
-        for (int i = 0; i < BS; ++i) b[0][i] = fragment(c, i);
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int i = 0; i < BS; ++i) if (d * BS + i < KS) b[d][i] = fragment(c, d * BS + i);
         __builtin_amdgcn_sched_barrier(0);   // (keep the reads together and in front: left alone, the scheduler re-pairs each with its MFMA)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            if (nb + 1 < NB) {
+            if (nb + DEPTH < NB) {
 #pragma unroll
-                for (int i = 0; i < BS; ++i) if ((nb + 1) * BS + i < KS) b[(nb + 1) & 1][i] = fragment(c, (nb + 1) * BS + i);
+                for (int i = 0; i < BS; ++i) if ((nb + DEPTH) * BS + i < KS) b[(nb + DEPTH) % NSLOT][i] = fragment(c, (nb + DEPTH) * BS + i);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (nb == 0) between();   // (no fence between the previous tile's epilogue and this batch's MFMAs: the scheduler interleaves them.
@@ -196,7 +202,7 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
                 if (nb * BS + i < KS) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][nb * BS + i], b[nb & 1][i], acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[mt][nb * BS + i], b[nb % NSLOT][i], acc[mt], 0, 0, 0);
                 }
         }
     };

@@ -31,6 +31,23 @@
 #define PPG_PIPE_B12 2      // fragment reads per batch in role B's conv1 / conv2 (0 = a tile's ten at once): 0 / 5 / 4 / 3 / 2 / 1:
                             // 0.3118 / 0.3129 / 0.3077 / 0.3027 / 0.3007 / 0.3058 ms per step on one GPU (profiles/r04)
 #endif
+#ifndef PPG_PIPE_D3
+#define PPG_PIPE_D3 1       // batches of fragment reads in flight ahead of the MFMAs in role A's conv3 (dconv's DEPTH)
+#endif
+#ifndef PPG_PIPE_D2
+#define PPG_PIPE_D2 1       // the same in role B's conv2
+#endif
+#ifndef PPG_PIPE_CONV2_PAIR
+#define PPG_PIPE_CONV2_PAIR 0   // role B's conv2: 1 = the wavefront's two position tiles as interleaved MFMA chains; 0 = tile after tile (dconv).
+                                // Measured (profiles/r05/e_*): the pair is 1 % SLOWER end to end -- conv2's own phase stays at 1270 cycles
+                                // and role A's conv3 on the same SIMD grows by what role B's denser MFMA stream takes from it
+#endif
+#ifndef PPG_PIPE_HEAD_CHAINS
+#define PPG_PIPE_HEAD_CHAINS 1  // independent accumulator chains of the head's eighteen MFMAs: 2 measured 1 % slower than 1 (profiles/r05/e_*)
+#endif
+#ifndef PPG_PIPE_CONV1X_LOOP
+#define PPG_PIPE_CONV1X_LOOP 0  // conv1x tile after tile (1) instead of the four tiles as one straight line (0)
+#endif
 #ifndef PPG_PIPE_SWP_B
 #define PPG_PIPE_SWP_B true   // role B's convolution loops software-pipelined (the epilogue of tile t behind the reads of tile t + 1)
 #endif
@@ -99,6 +116,163 @@ __device__ __forceinline__ int pipe_pick_handle(const KP &K, const Bases &bases,
         eb = in ? K.env_base[q] : eb;
     }
     return e - eb;
+}
+
+// conv1 of the pipeline on v_mfma_f32_16x16x32_bf16 (round 5).  The 32x32x16 form pads conv1 twice -- its 16 output channels to 32 MFMA
+// rows, and (channels-last 9x9 windows) its nine input channels to two blocks of eight: ten k-steps of which a quarter is real work.
+// Here M = the 16 output channels, N = 16 positions, and one k-step per kernel ROW ky holds everything that row contributes: the lane
+// quarters kq = 0, 1, 2 read the three taps' cells of channel block 0 (eight channels each), kq = 3 reads the position's cell of block
+// 1, which the staging fills with the NINTH channel of the three taps {c8(x - 1), c8(x), c8(x + 1), 0 ...}.  Three MFMAs of 16 cycles per
+// 16 positions instead of ten of 32 per 32; 12 registers of weights instead of 40; the bias is the accumulators' initial value.
+// Up to nine input channels (the reference's 7x7 / 9x9 windows); wider channels-last windows run the one-role kernels.
+struct Conv1X {
+    bf16x8 a[3];     // weight fragments of ky = 0, 1, 2: lane (r = lane & 15: output channel, kq = lane >> 4)
+    f32x4_t bias;    // of this lane's output channels 4 kq .. 4 kq + 3
+    int cell[4];     // element offset (from img) of this lane's position in its tile t: block 0 of area X0, cell of the position
+    template <class KP>
+    __device__ __forceinline__ void load(const KP &K, int lane, int bw) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) a[ky] = ((const GLOBAL_AS bf16x8 *)K.wc1x)[ky * 64 + lane];
+        bias = *(const GLOBAL_AS f32x4_t *)(K.bc1x + 4 * (lane >> 4));
+        const int col = lane & 15, n_full = K.ST * K.P;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = 16 * (bw + 4 * t) + col, nn = n < n_full ? n : 0;
+            const int s = div_small(nn, K.magic_P), p = nn - __mul24(s, K.P);
+            const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
+            cell[t] = __mul24(s, K.sample_stride) + (__mul24(y + 1, K.Wp) + (x + 1)) * 8;
+        }
+    }
+    __device__ __forceinline__ void landed() {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            u32x4_t v = __builtin_bit_cast(u32x4_t, a[ky]);
+            __asm__ volatile("" : "+v"(v));
+            a[ky] = __builtin_bit_cast(bf16x8, v);
+        }
+        __asm__ volatile("" : "+v"(bias));
+    }
+};
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// ReLU + round four accumulator registers to bf16 (relu_pack8's arithmetic)
+__device__ __forceinline__ u32x2_t relu_pack4(const f32x4_t &a) {
+    u32x2_t w;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f32x2 f = {a[2 * j], a[2 * j + 1]};
+        const s16x2 zero = {0, 0};
+        const s16x2 q = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(f, bf16x2)), zero);
+        w[j] = __builtin_bit_cast(uint32_t, q);
+    }
+    return w;
+}
+// One sub-group's conv1: X (input blocks at element offset xo) -> Y.  CB1 = 2: a second input block (the ninth channel's taps).
+template <int CB1, class KP>
+__device__ __forceinline__ void conv1x(const KP &K, const Conv1X &W, __bf16 *img, int xo, int ns, int bw, int lane, int dummy) {
+    const int kq = lane >> 4, col = lane & 15;
+    const int n_pos = ns * K.P, blk = K.Wp2 * 8;
+    // this lane quarter's B operand of kernel row ky = 1 relative to the position's cell: the tap kq - 1 of block 0, or (kq = 3)
+    // the position's own cell of block 1 (CB1 = 1: any cell of block 0 -- its weights are zero)
+    const int koff = kq < 3 ? (kq - 1) * 8 : (CB1 > 1 ? blk : 0);
+    const int yoff = (kq >> 1) * blk + (kq & 1) * 4;    // where this lane's four output channels go inside the position's Y cells
+#if PPG_PIPE_CONV1X_LOOP
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int nt = bw + 4 * t;
+        if (16 * nt >= n_pos) break;
+        const bool valid = 16 * nt + col < n_pos;
+        const __bf16 *base = img + W.cell[t] + xo + koff;
+        bf16x8 b[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) b[ky] = *(const bf16x8 *)(base + (ky - 1) * K.Wp * 8);
+        f32x4_t acc = W.bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.a[ky], b[ky], acc, 0, 0, 0);
+        const int at = valid ? W.cell[t] + K.off_y + yoff : dummy;
+        *(u32x2_t *)(img + at) = relu_pack4(acc);
+    }
+    return;
+#endif
+    // The wavefront's four tiles as ONE straight line: twelve fragment reads in front, then the four tiles' MFMA chains interleaved (a
+    // tile's three MFMAs depend on each other through the accumulator: tile by tile the chain ran at the matrix pipe's LATENCY, 290
+    // cycles per tile for 48 cycles of issue), then the four epilogues.  Tiles behind the sub-group's last position compute position 0
+    // again and store into the dummy slot (the last sub-group of a share only).
+    bf16x8 b[4][3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const __bf16 *base = img + W.cell[t] + xo + koff;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) b[t][ky] = *(const bf16x8 *)(base + (ky - 1) * K.Wp * 8);
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = W.bias;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.a[ky], b[t][ky], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool valid = 16 * (bw + 4 * t) + col < n_pos;
+        const int at = valid ? W.cell[t] + K.off_y + yoff : dummy;
+        *(u32x2_t *)(img + at) = relu_pack4(acc[t]);
+    }
+}
+
+// Role B's conv2 (16 -> 32 channels, one 32-row MFMA tile) over the wavefront's TWO position tiles at once: a tile's ten MFMAs depend on
+// each other through its accumulators (64 cycles from one to the next), so tile after tile the layer ran at that latency -- 1270 cycles
+// for 640 of issue.  Two independent chains interleaved fill the gaps.  Fragment reads two k-steps (four reads) ahead.
+template <class KP>
+__device__ __forceinline__ void conv2_pair(const KP &K, const ConvW<2, 1> &W, __bf16 *img, int in_off, int out_off, int out_blocks, int ns,
+                                           int bw, int lane, int dummy, const int *cells) {
+    constexpr int KS = ConvW<2, 1>::KS, KSB = ConvW<2, 1>::KS_BIAS, HB = ConvW<2, 1>::H_BIAS;
+    const int h = lane >> 5, col = lane & 31;
+    const int n_pos = ns * K.P, blk = K.Wp2 * 8;
+    if (32 * bw >= n_pos) return;
+    const int in0 = in_off + h * blk;
+    const int cb0 = 2 * h;
+    auto fragment = [&](int cell, int ks) -> bf16x8 {
+        bf16x8 v;
+        if (ks == KSB && HB == 0) {   // (the whole k-step is the bias block + nothing)
+            v = zero8();
+            if (h == HB) { v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
+        } else {
+            v = *(const bf16x8 *)(img + cell + in0 + W.offset(K, ks, 2 * blk));
+            if (ks == KSB && h == HB) { v = zero8(); v[0] = (__bf16)1.0f; v[1] = (__bf16)1.0f; }
+        }
+        return v;
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    bf16x8 b[3][2];   // a rolling window of three k-steps x two tiles
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[d][t] = fragment(cells[2 * t], d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 2 < KS) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[(ks + 2) % 3][t] = fragment(cells[2 * t], ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.a[0][ks], b[ks % 3][t], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const bool valid = 32 * (bw + 4 * t) + col < n_pos;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool real = valid && (cb0 + j < out_blocks);
+            const int at = real ? cells[2 * t] + out_off + (cb0 + j) * blk : dummy;
+            *(bf16x8 *)(img + at) = relu_pack8(acc[t], 8 * j);
+        }
+    }
 }
 
 // The fused launch's plan, computed by every workgroup for itself (no plan launch, no trip through memory): exclusive prefix sums of the
@@ -207,7 +381,8 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
     long long dp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dp_prev = (long long)clock64();
     auto dp_dump = [&] {
         if (K.xg && lane == 0)
-            for (int i = 0; i < 16; ++i) ((unsigned long long *)K.xg)[((size_t)blockIdx.x * 8 + wave) * 16 + i] = (unsigned long long)dp_acc[i];
+            for (int i = 0; i < 16; ++i)   // ([13]: species + 1 -- the fused launch's workgroups serve either)
+                ((unsigned long long *)K.xg)[((size_t)blockIdx.x * 8 + wave) * 16 + i] = i == 13 ? (unsigned long long)(K.species + 1) : (unsigned long long)dp_acc[i];
     };
 #else
     auto dp_dump = [] {};
@@ -308,10 +483,10 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 if (it >= 0 && it < G) {
                     const int left = nt_samples - it * K.ST, ns = left < K.ST ? left : K.ST;
                     if (K.flat_c == 64)
-                        dconv<4, 2, PPG_PIPE_B3, false, true>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
+                        dconv<4, 2, PPG_PIPE_B3, false, true, PPG_PIPE_D3>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
                                                               K.cout_blocks[2], 64, ns, wave, 4, lane, 0, dummy, cells);
                     else
-                    dconv<4, 2, PPG_PIPE_B3, false>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
+                    dconv<4, 2, PPG_PIPE_B3, false, false, PPG_PIPE_D3>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
                                                       K.cout_blocks[2], K.flat_c, ns, wave, 4, lane, 0, dummy);
                 }
                 PPG_DP(1);
@@ -343,15 +518,15 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
     // Role B is the longer chain, and its MFMAs are few and dependent: with equal priorities the SIMD serves role A's dense MFMA stream
     // first and the head's 18 MFMAs take as long as the whole of conv3 (profiles/r04) -- B goes first whenever it has something to issue.
     __builtin_amdgcn_s_setprio(PPG_PIPE_PRIO_B);
-    ConvW<CB1, 1> w1c;
+    Conv1X w1x;
     ConvW<2, 1> w2c;
     bf16x8 hf[HF];
-    w1c.load(K, K.wc1, lane);
+    w1x.load(K, lane, bw);
     w2c.load(K, K.wc2, lane);
 #pragma unroll
     for (int i = 0; i < HF; ++i) hf[i] = ((const GLOBAL_AS bf16x8 *)K.whw)[((size_t)bw * HF + i) * 64 + lane];
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    w1c.landed();
+    w1x.landed();
     w2c.landed();
 #pragma unroll
     for (int i = 0; i < HF; ++i) {
@@ -416,7 +591,11 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
             if (btid < ns * K.P) {
                 const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)row_of(g * K.ST + st_s) + st_p * K.p_stride;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) if (c < K.cin) pre[c] = (raw_t)src[c * K.c_stride];
+                for (int c = 0; c < (NCH < 9 ? NCH : 9); ++c) if (c < K.cin) pre[c] = (raw_t)src[c * K.c_stride];
+                if constexpr (CB1 > 1) {   // the ninth channel of the two neighbours along the image row (conv1x's block 1)
+                    pre[9] = (raw_t)src[8 * K.c_stride - (st_x > 0 ? K.p_stride : 0)];
+                    pre[10] = (raw_t)src[8 * K.c_stride + (st_x < K.IW - 1 ? K.p_stride : 0)];
+                }
             }
         };
         auto stage = [&](int g) {
@@ -425,14 +604,25 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 if constexpr (CH) {
                     const uint16_t *rh = (const uint16_t *)raw + st_raw;
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) pre[c] = (c < K.cin) ? (raw_t)rh[c * K.c_stride] : (raw_t)0;
+                    for (int c = 0; c < (NCH < 9 ? NCH : 9); ++c) pre[c] = (c < K.cin) ? (raw_t)rh[c * K.c_stride] : (raw_t)0;
+                    if constexpr (CB1 > 1) {
+                        pre[9] = (raw_t)rh[8 * K.c_stride - (st_x > 0 ? K.p_stride : 0)];
+                        pre[10] = (raw_t)rh[8 * K.c_stride + (st_x < K.IW - 1 ? K.p_stride : 0)];
+                    }
                 }
-#pragma unroll
-                for (int cb = 0; cb < CB1; ++cb) {
+                {   // block 0: channels 0-7 of the position
                     bf16x8 v = zero8();
 #pragma unroll
-                    for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = ObsRaw<OBS, NCH>::to_bf16(pre[8 * cb + c]);
-                    *(bf16x8 *)(img + st_img + ((g & 1) ? K.pipe_x1 : 0) + cb * K.Wp2 * 8) = v;
+                    for (int c = 0; c < (NCH < 8 ? NCH : 8); ++c) v[c] = ObsRaw<OBS, NCH>::to_bf16(pre[c]);
+                    *(bf16x8 *)(img + st_img + ((g & 1) ? K.pipe_x1 : 0)) = v;
+                }
+                if constexpr (CB1 > 1) {   // block 1: the ninth channel of the taps x - 1, x, x + 1 (conv1x); zero outside the image row
+                    bf16x8 v = zero8();
+                    const __bf16 z = (__bf16)0.0f;
+                    v[0] = st_x > 0 ? ObsRaw<OBS, NCH>::to_bf16(pre[9]) : z;
+                    v[1] = ObsRaw<OBS, NCH>::to_bf16(pre[8]);
+                    v[2] = st_x < K.IW - 1 ? ObsRaw<OBS, NCH>::to_bf16(pre[10]) : z;
+                    *(bf16x8 *)(img + st_img + ((g & 1) ? K.pipe_x1 : 0) + K.Wp2 * 8) = v;
                 }
             }
         };
@@ -458,14 +648,26 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
             if (it >= 1 && it - 1 < G) {   // head of sub-group it - 1: this wavefront's k-steps
                 const int g = it - 1, ns = group_ns(g);
                 const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + ((g & 1) ? K.pipe_f1 : K.off_f);
-                f32x4_t hacc;
+                f32x4_t hacc, hacc1;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hacc[i] = 0.0f;
+                for (int i = 0; i < 4; ++i) { hacc[i] = 0.0f; hacc1[i] = 0.0f; }
                 bf16x8 fv[HF];
 #pragma unroll
                 for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + f_koff(K, k_lo + i, kq));
+                if (PPG_PIPE_HEAD_CHAINS == 2) {
+                    // two chains (k-steps 0-8, 9-17), added at the end: the SAME partial sums as one chain of eighteen would NOT come out bit
+                    // for bit -- the one-role kernels keep one chain; the logits differ in the last bits (tests: tolerance, not equality)
+#pragma unroll
+                    for (int i = 0; i < HF / 2; ++i) {
+                        hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i], fv[i], hacc, 0, 0, 0);
+                        hacc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[HF / 2 + i], fv[HF / 2 + i], hacc1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hacc[i] += hacc1[i];
+                } else {
 #pragma unroll
                 for (int i = 0; i < HF; ++i) hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[i], fv[i], hacc, 0, 0, 0);
+                }
                 float *wr = red + (g & 1) * 1024;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wr[(bw * 16 + 4 * kq + i) * 16 + colh] = hacc[i];
@@ -475,7 +677,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 const int g = it + 1, ns = group_ns(g), xo = (g & 1) ? K.pipe_x1 : 0;
                 pipe_wait(ctr, b_target);
                 PPG_DP(6);
-                dconv<CB1, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B>(K, w1c, img, sample_stride, xo, K.off_y, K.cout_blocks[0], 0, ns, bw, 4, lane, 0, dummy, cells);
+                conv1x<CB1>(K, w1x, img, xo, ns, bw, lane, dummy);
                 PPG_DP(7);
                 b_target += 4;
                 pipe_arrive(ctr, lane);
@@ -484,7 +686,11 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 PPG_DP(5);
                 pipe_wait(ctr, b_target);
                 PPG_DP(8);
-                dconv<2, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy, cells);
+#if PPG_PIPE_CONV2_PAIR
+                conv2_pair(K, w2c, img, K.off_y, xo, K.cout_blocks[1], ns, bw, lane, dummy, cells);
+#else
+                dconv<2, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B, false, PPG_PIPE_D2>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy, cells);
+#endif
                 PPG_DP(9);
                 if constexpr (CH) park(g + 1, g + 1 < G);   // (every B wavefront has staged sub-group g out of `raw`: two private barriers ago)
             }

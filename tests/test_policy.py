@@ -11,6 +11,8 @@ margin between the best and the second-best logit exceeds twice that bound."""
 import json
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -431,8 +433,12 @@ def test_bfloat16_rows_of_other_windows_through_the_pipeline_kernels(Rp, Rq):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float64])
 def test_pipeline_and_one_role_kernels_give_the_same_logits_bit_for_bit(dt, monkeypatch):
-    """The two-role pipeline kernels (ppg_policy_pipe.h) do the arithmetic of the one-role direct-head kernels in the same order:
-    PPG_POLICY_PIPE=0 at creation time selects the latter for the same network -- identical logits, greedy AND sampled actions."""
+    """The two-role pipeline kernels (ppg_policy_pipe.h) against the one-role direct-head kernels (PPG_POLICY_PIPE=0 at creation time
+    selects the latter for the same network).  conv2, conv3 and the head do the same arithmetic in the same order in both; since round 5
+    the pipeline's FIRST convolution runs on v_mfma_f32_16x16x32_bf16 with one k-step per kernel row and the bias in the accumulators
+    (Conv1X), where the one-role kernels keep the 32x32x16 form with the bias as a bf16 pair in the GEMM: the same products summed in
+    another order.  Bit for bit: both launches of either family (greedy twice, sampled twice); across the families: logits within 2e-3
+    of the largest logit, and the same action wherever the one-role kernels' margin exceeds twice that."""
     from predpreygrass_amd.batched import BatchedPredPreyGrass
     from predpreygrass_amd.policy import FusedPolicy
     nets = make_nets(seed=51)
@@ -444,13 +450,24 @@ def test_pipeline_and_one_role_kernels_give_the_same_logits_bit_for_bit(dt, monk
     for pipe in ("1", "0"):
         monkeypatch.setenv("PPG_POLICY_PIPE", pipe)
         fused = FusedPolicy(nets[0], nets[1])
-        lg = fused.act(env, want_logits=True)
-        greedy = env.actions.clone()
-        fused.act(env, sample=True, seed=77)
-        torch.cuda.synchronize()
-        out.append((lg[0].clone(), lg[1].clone(), greedy, env.actions.clone()))
-    for a, b in zip(*out):
-        assert torch.equal(a, b)
+        runs = []
+        for _ in range(2):
+            lg = fused.act(env, want_logits=True)
+            greedy = env.actions.clone()
+            fused.act(env, sample=True, seed=77)
+            torch.cuda.synchronize()
+            runs.append((lg[0].clone(), lg[1].clone(), greedy, env.actions.clone()))
+        for a, b in zip(*runs):
+            assert torch.equal(a, b)            # run-to-run: bit for bit
+        out.append(runs[0])
+    n_rows = [int(env.env_state[:, w].sum()) for w in (_abi.ENV_N_PRED_ROWS, _abi.ENV_N_PREY_ROWS)]
+    for t in range(2):
+        a, b = out[0][t][:n_rows[t]], out[1][t][:n_rows[t]]
+        bound = 2e-3 * max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= bound, (t, float((a - b).abs().max()), bound)
+        top = b.topk(2, dim=1).values
+        sure = (top[:, 0] - top[:, 1]) > 2 * bound
+        assert bool(sure.float().mean() > 0.9) and torch.equal(a.argmax(1)[sure], b.argmax(1)[sure])
     assert bool(out[0][1].abs().sum() > 0) and not torch.equal(out[0][2], out[0][3])
 
 
@@ -662,3 +679,131 @@ def test_pipeline_barrier_status_stays_clean_over_a_rollout():
         "    print('PIPE-STATUS-CLEAN')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, PPG_HIP_LIB=lib))
     assert out.returncode == 0 and "PIPE-STATUS-CLEAN" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+# ---- the weight repack (MFMA operand order), restated in NumPy and checked against a plain convolution ON THE CPU --------------------
+def _bf16_round(a):
+    """float32 -> the nearest bfloat16 (ties to even), as float64."""
+    u = np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+def _bf16_bits_to_f64(bits):
+    return (np.asarray(bits, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def _pack(lib, spec, what):
+    n = ctypes.c_uint64(0)
+    assert lib.ppg_policy_pack(ctypes.byref(spec), what, None, 0, ctypes.byref(n)) == 0
+    out = np.zeros(n.value, dtype=np.uint16)
+    assert lib.ppg_policy_pack(ctypes.byref(spec), what, out.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n)) == 0
+    return _bf16_bits_to_f64(out)
+
+
+def _row_feature(r):   # MFMA row r of a 32-row tile computes this channel of the tile (csrc/ppg_policy.h: ORIENTATION)
+    return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)
+
+
+@pytest.mark.parametrize("layout,C,R,chans", [("hwc", 4, 9, (16, 32, 64)), ("hwc", 4, 7, (16, 32, 64)), ("chw", 4, 9, (16, 32, 64)),
+                                             ("hwc", 5, 9, (16, 32, 64, 64)), ("hwc", 4, 5, (12, 20, 40)), ("chw", 6, 5, (16, 24))])
+def test_weight_fragments_restated_in_numpy_equal_a_plain_convolution(layout, C, R, chans):
+    """what ppg_policy_create_spec uploads (ppg_policy_pack: device-free) read back through a NumPy restatement of
+    the MFMA operand order -- 32x32x16: lane (row = lane & 31, half = lane >> 5) holds A[row][8 half + j], K block q = 2 ks + half =
+    tap * CBIN + channel block, block 9 CBIN = the bias as bf16 head + remainder against B = {1, 1, 0..}, MFMA row -> channel by
+    _row_feature; the pipeline's first convolution as 16x16x32: one k-step per kernel row, lane quarters 0-2 = the three taps of
+    channels 0-7, quarter 3 = the ninth channel's three taps; the head as 16x16x32 over area F = [position][channels] -- against
+    torch's conv2d / linear on the bf16-rounded weights in float64.  A wrong lane, tap or channel block dies here, on the CPU."""
+    import __graft_entry__ as g
+    from predpreygrass_amd.policy import PolicyNet
+    lib = _abi.bind(ctypes.CDLL(g.build_hip()))
+    torch.manual_seed(C * 100 + R)
+    net = PolicyNet(R, 9, layout, obs_channels=C, conv_channels=chans)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    convs = sorted((k for k in sd if k.endswith("weight") and sd[k].dim() == 4), key=lambda k: int(k.split("cnn.")[1].split(".")[0]))
+    head = [k for k in sd if k.startswith("pi.") and k.endswith("weight")][0]
+    spec = _abi.PpgPolicySpec()
+    spec.obs_channels, spec.obs_range, spec.n_actions = C, R, 9
+    spec.layout = _abi.POLICY_LAYOUT_HWC if layout == "hwc" else _abi.POLICY_LAYOUT_CHW
+    spec.flatten = _abi.POLICY_FLATTEN_NHWC
+    spec.n_conv, spec.n_fc = len(chans), 1
+    keep = []
+    for l, k in enumerate(convs):
+        w, b = sd[k].numpy().astype(np.float32).copy(), sd[k[:-6] + "bias"].numpy().astype(np.float32).copy()
+        keep += [w, b]
+        spec.conv_out[l], spec.conv_w[l], spec.conv_b[l] = w.shape[0], w.ctypes.data, b.ctypes.data
+    hw, hb = sd[head].numpy().astype(np.float32).copy(), sd[head[:-6] + "bias"].numpy().astype(np.float32).copy()
+    keep += [hw, hb]
+    spec.fc_out[0], spec.fc_w[0], spec.fc_b[0] = 9, hw.ctypes.data, hb.ctypes.data
+    IH, IW, CIN = (C, R, R) if layout == "hwc" else (R, R, C)
+    rng = np.random.default_rng(7)
+    cin = CIN
+    for l, k in enumerate(convs):
+        w, b = keep[2 * l].astype(np.float64), keep[2 * l + 1].astype(np.float64)
+        cout = w.shape[0]
+        x = _bf16_round(rng.uniform(-2, 2, (cin, IH, IW)))
+        xp = np.zeros((cin + 16, IH + 2, IW + 2))
+        xp[:cin, 1:-1, 1:-1] = x
+        want = torch.nn.functional.conv2d(torch.from_numpy(x)[None], torch.from_numpy(_bf16_round(w)), torch.from_numpy(b), padding=1)[0].numpy()
+        # ---- 32x32x16 fragments [row tile][k-step][lane][8]
+        CBIN, MT = (2 if CIN > 8 else 1, 1) if l == 0 else (2, 1) if l == 1 else (4, 2) if l == 2 else (8, 2)
+        Q = 9 * CBIN
+        KS = (Q + 2) // 2
+        frag = _pack(lib, spec, l).reshape(MT, KS, 64, 8)
+        got = np.zeros((cout, IH, IW))
+        for mt in range(MT):
+            for r in range(32):
+                co = 32 * mt + _row_feature(r)
+                if co >= cout:
+                    assert not frag[mt, :, [r, r + 32], :].any()     # padding rows hold zeros
+                    continue
+                for ks in range(KS):
+                    for h in range(2):
+                        q, a = 2 * ks + h, frag[mt, ks, r + 32 * h]
+                        if q > Q:
+                            assert not a.any()
+                        elif q == Q:                                  # the bias block: B = {1, 1, 0, ...}
+                            got[co] += a[0] + a[1]
+                        else:
+                            tap, cb = divmod(q, CBIN)
+                            ky, kx = divmod(tap, 3)
+                            got[co] += np.einsum("j,jyx->yx", a, xp[8 * cb:8 * cb + 8, ky:ky + IH, kx:kx + IW])
+        assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max()), (l, np.abs(got - want).max())
+        # ---- the pipeline's first convolution: 16x16x32 fragments [kernel row][lane][8], bias in the accumulators
+        if l == 0 and CIN <= 9:
+            fx = _pack(lib, spec, _abi.POLICY_PACK_CONV1X).reshape(3, 64, 8)
+            gx = np.tile(b[:, None, None], (1, IH, IW)) if cout <= 16 else None
+            for ky in range(3):
+                for lane in range(64):
+                    co, kq, a = lane & 15, lane >> 4, fx[ky, lane]
+                    if co >= cout:
+                        assert not a.any()
+                        continue
+                    if kq < 3:      # the tap kx = kq of channels 0-7
+                        gx[co] += np.einsum("j,jyx->yx", a, xp[0:8, ky:ky + IH, kq:kq + IW])
+                    else:           # the ninth channel at the taps kx = 0, 1, 2; elements 3-7 unused
+                        assert not a[3:].any()
+                        for kx in range(3):
+                            gx[co] += a[kx] * xp[8, ky:ky + IH, kx:kx + IW]
+            assert np.abs(gx - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+        cin = cout
+    # ---- the head: 16x16x32 fragments [action tile][k-step][lane][8] over area F = [position][channels padded to blocks of 8]
+    P, cl = IH * IW, chans[-1]
+    flat_c = (cl + 7) // 8 * 8
+    ksteps = (P * flat_c + 31) // 32
+    fh = _pack(lib, spec, _abi.POLICY_PACK_HEAD).reshape(1, ksteps, 64, 8)
+    feat = _bf16_round(rng.uniform(0, 2, (cl, IH, IW)))           # conv output [channel][row][column]
+    F = np.zeros(ksteps * 32)
+    for q in range(P):
+        F[q * flat_c:q * flat_c + cl] = feat[:, q // IW, q % IW]
+    got = np.zeros(9)
+    for ks in range(ksteps):
+        for lane in range(64):
+            a, kq = lane & 15, lane >> 4
+            if a < 9:
+                got[a] += fh[0, ks, lane] @ F[32 * ks + 8 * kq:32 * ks + 8 * kq + 8]
+            else:
+                assert not fh[0, ks, lane].any()
+    flat = torch.from_numpy(feat).permute(1, 2, 0).reshape(-1)      # RLlib: channels-last flatten
+    want = (torch.from_numpy(_bf16_round(hw)) @ flat).numpy()
+    assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
