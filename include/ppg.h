@@ -558,6 +558,9 @@ int ppg_policy_describe(const ppg_policy_spec *spec, int32_t *out, int32_t n);
  * takes; out == NULL or capacity too small: only the size is reported (PPG_OK). */
 #define PPG_POLICY_PACK_CONV1X 100
 #define PPG_POLICY_PACK_HEAD 200
+#define PPG_POLICY_PACK_SLOTS 300 /* not weights: the two-role pipeline's slot table, one word per slot of a sub-group = sample << 8 |
+                                   * position (0xFFFF: empty) -- which position a lane of an MFMA tile computes; ordered so that a tile's
+                                   * cells fall into all LDS bank groups (csrc/ppg_policy.h: ppg_slot_table) */
 int ppg_policy_pack(const ppg_policy_spec *spec, int32_t what, uint16_t *out, uint64_t capacity, uint64_t *n_words);
 
 /* A device buffer for the caller-owned observation tensors whose physical pages are picked at random from a stretch of device

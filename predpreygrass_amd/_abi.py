@@ -152,7 +152,7 @@ POLICY_LAYOUT_CHW, POLICY_LAYOUT_HWC = 0, 1
 POLICY_FLATTEN_NCHW, POLICY_FLATTEN_NHWC = 0, 1
 POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_create_spec", "ppg_policy_destroy", "ppg_policy_act",
                   "ppg_policy_macs_per_observation", "ppg_policy_last_error", "ppg_policy_describe", "ppg_policy_pack"]
-POLICY_PACK_CONV1X, POLICY_PACK_HEAD = 100, 200
+POLICY_PACK_CONV1X, POLICY_PACK_HEAD, POLICY_PACK_SLOTS = 100, 200, 300
 
 
 SPREAD_SYMBOLS = ["ppg_alloc_spread", "ppg_free_spread", "ppg_spread_stats", "ppg_spread_last_error"]   # HIP library only, like the policy symbols

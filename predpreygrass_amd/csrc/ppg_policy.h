@@ -106,6 +106,8 @@ struct PolParams {
     int32_t pipe_raw, pipe_ni;    // bfloat16 rows of a multiple of 8 bytes: byte offset of the LDS area that takes a sub-group's rows as they
     uint32_t pipe_magic;          // lie in HBM, 8-byte loads per role-B thread and sub-group (0: one load per channel), ceil(2^32 / chunks per row),
     int32_t pipe_slots;           // samples whose chunks the 256 role-B threads cover at once: floor(256 / chunks per row)
+    const uint16_t *slot_tab;     // the pipeline's slot table [32 slot_tiles]: sample << 8 | position of a sub-group's slot (0xFFFF: none);
+    int32_t slot_tiles;           // ppg_slot_table
     const bf16x8 *wc1x;           // conv1 of the pipeline as three 16x16x32 fragments [ky][lane][8] (ppg_policy_pipe.h: Conv1X); its bias [16]
     const float *bc1x;
 #ifdef PPG_EXPERIMENTS
@@ -1179,12 +1181,64 @@ static bool ppg_pipe_enabled() {
     const char *e = getenv("PPG_POLICY_PIPE");
     return PPG_POLICY_PIPE && !(e && e[0] == '0' && e[1] == 0);
 }
+// The pipeline's SLOT TABLE (ppg_policy_direct.h: dconv_cells): the ST * P positions of a sub-group in an order in which slot n's cell of
+// the padded image -- 16-byte cell number sample * stride_cells + (y + 1) * Wp + x + 1 -- is congruent to n modulo 16.  A 32-slot MFMA
+// tile then is, bank-wise, a run of 32 consecutive cells: ds_read_b128's sixteen-lane groups and the stores' eight-lane groups touch every
+// bank once.  Possible iff no residue class holds more than two cells per tile; which classes the cells fall into depends on the
+// sample stride (ppg_pipe_layout tries the eight strides that keep the head's reads conflict-free).  Returns false if some class is
+// too full (the table is then the plain order: slot n = position n).
+static bool ppg_slot_table(int ST, int IH, int IW, int stride_elems, std::vector<uint16_t> &tab) {
+    const int P = IH * IW, Wp = IW + 1, tiles = (ST * P + 31) / 32, per_class = 2 * tiles, stride_cells = stride_elems / 8;
+    std::vector<std::vector<uint16_t>> cls(16);
+    for (int s = 0; s < ST; ++s)
+        for (int p = 0; p < P; ++p) {
+            const int y = p / IW, x = p % IW;
+            cls[(s * stride_cells + (y + 1) * Wp + x + 1) & 15].push_back((uint16_t)(s << 8 | p));
+        }
+    bool ok = true;
+    for (int r = 0; r < 16; ++r) ok = ok && (int)cls[r].size() <= per_class;
+    tab.assign((size_t)32 * tiles, 0xFFFFu);
+    if (!ok) {
+        for (int n = 0; n < ST * P; ++n) tab[n] = (uint16_t)((n / P) << 8 | (n % P));
+        return false;
+    }
+    // slot 16 k + r <- the k-th cell of class r, the classes' cells in (sample, position) order: a tile's two halves then hold
+    // neighbouring positions, and the first sub-group-of-a-share's short last sub-group leaves whole slots empty rather than scattered
+    for (int r = 0; r < 16; ++r)
+        for (size_t k = 0; k < cls[r].size(); ++k) tab[16 * k + r] = cls[r][k];
+    return true;
+}
+
 // LDS layout of the two-role pipeline kernels (ppg_policy_pipe.h) for rows of C x R x R elements read as P positions; blk = elements of
 // one channel block of a sample's padded image, f_elems = elements of an area F.  Device-free (ppg_policy_describe, CPU tests).
-static bool ppg_pipe_layout(int C, int R, int P, int blk, int f_elems, int tail_slack, ppgpol::PolParams &K, int *lds_bytes) {
+static bool ppg_pipe_layout_at(int C, int R, int P, int blk, int f_elems, int tail_slack, ppgpol::PolParams &K, int *lds_bytes, int stride);
+static bool ppg_pipe_layout(int C, int R, int P, int blk, int f_elems, int tail_slack, ppgpol::PolParams &K, int *lds_bytes,
+                            std::vector<uint16_t> *slot_tab = nullptr) {
     int stride = 10 * blk + 2 * f_elems;
     while (((stride / 2) % 64) % 8 != 4) stride += 8;   // consecutive samples 16 bytes x an odd number apart in the banks: the head's
                                                         // sixteen sample columns read conflict-free
+    // ... and of the eight such strides modulo 256 bytes the first for which the slot table exists (ppg_slot_table: whether a tile's
+    // cells can be spread over all bank groups depends on where consecutive samples' images start)
+    std::vector<uint16_t> tab;
+    const char *sw = getenv("PPG_POLICY_SLOTS");   // diagnostic switch: PPG_POLICY_SLOTS=0 at creation time keeps the plain order (A/B runs)
+    for (int k = 0; k < 8 && !(sw && sw[0] == '0' && sw[1] == 0); ++k) {
+        if (!ppg_pipe_layout_at(C, R, P, blk, f_elems, tail_slack, K, lds_bytes, stride + 16 * k)) break;
+        if (ppg_slot_table(K.ST, P / R, R, K.sample_stride, tab)) {
+            if (slot_tab) *slot_tab = tab;
+            K.slot_tiles = (int)tab.size() / 32;
+            return true;
+        }
+    }
+    if (!ppg_pipe_layout_at(C, R, P, blk, f_elems, tail_slack, K, lds_bytes, stride)) return false;
+    if (ppg_slot_table(K.ST, P / R, R, K.sample_stride, tab)) {   // (PPG_POLICY_SLOTS=0 and this stride happens to admit a table: not wanted)
+        tab.assign(tab.size(), 0xFFFFu);
+        for (int n = 0; n < K.ST * P; ++n) tab[n] = (uint16_t)((n / P) << 8 | (n % P));
+    }
+    if (slot_tab) *slot_tab = tab;
+    K.slot_tiles = (int)tab.size() / 32;
+    return true;
+}
+static bool ppg_pipe_layout_at(int C, int R, int P, int blk, int f_elems, int tail_slack, ppgpol::PolParams &K, int *lds_bytes, int stride) {
     const int fixed_p = 2 * 4096 + 64 + 2048 + 1024 + tail_slack;   // partial sums x 2, role B's counter, Gumbel noise x 2, dconv's dummy slots (64 lanes)
     const int row_bf16 = C * R * R * 2;   // bytes of a bfloat16 row; the area `raw` takes ST of them when they are whole 8-byte chunks
     const bool chunks = row_bf16 % 8 == 0;
@@ -1288,7 +1342,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
     // feature index of (channel c, position q) behind the flatten, or -1 for a padding channel
     const int flatten = sp.flatten;
     auto feature = [=](int c, int q) { return c >= cout_last ? -1 : flatten == PPG_POLICY_FLATTEN_NHWC ? q * cout_last + c : c * P + q; };
-    std::vector<uint16_t> f[PPG_POLICY_MAX_CONV + 4];   // conv layers, then up to three linear layers, then conv1 in the pipeline's form
+    std::vector<uint16_t> f[PPG_POLICY_MAX_CONV + 5];   // conv layers, then up to three linear layers, conv1 in the pipeline's form, its slot table
     std::vector<float> bias(256 + 256 + 32 + 16, 0.0f); // FC chain: b1, b2, b3; direct: head bias at [512]; the pipeline's conv1 bias at [544]
     int ci = CIN;
     for (int l = 0; l < sp.n_conv; ++l) {
@@ -1338,7 +1392,17 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
         ppg_pack_conv1x(sp.conv_w[0], sp.conv_out[0], CIN, f[PPG_POLICY_MAX_CONV + 3]);
         for (int c = 0; c < sp.conv_out[0] && c < 16; ++c) bias[544 + c] = sp.conv_b[0][c];
     }
-    const int NF = PPG_POLICY_MAX_CONV + 4;
+    // (the pipeline's LDS layout decides its slot table: computed here, before the upload, once more below for the parameter block)
+    int pipe_lds_early = 0;
+    const bool want_pipe = direct && ppg_pipe_enabled() && sp.n_conv == 3 && (n_actions + 15) / 16 == 1 && CIN <= 9;
+    if (want_pipe) {
+        ppgpol::PolParams Kt = K;
+        Kt.Wp = IW + 1; Kt.Wp2 = (IH + 2) * (IW + 1) + 1;
+        const int kfs = (P * 8 * ((cout_last + 7) / 8) + 31) / 32;
+        if ((kfs + 3) / 4 <= 18)
+            (void)ppg_pipe_layout(C, R, P, Kt.Wp2 * 8, kfs * 32 + 8, 18 * 32 * 2, Kt, &pipe_lds_early, &f[PPG_POLICY_MAX_CONV + 4]);
+    }
+    const int NF = PPG_POLICY_MAX_CONV + 5;
     size_t off[NF + 1], total = 0;
     for (int l = 0; l < NF; ++l) { off[l] = total; total += (f[l].size() * 2 + 255) / 256 * 256; }
     off[NF] = total; total += bias.size() * 4;
@@ -1375,6 +1439,7 @@ int ppg_policy_create_spec(int32_t device, const ppg_policy_spec *spec, ppg_poli
     K.bc1 = K.bc2 = K.bc3 = nullptr;   // (the convolutions' biases ride in their fragments)
     K.b1 = db; K.b2 = db + 256; K.b3 = db + 512; K.bh = db + 512;
     K.wc1x = (const ppgpol::bf16x8 *)(dw + off[PPG_POLICY_MAX_CONV + 3]); K.bc1x = db + 544;
+    K.slot_tab = (const uint16_t *)(dw + off[PPG_POLICY_MAX_CONV + 4]);
     p->grid = 2 * prop.multiProcessorCount;
 #ifdef PPG_EXPERIMENTS
     if (const char *g = getenv("PPG_POLICY_GRID")) p->grid = atoi(g) > 0 ? atoi(g) : p->grid;   // resident workgroups
@@ -1482,6 +1547,15 @@ int ppg_policy_pack(const ppg_policy_spec *spec, int32_t what, uint16_t *out, ui
     } else if (what == PPG_POLICY_PACK_CONV1X) {
         if (CIN > 9) return ppg_policy_fail(nullptr, PPG_EINVAL, "the pipeline's first convolution takes up to nine input channels (found %d)", CIN);
         ppg_pack_conv1x(sp.conv_w[0], sp.conv_out[0], CIN, f);
+    } else if (what == PPG_POLICY_PACK_SLOTS) {
+        ppgpol::PolParams K;
+        memset(&K, 0, sizeof K);
+        const int cb = (sp.conv_out[sp.n_conv - 1] + 7) / 8, kfs = (P * 8 * cb + 31) / 32;
+        K.Wp = IW + 1; K.Wp2 = (IH + 2) * (IW + 1) + 1;
+        int lds = 0;
+        if (!(sp.n_fc == 1 && sp.n_conv == 3 && (sp.n_actions + 15) / 16 == 1 && (kfs + 3) / 4 <= 18 && CIN <= 9 &&
+              ppg_pipe_layout(sp.obs_channels, sp.obs_range, P, K.Wp2 * 8, kfs * 32 + 8, 18 * 32 * 2, K, &lds, &f)))
+            return ppg_policy_fail(nullptr, PPG_EINVAL, "PPG_POLICY_PACK_SLOTS: not a network of the two-role pipeline");
     } else if (what == PPG_POLICY_PACK_HEAD) {
         if (sp.n_fc != 1) return ppg_policy_fail(nullptr, PPG_EINVAL, "PPG_POLICY_PACK_HEAD: the network has hidden head layers");
         ppg_pack_head(sp.fc_w[0], sp.n_actions, P, sp.conv_out[sp.n_conv - 1], sp.flatten == PPG_POLICY_FLATTEN_NHWC, f);

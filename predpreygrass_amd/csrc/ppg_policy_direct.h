@@ -60,19 +60,25 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // partial logits in LDS: [wavefront][action tile (head_mt of them)][action row][sample column] floats = head_mt * 4 KB
 
-// The two words per tile dconv() takes as `pre` (positions beyond the ST * P of a full sub-group look at position 0 of sample 0: their
-// results are never stored).
+// The words per tile dconv() takes as `pre` (the pipeline kernels): which position a lane computes in the wavefront's tiles nt_first and
+// nt_first + nt_step comes from the policy's SLOT TABLE (PolParams::slot_tab, built by ppg_slot_table on the host): slot n of a
+// sub-group -> (sample, position), ordered so that slot n's cell of the padded image lies in LDS bank group n mod 16 -- a tile's
+// sixteen-lane read groups and eight-lane write groups then hit every bank once, whatever the image's row length (consecutive
+// positions do that only inside an image row: 45 % of the pipeline kernels' LDS cycles were conflicts of tiles crossing row ends).
+// pre[2 t] = sample base + 8 x padded position (the element of its cell in channel block 0 of area 0), pre[2 t + 1] = (sample base + 64 x
+// position) | (position & 7), pre[4 + t] = the sample (255: the slot holds no position -- its results are never stored).
 template <class KP>
-__device__ __forceinline__ void dconv_cells(const KP &K, int sample_stride, int nt_first, int nt_step, int lane, int (&pre)[4]) {
-    const int col = lane & 31, n_full = K.ST * K.P;
+__device__ __forceinline__ void dconv_cells(const KP &K, int sample_stride, int nt_first, int nt_step, int lane, int (&pre)[6]) {
+    const int col = lane & 31;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int n = 32 * (nt_first + t * nt_step) + col, nn = n < n_full ? n : 0;
-        const int s = div_small(nn, K.magic_P), p = nn - __mul24(s, K.P);
+        const uint32_t e = K.slot_tab[32 * (nt_first + t * nt_step) + col];
+        const int sv = (int)(e >> 8), s = sv == 255 ? 0 : sv, p = sv == 255 ? 0 : (int)(e & 255u);
         const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
         const int sb = __mul24(s, sample_stride);
         pre[2 * t] = sb + (__mul24(y + 1, K.Wp) + (x + 1)) * 8;
         pre[2 * t + 1] = (sb + p * 64) | (p & 7);
+        pre[4 + t] = sv;
     }
 }
 
@@ -116,7 +122,8 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
     constexpr int NB = BATCH ? (KS + BATCH - 1) / BATCH : 1, BS = BATCH ? BATCH : KS;   // batches of fragment reads per tile
     const int h = lane >> 5, col = lane & 31;
     const int n_pos = ns * K.P;
-    const int n_tiles = (n_pos + 31) / 32;
+    // (with a slot table every tile holds positions of every sample: all of them run as long as there is a sample at all)
+    const int n_tiles = pre ? (ns > 0 ? K.slot_tiles : 0) : (n_pos + 31) / 32;
     if (nt_first >= n_tiles) return;
     const int blk = K.Wp2 * 8;
     const int in0 = in_off + (CBIN > 1 ? h : 0) * blk;
@@ -130,6 +137,7 @@ __device__ __forceinline__ void dconv(const KP &K, const ConvW<CBIN, MT> &W, __b
         if (pre) {   // (compile-time after inlining: the caller passes an array or nothing)
             const int t = nt == nt_first ? 0 : 1;
             const int cell = t ? pre[2] : pre[0], fp = t ? pre[3] : pre[1];
+            c.valid = (t ? pre[5] : pre[4]) < ns;
             c.in_base = cell + in0;
             c.out_base = F64 ? (fp & ~7) + out_off : cell + out_off + __mul24(cb0, cb_step);
             c.swz = F64 ? (fp & 7) : 0;

@@ -129,18 +129,21 @@ struct Conv1X {
     bf16x8 a[3];     // weight fragments of ky = 0, 1, 2: lane (r = lane & 15: output channel, kq = lane >> 4)
     f32x4_t bias;    // of this lane's output channels 4 kq .. 4 kq + 3
     int cell[4];     // element offset (from img) of this lane's position in its tile t: block 0 of area X0, cell of the position
+    int smp[4];      // ... and its sample (255: the slot holds no position)
     template <class KP>
     __device__ __forceinline__ void load(const KP &K, int lane, int bw) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) a[ky] = ((const GLOBAL_AS bf16x8 *)K.wc1x)[ky * 64 + lane];
         bias = *(const GLOBAL_AS f32x4_t *)(K.bc1x + 4 * (lane >> 4));
-        const int col = lane & 15, n_full = K.ST * K.P;
+        const int col = lane & 15;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = 16 * (bw + 4 * t) + col, nn = n < n_full ? n : 0;
-            const int s = div_small(nn, K.magic_P), p = nn - __mul24(s, K.P);
+        for (int t = 0; t < 4; ++t) {   // (the slot table: dconv_cells)
+            const int n = 16 * (bw + 4 * t) + col;
+            const uint32_t e = n < 32 * K.slot_tiles ? (uint32_t)K.slot_tab[n] : 0xFFFFu;
+            const int sv = (int)(e >> 8), s = sv == 255 ? 0 : sv, p = sv == 255 ? 0 : (int)(e & 255u);
             const int y = div_small(p, K.magic_R), x = p - __mul24(y, K.IW);
             cell[t] = __mul24(s, K.sample_stride) + (__mul24(y + 1, K.Wp) + (x + 1)) * 8;
+            smp[t] = sv;
         }
     }
     __device__ __forceinline__ void landed() {
@@ -169,8 +172,8 @@ __device__ __forceinline__ u32x2_t relu_pack4(const f32x4_t &a) {
 // One sub-group's conv1: X (input blocks at element offset xo) -> Y.  CB1 = 2: a second input block (the ninth channel's taps).
 template <int CB1, class KP>
 __device__ __forceinline__ void conv1x(const KP &K, const Conv1X &W, __bf16 *img, int xo, int ns, int bw, int lane, int dummy) {
-    const int kq = lane >> 4, col = lane & 15;
-    const int n_pos = ns * K.P, blk = K.Wp2 * 8;
+    const int kq = lane >> 4;
+    const int blk = K.Wp2 * 8;
     // this lane quarter's B operand of kernel row ky = 1 relative to the position's cell: the tap kq - 1 of block 0, or (kq = 3)
     // the position's own cell of block 1 (CB1 = 1: any cell of block 0 -- its weights are zero)
     const int koff = kq < 3 ? (kq - 1) * 8 : (CB1 > 1 ? blk : 0);
@@ -178,9 +181,8 @@ __device__ __forceinline__ void conv1x(const KP &K, const Conv1X &W, __bf16 *img
 #if PPG_PIPE_CONV1X_LOOP
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int nt = bw + 4 * t;
-        if (16 * nt >= n_pos) break;
-        const bool valid = 16 * nt + col < n_pos;
+        if (ns <= 0) break;
+        const bool valid = W.smp[t] < ns;
         const __bf16 *base = img + W.cell[t] + xo + koff;
         bf16x8 b[3];
 #pragma unroll
@@ -213,7 +215,7 @@ __device__ __forceinline__ void conv1x(const KP &K, const Conv1X &W, __bf16 *img
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.a[ky], b[t][ky], acc[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const bool valid = 16 * (bw + 4 * t) + col < n_pos;
+        const bool valid = W.smp[t] < ns;
         const int at = valid ? W.cell[t] + K.off_y + yoff : dummy;
         *(u32x2_t *)(img + at) = relu_pack4(acc[t]);
     }
@@ -226,9 +228,9 @@ template <class KP>
 __device__ __forceinline__ void conv2_pair(const KP &K, const ConvW<2, 1> &W, __bf16 *img, int in_off, int out_off, int out_blocks, int ns,
                                            int bw, int lane, int dummy, const int *cells) {
     constexpr int KS = ConvW<2, 1>::KS, KSB = ConvW<2, 1>::KS_BIAS, HB = ConvW<2, 1>::H_BIAS;
-    const int h = lane >> 5, col = lane & 31;
-    const int n_pos = ns * K.P, blk = K.Wp2 * 8;
-    if (32 * bw >= n_pos) return;
+    const int h = lane >> 5;
+    const int blk = K.Wp2 * 8;
+    if (ns <= 0) return;
     const int in0 = in_off + h * blk;
     const int cb0 = 2 * h;
     auto fragment = [&](int cell, int ks) -> bf16x8 {
@@ -265,7 +267,7 @@ __device__ __forceinline__ void conv2_pair(const KP &K, const ConvW<2, 1> &W, __
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const bool valid = 32 * (bw + 4 * t) + col < n_pos;
+        const bool valid = cells[4 + t] < ns;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool real = valid && (cb0 + j < out_blocks);
@@ -431,7 +433,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         const float bias_r = (a16 < K.n_actions) ? K.bh[a16] : 0.0f;
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w3c.landed();
-        int cells[4];   // this wavefront's two position tiles are the same positions in every sub-group: their LDS offsets once per launch
+        int cells[6];   // this wavefront's two position tiles are the same positions in every sub-group: their LDS offsets once per launch
         dconv_cells(K, sample_stride, wave, 4, lane, cells);
         for (int j = 0; j < tpw; ++j) {
             const int tile = (int)blockIdx.x * tpw + j;
@@ -535,7 +537,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         hf[i] = __builtin_bit_cast(bf16x8, v);
     }
     uint32_t b_target = 0;
-    int cells[4];   // (as in role A: the positions of this wavefront's two tiles, once per launch)
+    int cells[6];   // (as in role A: the positions of this wavefront's two tiles, once per launch)
     dconv_cells(K, sample_stride, bw, 4, lane, cells);
     // bfloat16 rows whose size is a multiple of 8 bytes (K.pipe_ni > 0) come in as they lie in HBM: ALIGNED 8-byte chunks, consecutive
     // lanes consecutive chunks (two or three loads per thread and sub-group), parked in the LDS area `raw` one iteration later and picked
@@ -546,7 +548,9 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
     auto row_of = [&](int s_tile) -> const GLOBAL_AS unsigned char * { return (const GLOBAL_AS unsigned char *)(uintptr_t)tab[2 * s_tile]; };
     // a thread's place in the sub-group never changes: the position it stages, and (row chunks) chunk ch_w of the samples ch_q,
     // ch_q + K.pipe_slots, ...: consecutive lanes consecutive chunks of one row
-    const int st_s = div_small(btid, K.magic_P), st_p = btid - __mul24(st_s, K.P);
+    // (thread t stages the position of slot t: the eight lanes of a store group then write eight different bank groups)
+    const uint32_t st_e = btid < 32 * K.slot_tiles ? (uint32_t)K.slot_tab[btid] : 0xFFFFu;
+    const int st_sv = (int)(st_e >> 8), st_s = st_sv == 255 ? 0 : st_sv, st_p = st_sv == 255 ? 0 : (int)(st_e & 255u);
     const int st_y = div_small(st_p, K.magic_R), st_x = st_p - __mul24(st_y, K.IW);
     const int st_img = __mul24(st_s, sample_stride) + (__mul24(st_y + 1, K.Wp) + (st_x + 1)) * 8;
     const int st_raw = __mul24(st_s, K.obs_elems) + st_p * K.p_stride;
@@ -588,7 +592,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
             const int ns = group_ns(g);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) pre[c] = (raw_t)0;
-            if (btid < ns * K.P) {
+            if (st_sv < ns) {
                 const GLOBAL_AS elem_t *src = (const GLOBAL_AS elem_t *)row_of(g * K.ST + st_s) + st_p * K.p_stride;
 #pragma unroll
                 for (int c = 0; c < (NCH < 9 ? NCH : 9); ++c) if (c < K.cin) pre[c] = (raw_t)src[c * K.c_stride];
@@ -600,7 +604,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         };
         auto stage = [&](int g) {
             const int ns = group_ns(g);
-            if (btid < ns * K.P) {
+            if (st_sv < ns) {
                 if constexpr (CH) {
                     const uint16_t *rh = (const uint16_t *)raw + st_raw;
 #pragma unroll

@@ -432,7 +432,7 @@ def test_bfloat16_rows_of_other_windows_through_the_pipeline_kernels(Rp, Rq):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float64])
-def test_pipeline_and_one_role_kernels_give_the_same_logits_bit_for_bit(dt, monkeypatch):
+def test_pipeline_and_one_role_kernels_agree_and_each_is_bit_stable(dt, monkeypatch):
     """The two-role pipeline kernels (ppg_policy_pipe.h) against the one-role direct-head kernels (PPG_POLICY_PIPE=0 at creation time
     selects the latter for the same network).  conv2, conv3 and the head do the same arithmetic in the same order in both; since round 5
     the pipeline's FIRST convolution runs on v_mfma_f32_16x16x32_bf16 with one k-step per kernel row and the bias in the accumulators
@@ -807,3 +807,57 @@ def test_weight_fragments_restated_in_numpy_equal_a_plain_convolution(layout, C,
     flat = torch.from_numpy(feat).permute(1, 2, 0).reshape(-1)      # RLlib: channels-last flatten
     want = (torch.from_numpy(_bf16_round(hw)) @ flat).numpy()
     assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("layout,C,R", [("hwc", 4, 9), ("hwc", 4, 7), ("hwc", 5, 9), ("hwc", 4, 5), ("hwc", 6, 3), ("chw", 4, 9), ("chw", 4, 7), ("chw", 8, 5)])
+def test_slot_table_spreads_every_tile_over_all_bank_groups(layout, C, R):
+    """The two-role pipeline's slot table (ppg_policy_pack: PPG_POLICY_PACK_SLOTS, device-free): every position of a sub-group exactly
+    once; and where the table exists (the reference's 7x7 and 9x9 windows among them) slot n's cell of the padded image -- 16-byte cell
+    sample * stride + (y + 1) * (W + 1) + x + 1 -- is congruent to n modulo 16, i.e. the sixteen lanes of a ds_read_b128 group (lanes
+    0-3, 12-15, 20-27 / 4-11, 16-19, 28-31 of a half) read sixteen different bank groups and the eight lanes of a store group eight."""
+    import __graft_entry__ as g
+    lib = _abi.bind(ctypes.CDLL(g.build_hip()))
+    spec = _abi.PpgPolicySpec()
+    spec.obs_channels, spec.obs_range, spec.n_actions = C, R, 9
+    spec.layout = _abi.POLICY_LAYOUT_HWC if layout == "hwc" else _abi.POLICY_LAYOUT_CHW
+    spec.flatten, spec.n_conv, spec.n_fc = _abi.POLICY_FLATTEN_NHWC, 3, 1
+    IH, IW, CIN = (C, R, R) if layout == "hwc" else (R, R, C)
+    keep = []
+    cin = CIN
+    for l, co in enumerate((16, 32, 64)):
+        w, b = np.zeros((co, cin, 3, 3), np.float32), np.zeros(co, np.float32)
+        keep += [w, b]
+        spec.conv_out[l], spec.conv_w[l], spec.conv_b[l] = co, w.ctypes.data, b.ctypes.data
+        cin = co
+    hw, hb = np.zeros((9, IH * IW * 64), np.float32), np.zeros(9, np.float32)
+    spec.fc_out[0], spec.fc_w[0], spec.fc_b[0] = 9, hw.ctypes.data, hb.ctypes.data
+    out = (ctypes.c_int32 * 12)()
+    assert lib.ppg_policy_describe(ctypes.byref(spec), out, 12) == 0
+    if out[0] != 3:
+        pytest.skip("not a network of the two-role pipeline")
+    st, stride_cells = out[1], out[5] // 16
+    n = ctypes.c_uint64(0)
+    assert lib.ppg_policy_pack(ctypes.byref(spec), _abi.POLICY_PACK_SLOTS, None, 0, ctypes.byref(n)) == 0
+    tab = np.zeros(n.value, dtype=np.uint16)
+    assert lib.ppg_policy_pack(ctypes.byref(spec), _abi.POLICY_PACK_SLOTS, tab.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n)) == 0
+    P = IH * IW
+    assert len(tab) % 32 == 0 and len(tab) >= st * P and len(tab) < st * P + 32
+    used = tab[tab != 0xFFFF]
+    assert sorted(used.tolist()) == sorted((s << 8 | p) for s in range(st) for p in range(P))     # every position exactly once
+    s_, p_ = used >> 8, used & 255
+    cell = s_.astype(np.int64) * stride_cells + (p_ // IW + 1) * (IW + 1) + p_ % IW + 1
+    spread = np.array_equal(cell % 16, np.nonzero(tab != 0xFFFF)[0] % 16)
+    if (layout, R) in (("hwc", 9), ("hwc", 7)):
+        assert spread                                   # the reference's networks get conflict-free tiles
+    if spread:
+        for t in range(len(tab) // 32):                 # restated per lane group of one 32-lane half
+            for group in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+                c = [int(x) for k in group for x in [tab[32 * t + k]] if x != 0xFFFF]
+                cells = [(v >> 8) * stride_cells + ((v & 255) // IW + 1) * (IW + 1) + (v & 255) % IW + 1 for v in c]
+                assert len({v % 16 for v in cells}) == len(cells)
+            for w in range(4):
+                c = [int(x) for x in tab[32 * t + 8 * w:32 * t + 8 * w + 8] if x != 0xFFFF]
+                cells = [(v >> 8) * stride_cells + ((v & 255) // IW + 1) * (IW + 1) + (v & 255) % IW + 1 for v in c]
+                assert len({v % 8 for v in cells}) == len(cells)
+    else:                                               # the plain order
+        assert np.array_equal(used, np.array([(s << 8 | p) for s in range(st) for p in range(P)], dtype=np.uint16))
