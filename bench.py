@@ -277,6 +277,9 @@ def parse_args(argv):
                          "(SURVEY 8(f) N4; no observation leaves the GPU, roofline = bf16 MFMA); dict_api: the drop-in classes an existing "
                          "script imports -- PredPreyGrass(config).step(action_dict) for one env and VectorPredPreyGrass(64) -- driven from "
                          "the host like the reference's random_policy.py, every call crossing PCIe both ways (calls/s; latency-bound)")
+    ap.add_argument("--policy-open-loop", action="store_true",
+                    help="policy_rollout, timing experiments only: the policy's actions go to a scratch tensor and the envs are stepped with "
+                         "device-side random actions -- the population then does not depend on what the (possibly ablated) kernels compute")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0,
                     help="cpu_baseline: wall seconds of the all-cores leg (a single-thread leg of a third of that runs first)")
@@ -471,15 +474,19 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
                  "depth": "channels-last, (R - 1) // 2 convolutions 16/32/64/64.. (the newer tune scripts' build_module_spec), ONE Linear head"}[args.policy_arch]
     env.reset()
     t_step = [0]
+    scratch_actions = [torch.empty_like(env.actions)] if args.policy_open_loop else None
 
     def one_step(timed=None):
         if timed is not None:
             timed[0].record()
-        fused.act(env, sample=True, seed=args.seed * 1000003 + t_step[0])
+        fused.act(env, actions=scratch_actions, sample=True, seed=args.seed * 1000003 + t_step[0])
         if timed is not None:
             timed[1].record()
         t_step[0] += 1
-        env.step(env.actions, auto_reset=True)
+        if args.policy_open_loop:
+            env.step(random_actions=True, auto_reset=True)
+        else:
+            env.step(env.actions, auto_reset=True)
 
     preroll = min(args.preroll_min, 512) if args.preroll_max > 0 else 0    # (a forward pass costs ~10x a step: shorter pre-roll)
     for _ in range(preroll + args.warmup):
@@ -531,6 +538,7 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
                              "in place, actions sampled on the device, then ppg_step with those actions and auto-reset"),
                 "envs_per_gpu": B, "parallelism": f"batch-sharded x{n_gpus}, no data-path collective", "preroll_steps": preroll,
                 "mean_agents_per_env": round((n_pred + n_prey) / (B * args.steps), 2),
+                **({"open_loop": "TIMING EXPERIMENT: the envs were stepped with random actions, the policy's actions discarded"} if args.policy_open_loop else {}),
                 "bytes_per_agent_a_consumer_has_to_move": 1,
             },
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -45,6 +45,15 @@
 #ifndef PPG_PIPE_HEAD_CHAINS
 #define PPG_PIPE_HEAD_CHAINS 1  // independent accumulator chains of the head's eighteen MFMAs: 2 measured 1 % slower than 1 (profiles/r05/e_*)
 #endif
+#ifndef PPG_PIPE_ABLATE
+#define PPG_PIPE_ABLATE 0   // timing-only ablation builds (tools/gpu_r5_pipe_ablate.sh; never the product -- the results are then meaningless):
+                            // 1 no head, 2 no staging, 4 no conv1, 8 no conv2, 16 no conv3, 32 no logits / actions, 64 no Gumbel noise,
+                            // 128 no row fetch / park
+#endif
+#ifndef PPG_PIPE_HOFF
+#define PPG_PIPE_HOFF 0   // 1: the head's eighteen operand offsets in registers instead of recomputed per sub-group -- measured 2 % SLOWER
+                          // (profiles/r05/e_*: eighteen more live registers in role B cost more than the address arithmetic)
+#endif
 #ifndef PPG_PIPE_CONV1X_LOOP
 #define PPG_PIPE_CONV1X_LOOP 0  // conv1x tile after tile (1) instead of the four tiles as one straight line (0)
 #endif
@@ -444,20 +453,45 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
             build_table(tile, n0, nt_samples);
             PPG_DP(0);
             for (int it = -1; it <= G + 1; ++it) {
-                if (it >= 2 && 4 * wave < K.ST && 4 * wave < nt_samples - (it - 2) * K.ST) {   // (this wavefront's four samples: 4 wave .. 4 wave + 3)
-                    // thread (sample smp, action a16) of sub-group it - 2: bias + the four partial sums in wavefront order = the logit; then
-                    // the sixteen lanes of a sample pick the action: argmax, or Gumbel-max -- the first maximum wins, as in a loop over the
-                    // actions.  The Gumbel noise was computed one iteration ago by ANOTHER wavefront (below) and waits in LDS.
-                    const int g = it - 2, left = nt_samples - g * K.ST, ns = left < K.ST ? left : K.ST;
+                // thread (sample smp, action a16) of sub-group it - 2: bias + the four partial sums in wavefront order = the logit; then
+                // the sixteen lanes of a sample pick the action: argmax, or Gumbel-max -- the first maximum wins, as in a loop over the
+                // actions.  The Gumbel noise was computed one iteration ago by ANOTHER wavefront (below) and waits in LDS.
+                // Its LDS reads (partial sums, table entry, noise: complete since the iteration's barrier) are issued HERE, in front of
+                // conv3, and consumed behind it: three dependent LDS round trips less on the wavefronts that carry the most work.
+                const bool do_act = !(PPG_PIPE_ABLATE & 32) && it >= 2 && 4 * wave < K.ST && 4 * wave < nt_samples - (it - 2) * K.ST;   // (this wavefront's four samples: 4 wave .. 4 wave + 3)
+                float act_part[4] = {0.0f, 0.0f, 0.0f, 0.0f}, act_noise = 0.0f;
+                unsigned long long act_er = 0;
+                int act_ns = 0, act_s_local = 0;
+                if (do_act) {
+                    const int g = it - 2, left = nt_samples - g * K.ST;
+                    act_ns = left < K.ST ? left : K.ST;
                     const float *rd = red + (g & 1) * 1024;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) act_part[w] = rd[(w * 16 + a16) * 16 + smp];
+                    act_s_local = g * K.ST + (smp < act_ns ? smp : 0);
+                    act_er = tab[2 * act_s_local + 1];
+                    if (K.sample) act_noise = noise[(g & 1) * 256 + btid];
+                }
+                PPG_DP(3);
+                if (!(PPG_PIPE_ABLATE & 16) && it >= 0 && it < G) {
+                    const int left = nt_samples - it * K.ST, ns = left < K.ST ? left : K.ST;
+                    if (K.flat_c == 64)
+                        dconv<4, 2, PPG_PIPE_B3, false, true, PPG_PIPE_D3>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
+                                                              K.cout_blocks[2], 64, ns, wave, 4, lane, 0, dummy, cells);
+                    else
+                    dconv<4, 2, PPG_PIPE_B3, false, false, PPG_PIPE_D3>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
+                                                      K.cout_blocks[2], K.flat_c, ns, wave, 4, lane, 0, dummy);
+                }
+                PPG_DP(1);
+                if (do_act) {
+                    const int ns = act_ns, s_local = act_s_local;
                     float v = bias_r;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) v += rd[(w * 16 + a16) * 16 + smp];
-                    const int s_local = g * K.ST + (smp < ns ? smp : 0);
-                    const unsigned long long er = tab[2 * s_local + 1];
+                    for (int w = 0; w < 4; ++w) v += act_part[w];
+                    const unsigned long long er = act_er;
                     const uint32_t e = (uint32_t)er, row = (uint32_t)(er >> 32);
                     if (K.logits && smp < ns && a16 < K.n_actions) K.logits[(size_t)(n0 + s_local) * K.n_actions + a16] = v;
-                    if (K.sample) v += noise[(g & 1) * 256 + btid];
+                    if (K.sample) v += act_noise;
                     if (a16 >= K.n_actions) v = -INFINITY;
                     int best = a16;
                     // all-reduce over the sample's sixteen lanes on the DPP cross-lane paths: partners lane ^ 1, lane ^ 2, then 7 - lane and
@@ -481,21 +515,11 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                         base[(size_t)b * K.S + K.slot0 + row] = (int8_t)best;
                     }
                 }
-                PPG_DP(3);
-                if (it >= 0 && it < G) {
-                    const int left = nt_samples - it * K.ST, ns = left < K.ST ? left : K.ST;
-                    if (K.flat_c == 64)
-                        dconv<4, 2, PPG_PIPE_B3, false, true, PPG_PIPE_D3>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
-                                                              K.cout_blocks[2], 64, ns, wave, 4, lane, 0, dummy, cells);
-                    else
-                    dconv<4, 2, PPG_PIPE_B3, false, false, PPG_PIPE_D3>(K, w3c, img, sample_stride, (it & 1) ? K.pipe_x1 : 0, (it & 1) ? K.pipe_f1 : K.off_f,
-                                                      K.cout_blocks[2], K.flat_c, ns, wave, 4, lane, 0, dummy);
-                }
-                PPG_DP(1);
+                PPG_DP(14);
                 // Gumbel noise of sub-group it - 1 (needed in the next iteration): -log(-log u), u from Philox keyed by (seed, env, row
                 // slot, action) as in phase_head.  Sample s is served by wavefront (s / 4 + 2) & 3: with 7 samples per sub-group the
                 // wavefronts 2, 3 -- which have no sample to pick actions for and would wait at the barrier -- do all of it.
-                if (K.sample && it >= 1 && it - 1 < G) {
+                if (!(PPG_PIPE_ABLATE & 64) && K.sample && it >= 1 && it - 1 < G) {
                     const int g = it - 1, left = nt_samples - g * K.ST, ns = left < K.ST ? left : K.ST;
                     const int s0 = 4 * ((wave + 2) & 3);
                     if (s0 < ns) {
@@ -537,6 +561,11 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         hf[i] = __builtin_bit_cast(bf16x8, v);
     }
     uint32_t b_target = 0;
+#if PPG_PIPE_HOFF
+    int hoff[HF];   // where this lane's eighteen head operands lie in a sample's area F: the same in every sub-group -- once per launch
+#pragma unroll
+    for (int i = 0; i < HF; ++i) { hoff[i] = f_koff(K, k_lo + i, kq); __asm__ volatile("" : "+v"(hoff[i])); }
+#endif
     int cells[6];   // (as in role A: the positions of this wavefront's two tiles, once per launch)
     dconv_cells(K, sample_stride, bw, 4, lane, cells);
     // bfloat16 rows whose size is a multiple of 8 bytes (K.pipe_ni > 0) come in as they lie in HBM: ALIGNED 8-byte chunks, consecutive
@@ -644,12 +673,12 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
             // fetch -> WAIT -> conv2: the waits of the two private barriers find most arrivals done
             const bool more = it + 1 < G;   // sub-group it + 1: rows -> X, conv1, conv2
             if (more) {
-                stage(it + 1);
+                if (!(PPG_PIPE_ABLATE & 2)) stage(it + 1);
                 b_target += 4;
                 pipe_arrive(ctr, lane);
             }
             PPG_DP(11);
-            if (it >= 1 && it - 1 < G) {   // head of sub-group it - 1: this wavefront's k-steps
+            if (!(PPG_PIPE_ABLATE & 1) && it >= 1 && it - 1 < G) {   // head of sub-group it - 1: this wavefront's k-steps
                 const int g = it - 1, ns = group_ns(g);
                 const __bf16 *fb = img + __mul24(colh < ns ? colh : 0, sample_stride) + ((g & 1) ? K.pipe_f1 : K.off_f);
                 f32x4_t hacc, hacc1;
@@ -657,7 +686,11 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 for (int i = 0; i < 4; ++i) { hacc[i] = 0.0f; hacc1[i] = 0.0f; }
                 bf16x8 fv[HF];
 #pragma unroll
+#if PPG_PIPE_HOFF
+                for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + hoff[i]);
+#else
                 for (int i = 0; i < HF; ++i) fv[i] = *(const bf16x8 *)(fb + f_koff(K, k_lo + i, kq));
+#endif
                 if (PPG_PIPE_HEAD_CHAINS == 2) {
                     // two chains (k-steps 0-8, 9-17), added at the end: the SAME partial sums as one chain of eighteen would NOT come out bit
                     // for bit -- the one-role kernels keep one chain; the logits differ in the last bits (tests: tolerance, not equality)
@@ -681,11 +714,12 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 const int g = it + 1, ns = group_ns(g), xo = (g & 1) ? K.pipe_x1 : 0;
                 pipe_wait(ctr, b_target);
                 PPG_DP(6);
-                conv1x<CB1>(K, w1x, img, xo, ns, bw, lane, dummy);
+                if (!(PPG_PIPE_ABLATE & 4)) conv1x<CB1>(K, w1x, img, xo, ns, bw, lane, dummy);
                 PPG_DP(7);
                 b_target += 4;
                 pipe_arrive(ctr, lane);
-                if constexpr (CH) fetch(g + 1 < G ? g + 1 : g);   // (unconditional, like the loads in it; the last one is not parked)
+                if (PPG_PIPE_ABLATE & 128) { }
+                else if constexpr (CH) fetch(g + 1 < G ? g + 1 : g);   // (unconditional, like the loads in it; the last one is not parked)
                 else if (g + 1 < G) request(g + 1);
                 PPG_DP(5);
                 pipe_wait(ctr, b_target);
@@ -693,10 +727,12 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
 #if PPG_PIPE_CONV2_PAIR
                 conv2_pair(K, w2c, img, K.off_y, xo, K.cout_blocks[1], ns, bw, lane, dummy, cells);
 #else
+                if (!(PPG_PIPE_ABLATE & 8))
                 dconv<2, 1, PPG_PIPE_B12, PPG_PIPE_SWP_B, false, PPG_PIPE_D2>(K, w2c, img, sample_stride, K.off_y, xo, K.cout_blocks[1], 0, ns, bw, 4, lane, 0, dummy, cells);
 #endif
                 PPG_DP(9);
-                if constexpr (CH) park(g + 1, g + 1 < G);   // (every B wavefront has staged sub-group g out of `raw`: two private barriers ago)
+                if (PPG_PIPE_ABLATE & 128) { }
+                else if constexpr (CH) park(g + 1, g + 1 < G);   // (every B wavefront has staged sub-group g out of `raw`: two private barriers ago)
             }
             __syncthreads();
             PPG_DP(10);

@@ -10,7 +10,7 @@ mkdir -p gpurun_out
 for rep in 1 2; do
   for name in "$@"; do
     if [ "$name" = base ]; then unset PPG_HIP_LIB; else export PPG_HIP_LIB=$GRAFT_REPO_ROOT/tools/_build/libppg_hip_$name.so; fi
-    PPG_POLICY_ITER_P=8500 python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --no-cpu-baseline 2>> gpurun_out/${tag}_bench.err | python3 -c "
+    python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --no-cpu-baseline 2>> gpurun_out/${tag}_bench.err | python3 -c "
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('rep $rep  %-16s ms_per_step %.5f  policy kernel_ms %.5f  %.2f M env-steps/s  frac %.4f' % ('$name', d['ms_per_step'], d['roofline']['kernel_ms'], d['value'] / 1e6, d['roofline']['frac']))" >> gpurun_out/${tag}_ab.txt
