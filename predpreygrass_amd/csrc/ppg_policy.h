@@ -1006,6 +1006,9 @@ PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_bf16, 2, 16)
 
 #include "ppg_policy_direct.h"
 #include "ppg_policy_pipe.h"
+#ifdef PPG_WITH_PIPE4   // (an experiment that lost: see the file's header; not part of the product build)
+#include "ppg_policy_pipe4.h"
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side
@@ -1909,13 +1912,27 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
         {{ppgpol::ppg_policy_pipe2_16_8_f64, ppgpol::ppg_policy_pipe2_16_8_f32, ppgpol::ppg_policy_pipe2_16_8_bf16},
          {ppgpol::ppg_policy_pipe2_16_16_f64, ppgpol::ppg_policy_pipe2_16_16_f32, ppgpol::ppg_policy_pipe2_16_16_bf16}}};
     const int dt = K2.q.obs_f32 == 2 ? 2 : K2.q.obs_f32 ? 1 : 0;
+#ifdef PPG_WITH_PIPE4
+    // the four-role pipeline (ppg_policy_pipe4.h: sixteen wavefronts per workgroup; same LDS layout, bit-identical results, 18 % slower:
+    // profiles/r05/i_*) -- experiment builds only; PPG_POLICY_PIPE4=0 selects the two-role kernels there
+    const fused_fn fn4[2][2][3] = {
+        {{ppgpol::ppg_policy_pipe4_8_8_f64, ppgpol::ppg_policy_pipe4_8_8_f32, ppgpol::ppg_policy_pipe4_8_8_bf16},
+         {ppgpol::ppg_policy_pipe4_8_16_f64, ppgpol::ppg_policy_pipe4_8_16_f32, ppgpol::ppg_policy_pipe4_8_16_bf16}},
+        {{ppgpol::ppg_policy_pipe4_16_8_f64, ppgpol::ppg_policy_pipe4_16_8_f32, ppgpol::ppg_policy_pipe4_16_8_bf16},
+         {ppgpol::ppg_policy_pipe4_16_16_f64, ppgpol::ppg_policy_pipe4_16_16_f32, ppgpol::ppg_policy_pipe4_16_16_bf16}}};
+    const char *p4 = getenv("PPG_POLICY_PIPE4");
+    const bool pipe4 = !(p4 && p4[0] == '0' && p4[1] == 0);
+    const fused_fn f = pipe4 ? fn4[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt] : fn[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt];
+#else
+    const bool pipe4 = false;
     const fused_fn f = fn[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt];
+#endif
 #ifdef PPG_DIRECT_PROFILE   // diagnostic build: per-wavefront phase cycles of launch number PPG_DIRECT_PROFILE_RUN (default 300) -> $PPG_DIRECT_PROFILE_FILE.fused
     static int dp_runs = 0;
     static unsigned long long *dp_buf = nullptr;
     const char *dp_path = getenv("PPG_DIRECT_PROFILE_FILE");
     const int dp_at = getenv("PPG_DIRECT_PROFILE_RUN") ? atoi(getenv("PPG_DIRECT_PROFILE_RUN")) : 300;
-    const size_t dp_bytes = (size_t)prey->grid * 8 * 16 * 8;
+    const size_t dp_bytes = (size_t)prey->grid * 16 * 16 * 8;   // (sixteen wavefronts per workgroup in the four-role kernels)
     if (dp_path && !dp_buf) {
         PPG_POL_TRY(prey, hipMalloc((void **)&dp_buf, dp_bytes));
         PPG_POL_TRY(prey, hipMemset(dp_buf, 0, dp_bytes));
@@ -1930,7 +1947,7 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
     rc = ppg_pipe_debug_arm(prey);
     if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
 #endif
-    hipLaunchKernelGGL(f, dim3((unsigned)prey->grid), dim3(512), (size_t)lds, (hipStream_t)stream, K2);
+    hipLaunchKernelGGL(f, dim3((unsigned)prey->grid), dim3(pipe4 ? 1024 : 512), (size_t)lds, (hipStream_t)stream, K2);
     PPG_POL_TRY(prey, hipGetLastError());
 #ifdef PPG_PIPE_DEBUG
     rc = ppg_pipe_debug_check(prey);
@@ -1942,7 +1959,7 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
         std::vector<unsigned long long> host(dp_bytes / 8);
         PPG_POL_TRY(prey, hipMemcpy(host.data(), dp_buf, dp_bytes, hipMemcpyDeviceToHost));
         char name[512];
-        snprintf(name, sizeof name, "%s.fused", dp_path);
+        snprintf(name, sizeof name, "%s.%s", dp_path, pipe4 ? "fused4" : "fused");
         if (FILE *fo = fopen(name, "wb")) { fwrite(host.data(), 8, host.size(), fo); fclose(fo); }
     }
 #endif

@@ -179,7 +179,8 @@ __device__ __forceinline__ u32x2_t relu_pack4(const f32x4_t &a) {
     return w;
 }
 // One sub-group's conv1: X (input blocks at element offset xo) -> Y.  CB1 = 2: a second input block (the ninth channel's taps).
-template <int CB1, class KP>
+// LOOP: tile after tile (12 registers of operands; the four-role kernels' 128-register budget) instead of the straight line below.
+template <int CB1, bool LOOP = (PPG_PIPE_CONV1X_LOOP != 0), class KP>
 __device__ __forceinline__ void conv1x(const KP &K, const Conv1X &W, __bf16 *img, int xo, int ns, int bw, int lane, int dummy) {
     const int kq = lane >> 4;
     const int blk = K.Wp2 * 8;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void conv1x(const KP &K, const Conv1X &W, __bf16 *img
     // the position's own cell of block 1 (CB1 = 1: any cell of block 0 -- its weights are zero)
     const int koff = kq < 3 ? (kq - 1) * 8 : (CB1 > 1 ? blk : 0);
     const int yoff = (kq >> 1) * blk + (kq & 1) * 4;    // where this lane's four output channels go inside the position's Y cells
-#if PPG_PIPE_CONV1X_LOOP
+    if constexpr (LOOP) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (ns <= 0) break;
@@ -203,7 +204,7 @@ __device__ __forceinline__ void conv1x(const KP &K, const Conv1X &W, __bf16 *img
         *(u32x2_t *)(img + at) = relu_pack4(acc);
     }
     return;
-#endif
+    }
     // The wavefront's four tiles as ONE straight line: twelve fragment reads in front, then the four tiles' MFMA chains interleaved (a
     // tile's three MFMAs depend on each other through the accumulator: tile by tile the chain ran at the matrix pipe's LATENCY, 290
     // cycles per tile for 48 cycles of issue), then the four epilogues.  Tiles behind the sub-group's last position compute position 0
@@ -289,11 +290,12 @@ __device__ __forceinline__ void conv2_pair(const KP &K, const ConvW<2, 1> &W, __
 // The fused launch's plan, computed by every workgroup for itself (no plan launch, no trip through memory): exclusive prefix sums of the
 // envs' predator / prey row counts (env words 0, 1: one 8-byte load per env) over the concatenated envs of all handles, in LDS:
 // scratch = [512 threads][2] partial sums | pre_pred[n_envs] | pre_prey[n_envs].  512 threads; ends with a workgroup barrier.
-constexpr int FUSED_PART_WORDS = 1024, FUSED_MAX_ENVS = 8192, FUSED_RUN = FUSED_MAX_ENVS / 512;
-template <class KP>
+constexpr int FUSED_PART_WORDS = 1024, FUSED_MAX_ENVS = 8192;
+template <int NT, class KP>   // NT threads (512: the two-role kernels, 1024: ppg_policy_pipe4.h)
 __device__ __forceinline__ void fused_prefix_sums(const KP &K, uint32_t *scratch, int tid, uint32_t &tot_pred, uint32_t &tot_prey) {
     static_assert(PPG_ENV_N_PRED_ROWS == 0 && PPG_ENV_N_PREY_ROWS == 1, "the two row counts are one 8-byte load");
-    const int per = (K.n_envs + 511) / 512;
+    constexpr int FUSED_RUN = FUSED_MAX_ENVS / NT, NWAVES = NT / 64;
+    const int per = (K.n_envs + NT - 1) / NT;
     const int lo = tid * per < K.n_envs ? tid * per : K.n_envs, hi = (lo + per) < K.n_envs ? (lo + per) : K.n_envs;
     auto count_of = [&](int e) -> u32x2_t {
         const int32_t *base;
@@ -317,12 +319,12 @@ __device__ __forceinline__ void fused_prefix_sums(const KP &K, uint32_t *scratch
         const uint32_t vp = (uint32_t)__shfl_up((int)ip, d, 64), vq = (uint32_t)__shfl_up((int)iq, d, 64);
         if (lane >= d) { ip += vp; iq += vq; }
     }
-    u32x2_t *part = (u32x2_t *)scratch;   // [8] wavefront totals
+    u32x2_t *part = (u32x2_t *)scratch;   // [NWAVES] wavefront totals
     if (lane == 63) { const u32x2_t t = {ip, iq}; part[wave] = t; }
     __syncthreads();
     uint32_t bp = ip - sp, bq = iq - sq, allp = 0, allq = 0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < NWAVES; ++w) {
         const u32x2_t t = part[w];
         if (w < wave) { bp += t[0]; bq += t[1]; }
         allp += t[0]; allq += t[1];
@@ -773,16 +775,10 @@ struct PolParams2 {
 };
 typedef const __attribute__((address_space(4))) PolParams2 *K2Ptr;
 
-template <int OBS, int NCHQ, int NCHP>
-__device__ __forceinline__ void fused_main(K2Ptr K2, unsigned char *lds) {
-    const int tid = (int)threadIdx.x;
-    uint32_t *scratch = (uint32_t *)(lds + K2->scratch_off);
-    uint32_t n_pred, n_prey;
-    fused_prefix_sums(K2->q, scratch, tid, n_pred, n_prey);
-    const int G = (int)gridDim.x;
-    const int sgq = ((int)n_prey + K2->q.ST - 1) / K2->q.ST, sgp = ((int)n_pred + K2->p.ST - 1) / K2->p.ST;   // sub-groups of either species
-    if (sgq == 0 && sgp == 0) return;
-    int n_q;
+// How many of the launch's G workgroups serve the prey (the others: the predators), from the species' sub-group counts.  false: no
+// observation row anywhere.
+__device__ __forceinline__ bool fused_split(K2Ptr K2, int G, int sgq, int sgp, int &n_q) {
+    if (sgq == 0 && sgp == 0) return false;
     if (sgp == 0) n_q = G;
     else if (sgq == 0) n_q = 0;
     else if (G < 2) n_q = G;   // (one workgroup: the prey only -- never the case on a GPU)
@@ -803,21 +799,36 @@ __device__ __forceinline__ void fused_main(K2Ptr K2, unsigned char *lds) {
         n_q = best;
     }
     n_q = __builtin_amdgcn_readfirstlane(n_q);
-    const int wg = (int)blockIdx.x;
-    {   // A share longer than the workgroup's sample table comes as several tiles, and the first tile's images overwrite the prefix sums
-        // in LDS: such a workgroup puts them into memory first (K2->pre_g: every workgroup would write the SAME words there; it reads back
-        // its own stores) and bisects there for its later tiles -- twelve dependent L2 reads per sample instead of LDS reads.
-        const bool is_q = wg < n_q;
-        const int st = is_q ? K2->q.ST : K2->p.ST, rt = is_q ? K2->q.range_tile : K2->p.range_tile, n_w = is_q ? n_q : G - n_q;
-        const int sg = is_q ? sgq : sgp;
-        const int share = __builtin_amdgcn_readfirstlane(st * ((sg + n_w - 1) / n_w));
-        if (share > rt) {
-            const uint32_t *src = scratch + FUSED_PART_WORDS;
-            for (int i = tid; i < 2 * K2->q.n_envs; i += 512) K2->pre_g[i] = src[i];
-            __threadfence();
-            __syncthreads();
-        }
+    return true;
+}
+// A share longer than the workgroup's sample table comes as several tiles, and the first tile's images overwrite the prefix sums in LDS:
+// such a workgroup puts them into memory first (K2->pre_g: every workgroup would write the SAME words there; it reads back its own
+// stores) and bisects there for its later tiles -- twelve dependent L2 reads per sample instead of LDS reads.
+__device__ __forceinline__ void fused_long_share(K2Ptr K2, const uint32_t *scratch, int tid, int n_threads, int wg, int n_q, int G, int sgq, int sgp) {
+    const bool is_q = wg < n_q;
+    const int st = is_q ? K2->q.ST : K2->p.ST, rt = is_q ? K2->q.range_tile : K2->p.range_tile, n_w = is_q ? n_q : G - n_q;
+    const int sg = is_q ? sgq : sgp;
+    const int share = __builtin_amdgcn_readfirstlane(st * ((sg + n_w - 1) / n_w));
+    if (share > rt) {
+        const uint32_t *src = scratch + FUSED_PART_WORDS;
+        for (int i = tid; i < 2 * K2->q.n_envs; i += n_threads) K2->pre_g[i] = src[i];
+        __threadfence();
+        __syncthreads();
     }
+}
+
+template <int OBS, int NCHQ, int NCHP>
+__device__ __forceinline__ void fused_main(K2Ptr K2, unsigned char *lds) {
+    const int tid = (int)threadIdx.x;
+    uint32_t *scratch = (uint32_t *)(lds + K2->scratch_off);
+    uint32_t n_pred, n_prey;
+    fused_prefix_sums<512>(K2->q, scratch, tid, n_pred, n_prey);
+    const int G = (int)gridDim.x;
+    const int sgq = ((int)n_prey + K2->q.ST - 1) / K2->q.ST, sgp = ((int)n_pred + K2->p.ST - 1) / K2->p.ST;   // sub-groups of either species
+    int n_q;
+    if (!fused_split(K2, G, sgq, sgp, n_q)) return;
+    const int wg = (int)blockIdx.x;
+    fused_long_share(K2, scratch, tid, 512, wg, n_q, G, sgq, sgp);
     // (each species' parameter block through an address the optimiser cannot see through: known to be kernel arguments, the scalar loads
     //  of BOTH blocks' fields are hoisted into this function's entry and kept -- 228 spilled scalar registers, their reloads in the
     //  head's and the convolutions' loops)

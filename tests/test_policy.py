@@ -505,6 +505,41 @@ def test_one_fused_launch_gives_what_the_separate_launches_give(batch, steps, dt
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch,steps,dt", [(4096, 150, torch.bfloat16), (700, 60, torch.float64), (700, 60, torch.float32),
+                                            (6500, 500, torch.bfloat16), (3, 30, torch.bfloat16), (1, 5, torch.bfloat16)])
+def test_four_role_pipeline_gives_what_the_two_role_pipeline_gives(batch, steps, dt, monkeypatch):
+    """The four-role kernels (ppg_policy_pipe4.h: sixteen wavefronts per workgroup, conv3 split by output channel halves, the head and
+    the row fetch on wavefronts of their own) run every output's instructions in the two-role kernels' order: identical logits, greedy
+    AND sampled actions (PPG_POLICY_PIPE4=0 selects the two-role fused launch) -- the benchmark's size, float64 / float32 rows, shares of
+    several tiles, fewer rows than workgroups, one env."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy
+    if b"ppg_policy_pipe4_16_8_bf16" not in open(_abi.LIB_PATH, "rb").read():
+        pytest.skip("the four-role kernels are an experiment build (-DPPG_WITH_PIPE4): measured 18 % slower, profiles/r05/i_*")
+    nets = make_nets(seed=54)
+    env = BatchedPredPreyGrass(dict(config_env), batch_size=batch, device="cuda:0", obs_dtype=dt, seed=16)
+    env.reset()
+    for _ in range(steps):
+        env.step(random_actions=True, auto_reset=True)
+    fused = FusedPolicy(nets[0], nets[1])
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PPG_POLICY_PIPE4", mode)
+        env.actions.fill_(_abi.ACTION_NONE)
+        lg = fused.act(env, want_logits=True)
+        greedy = env.actions.clone()
+        fused.act(env, sample=True, seed=79)
+        torch.cuda.synchronize()
+        out.append((lg[0].clone(), lg[1].clone(), greedy, env.actions.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert bool(out[0][1].abs().sum() > 0) and (batch < 10 or not torch.equal(out[0][2], out[0][3]))
+    env.step(env.actions, auto_reset=True)
+    torch.cuda.synchronize()
+    assert (env.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()
+
+
+@pytest.mark.gpu
 def test_fused_launch_over_several_sub_batches_and_an_extinct_species(monkeypatch):
     """The fused launch over three handles (the envs of a GPU as sub-batches), and with one species extinct everywhere (every
     workgroup then serves the other one)."""
