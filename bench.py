@@ -41,7 +41,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r04", "bench_driver_summary.json")
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r05", "bench_driver_summary.json")
 
 
 def device_state():
@@ -277,6 +277,9 @@ def parse_args(argv):
                          "(SURVEY 8(f) N4; no observation leaves the GPU, roofline = bf16 MFMA); dict_api: the drop-in classes an existing "
                          "script imports -- PredPreyGrass(config).step(action_dict) for one env and VectorPredPreyGrass(64) -- driven from "
                          "the host like the reference's random_policy.py, every call crossing PCIe both ways (calls/s; latency-bound)")
+    ap.add_argument("--policy-graph", action="store_true",
+                    help="policy_rollout: the step (policy launch + ppg_step + the key's increment) captured once into a HIP graph and "
+                         "replayed (predpreygrass_amd.policy.GraphedPolicyStep); the event leg stays un-graphed")
     ap.add_argument("--policy-open-loop", action="store_true",
                     help="policy_rollout, timing experiments only: the policy's actions go to a scratch tensor and the envs are stepped with "
                          "device-side random actions -- the population then does not depend on what the (possibly ablated) kernels compute")
@@ -491,6 +494,11 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
     preroll = min(args.preroll_min, 512) if args.preroll_max > 0 else 0    # (a forward pass costs ~10x a step: shorter pre-roll)
     for _ in range(preroll + args.warmup):
         one_step()
+    graphed = None
+    if args.policy_graph and not args.policy_open_loop:
+        from predpreygrass_amd.policy import GraphedPolicyStep
+        graphed = GraphedPolicyStep(fused, env, seed=args.seed * 1000003 + t_step[0])
+        graphed.replay(args.warmup)
     torch.cuda.synchronize(device)
     env.env_state[:, _abi.ENV_OBS_PRED:_abi.ENV_OBS_PREY + 1] = 0
     torch.cuda.synchronize(device)
@@ -499,8 +507,11 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
     # the timed region: exactly --steps steps, NO events inside (an event record between two kernels of a stream costs ~5 us of idle
     # GPU on each side of the policy call: rocprofv3 timestamps, profiles/r04/v_policy_rollout_step_timeline.txt)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step()
+    if graphed is not None:
+        graphed.replay(args.steps)
+    else:
+        for k in range(args.steps):
+            one_step()
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
@@ -538,18 +549,24 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
                              "in place, actions sampled on the device, then ppg_step with those actions and auto-reset"),
                 "envs_per_gpu": B, "parallelism": f"batch-sharded x{n_gpus}, no data-path collective", "preroll_steps": preroll,
                 "mean_agents_per_env": round((n_pred + n_prey) / (B * args.steps), 2),
+                **({"hip_graph": "the timed region replays ONE captured step (policy launch, ppg_step, key increment): GraphedPolicyStep"} if graphed is not None else {}),
                 **({"open_loop": "TIMING EXPERIMENT: the envs were stepped with random actions, the policy's actions discarded"} if args.policy_open_loop else {}),
                 "bytes_per_agent_a_consumer_has_to_move": 1,
             },
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": {"rllib": "ppg_policy_pipe{8,16}_", "depth": "ppg_policy_pipe8_ (predators) + ppg_policy_deep16_ (prey) "}.get(args.policy_arch, "ppg_policy_forward_") + args.obs_dtype,
+                         "kernel": {"rllib": "ppg_policy_pipe2_16_8_" if os.environ.get("PPG_POLICY_FUSED", "1") != "0" else "ppg_policy_pipe{8,16}_", "depth": "ppg_policy_pipe8_ (predators) + ppg_policy_deep16_ (prey) "}.get(args.policy_arch, "ppg_policy_forward_") + args.obs_dtype,
                          "policy_arch": args.policy_arch,
                          "macs_per_observation": [fused.macs_per_observation(0), fused.macs_per_observation(1)],
                          "kernel_ms": round(pol_ms / args.steps, 5),
+                         "kernel_ms_leg": f"a SECOND leg of {ev_steps} steps with HIP events around every policy call (an event record between two "
+                                          "kernels costs ~5 us of idle GPU, so the timed region has none): kernel_ms, achieved and frac come "
+                                          "from it and its own observation counts; value and ms_per_step from the event-free timed region",
                          "flops_per_step": int(flops / args.steps),
+                         "flops_per_step_event_leg": int(ev_flops / ev_steps),
                          "note": "flops = 2 x multiply-accumulates of the network's layers (no padding counted) x observations evaluated; "
-                                 "kernel_ms = both species' forward launches + their plan launches per step (HIP events on the stream)"},
+                                 "kernel_ms = the policy's launch(es) per step: ONE fused launch for both species (ppg_policy_pipe2_*; "
+                                 "PPG_POLICY_FUSED=0: a plan launch + one forward launch per species)"},
         }
         out.update(per_rank_summary(per_rank, n_gpus, B))
         if not args.no_cpu_baseline and n_gpus == 1:
@@ -975,7 +992,7 @@ def main(argv=None, backend=None):
             scale = (run_bytes / args.steps / n_sub) / prof["counted_bytes_per_launch"]
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"] * scale)
             traffic_origin = "profiles_fallback"
-            traffic_src = (f"profiles/r04/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+            traffic_src = (f"profiles/r05/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            f"{prof['hbm_traffic_per_launch_bytes']['total_corrected']} B per launch at "
                            f"{prof['mean_agents_per_env']} agents/env, scaled x{scale:.4f} by this run's counted bytes")
     except Exception:

@@ -492,6 +492,9 @@ typedef struct ppg_policy ppg_policy;
 
 #define PPG_POLICY_ARGMAX 0x0u  /* action = argmax of the logits (first maximum) */
 #define PPG_POLICY_SAMPLE 0x1u  /* action ~ softmax(logits): Gumbel-max with Philox4x32-10 keyed by (seed, env, row) */
+#define PPG_POLICY_SEED_ON_DEVICE 0x2u /* `seed` is the address of a uint64 in DEVICE memory that the kernel reads when it runs: a step
+                                        * captured into a hipGraph (policy + ppg_step + an increment of that word) can then be replayed
+                                        * with a fresh key every time.  Pipeline networks (the reference's) with both policies given. */
 
 /* How the convolution output [channel][position] is flattened into the first Linear layer's input:
  *   PPG_POLICY_FLATTEN_NCHW  torch.flatten of a channel-first tensor: feature = channel * P + position

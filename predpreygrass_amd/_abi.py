@@ -147,7 +147,7 @@ class PpgPolicySpec(C.Structure):
                 ("fc_w", C.c_void_p * POLICY_MAX_FC), ("fc_b", C.c_void_p * POLICY_MAX_FC)]
 
 
-POLICY_ARGMAX, POLICY_SAMPLE = 0x0, 0x1
+POLICY_ARGMAX, POLICY_SAMPLE, POLICY_SEED_ON_DEVICE = 0x0, 0x1, 0x2
 POLICY_LAYOUT_CHW, POLICY_LAYOUT_HWC = 0, 1
 POLICY_FLATTEN_NCHW, POLICY_FLATTEN_NHWC = 0, 1
 POLICY_SYMBOLS = ["ppg_policy_create", "ppg_policy_create_layout", "ppg_policy_create_spec", "ppg_policy_destroy", "ppg_policy_act",

@@ -66,6 +66,7 @@ struct PolParams {
     int32_t debug_skip;           // ablation builds only (-DPPG_EXPERIMENTS + env PPG_POLICY_SKIP; always 0 in the product): 1 no convolutions,
                                   // 2 no FC1, 4 no observation staging, 8 no conv3, 16 no conv1/conv2, 32 no conv3 stores
     uint32_t seed_lo, seed_hi;
+    const uint64_t *seed_dev;     // PPG_POLICY_SEED_ON_DEVICE: the key is read from here by the kernel (seed_lo / seed_hi unused)
     // weights in fragment order (device, bf16) and biases (float)
     const bf16x8 *wc1, *wc2, *wc3, *w1, *w2, *w3;
     const float *bc1, *bc2, *bc3, *b1, *b2, *b3;
@@ -1715,6 +1716,7 @@ static int ppg_policy_fill(ppg_policy *p, int species, ppg_handle *const *handle
     memset(&L, 0, sizeof L);
     K.species = species; K.obs_f32 = h0->base.obs_f32; K.sample = (flags & PPG_POLICY_SAMPLE) ? 1 : 0;
     K.seed_lo = (uint32_t)seed ^ (species ? 0x9E3779B9u : 0u); K.seed_hi = (uint32_t)(seed >> 32);
+    K.seed_dev = (flags & PPG_POLICY_SEED_ON_DEVICE) ? (const uint64_t *)(uintptr_t)seed : nullptr;
     K.S = h0->base.S; K.cap = species ? h0->base.cap_prey : h0->base.cap_pred; K.slot0 = species ? h0->base.cap_pred : 0;
     K.n_handles = n; L.n_handles = n;
     L.word = species ? PPG_ENV_N_PREY_ROWS : PPG_ENV_N_PRED_ROWS;
@@ -1971,11 +1973,13 @@ int ppg_policy_act(ppg_policy *pred, ppg_policy *prey, ppg_handle *const *handle
     ppg_policy *any = pred ? pred : prey;
     if (!any) return PPG_EINVAL;
     if (!handles || !actions || n < 1 || n > ppgpol::MAX_HANDLES || !handles[0]) return ppg_policy_fail(any, PPG_EINVAL, "bad handle list");
-    if (flags & ~PPG_POLICY_SAMPLE) return ppg_policy_fail(any, PPG_EINVAL, "unknown policy flags 0x%x", flags);
+    if (flags & ~(PPG_POLICY_SAMPLE | PPG_POLICY_SEED_ON_DEVICE)) return ppg_policy_fail(any, PPG_EINVAL, "unknown policy flags 0x%x", flags);
     if (pred && prey && pred->pipe && prey->pipe && pred->device == prey->device && pred->grid == prey->grid && ppg_fused_enabled()) {
         const int rc = ppg_policy_run_fused(pred, prey, handles, n, actions, flags, seed, logits_pred, logits_prey, stream);
         if (rc != 1) return rc;
     }
+    if (flags & PPG_POLICY_SEED_ON_DEVICE)
+        return ppg_policy_fail(any, PPG_EINVAL, "PPG_POLICY_SEED_ON_DEVICE is for the one-launch form: both species' pipeline policies on one device");
     // (a failure is also reported through ppg_policy_last_error(NULL), whichever of the two policies it came from)
     // The predators are few (a third of the chip's workgroup slots at 4096 envs): their launch goes to a side stream that is
     // forked from and joined back into `stream` with events, so that it fills the CUs the prey launch leaves idle.

@@ -442,6 +442,13 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         ConvW<4, 2> w3c;
         w3c.load(K, K.wc3, lane, 0);
         const float bias_r = (a16 < K.n_actions) ? K.bh[a16] : 0.0f;
+        // the Philox key: the launch's argument, or (PPG_POLICY_SEED_ON_DEVICE: a step replayed from a hipGraph) a word in memory
+        uint32_t seed_lo = K.seed_lo, seed_hi = K.seed_hi;
+        if (K.seed_dev) {
+            const uint64_t sd = *K.seed_dev;
+            seed_lo = (uint32_t)sd ^ (K.species ? 0x9E3779B9u : 0u);
+            seed_hi = (uint32_t)(sd >> 32);
+        }
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w3c.landed();
         int cells[6];   // this wavefront's two position tiles are the same positions in every sub-group: their LDS offsets once per launch
@@ -528,7 +535,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                         const int sm = s0 + (lane >> 4);
                         const unsigned long long er = tab[2 * (g * K.ST + (sm < ns ? sm : 0)) + 1];
                         uint32_t rnd[4];
-                        philox((uint32_t)er, (uint32_t)K.slot0 + (uint32_t)(er >> 32), (uint32_t)(a16 >> 2), 0x504F4C31u, K.seed_lo, K.seed_hi, rnd);
+                        philox((uint32_t)er, (uint32_t)K.slot0 + (uint32_t)(er >> 32), (uint32_t)(a16 >> 2), 0x504F4C31u, seed_lo, seed_hi, rnd);
                         const uint32_t r = (a16 & 3) == 0 ? rnd[0] : (a16 & 3) == 1 ? rnd[1] : (a16 & 3) == 2 ? rnd[2] : rnd[3];
                         const float u = (float)(r >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // 23 bits: 2^-24 <= u < 1, exactly
                         noise[(g & 1) * 256 + sm * 16 + a16] = -__logf(-__logf(u));

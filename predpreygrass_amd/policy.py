@@ -251,7 +251,9 @@ class FusedPolicy:
         """Actions for every row in use of `envs` (a BatchedPredPreyGrass or a list of sub-batches of one GPU), written into
         each env's `.actions` tensor (or the given list of int8 [B_k, S] tensors).  Stream-ordered like a step: launch it on
         a stream that is ordered behind the envs' last step.  want_logits: also return (logits_pred, logits_prey) float32
-        [rows in use, n_actions] in env-major row order -- sized for the row capacity, the caller slices by the counts."""
+        [rows in use, n_actions] in env-major row order -- sized for the row capacity, the caller slices by the counts.
+        seed: an int, or a one-element int64 tensor on the device -- the kernel then reads the Philox key from it when it RUNS
+        (`PPG_POLICY_SEED_ON_DEVICE`): what a step captured into a HIP graph needs (`GraphedPolicyStep`)."""
         envs = list(envs) if isinstance(envs, (list, tuple)) else [envs]
         acts = [e.actions for e in envs] if actions is None else list(actions)
         for e, a in zip(envs, acts):
@@ -273,8 +275,14 @@ class FusedPolicy:
                         lg[t] = torch.zeros((cap, net.n_actions), dtype=torch.float32, device=self.device)
             if stream is not None and not isinstance(stream, torch.cuda.Stream):
                 on.synchronize()
+        flags = _abi.POLICY_SAMPLE if sample else _abi.POLICY_ARGMAX
+        if isinstance(seed, torch.Tensor):
+            if seed.dtype != torch.int64 or seed.numel() != 1 or seed.device != self.device:
+                raise ValueError("a device-resident seed is a one-element int64 tensor on the policy's device")
+            flags |= _abi.POLICY_SEED_ON_DEVICE
+            seed = seed.data_ptr()
         rc = self._lib.ppg_policy_act(self._handles[0], self._handles[1], handles, n, aptr,
-                                      _abi.POLICY_SAMPLE if sample else _abi.POLICY_ARGMAX, int(seed) & (2 ** 64 - 1),
+                                      flags, int(seed) & (2 ** 64 - 1),
                                       C.c_void_p(lg[0].data_ptr()) if lg[0] is not None else None,
                                       C.c_void_p(lg[1].data_ptr()) if lg[1] is not None else None, envs[0]._stream(stream))
         if rc != 0:
@@ -295,3 +303,40 @@ class FusedPolicy:
             self.close()
         except Exception:
             pass
+
+
+class GraphedPolicyStep:
+    """One closed-loop step -- the policy on every observation row, `ppg_step` with its actions, auto-reset -- captured ONCE into a HIP
+    graph and replayed: two kernel launches and an increment of the Philox key per replay, no launch arguments built on the host, no
+    gaps between the kernels.  (`tune_ppo_base_environment.py:106-141` + `BASE:219-473` as one device-side loop body.)
+
+        loop = GraphedPolicyStep(fused, env, seed=0); loop.replay(1000)
+
+    The key of step t is seed + t, kept in a device word the captured increment advances; results equal `fused.act(env, sample=True,
+    seed=seed + t); env.step(env.actions, auto_reset=True)` step by step (tests/test_policy.py)."""
+
+    def __init__(self, fused: "FusedPolicy", env, seed: int = 0, sample: bool = True, auto_reset: bool = True):
+        self.fused, self.env = fused, env
+        dev = env.device
+        self.seed = torch.full((1,), int(seed), dtype=torch.int64, device=dev)
+        self._one = torch.ones((1,), dtype=torch.int64, device=dev)
+
+        def body():
+            fused.act(env, sample=sample, seed=self.seed)
+            env.step(env.actions, auto_reset=auto_reset)
+            self.seed.add_(self._one)
+        # (one uncaptured pass on a side stream first: lazy allocations and attribute calls of the library must not fall into the capture)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            body()
+
+    def replay(self, n: int = 1):
+        for _ in range(n):
+            self.graph.replay()
+        return self

@@ -896,3 +896,34 @@ def test_slot_table_spreads_every_tile_over_all_bank_groups(layout, C, R):
                 assert len({v % 8 for v in cells}) == len(cells)
     else:                                               # the plain order
         assert np.array_equal(used, np.array([(s << 8 | p) for s in range(st) for p in range(P)], dtype=np.uint16))
+
+
+@pytest.mark.gpu
+def test_a_step_replayed_from_a_hip_graph_equals_the_launches_it_was_captured_from():
+    """GraphedPolicyStep: policy launch + ppg_step + the Philox key's increment captured once, replayed 40 times -- the envs end up in
+    exactly the state 40 explicit (act, step) pairs with keys seed, seed + 1, ... leave them in (row tables and observations bit for
+    bit); the key word has advanced by one per replay."""
+    from predpreygrass_amd.batched import BatchedPredPreyGrass
+    from predpreygrass_amd.policy import FusedPolicy, GraphedPolicyStep
+    nets = make_nets(seed=61)
+    fused = FusedPolicy(nets[0], nets[1])
+    envs = [BatchedPredPreyGrass(dict(config_env), batch_size=600, device="cuda:0", obs_dtype=torch.bfloat16, seed=21) for _ in range(2)]
+    for e in envs:
+        e.reset()
+        for _ in range(30):
+            e.step(random_actions=True, auto_reset=True)
+    torch.cuda.synchronize()
+    a, b = envs
+    for name in ("row_xy", "row_energy", "env_state"):
+        assert torch.equal(getattr(a, name), getattr(b, name))
+    n = 40
+    loop = GraphedPolicyStep(fused, a, seed=1000)        # (its warm-up pass is step 0 with key 1000, the capture pass is not executed)
+    loop.replay(n - 1)
+    for t in range(n):
+        fused.act(b, sample=True, seed=1000 + t)
+        b.step(b.actions, auto_reset=True)
+    torch.cuda.synchronize()
+    assert int(loop.seed.item()) == 1000 + n
+    for name in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "row_cumrew", "env_state", "grass_energy", "obs_pred", "obs_prey", "actions"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert (a.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all() and (a.env_state[:, _abi.ENV_CALLS] == 30 + n).all()

@@ -25,7 +25,7 @@ done
 python3 bench.py --envs 256 --steps 2000 --warmup 100 --no-cpu-baseline --sustained-steps 0 > gpurun_out/${tag}_bench_c2_256envs.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --workload dict_api > gpurun_out/${tag}_bench_dict_api.json 2>> gpurun_out/${tag}_bench.err
 PPG_POLICY_FUSED=0 python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_policy_rollout_separate_launches.json 2>> gpurun_out/${tag}_bench.err
-PPG_HIP_LIB=$GRAFT_REPO_ROOT/tools/_build/libppg_hip_c1loop.so python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_policy_rollout_conv1x_loop.json 2>> gpurun_out/${tag}_bench.err
+PPG_POLICY_SLOTS=0 python3 bench.py --workload policy_rollout --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${tag}_bench_policy_rollout_plain_slot_order.json 2>> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_ptrace -o t -- python3 bench.py --workload policy_rollout --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_policy_under_trace.json 2> gpurun_out/${tag}_ptrace.err
 find gpurun_out/${tag}_ptrace -name '*kernel_stats.csv' -exec cp {} gpurun_out/${tag}_kernel_stats_policy.csv \;
 rm -rf gpurun_out/${tag}_ptrace
@@ -69,3 +69,5 @@ PY
 done
 tail -c 900 gpurun_out/${tag}_summary.log
 cat gpurun_out/${tag}_ab_plans.txt gpurun_out/${tag}_bare_pattern.txt
+PPG_DIRECT_PROFILE_RUN=300 bash tools/gpu_pipe_profile.sh ${tag} > /dev/null 2>&1
+cat gpurun_out/${tag}_pipe_profile.txt | grep "==\|per iteration"
