@@ -426,6 +426,29 @@ struct Env {
             return (wall_at(x + ddx, y) || wall_at(x, y + ddy)) ? (uint32_t)MV_CORNER_CUT : (uint32_t)MV_NONE;
         return los_clear(x, y, tx, ty) ? (uint32_t)MV_NONE : (uint32_t)MV_LOS;
     }
+    // The same for moves of at most two cells per axis (action ranges 3 and 5, all the reference configures), without a loop:
+    // a one-cell diagonal looks at the two cells beside the corner (WO:474-480); a two-cell move has exactly ONE cell strictly
+    // between its ends -- bresenham's minor axis steps with the first major step only when both displacements are 2 -- and
+    // the three bits are read side by side.
+    PPG_MEMBER uint32_t wall_verdict_near(int x, int y, int tx, int ty) const {
+        const int ddx = tx - x, ddy = ty - y;
+        const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
+        const int sx = (ddx > 0) - (ddx < 0), sy = (ddy > 0) - (ddy < 0);
+        const bool diag1 = adx == 1 && ady == 1, far = adx == 2 || ady == 2;
+        int ax = tx, ay = ty, bx = tx, by = ty;
+        if (diag1) { ax = tx; ay = y; bx = x; by = ty; }
+        if (far) {
+            ax = adx >= ady ? x + sx : x;
+            ay = adx >= ady ? (ady == 2 ? y + sy : y) : y + sy;
+            bx = ax; by = ay;
+        }
+        const bool wt = wall_at(tx, ty), wa = wall_at(ax, ay), wb = wall_at(bx, by);
+        if (wt) return MV_WALL;
+        if (!C.los_move || (adx | ady) == 0) return MV_NONE;
+        if (diag1) return (wa || wb) ? (uint32_t)MV_CORNER_CUT : (uint32_t)MV_NONE;
+        if (far) return wa ? (uint32_t)MV_LOS : (uint32_t)MV_NONE;
+        return MV_NONE;
+    }
     PPG_MEMBER void set_move_info(int r, uint32_t code) { keep[r] = (keep[r] & ~7u) | code; }
 
     // alive rows of `type` standing on s_xy, per register
@@ -826,24 +849,42 @@ struct Env {
     }
 
     // ---- step 2: movement in action order (BASE:259-276, _get_move BASE:495-509) ------
-    // One agent: row (r,k); r may be a run-time register index (explicit-order path) -- with a
-    // compile-time r every (q == r) below folds away.
-    PPG_MEMBER void move_agent(int r, int k, uint64_t (&pos)[T]) {
-        const int type = type_of(r);
+    // What an acting row wants, computed for all rows at once before anybody moves (nothing another agent does changes it:
+    // _get_move reads the agent's own position and action only, BASE:495-505): bits 0-15 the clipped target cell, bits 16-20 the
+    // squared displacement (second generation: the move's energy cost, RQ:301-313), bits 24-26 what the walls say (WO:466-488).
+    // A target the walls refuse as a WALL cell is the agent's own cell (WO:469-471).
+    PPG_MEMBER uint32_t move_wish(int r, bool acts) const {
         const int G1 = P.G - 1;
-        const uint32_t s_xy = xy_at(r, k);
-        const int a = act_at(r, k);
-        int dx, dy;
-        move_vector(a, GEN2 && ((id_at(r, k) >> 16) & 1u), dx, dy);
-        int tx = (int)(s_xy >> 8) + dx, ty = (int)(s_xy & 255u) + dy;
+        int dx = 0, dy = 0;
+        if (act[r] >= 0) move_vector(act[r], GEN2 && ((id[r] >> 16) & 1), dx, dy);
+        const int x = (int)(xy[r] >> 8), y = (int)(xy[r] & 255u);
+        int tx = x + dx, ty = y + dy;
         tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);  // np.clip, BASE:505
         ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
         uint32_t verdict = MV_NONE;
-        if (WALLS) {  // WO:469-471: a wall cell is never entered -- the agent stays where it is
-            verdict = wall_verdict((int)(s_xy >> 8), (int)(s_xy & 255u), tx, ty);
-            if (verdict == MV_WALL) { tx = (int)(s_xy >> 8); ty = (int)(s_xy & 255u); }
+        if (WALLS && acts) {
+            verdict = (C.ar[0] <= 5 && C.ar[1] <= 5) ? wall_verdict_near(x, y, tx, ty) : wall_verdict(x, y, tx, ty);
+            if (verdict == MV_WALL) { tx = x; ty = y; }
         }
-        const uint32_t t_xy = ((uint32_t)tx << 8) | (uint32_t)ty;
+        const int ddx = tx - x, ddy = ty - y;
+        return ((uint32_t)tx << 8) | (uint32_t)ty | ((uint32_t)(ddx * ddx + ddy * ddy) << 16) | (verdict << 24);
+    }
+    PPG_MEMBER uint32_t wish_at(const uint32_t (&wish)[T], int r, int k) const {
+        uint32_t v = wv::readlane(wish[0], k);
+#pragma unroll
+        for (int q = 1; q < T; ++q) { const uint32_t vq = wv::readlane(wish[q], k); v = (q == r) ? vq : v; }
+        return v;
+    }
+
+    // One agent at its turn: row (r,k); r may be a run-time register index (explicit-order path) -- with a
+    // compile-time r every (q == r) below folds away.  moved[]: rows that changed cell (their move cost is charged by the caller,
+    // lane-parallel); sp[]: rows whose energy after that cost still shows as positive on the grid.
+    PPG_MEMBER void move_agent(int r, int k, uint64_t (&pos)[T], const uint32_t (&wish)[T], uint64_t (&moved)[T], const uint64_t (&sp)[T], bool costly) {
+        const int type = type_of(r);
+        const uint32_t s_xy = xy_at(r, k);
+        const uint32_t w = wish_at(wish, r, k);
+        const uint32_t t_xy = w & 0xFFFFu;
+        const uint32_t verdict = w >> 24;
         uint64_t mt[T], mo[T];
         match(type, t_xy, mt);
         uint64_t occ = 0;  // grid[type, target] > 0 (BASE:506): an owner with positive energy sits there
@@ -876,17 +917,11 @@ struct Env {
                 owns[q] &= ~mt[q];
                 others |= mt[q] & ~((q == r) ? bit64(k) : 0ull);
             }
-            if (GEN2 && t_xy != s_xy && C.move_factor != 0.0) {
-                // _get_movement_energy_cost (RQ:301-313): distance * factor * energy, paid before the grid write (RQ:526,538)
-                const int ddx = tx - (int)(s_xy >> 8), ddy = ty - (int)(s_xy & 255u);
-                const double s_e = e_at(r, k);
-                const double ne = s_e - move_distance(ddx * ddx + ddy * ddy) * C.move_factor * s_e;
-                const bool still_pos = (float)ne > 0.0f;
+            if (GEN2 && costly && t_xy != s_xy) {
+                // _get_movement_energy_cost (RQ:301-313) is paid before the grid write (RQ:526,538): the grid shows the energy after it
 #pragma unroll
-                for (int q = 0; q < T; ++q) {
-                    e[q] = (q == r) ? writelane_f64(e[q], k, ne) : e[q];
-                    if (q == r) pos[q] = still_pos ? (pos[q] | bit64(k)) : (pos[q] & ~bit64(k));
-                }
+                for (int q = 0; q < T; ++q)
+                    if (q == r) { moved[q] |= bit64(k); pos[q] = (pos[q] & ~bit64(k)) | (sp[q] & bit64(k)); }
             }
         }
 #pragma unroll
@@ -894,10 +929,21 @@ struct Env {
         if (others) cooc[type] = true;
     }
 
+    // one more agent touches the cell (its own, or the target of its move): counts on the -- at this point all-zero -- channel maps
+    PPG_MEMBER void touch(int ch, uint32_t s_xy) { wv::lds_count(chmap(ch) + cell_of(s_xy)); }
+
     PPG_MEMBER void move(const uint64_t (&acted)[T]) {
         uint64_t pos[T];  // grid value > 0 requires the owner's energy > 0 (BASE:506)
+        uint32_t wish[T];
+        uint64_t moved[T], sp[T];
+        const bool costly = GEN2 && C.move_factor != 0.0;
 #pragma unroll
-        for (int r = 0; r < T; ++r) pos[r] = wv::ballot(shown_positive(r)) & alive[r];
+        for (int r = 0; r < T; ++r) {
+            pos[r] = wv::ballot(shown_positive(r)) & alive[r];
+            wish[r] = move_wish(r, (acted[r] >> ln) & 1ull);
+            moved[r] = 0; sp[r] = 0;
+            if (costly) sp[r] = wv::ballot((float)(e[r] - move_distance((int)((wish[r] >> 16) & 31u)) * C.move_factor * e[r]) > 0.0f);
+        }
         if (ORDERED && C.act_rank) {
 #pragma unroll
             for (int type = 0; type < 2; ++type) {
@@ -905,113 +951,87 @@ struct Env {
                 for (int i = 0; i < n; ++i) {
                     int r, k;
                     ordered_row(type, i, r, k);
-                    move_agent(r, k, pos);
+                    move_agent(r, k, pos, wish, moved, sp, costly);
                 }
             }
-            return;
-        }
-        // An agent whose old cell and target cell are touched by no other agent of its type commutes
-        // with all others: its move cannot be blocked (an empty target cell holds 0, see the header)
-        // and nobody reads or writes its cells.  Those agents move lane-parallel; only agents that
-        // share a cell with someone (contested target, target occupied, someone entering my cell)
-        // go through the ordered loop.  Cells are claimed on the (all-zero) channel maps.
+        } else {
+            // An agent whose old cell and target cell are touched by no other agent of its type commutes
+            // with all others: its move cannot be blocked (an empty target cell holds 0, see the header)
+            // and nobody reads or writes its cells.  Those agents move lane-parallel; only agents that
+            // share a cell with someone (contested target, target occupied, someone entering my cell)
+            // go through the ordered loop.  Who touches a cell is COUNTED on the (all-zero) channel maps,
+            // both species at once (they never meet on a channel): every live agent counts on its own cell,
+            // every agent that wants to leave on its target; alone = both counts are 1.
+#ifdef PPG_PROFILE_MOVE   // (diagnostic build: cycles of the lane-parallel part / of the ordered loop, agents in the ordered loop)
+            const unsigned long long mv_t0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+            bool mover[T];
 #pragma unroll
-        for (int type = 0; type < 2; ++type) {
+            for (int r = 0; r < T; ++r) {
+                mover[r] = ((acted[r] >> ln) & 1ull) && (wish[r] & 0xFFFFu) != xy[r];
+                if ((alive[r] >> ln) & 1ull) touch(1 + type_of(r), xy[r]);
+                if (mover[r]) touch(1 + type_of(r), wish[r] & 0xFFFFu);
+            }
+            wv::sync();
             uint64_t todo[T];
 #pragma unroll
-            for (int r = 0; r < T; ++r) todo[r] = (type_of(r) == type) ? acted[r] : 0ull;
-            if (!cooc[type]) {
-                map_t *A = chmap(1 + type), *F = chmap(0);
-                const int G1 = P.G - 1;
-                uint32_t t_xy[T], rd[T], verdict[T];
-                bool mover[T];
+            for (int r = 0; r < T; ++r) {
+                map_t *A = chmap(1 + type_of(r));
+                bool c = false;
+                if ((alive[r] >> ln) & 1ull) c = A[cell_of(xy[r])] != 1 || (mover[r] && A[cell_of(wish[r] & 0xFFFFu)] != 1);
+                // a move the walls refuse still has to see whether its target is occupied at its turn (the reported
+                // reason depends on it, WO:472-488): ordered loop
+                if (WALLS && ((wish[r] >> 24) == MV_CORNER_CUT || (wish[r] >> 24) == MV_LOS)) c = true;
+                todo[r] = (cooc[type_of(r)] ? ~0ull : wv::ballot(c)) & acted[r];
+            }
 #pragma unroll
-                for (int r = 0; r < T; ++r) {
-                    if (type_of(r) != type) continue;
-                    int dx = 0, dy = 0;
-                    if (act[r] >= 0) move_vector(act[r], GEN2 && ((id[r] >> 16) & 1), dx, dy);
-                    int tx = (int)(xy[r] >> 8) + dx, ty = (int)(xy[r] & 255u) + dy;
-                    tx = tx < 0 ? 0 : (tx > G1 ? G1 : tx);
-                    ty = ty < 0 ? 0 : (ty > G1 ? G1 : ty);
-                    t_xy[r] = ((uint32_t)tx << 8) | (uint32_t)ty;
-                    verdict[r] = MV_NONE;
-                    if (WALLS && ((acted[r] >> ln) & 1ull)) {
-                        verdict[r] = wall_verdict((int)(xy[r] >> 8), (int)(xy[r] & 255u), tx, ty);
-                        if (verdict[r] == MV_WALL) t_xy[r] = xy[r];   // WO:469-471
-                    }
-                    mover[r] = ((acted[r] >> ln) & 1ull) && t_xy[r] != xy[r];
-                    rd[r] = 0;
-                    if ((alive[r] >> ln) & 1ull) A[cell_of(xy[r])] = to_map(1 + type, validx(r, ln));  // sitters
-                }
-                wv::sync();
-#pragma unroll
-                for (int r = 0; r < T; ++r) {
-                    if (type_of(r) != type) continue;
-                    if (mover[r]) {
-                        rd[r] = A[cell_of(t_xy[r])];
-                        if (rd[r] != 0u) F[cell_of(t_xy[r])] = 1;  // somebody sits on my target
-                    }
-                }
-                wv::sync();
-#pragma unroll
-                for (int r = 0; r < T; ++r) {
-                    if (type_of(r) != type) continue;
-                    if (mover[r] && rd[r] == 0u) A[cell_of(t_xy[r])] = to_map(1 + type, validx(r, ln));  // claim
-                }
-                wv::sync();
-#pragma unroll
-                for (int r = 0; r < T; ++r) {
-                    if (type_of(r) != type) continue;
-                    if (mover[r] && rd[r] == 0u && A[cell_of(t_xy[r])] != to_map(1 + type, validx(r, ln)))
-                        F[cell_of(t_xy[r])] = 1;  // contested target
-                }
-                wv::sync();
-                uint64_t cx[T];
-#pragma unroll
-                for (int r = 0; r < T; ++r) {
-                    cx[r] = 0;
-                    if (type_of(r) != type) continue;
-                    bool c = false;
-                    if ((alive[r] >> ln) & 1ull) c = F[cell_of(xy[r])] != 0 || (mover[r] && F[cell_of(t_xy[r])] != 0);
-                    // a move the walls refuse still has to see whether its target is occupied at its turn (the reported
-                    // reason depends on it, WO:472-488): ordered loop
-                    if (WALLS && (verdict[r] == MV_CORNER_CUT || verdict[r] == MV_LOS)) c = true;
-                    cx[r] = wv::ballot(c) & acted[r];
-                }
-#pragma unroll
-                for (int r = 0; r < T; ++r) {
-                    if (type_of(r) != type) continue;
-                    if ((alive[r] >> ln) & 1ull) {
-                        A[cell_of(xy[r])] = 0; F[cell_of(xy[r])] = 0;
-                        if (mover[r]) { A[cell_of(t_xy[r])] = 0; F[cell_of(t_xy[r])] = 0; }
-                    }
-                }
-                wv::sync();
-#pragma unroll
-                for (int r = 0; r < T; ++r) {
-                    if (type_of(r) != type) continue;
-                    const uint64_t simple = acted[r] & ~cx[r];
-                    if (WALLS && ((simple >> ln) & 1ull))  // nobody else touches its cells: the target is free, or its own cell
-                        set_move_info(r, verdict[r] == MV_WALL ? (uint32_t)MV_WALL
-                                         : (t_xy[r] == xy[r] && shown_positive(r)) ? (uint32_t)MV_OCCUPIED : (uint32_t)MV_NONE);
-                    if (GEN2 && ((simple >> ln) & 1ull) && t_xy[r] != xy[r] && C.move_factor != 0.0) {  // RQ:301-313,526
-                        const int ddx = (int)(t_xy[r] >> 8) - (int)(xy[r] >> 8), ddy = (int)(t_xy[r] & 255u) - (int)(xy[r] & 255u);
-                        e[r] = e[r] - move_distance(ddx * ddx + ddy * ddy) * C.move_factor * e[r];
-                    }
-                    if ((simple >> ln) & 1ull) xy[r] = t_xy[r];   // BASE:263
-                    owns[r] |= simple;                            // grid[new] = energy, BASE:269/273
-                    todo[r] = cx[r];
+            for (int r = 0; r < T; ++r) {   // (in program order behind the reads above: one wavefront's LDS accesses do not overtake each other)
+                map_t *A = chmap(1 + type_of(r));
+                if ((alive[r] >> ln) & 1ull) {
+                    A[cell_of(xy[r])] = 0;
+                    if (mover[r]) A[cell_of(wish[r] & 0xFFFFu)] = 0;
                 }
             }
+            wv::sync();
+#pragma unroll
+            for (int r = 0; r < T; ++r) {
+                const uint64_t simple = acted[r] & ~todo[r];
+                if (WALLS && ((simple >> ln) & 1ull))  // nobody else touches its cells: the target is free, or its own cell
+                    set_move_info(r, (wish[r] >> 24) == MV_WALL ? (uint32_t)MV_WALL
+                                     : (!mover[r] && shown_positive(r)) ? (uint32_t)MV_OCCUPIED : (uint32_t)MV_NONE);
+                if ((simple >> ln) & 1ull) xy[r] = wish[r] & 0xFFFFu;   // BASE:263
+                if (costly) moved[r] = simple & wv::ballot(mover[r]);
+                owns[r] |= simple;                            // grid[new] = energy, BASE:269/273
+            }
+#ifdef PPG_PROFILE_MOVE
+            const unsigned long long mv_t1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            unsigned long long mv_n = 0, mv_all = 0;
+#pragma unroll
+            for (int r = 0; r < T; ++r) { mv_n += (unsigned long long)wv::popc(todo[r]); mv_all += (unsigned long long)wv::popc(acted[r]); }
+#endif
 #pragma unroll
             for (int r = 0; r < T; ++r) {
                 uint64_t m = todo[r];
                 while (m) {
                     const int k = wv::ctz(m);
                     m &= m - 1;
-                    move_agent(r, k, pos);
+                    move_agent(r, k, pos, wish, moved, sp, costly);
                 }
             }
+#ifdef PPG_PROFILE_MOVE
+            const unsigned long long mv_t2 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (C.prof && ln == 0) {
+                C.prof[(size_t)b * 16 + 13] = mv_t1 - mv_t0; C.prof[(size_t)b * 16 + 14] = mv_t2 - mv_t1; C.prof[(size_t)b * 16 + 15] = (mv_all << 16) | mv_n;
+            }
+#endif
+        }
+        if (costly) {   // RQ:301-313,526: distance * factor * energy, for every agent that changed cell
+#pragma unroll
+            for (int r = 0; r < T; ++r)
+                if ((moved[r] >> ln) & 1ull) e[r] = e[r] - move_distance((int)((wish[r] >> 16) & 31u)) * C.move_factor * e[r];
         }
     }
 

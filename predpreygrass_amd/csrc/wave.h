@@ -73,6 +73,17 @@ PPG_DEVICE double shfl_xor_f64(double v, int mask) {
 // would also drain vmcnt(0), i.e. wait for every outstanding observation store to reach HBM.)
 PPG_DEVICE void sync() { __asm__ volatile("" ::: "memory"); }
 
+// Count one more on an 8- or 16-bit LDS counter that other lanes may be counting on too (ds_add_u32 on the word that holds it;
+// a counter never reaches its field's width: at most capacity + 1 agents touch a cell).
+PPG_DEVICE void lds_count(uint8_t *p) {
+    const uint32_t low = (uint32_t)(uintptr_t)p & 3u;   // (the word's address stays derived from p: the access stays a DS instruction)
+    __hip_atomic_fetch_add((uint32_t *)(p - low), 1u << (8u * low), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+PPG_DEVICE void lds_count(uint16_t *p) {
+    const uint32_t low = (uint32_t)(uintptr_t)p & 2u;
+    __hip_atomic_fetch_add((uint32_t *)((unsigned char *)p - low), 1u << (8u * low), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // all of this wave's outstanding global loads have returned (used before overwriting memory other lanes just read)
 PPG_DEVICE void drain_loads() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

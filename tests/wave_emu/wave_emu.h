@@ -230,6 +230,9 @@ inline void wg_barrier() {
 }
 inline void wg_barrier_lds() { wg_barrier(); }
 inline void sync() { (void)exchange(0); }
+// (lanes are fibers that only switch at collectives: a plain increment is atomic here)
+inline void lds_count(uint8_t *p) { *p = (uint8_t)(*p + 1); }
+inline void lds_count(uint16_t *p) { *p = (uint16_t)(*p + 1); }
 inline void drain_loads() { (void)exchange(0); }  // lanes run one after another here: a collective orders reads before writes
 inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline int popc(uint64_t m) { return __builtin_popcountll(m); }

@@ -15,7 +15,10 @@ CSRC = os.path.join(ROOT, "predpreygrass_amd", "csrc")
 LIB = os.path.join(ROOT, "tools", "_build", "libppg_hip_prof.so")  # diagnostic build, git-ignored
 os.makedirs(os.path.dirname(LIB), exist_ok=True)
 import __graft_entry__ as graft
-graft.build_hip(force=not os.path.exists(LIB), extra_flags=["-DPPG_PROFILE_PHASES"], out=LIB)
+MOVE = "--move-detail" in sys.argv   # (non-cooperative plans only: slots 13-15 of the stamp buffer)
+if MOVE:
+    LIB = LIB.replace("_prof.so", "_profmove.so")
+graft.build_hip(force=not os.path.exists(LIB), extra_flags=["-DPPG_PROFILE_PHASES"] + (["-DPPG_PROFILE_MOVE"] if MOVE else []), out=LIB)
 lib = _abi.bind(ctypes.CDLL(LIB))
 _abi._lib = lib  # this process only
 lib.ppg_debug_set_profile_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -73,9 +76,19 @@ for it in range(N):
     n = (es[ok][:, 0] + es[ok][:, 1])
     rows.append((n.mean(), n.max(), np.corrcoef(n, whole)[0, 1]))
     span = p[ok][:, NS].max() - p[ok][:, 0].min()
+    if MOVE and not COOP:
+        mv = p[ok][:, 13:16]
+        n_ord = np.bitwise_and(mv[:, 2].astype(np.int64), 0xFFFF); n_all = mv[:, 2].astype(np.int64) >> 16
+        movedetail = locals().get("movedetail", [])
+        movedetail.append((mv[:, 0].mean(), mv[:, 1].mean(), n_ord.mean(), n_all.mean(), (mv[:, 1] / np.maximum(n_ord, 1)).mean(),
+                           mv[slow, 0].mean(), mv[slow, 1].mean(), n_ord[slow].mean()))
 print("phase               mean cyc   share | slowest-1%% cyc  share")
 for k, n in enumerate(names):
     print(f"{n:18s} {acc[k]/N:9.0f}  {acc[k]/acc.sum():6.1%} | {accmax[k]/N:9.0f}  {accmax[k]/accmax.sum():6.1%}")
 t = np.array(tot); r = np.array(rows)
 print(f"wave cycles: mean {t[:,0].mean():.0f}  p99 {t[:,2].mean():.0f}  max {t[:,1].mean():.0f};  first-start..last-end span {span:.0f}")
 print(f"rows/env: mean {r[:,0].mean():.1f} max {r[:,1].mean():.0f}; corr(rows, cycles) {r[:,2].mean():.3f}")
+if MOVE and not COOP:
+    m = np.array(movedetail).mean(axis=0)
+    print(f"move detail: lane-parallel part {m[0]:.0f} cyc, ordered loop {m[1]:.0f} cyc for {m[2]:.2f} of {m[3]:.1f} acting agents ({m[4]:.0f} cyc per ordered agent);"
+          f" slowest 1 %: parallel {m[5]:.0f}, ordered {m[6]:.0f} for {m[7]:.1f} agents")
