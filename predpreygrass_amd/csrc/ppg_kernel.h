@@ -867,7 +867,7 @@ struct Env {
             if (verdict == MV_WALL) { tx = x; ty = y; }
         }
         const int ddx = tx - x, ddy = ty - y;
-        return ((uint32_t)tx << 8) | (uint32_t)ty | ((uint32_t)(ddx * ddx + ddy * ddy) << 16) | (verdict << 24);
+        return ((uint32_t)tx << 8) | (uint32_t)ty | (((uint32_t)(ddx * ddx + ddy * ddy) & 31u) << 16) | (verdict << 24);
     }
     PPG_MEMBER uint32_t wish_at(const uint32_t (&wish)[T], int r, int k) const {
         uint32_t v = wv::readlane(wish[0], k);
@@ -900,6 +900,9 @@ struct Env {
         if (t_xy == s_xy) {
 #pragma unroll
             for (int q = 0; q < T; ++q) mo[q] = mt[q];
+        } else if (!cooc[type]) {   // no cell holds two live agents of this type: the agent is alone on its cell
+#pragma unroll
+            for (int q = 0; q < T; ++q) mo[q] = (q == r) ? bit64(k) : 0ull;
         } else {
             match(type, s_xy, mo);
         }
@@ -937,12 +940,19 @@ struct Env {
         uint32_t wish[T];
         uint64_t moved[T], sp[T];
         const bool costly = GEN2 && C.move_factor != 0.0;
+        // distance * factor per squared displacement (RQ:310-312), once per wavefront in the LDS scratch (behind the explicit-order
+        // path's row lists) instead of a chain of selects per row register
+        double *cost = (double *)scr + 32;
+        if (costly) {
+            if (ln < 32) cost[ln] = ln < 19 ? move_distance(ln) * C.move_factor : 0.0;   // (rows not in use index anything below 32)
+            wv::sync();
+        }
 #pragma unroll
         for (int r = 0; r < T; ++r) {
             pos[r] = wv::ballot(shown_positive(r)) & alive[r];
             wish[r] = move_wish(r, (acted[r] >> ln) & 1ull);
             moved[r] = 0; sp[r] = 0;
-            if (costly) sp[r] = wv::ballot((float)(e[r] - move_distance((int)((wish[r] >> 16) & 31u)) * C.move_factor * e[r]) > 0.0f);
+            if (costly) sp[r] = wv::ballot((float)(e[r] - cost[(wish[r] >> 16) & 31u] * e[r]) > 0.0f);
         }
         if (ORDERED && C.act_rank) {
 #pragma unroll
@@ -1031,7 +1041,7 @@ struct Env {
         if (costly) {   // RQ:301-313,526: distance * factor * energy, for every agent that changed cell
 #pragma unroll
             for (int r = 0; r < T; ++r)
-                if ((moved[r] >> ln) & 1ull) e[r] = e[r] - move_distance((int)((wish[r] >> 16) & 31u)) * C.move_factor * e[r];
+                if ((moved[r] >> ln) & 1ull) e[r] = e[r] - cost[(wish[r] >> 16) & 31u] * e[r];
         }
     }
 
