@@ -16,8 +16,8 @@
 #define PPG_K2(name, NQ, MODE, FAST) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K3(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
 #define PPG_K4(name, NQ, MODE) PPG_KERNEL(name, (NQ <= 2 ? 4 : 2))(const ppg::KParams P);
-#define PPG_KW3(name, NQ) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
-#define PPG_KW4(name, NQ) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), 4)(const ppg::KParams P);
+#define PPG_KW3(name, NQ, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
+#define PPG_KW4(name, NQ, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KW(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KW2(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KC(name, NQ, GEN2, NW) PPG_KERNEL_NW(name, 4, NW)(const ppg::KParams P);
@@ -250,11 +250,11 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     } else if (mode == ppg::MODE_STEP && wp.nw > 1) {   // several waves per env: wave 0 steps, all of them write the final observations
         const int qi = h->nq == 1 ? 0 : h->nq == 2 ? 1 : 2;
         if (h->drive) {
-            static const ppg_kernel_fn w4[3] = {ppgw4_step_q1, ppgw4_step_q2, ppgw4_step_q4};
-            fn = w4[qi];
+            static const ppg_kernel_fn w4[2][3] = {{ppgw4_step_q1, ppgw4_step_q2, ppgw4_step_q4}, {ppgwp4_step_q1, ppgwp4_step_q2, ppgwp4_step_q4}};
+            fn = w4[wp.nw == 2 ? 1 : 0][qi];
         } else if (h->gen2 && h->cfg2.walls) {
-            static const ppg_kernel_fn w3[3] = {ppgw3_step_q1, ppgw3_step_q2, ppgw3_step_q4};
-            fn = w3[qi];
+            static const ppg_kernel_fn w3[2][3] = {{ppgw3_step_q1, ppgw3_step_q2, ppgw3_step_q4}, {ppgwp3_step_q1, ppgwp3_step_q2, ppgwp3_step_q4}};
+            fn = w3[wp.nw == 2 ? 1 : 0][qi];
         } else if (wp.nw == 16) {
             static const ppg_kernel_fn w16[3] = {ppgw16_step_q1, ppgw16_step_q2, ppgw16_step_q4};
             fn = w16[qi];

@@ -383,7 +383,7 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
     ppg_wave_plan_t p = {1, 0, 0};
     if (h->forced.nw > 0) {
         p = h->forced;
-        if (walls || h->drive) { p.nw = p.nw > 1 ? 4 : 1; p.min_rows = 0; p.coop_e = 0; }   // (four-wave kernels only, helpers always stay)
+        if (walls || h->drive) { p.nw = p.nw == 2 ? 2 : p.nw > 1 ? 4 : 1; p.min_rows = 0; p.coop_e = 0; }   // (pair and four-wave kernels, helpers always stay)
         if (h->cfg.kickback) { p.nw = 1; p.coop_e = 0; }
         if (p.coop_e > 0 && !h->coop_ok) p.coop_e = 0;
         if (p.coop_e > 0) {
@@ -393,14 +393,16 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
             p.min_rows = 0;
         } else {
             if (p.nw != 1 && p.nw != 2 && p.nw != 4 && p.nw != 8 && p.nw != 16) p.nw = 4;
-            if (p.nw == 2 && (h->gen2 || h->drive)) p.nw = 4;                                  // the pair kernels exist for the base family
+            if (p.nw == 2 && h->gen2 && !walls) p.nw = 4;                                      // no pair kernels for the second generation without walls
             if (p.nw == 16 && (h->gen2 || h->base.nch_p > 2 || h->base.nch_q > 3 || h->nq > 2)) p.nw = 8;  // sixteen waves: base family, register descriptors, <= 128 prey rows
         }
         return p;
     }
     if (h->cfg.kickback) return p;   // (single-wave kernels only)
     if (h->drive) {
-        p.nw = 4;
+        // a full GPU: two waves per env keep twice the envs in flight at 128 registers (183 vs 192 us per 4096-env step, round 5);
+        // the walls variant's observation phase is the longer part of its env, four waves stay faster there (95 vs 106 us)
+        p.nw = in_flight > 3072 ? 2 : 4;
     } else if (walls) {
         p.nw = 4;
     } else if (in_flight <= 512) {

@@ -46,9 +46,10 @@
     PPG_KW2(ppgw28_step_q##NQ, NQ, true, 8)                           \
     PPG_KW2(ppgw28_step_q##NQ##g, NQ, false, 8)
 
-// walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>; ppgw3_step: 4 waves per env)
+// walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>; ppgw3_step: 4 waves per env, ppgwp3_step: 2)
 #define PPG_DEFINE_KERNELS3(NQ)                                       \
-    PPG_KW3(ppgw3_step_q##NQ, NQ)                                     \
+    PPG_KW3(ppgw3_step_q##NQ, NQ, 4)                                  \
+    PPG_KW3(ppgwp3_step_q##NQ, NQ, 2)                                 \
     PPG_K3(ppg3_step_q##NQ, NQ, ppg::MODE_STEP)                       \
     PPG_K3(ppg3_reset_q##NQ, NQ, ppg::MODE_RESET)                     \
     PPG_K3(ppg3_observe_q##NQ, NQ, ppg::MODE_OBSERVE)                 \
@@ -58,7 +59,8 @@
 
 // drive-conditioned variant of the base family: generic observation geometry only (ppg4_<mode>_q<NQ>)
 #define PPG_DEFINE_KERNELS4(NQ)                                       \
-    PPG_KW4(ppgw4_step_q##NQ, NQ)                                     \
+    PPG_KW4(ppgw4_step_q##NQ, NQ, 4)                                  \
+    PPG_KW4(ppgwp4_step_q##NQ, NQ, 2)                                 \
     PPG_K4(ppg4_step_q##NQ, NQ, ppg::MODE_STEP)                       \
     PPG_K4(ppg4_reset_q##NQ, NQ, ppg::MODE_RESET)                     \
     PPG_K4(ppg4_observe_q##NQ, NQ, ppg::MODE_OBSERVE)                 \

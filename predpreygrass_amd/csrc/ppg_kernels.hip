@@ -36,10 +36,10 @@
     PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, false, false, false, NW>(P, lds); }
 #define PPG_KW2(name, NQ, FAST, NW)                                                          \
     PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_GEN2 : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, FAST, true, false, false, NW>(P, lds); }
-#define PPG_KW3(name, NQ)                                                                    \
-    PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_WALLS : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, true, true, false, 4>(P, lds); }
-#define PPG_KW4(name, NQ)                                                                    \
-    PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_DRIVE : 2), 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, 4>(P, lds); }
+#define PPG_KW3(name, NQ, NW)                                                                \
+    PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_WALLS : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, true, true, false, NW>(P, lds); }
+#define PPG_KW4(name, NQ, NW)                                                                \
+    PPG_KERNEL_NW(name, (NQ <= 2 ? PPG_WPE_DRIVE : 2), NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::env_main<NQ, ppg::MODE_STEP, false, false, false, true, NW>(P, lds); }
 #define PPG_KC(name, NQ, GEN2, NW)                                                           \
     PPG_KERNEL_NW(name, PPG_WPE, NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_main<NQ, GEN2, NW>(P, lds); }
 #define PPG_KCR(name, NQ, GEN2, NW)                                                          \

@@ -36,7 +36,8 @@ def make_gen2(cfg, B, **kw):
     ("8", ["even_obs_seed0"], None),            # even windows, ends with the truncation call
     ("4", ["kickback_fast_seed5"], 120),        # reward kick-backs to grandparents
     ("4", ["drive_default_seed2"], 100),        # drive variant: four-wave kernel with per-wave window staging
-    ("8", ["drive_custom_lists_big_windows_seed4"], 60),   # (8 asks for the variant's only multi-wave kernel: 4)
+    ("8", ["drive_custom_lists_big_windows_seed4"], 60),   # (8 asks for the variant's widest multi-wave kernel: 4)
+    ("2", ["drive_default_seed2"], 60),         # drive variant: the pair kernel
 ])
 def test_base_family_golden_cases_multiwave(waves, names, max_calls, monkeypatch):
     monkeypatch.setenv("PPG_EMU_WAVES", waves)
@@ -45,7 +46,7 @@ def test_base_family_golden_cases_multiwave(waves, names, max_calls, monkeypatch
 
 def test_wave_count_takes_effect(monkeypatch):
     lib = emu_backend.library()
-    for waves, drive, expect in (("1", False, 1), ("2", False, 2), ("4", False, 4), ("8", False, 8), ("8", True, 4), ("2", True, 4)):
+    for waves, drive, expect in (("1", False, 1), ("2", False, 2), ("4", False, 4), ("8", False, 8), ("8", True, 4), ("2", True, 2)):
         monkeypatch.setenv("PPG_EMU_WAVES", waves)
         env = make_base({**config_env, "enable_drive_channels": drive}, 1)
         env.reset(seed=1)
@@ -58,6 +59,8 @@ def test_wave_count_takes_effect(monkeypatch):
     ("8", "rq_base_seed3"),
     ("4", "wo_zigzag_seed1"),                   # walls: line-of-sight staging area per wave
     ("4", "wo_los_two_types_seed5"),
+    ("2", "wo_zigzag_seed1"),                   # walls: the pair kernel
+    ("2", "wo_los_two_types_seed5"),
 ])
 def test_second_generation_golden_cases_multiwave(waves, name, monkeypatch):
     monkeypatch.setenv("PPG_EMU_WAVES", waves)

@@ -228,11 +228,11 @@ def test_drive_conditioned_variant_on_gpu():
 
 
 @pytest.mark.parametrize("cap,G,prey0,grass0", [(64, 14, 8, 30), (128, 14, 80, 100), (256, 18, 170, 140)])
-@pytest.mark.parametrize("multi", [1, 4])
+@pytest.mark.parametrize("multi", [1, 2, 4])
 def test_drive_variant_every_register_count_on_gpu(cap, G, prey0, grass0, multi):
-    """ppg4_step_q{1,2,4} and ppgw4_step_q{1,2,4}: 64 / 128 / 256 prey rows per env (1, 2, 4 prey registers; the configs
-    start with 8 / 80 / 170 prey so that the upper registers are in use), one and four waves per env; every fourth call
-    against the oracle."""
+    """ppg4_step_q{1,2,4}, ppgwp4_step_q{1,2,4} and ppgw4_step_q{1,2,4}: 64 / 128 / 256 prey rows per env (1, 2, 4 prey registers;
+    the configs start with 8 / 80 / 170 prey so that the upper registers are in use), one, two and four waves per env; every fourth
+    call against the oracle."""
     cfg = {**config_env, "enable_drive_channels": True, "grid_size": G, "initial_num_grass": grass0,
            "n_initial_active_predator": 6, "n_initial_active_prey": prey0, "max_steps": 80,
            "predator_creation_energy_threshold": 30.0, "prey_creation_energy_threshold": 12.0}

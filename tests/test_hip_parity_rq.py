@@ -140,7 +140,9 @@ def test_walls_golden_cases_on_gpu(name):
     replay_golden_case(make_env, name)
 
 
-def test_walls_random_rollout_matches_oracle_on_gpu():
+@pytest.mark.parametrize("waves", [None, 1, 2, 4])
+def test_walls_random_rollout_matches_oracle_on_gpu(waves):
+    """ppg3_step, ppgwp3_step (two wavefronts per env) and ppgw3_step (four); None = what the library picks."""
     case = RQGoldenCase("wo_los_two_types_seed5")
     cfg, walls = case.config, case.wall_xy
 
@@ -149,6 +151,9 @@ def test_walls_random_rollout_matches_oracle_on_gpu():
         o.set_walls(walls)
         return o
     env = make_env(cfg, 64, walls=True)
+    if waves is not None:
+        env.set_wave_plan(waves)
+        assert env.wave_plan()[0] == waves
     env.set_walls(walls)
     n_resets, stats = rollout_vs_oracle(env, oracle, seed0=31, n_calls=250, check_every=5, check_grid=True)
     assert stats["births"] > 20 and n_resets > 10

@@ -94,7 +94,7 @@ static int backend_rebalance(ppg_handle *h, int wp, int wq, void *) {
 static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *) {
     EmuLaunch L{&P, h->nq, mode, h->drive ? 3 : h->gen2 ? (h->cfg2.walls ? 2 : 1) : 0, 1};
     // The HIP backend picks the multi-wave step kernels from the batch size (ppg_use_multiwave); here the tests ask for
-    // them explicitly: PPG_EMU_WAVES=4|8 (walls / drive have a four-wave kernel only, as in the library).
+    // them explicitly: PPG_EMU_WAVES=2|4|8 (walls / drive have pair and four-wave kernels, as in the library).
     if ((mode == ppg::MODE_STEP || mode == ppg::MODE_ROLLOUT) && P.coop_e > 0) {   // cooperative kernels (ppg_set_wave_plan): coop_e envs per workgroup of plan.nw waves
         L.nw = h->plan.nw;
         const int groups = (h->batch + P.coop_e - 1) / P.coop_e;
@@ -104,7 +104,7 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     if (mode == ppg::MODE_STEP) {
         const char *w = getenv("PPG_EMU_WAVES");
         const int nw = w ? atoi(w) : 1;
-        if (nw == 4 || (nw == 8 && L.gen2 < 2) || (nw == 2 && L.gen2 == 0)) L.nw = nw;
+        if (nw == 4 || (nw == 8 && L.gen2 < 2) || (nw == 2 && L.gen2 != 1)) L.nw = nw;
         else if (nw == 8 || nw == 2) L.nw = 4;
         else if (nw != 1 && nw != 0) return ppg_fail(h, PPG_EINVAL, "PPG_EMU_WAVES=%d (1, 2, 4 or 8)", nw);
     }

@@ -49,7 +49,7 @@ void run(const ppg::KParams &P, int mode, int nw) {
     }
 #endif
     if (nw == 4) { run_nw<FAST, 4>(P); return; }
-#if PPG_EMU_FAMILY == 0
+#if PPG_EMU_FAMILY != 1
     if (nw == 2) { run_nw<FAST, 2>(P); return; }
 #endif
 #if PPG_EMU_FAMILY < 2
