@@ -286,10 +286,12 @@ def parse_args(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0,
                     help="cpu_baseline: wall seconds of the all-cores leg (a single-thread leg of a third of that runs first)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=None,
                     help="independent sub-batches per GPU, each on its own HIP stream (1 = one launch per step).  2 vs 3 with the "
                          "cooperative kernels, us per 4096-env step in one gpurun call each: GPU in its fast state 68.3 / 71.2, 67.2 / "
-                         "66.4; in its slow state 87.7 / 83.6, 76.8 / 71.0 -- three are never far behind and clearly ahead when it counts")
+                         "66.4; in its slow state 87.7 / 83.6, 76.8 / 71.0 -- three are never far behind and clearly ahead when it counts.  "
+                         "Default: 3; the walls and drive workloads 2 (their kernels are bound by per-env work, not by the write streams: "
+                         "92.3 vs 94.9 and 180.1 vs 183.3 us per step, profiles/r05/l_walls_drive_pair_kernels_ab.txt)")
     ap.add_argument("--sustained-steps", type=int, default=2000,
                     help="after the timed region: a second leg of this many steps timed with HIP events on the launch streams "
                          "(roofline.kernel_ms_sustained); 0 = skip")
@@ -654,7 +656,7 @@ def main(argv=None, backend=None):
             cfg["enable_drive_channels"] = True
     B = args.envs
     obs_dtype = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[args.obs_dtype]
-    n_sub = max(1, args.streams)
+    n_sub = max(1, args.streams if args.streams is not None else (2 if args.workload in ("walls", "drive") else 3))
     setup = (lambda e: e.set_walls(cfg["manual_wall_positions"])) if args.workload == "walls" else None
     def build_group(spread):
         return SubBatchedPredPreyGrass(cfg, batch_size=B, n_sub=n_sub, device=device, obs_dtype=obs_dtype, env_class=env_class,
