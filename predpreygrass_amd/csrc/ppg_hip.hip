@@ -21,6 +21,7 @@
 #define PPG_KW(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KW2(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KC(name, NQ, GEN2, NW) PPG_KERNEL_NW(name, 4, NW)(const ppg::KParams P);
+#define PPG_KCH(name, NQ) PPG_KERNEL_NW(name, 8, 4)(const ppg::KParams P);
 #define PPG_KCR(name, NQ, GEN2, NW) PPG_KERNEL_NW(name, 4, NW)(const ppg::KParams P);
 #include "ppg_kernel_list.h"
 
@@ -240,6 +241,8 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
         static const ppg_kernel_fn c[4][2] = {{ppgc_step_q1, ppgc_step_q2}, {ppgc8_step_q1, ppgc8_step_q2}, {ppgc16_step_q1, ppgc16_step_q2},
                                               {ppgc6_step_q1, ppgc6_step_q2}};
         fn = c[wp.nw == 8 ? 1 : wp.nw == 16 ? 2 : wp.nw == 6 ? 3 : 0][h->nq == 1 ? 0 : 1];
+        if (!h->gen2 && wp.nw == 4 && P.obs_f32 == 2 && ppg_coop_high_occupancy(h, wp.coop_e))   // bfloat16 rows: the 64-register build, 8 workgroups per CU
+            fn = h->nq == 1 ? ppgch_step_q1 : ppgch_step_q2;
         if (h->gen2) fn = h->nq == 1 ? ppgc2_step_q1 : ppgc2_step_q2;   // (second generation: four-wave cooperative kernels)
         if (mode == ppg::MODE_ROLLOUT)   // (ppg_rollout: the fused form of the four-wave cooperative kernels)
             fn = h->gen2 ? (h->nq == 1 ? ppgc2_rollout_q1 : ppgc2_rollout_q2) : (h->nq == 1 ? ppgc_rollout_q1 : ppgc_rollout_q2);

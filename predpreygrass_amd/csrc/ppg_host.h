@@ -735,11 +735,17 @@ int ppg_export_grid(ppg_handle *h, double *grid_out, void *stream) {
 
 int32_t ppg_lds_bytes(const ppg_handle *h) { return h ? h->base.lds_bytes : 0; }
 
+// bfloat16 rows on the four-wave cooperative kernel: its 64-register build when eight workgroups fit a CU's LDS
+static bool ppg_coop_high_occupancy(const ppg_handle *h, int coop_e) {
+    return !h->gen2 && h->cfg.obs_dtype == 2 && ppg_coop_lds_bytes(h, coop_e) * 8 <= 160 * 1024 && !getenv("PPG_COOP_NO_HIGH_OCCUPANCY");
+}
+
 const char *ppg_step_kernel_name(ppg_handle *h) {
     if (!h) return "";
     const ppg_wave_plan_t wp = h->plan;
     if (wp.coop_e > 0) {   // ppgc_step_q<NQ> (4 waves) / ppgc8_ / ppgc16_
-        snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc%s_step_q%d", h->gen2 ? "2" : wp.nw == 8 ? "8" : wp.nw == 16 ? "16" : wp.nw == 6 ? "6" : "", h->nq);
+        snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc%s_step_q%d",
+                 h->gen2 ? "2" : wp.nw == 8 ? "8" : wp.nw == 16 ? "16" : wp.nw == 6 ? "6" : ppg_coop_high_occupancy(h, wp.coop_e) ? "h" : "", h->nq);
         return h->kernel_name;
     }
     const bool walls = h->gen2 && h->cfg2.walls, fast = h->base.nch_p <= 2 && h->base.nch_q <= 3 && !walls && !h->drive;

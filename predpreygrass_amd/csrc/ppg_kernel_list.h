@@ -33,6 +33,7 @@
 // cooperative step kernels of the base family (Env's COOP): coop_e envs per workgroup of 4 / 8 / 16 wavefronts
 #define PPG_DEFINE_KERNELSC(NQ)                                       \
     PPG_KC(ppgc_step_q##NQ, NQ, false, 4)                             \
+    PPG_KCH(ppgch_step_q##NQ, NQ)                                     \
     PPG_KC(ppgc6_step_q##NQ, NQ, false, 6)                            \
     PPG_KC(ppgc8_step_q##NQ, NQ, false, 8)                            \
     PPG_KC(ppgc16_step_q##NQ, NQ, false, 16)                          \
