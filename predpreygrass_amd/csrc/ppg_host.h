@@ -602,6 +602,18 @@ static ppg::KParams ppg_planned_step_params(const ppg_handle *h) {
         P.off_lut2 = wp.coop_e * P.lds_env_bytes;
         P.off_ctl = P.off_lut2 + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16;
         P.lds_bytes = ppg_coop_lds_bytes(h, wp.coop_e);
+        // float64 / float32 rows: at most FIVE four-wave workgroups (ten envs) per CU although registers and LDS admit six -- a CU
+        // then has fewer scattered write streams open at a time: 66.8 -> 68.2 M env-steps/s on the headline workload, the driver's
+        // command 62.1 -> 63.0 M (profiles/r05/n_coop_workgroups_per_cu.txt; four: the same; three: -13 %).  Done by asking for LDS
+        // the kernel does not use.  bfloat16 rows go the other way (ppgch_step: eight per CU).  PPG_COOP_WGS_PER_CU=0: no limit.
+        if (wp.nw == 4 && h->cfg.obs_dtype != 2) {
+            const char *ev = getenv("PPG_COOP_WGS_PER_CU");
+            const int per_cu = ev ? atoi(ev) : 5;
+            if (per_cu > 0 && per_cu < 16) {
+                const int floor_bytes = 160 * 1024 / (per_cu + 1) + 16;
+                if (P.lds_bytes < floor_bytes) P.lds_bytes = floor_bytes;
+            }
+        }
         P.env_order = h->base.env_order;
         P.vis_masks = h->base.vis_masks;
     }
