@@ -24,4 +24,6 @@ for seed in range(first, first + n):
             traceback.print_exc()
             if len(fails) > 10:
                 break
+    if (seed - first) % 20 == 19:   # (progress: a run that is cut off still says what it covered)
+        print("progress", counts, "fails", len(fails), f"{time.time() - t0:.0f} s", flush=True)
 print("ok", counts, "fails", fails, f"{time.time() - t0:.0f} s")
