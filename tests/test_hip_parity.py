@@ -299,16 +299,19 @@ def test_cooperative_random_rollout_matches_oracle_on_gpu(over, B, calls, cap, w
     rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=778, n_calls=calls, check_every=5, check_grid=True)
 
 
-@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.bfloat16])
 def test_cooperative_step_kernels_give_identical_results(dtype):
     """ppgc_step (4 envs x 4 waves), ppgc8_step, ppgc16_step and odd env counts per workgroup against the one-wave kernel on 1000
-    envs x 200 calls with auto-reset: tables and observations bit for bit."""
+    envs x 200 calls with auto-reset: tables and observations bit for bit.  bfloat16 rows: the four-wave kernel is its 64-register
+    build ppgch_step (eight workgroups per CU)."""
     names = ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state", "grass_energy", "obs_pred", "obs_prey")
     results = []
-    for waves, coop in ((1, 0), (4, 4), (8, 8), (16, 5), (4, 1)):
+    for waves, coop in ((1, 0), (4, 4), (8, 8), (16, 5), (4, 1), (4, 2)):
         env = make_env(dict(config_env), 1000, obs_dtype=dtype)
         env.set_wave_plan(waves, 0, coop)
         assert env.wave_plan() == (waves, 0, coop)
+        if waves == 4:   # (eight workgroups of one or two envs fit a CU's LDS, of four they do not)
+            assert env.step_kernel_name() == ("ppgch_step_q2" if dtype == torch.bfloat16 and coop <= 2 else "ppgc_step_q2")
         env.reset(seed=12)
         for _ in range(200):
             env.step(random_actions=True, auto_reset=True)
