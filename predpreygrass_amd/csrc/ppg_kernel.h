@@ -96,7 +96,7 @@ struct KParams {
     // per-cell line-of-sight masks, precomputed from the (static) walls by ppg_walls_changed: bit (dx + vis_neg) * vis_w + (dy + vis_neg)
     // of cell (x, y)'s vis_words words = "(x + dx, y + dy) is in the grid and no wall lies strictly between" (WO:492-525, 577-589)
     int32_t vis_neg, vis_w, vis_words;
-    int32_t pad4_;
+    int32_t obs_tiles;            // 1: observation rows in the policy kernels' cell layout (ppg_config.obs_dtype 3; blk_p / blk_q elements)
     uint32_t rp_magic, rq_magic;  // ceil(2^32 / Rp), ceil(2^32 / Rq): cell / R == mulhi(cell, magic) for cell < R*R
     uint32_t np_magic, nq_magic;  // ceil(2^32 / Rp^2), ceil(2^32 / Rq^2): element / R^2 for element < 8 R^2
     uint32_t *vis_masks;          // library-owned [B, G*G, vis_words]; NULL = not computed: observations walk the lines themselves
@@ -156,7 +156,7 @@ struct KParams {
     int32_t lds_env_bytes;     // LDS region of one env (map / val / scr offsets above are relative to it)
     int32_t off_lut2;          // from the start of dynamic LDS: the workgroup's copy of obs_lut2
     int32_t off_ctl;           // from the start of dynamic LDS: control words (Env::CTL_*)
-    int32_t blk_p, blk_q;      // elements per observation block: 4 Rp^2, 4 Rq^2
+    int32_t blk_p, blk_q;      // elements per observation block: channels x Rp^2, channels x Rq^2 (or the cell layout's: obs_tiles)
     uint32_t bp_magic, bq_magic;  // ceil(2^32 / blk): element / blk == mulhi(element, magic)
     const uint32_t *coop_tab;  // library-owned: blk_p + blk_q observation descriptors (bits 0-15 the signed map offset of element
                                // (channel, i, j) of a species' (4,R,R) block relative to the observer's padded cell, channel * map_n
@@ -1607,7 +1607,7 @@ struct Env {
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0);   // (arithmetic, not a select of fields: see window_sum)
         double dv[4] = {0.0, 0.0, 0.0, 0.0};
         if (DRIVE) drive_features(type, s_e, s_xy, dv);
-        const int blk = (DRIVE ? 4 + (type ? C.n_drive[1] : C.n_drive[0]) : (WALLS && C.vis_channel ? 5 : 4)) * R * R;
+        const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);   // channels x R x R, or the cell layout's elements (KParams::obs_tiles)
         const int off = (R - 1) / 2;
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;

@@ -151,7 +151,7 @@ class BatchedRedQueen(BatchedPredPreyGrass):
             c.n_possible[p], c.n_initial[p] = self.n_possible[p], self.n_initial[p]
         c.n_grass = self.n_grass
         c.pred_capacity, c.prey_capacity, c.grass_capacity = self.pred_capacity, self.prey_capacity, self.grass_capacity
-        c.obs_dtype = {torch.float64: 0, torch.float32: 1, torch.bfloat16: 2}[obs_dtype]
+        c.obs_dtype = self._abi_obs_dtype()
         c.type_1_action_range, c.type_2_action_range = self.action_ranges
         c.reproduction_cooldown_steps = self.cooldown
         for name in _abi.GEN2_TYPED:
