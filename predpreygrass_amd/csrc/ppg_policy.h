@@ -705,15 +705,15 @@ __device__ __forceinline__ KPtr uniform(KPtr p) { return (KPtr)uniform((uintptr_
 // written to LDS, one sub-group later); the 16-channel float64 variant converts to float at once (64 registers otherwise).
 template <int OBS, int NCH>
 struct ObsRaw {
-    typedef typename std::conditional<OBS == 2, uint16_t, typename std::conditional<OBS == 1, float, double>::type>::type elem;
+    typedef typename std::conditional<OBS >= 2, uint16_t, typename std::conditional<OBS == 1, float, double>::type>::type elem;
     // (bfloat16 rows travel as the zero-extended 16 bits in a register of their own: two 16-bit values in one register would be
     //  packed as soon as they are loaded, i.e. waited for)
-    typedef typename std::conditional<OBS == 2, uint32_t, typename std::conditional<OBS == 0 && (NCH > 8), float, elem>::type>::type type;
+    typedef typename std::conditional<OBS >= 2, uint32_t, typename std::conditional<OBS == 0 && (NCH > 8), float, elem>::type>::type type;
     // (the empty asm pins the conversion -- and with it the wait for the load -- to the place where the value is staged: a pure
     //  function of a loaded value is otherwise scheduled right behind its load)
     static __device__ __forceinline__ __bf16 to_bf16(type v) {
         __asm__ volatile("" : "+v"(v));
-        if constexpr (OBS == 2) return __builtin_bit_cast(__bf16, (uint16_t)v);
+        if constexpr (OBS >= 2) return __builtin_bit_cast(__bf16, (uint16_t)v);
         else return (__bf16)(float)v;
     }
 };
@@ -1714,7 +1714,11 @@ static int ppg_policy_fill(ppg_policy *p, int species, ppg_handle *const *handle
     if (p->n_actions != 9 && !h0->gen2) return ppg_policy_fail(p, PPG_EINVAL, "the base env has 9 actions, the policy %d", p->n_actions);
     K = p->base;
     memset(&L, 0, sizeof L);
-    K.species = species; K.obs_f32 = h0->base.obs_f32; K.sample = (flags & PPG_POLICY_SAMPLE) ? 1 : 0;
+    K.species = species; K.obs_f32 = h0->base.obs_tiles ? 3 : h0->base.obs_f32; K.sample = (flags & PPG_POLICY_SAMPLE) ? 1 : 0;
+    if (h0->base.obs_tiles) {   // rows in the cell layout (ppg_config.obs_dtype 3): the pipeline kernels' own staging format
+        if (!p->pipe) return ppg_policy_fail(p, PPG_EINVAL, "observation rows in the cell layout (obs_dtype 3) are read by the pipeline kernels only; this network runs the %s kernels", p->direct ? "one-role" : "fully connected");
+        K.obs_elems = species ? h0->base.blk_q : h0->base.blk_p;
+    }
     K.seed_lo = (uint32_t)seed ^ (species ? 0x9E3779B9u : 0u); K.seed_hi = (uint32_t)(seed >> 32);
     K.seed_dev = (flags & PPG_POLICY_SEED_ON_DEVICE) ? (const uint64_t *)(uintptr_t)seed : nullptr;
     K.S = h0->base.S; K.cap = species ? h0->base.cap_prey : h0->base.cap_pred; K.slot0 = species ? h0->base.cap_pred : 0;
@@ -1727,7 +1731,7 @@ static int ppg_policy_fill(ppg_policy *p, int species, ppg_handle *const *handle
         const int channels = h->drive ? 4 + h->cfg.n_drive[species] : (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
         if (channels != p->obs_channels)
             return ppg_policy_fail(p, PPG_EINVAL, "the policy reads %d-channel observations, handle %d writes %d channels", p->obs_channels, k, channels);
-        if ((species ? h->base.Rq : h->base.Rp) != R || h->base.S != K.S || h->base.obs_f32 != K.obs_f32 || h->device != p->device)
+        if ((species ? h->base.Rq : h->base.Rp) != R || h->base.S != K.S || h->base.obs_f32 != h0->base.obs_f32 || h->base.obs_tiles != h0->base.obs_tiles || h->device != p->device)
             return ppg_policy_fail(p, PPG_EINVAL, "handle %d has another geometry / dtype / device than handle 0", k);
         if (!actions[k]) return ppg_policy_fail(p, PPG_EINVAL, "actions[%d] is NULL", k);
         K.env_base[k] = L.env_base[k] = total;
@@ -1756,6 +1760,8 @@ static int ppg_policy_run(ppg_policy *p, int species, ppg_handle *const *handles
         const int rc = ppg_policy_fill(p, species, handles, n, actions, flags, seed, logits, K, L, total);
         if (rc != PPG_OK) return rc;
     }
+    if (K.obs_f32 == 3)
+        return ppg_policy_fail(p, PPG_EINVAL, "observation rows in the cell layout (obs_dtype 3) need the one-launch form: both species' pipeline policies in one ppg_policy_act call");
     {
         const int rc = ppg_policy_ensure_plan(p, total, K.cap);
         if (rc != PPG_OK) return rc;
@@ -1908,12 +1914,12 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
     K2.iter_q = ppg_env_int("PPG_POLICY_ITER_Q", 7500);
     K2.iter_p = ppg_env_int("PPG_POLICY_ITER_P", 8500);
     typedef void (*fused_fn)(const ppgpol::PolParams2);
-    const fused_fn fn[2][2][3] = {
-        {{ppgpol::ppg_policy_pipe2_8_8_f64, ppgpol::ppg_policy_pipe2_8_8_f32, ppgpol::ppg_policy_pipe2_8_8_bf16},
-         {ppgpol::ppg_policy_pipe2_8_16_f64, ppgpol::ppg_policy_pipe2_8_16_f32, ppgpol::ppg_policy_pipe2_8_16_bf16}},
-        {{ppgpol::ppg_policy_pipe2_16_8_f64, ppgpol::ppg_policy_pipe2_16_8_f32, ppgpol::ppg_policy_pipe2_16_8_bf16},
-         {ppgpol::ppg_policy_pipe2_16_16_f64, ppgpol::ppg_policy_pipe2_16_16_f32, ppgpol::ppg_policy_pipe2_16_16_bf16}}};
-    const int dt = K2.q.obs_f32 == 2 ? 2 : K2.q.obs_f32 ? 1 : 0;
+    const fused_fn fn[2][2][4] = {
+        {{ppgpol::ppg_policy_pipe2_8_8_f64, ppgpol::ppg_policy_pipe2_8_8_f32, ppgpol::ppg_policy_pipe2_8_8_bf16, ppgpol::ppg_policy_pipe2_8_8_cells},
+         {ppgpol::ppg_policy_pipe2_8_16_f64, ppgpol::ppg_policy_pipe2_8_16_f32, ppgpol::ppg_policy_pipe2_8_16_bf16, ppgpol::ppg_policy_pipe2_8_16_cells}},
+        {{ppgpol::ppg_policy_pipe2_16_8_f64, ppgpol::ppg_policy_pipe2_16_8_f32, ppgpol::ppg_policy_pipe2_16_8_bf16, ppgpol::ppg_policy_pipe2_16_8_cells},
+         {ppgpol::ppg_policy_pipe2_16_16_f64, ppgpol::ppg_policy_pipe2_16_16_f32, ppgpol::ppg_policy_pipe2_16_16_bf16, ppgpol::ppg_policy_pipe2_16_16_cells}}};
+    const int dt = K2.q.obs_f32 == 3 ? 3 : K2.q.obs_f32 == 2 ? 2 : K2.q.obs_f32 ? 1 : 0;
 #ifdef PPG_WITH_PIPE4
     // the four-role pipeline (ppg_policy_pipe4.h: sixteen wavefronts per workgroup; same LDS layout, bit-identical results, 18 % slower:
     // profiles/r05/i_*) -- experiment builds only; PPG_POLICY_PIPE4=0 selects the two-role kernels there
@@ -1923,8 +1929,8 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
         {{ppgpol::ppg_policy_pipe4_16_8_f64, ppgpol::ppg_policy_pipe4_16_8_f32, ppgpol::ppg_policy_pipe4_16_8_bf16},
          {ppgpol::ppg_policy_pipe4_16_16_f64, ppgpol::ppg_policy_pipe4_16_16_f32, ppgpol::ppg_policy_pipe4_16_16_bf16}}};
     const char *p4 = getenv("PPG_POLICY_PIPE4");
-    const bool pipe4 = !(p4 && p4[0] == '0' && p4[1] == 0);
-    const fused_fn f = pipe4 ? fn4[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt] : fn[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt];
+    const bool pipe4 = !(p4 && p4[0] == '0' && p4[1] == 0) && dt < 3;
+    const fused_fn f = pipe4 ? fn4[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt < 3 ? dt : 2] : fn[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt];
 #else
     const bool pipe4 = false;
     const fused_fn f = fn[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt];

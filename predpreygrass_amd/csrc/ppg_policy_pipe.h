@@ -424,7 +424,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
             const int row = (int)(n - (!FUSED ? K.plan[PLAN_HDR + e] : n0 == begin ? pre[e] : __builtin_nontemporal_load(&pre_g[e])));
             const unsigned char *base;
             const int b = pipe_pick_handle(K, K.obs, e, base);
-            tab[2 * i] = (unsigned long long)(uintptr_t)(base + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS == 2 ? 2 : OBS == 1 ? 4 : 8));
+            tab[2 * i] = (unsigned long long)(uintptr_t)(base + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS >= 2 ? 2 : OBS == 1 ? 4 : 8));
             tab[2 * i + 1] = (unsigned long long)(uint32_t)e | ((unsigned long long)(uint32_t)row << 32);
         }
         __syncthreads();
@@ -608,6 +608,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         auto group_ns = [&](int g) { const int left = nt_samples - g * K.ST; return left < K.ST ? left : K.ST; };
         raw_t pre[NCH];
         u32x2_t chunk[PIPE_CHUNKS];
+        u32x4_t cellv[2];   // OBS == 3 (rows in the cell layout, ppg_config.obs_dtype 3): this thread's position as it will lie in the image
         auto fetch = [&](int g) {   // row chunks: chunk ch_w of this thread's samples of sub-group g -> registers
             // (every load unconditional, the sample clamped: a load under a condition is merged with its default value by a register
             //  copy right behind it -- a wait for the whole memory round trip, 1500-3700 cycles per sub-group: profiles/r04)
@@ -628,6 +629,15 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         };
         auto request = [&](int g) {   // (a B thread stages one position: ST * P <= 256, ppg_policy_create_spec)
             const int ns = group_ns(g);
+            if constexpr (OBS == 3) {
+                // the row IS the staged layout: the position's cell(s), one or two aligned 16-byte loads (unconditional, the sample
+                // clamped -- see fetch), written to the image one iteration later as they are: no `raw` area, no LDS read, no packing
+                const int last = ns - 1, s = st_s < last ? st_s : last;
+                const GLOBAL_AS unsigned char *src = row_of(g * K.ST + s) + st_p * (CB1 > 1 ? 32 : 16);
+                cellv[0] = *(const GLOBAL_AS u32x4_t *)src;
+                if constexpr (CB1 > 1) cellv[1] = *(const GLOBAL_AS u32x4_t *)(src + 16);
+                return;
+            }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) pre[c] = (raw_t)0;
             if (st_sv < ns) {
@@ -642,6 +652,20 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         };
         auto stage = [&](int g) {
             const int ns = group_ns(g);
+            if constexpr (OBS == 3) {
+                if (st_sv < ns) {
+                    __bf16 *cell = img + st_img + ((g & 1) ? K.pipe_x1 : 0);
+                    u32x4_t v0 = cellv[0];
+                    __asm__ volatile("" : "+v"(v0));   // (the wait for the load stays here)
+                    *(u32x4_t *)cell = v0;
+                    if constexpr (CB1 > 1) {
+                        u32x4_t v1 = cellv[1];
+                        __asm__ volatile("" : "+v"(v1));
+                        *(u32x4_t *)(cell + K.Wp2 * 8) = v1;
+                    }
+                }
+                return;
+            }
             if (st_sv < ns) {
                 if constexpr (CH) {
                     const uint16_t *rh = (const uint16_t *)raw + st_raw;
@@ -685,6 +709,9 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 if (!(PPG_PIPE_ABLATE & 2)) stage(it + 1);
                 b_target += 4;
                 pipe_arrive(ctr, lane);
+                // (cells: the next sub-group's loads go out NOW and have the whole iteration to land -- the __syncthreads at its end waits
+                //  for every outstanding load of the workgroup)
+                if constexpr (OBS == 3) request(it + 2 < G ? it + 2 : G - 1);
             }
             PPG_DP(11);
             if (!(PPG_PIPE_ABLATE & 1) && it >= 1 && it - 1 < G) {   // head of sub-group it - 1: this wavefront's k-steps
@@ -729,6 +756,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 pipe_arrive(ctr, lane);
                 if (PPG_PIPE_ABLATE & 128) { }
                 else if constexpr (CH) fetch(g + 1 < G ? g + 1 : g);   // (unconditional, like the loads in it; the last one is not parked)
+                else if constexpr (OBS == 3) { }
                 else if (g + 1 < G) request(g + 1);
                 PPG_DP(5);
                 pipe_wait(ctr, b_target);
@@ -868,5 +896,10 @@ PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_16_f64, 0, 16, 16)
 PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_bf16, 2, 8, 16)
 PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_f32, 1, 8, 16)
 PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_f64, 0, 8, 16)
+// rows in the cell layout (ppg_config.obs_dtype 3)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_8_cells, 3, 16, 8)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_8_cells, 3, 8, 8)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_16_cells, 3, 16, 16)
+PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_cells, 3, 8, 16)
 
 }  // namespace ppgpol
