@@ -45,6 +45,9 @@
 #ifndef PPG_PIPE_HEAD_CHAINS
 #define PPG_PIPE_HEAD_CHAINS 1  // independent accumulator chains of the head's eighteen MFMAs: 2 measured 1 % slower than 1 (profiles/r05/e_*)
 #endif
+#ifndef PPG_PIPE_FETCH_EARLY
+#define PPG_PIPE_FETCH_EARLY 0   // 1: the chunk loads of sub-group it + 2 go out right behind the staging of sub-group it + 1 (experiment, profiles/r05/r_*)
+#endif
 #ifndef PPG_PIPE_ABLATE
 #define PPG_PIPE_ABLATE 0   // timing-only ablation builds (tools/gpu_r5_pipe_ablate.sh; never the product -- the results are then meaningless):
                             // 1 no head, 2 no staging, 4 no conv1, 8 no conv2, 16 no conv3, 32 no logits / actions, 64 no Gumbel noise,
@@ -712,6 +715,9 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 // (cells: the next sub-group's loads go out NOW and have the whole iteration to land -- the __syncthreads at its end waits
                 //  for every outstanding load of the workgroup)
                 if constexpr (OBS == 3) request(it + 2 < G ? it + 2 : G - 1);
+#if PPG_PIPE_FETCH_EARLY
+                else if constexpr (CH) fetch(it + 2 < G ? it + 2 : G - 1);
+#endif
             }
             PPG_DP(11);
             if (!(PPG_PIPE_ABLATE & 1) && it >= 1 && it - 1 < G) {   // head of sub-group it - 1: this wavefront's k-steps
@@ -755,7 +761,11 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 b_target += 4;
                 pipe_arrive(ctr, lane);
                 if (PPG_PIPE_ABLATE & 128) { }
+#if PPG_PIPE_FETCH_EARLY
+                else if constexpr (CH) { }
+#else
                 else if constexpr (CH) fetch(g + 1 < G ? g + 1 : g);   // (unconditional, like the loads in it; the last one is not parked)
+#endif
                 else if constexpr (OBS == 3) { }
                 else if (g + 1 < G) request(g + 1);
                 PPG_DP(5);
