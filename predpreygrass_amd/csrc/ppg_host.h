@@ -666,6 +666,9 @@ static ppg::KParams ppg_planned_step_params(const ppg_handle *h) {
         P.env_order = h->base.env_order;
         P.vis_masks = h->base.vis_masks;
     }
+    else if (const char *pad = getenv("PPG_STEP_LDS_PAD")) {   // experiment (profiles/r05/s_*): fewer envs per CU for the multi-wave kernels
+        P.lds_bytes += atoi(pad);
+    }
     P.helper_min_rows = wp.min_rows;
     return P;
 }
