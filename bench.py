@@ -83,6 +83,87 @@ def device_state():
     return state
 
 
+_SAMPLER_CODE = r"""
+import subprocess, sys, time
+exe, path = sys.argv[1], sys.argv[2]
+t_end = time.time() + 600.0            # (never outlives a bench run by long, whatever happens to the parent)
+while time.time() < t_end:
+    t = time.time()
+    try:
+        out = subprocess.run([exe, "--showtemp", "--showclocks", "--showpower", "--showpids"], capture_output=True, text=True, timeout=20).stdout
+    except Exception as exc:
+        out = "ERR " + repr(exc)
+    with open(path, "a") as f:
+        f.write("@@ %.3f %.3f\n%s\n" % (t, time.time(), out))
+    time.sleep(0.3)
+"""
+
+
+def start_state_sampler():
+    """A side process that asks rocm-smi for clocks / power / temperatures / KFD processes a few times per second, started BEFORE this
+    process touches the GPU and with the profiler hooks stripped from its environment: on the GPU boxes a process that has initialised
+    the GPU may not exec another program (rocm-smi is a script), and under LD_PRELOAD every child would initialise it.  Returns
+    (Popen, path) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if exe is None:
+        return None, "rocm-smi is neither on PATH nor under /opt/rocm/bin"
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "HSA_TOOLS"))}
+    try:
+        fd, path = tempfile.mkstemp(prefix="ppg_bench_state_", suffix=".txt")
+        os.close(fd)
+        proc = subprocess.Popen([sys.executable, "-c", _SAMPLER_CODE, exe, path], env=env, stdin=subprocess.DEVNULL,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    except Exception as exc:
+        return None, f"the sampler could not be started: {type(exc).__name__}: {str(exc)[:160]}"
+    return proc, path
+
+
+def sampled_state(path, t0, t1):
+    """The last rocm-smi sample that was taken entirely inside [t0, t1] (wall clock), parsed like device_state(); None if there is none."""
+    import re
+    try:
+        text = open(path).read()
+    except OSError:
+        return None
+    best = None
+    for block in text.split("@@ ")[1:]:
+        head, _, body = block.partition("\n")
+        try:
+            ta, tb = (float(x) for x in head.split()[:2])
+        except ValueError:
+            continue
+        if ta >= t0 and tb <= t1 and "GPU[0]" in body:
+            best = (ta, tb, body)
+    if best is None:
+        return None
+    state = {"sampled_by": "a side process started before this one touched the GPU (rocm-smi, %.2f s per call)" % (best[1] - best[0])}
+    pids = 0
+    in_pids = False
+    for line in best[2].splitlines():
+        if line.startswith("PID"):
+            in_pids = True
+            continue
+        if in_pids and re.match(r"^\d+\s", line):
+            pids += 1
+        m = re.search(r"GPU\[0\]\s*:\s*(.+?):\s*(.+)$", line)
+        if not m:
+            continue
+        key, val = m.group(1).strip(), m.group(2).strip()
+        if key.startswith("Temperature"):
+            state["temp_" + key.split("(Sensor ")[-1].split(")")[0].strip().replace(" ", "_") + "_C"] = val
+        elif "clock level" in key and key.split()[0] in ("sclk", "mclk", "fclk", "socclk"):
+            mm = re.search(r"\((\d+)Mhz\)", val)
+            state[key.split()[0] + "_MHz"] = int(mm.group(1)) if mm else val
+        elif "Power" in key:
+            state["power_W"] = val
+    # KFD processes on the node's GPUs as rocm-smi lists them (this bench is one of them): more than a handful = the lease shares its GPU
+    state["kfd_processes_listed"] = pids
+    return state
+
+
 def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
     """The CPU oracle (C restatement of the reference step(), kind "port") timed on this host on a
     bounded sample of the same workload: one env per thread, random actions, auto-reset."""
@@ -615,6 +696,12 @@ def main(argv=None, backend=None):
     if want_pmc and not args.traffic_child and world == 1 and not args.force_dist and not (backend and backend.dry):
         pmc = measure_traffic(argv, args)
 
+    # clocks / power / who else is on the GPU while the loop runs: a side process, started before this one touches the GPU
+    sampler = (None, "not started: dry run, a rank other than 0, a PMC child run or no sustained leg")
+    if not (backend and backend.dry) and int(os.environ.get("RANK", "0")) == 0 and not args.traffic_child and args.sustained_steps > 0 \
+            and args.workload not in ("policy_rollout", "dict_api"):
+        sampler = start_state_sampler()
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -815,12 +902,37 @@ def main(argv=None, backend=None):
 
     # clocks / power / temperatures WHILE the same loop runs (untimed extra steps on rank 0 for as long as one rocm-smi call takes)
     dev_state = {"unavailable": "not sampled: " + ("dry run" if dry else "not rank 0" if rank != 0 else "PMC child run" if args.traffic_child
-                                                   else "--sustained-steps 0" if args.sustained_steps <= 0 else "a profiler is attached "
-                                                   "(LD_PRELOAD / ROCP* in the environment: rocm-smi would be an exec from a GPU-initialised process)")}
+                                                   else "--sustained-steps 0" if args.sustained_steps <= 0 else str(sampler[1]))}
     # (never under a profiler: its preloaded library initialises the GPU in every child process, and rocm-smi is a `#!/usr/bin/env python3`
     #  script -- an exec from a GPU-initialised process, which the GPU boxes refuse)
     under_profiler = bool(os.environ.get("LD_PRELOAD")) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
-    if not dry and rank == 0 and not args.traffic_child and args.sustained_steps > 0 and not under_profiler:
+    if sampler[0] is not None:
+        # untimed extra steps until the side process has taken one whole sample while they ran (at most 6 s)
+        t_lo = time.time()
+        got = None
+        while got is None and time.time() - t_lo < 6.0:
+            for _ in range(64):
+                one_step()
+            backend.synchronize(device)
+            got = sampled_state(sampler[1], t_lo, time.time())
+        try:
+            sampler[0].kill()           # (this exact child)
+            sampler[0].wait(timeout=5)
+        except Exception:
+            pass
+        try:
+            os.unlink(sampler[1])
+        except OSError:
+            pass
+        if got is not None:
+            try:
+                got["gpu_uuid"] = str(torch.cuda.get_device_properties(torch.cuda.current_device()).uuid)
+            except Exception:
+                pass
+            dev_state = got
+        else:
+            dev_state = {"unavailable": "the side sampler (rocm-smi in a process started before the GPU was touched) produced no whole sample in 6 s of stepping"}
+    elif not dry and rank == 0 and not args.traffic_child and args.sustained_steps > 0 and not under_profiler:
         import threading
         box = {}
         th = threading.Thread(target=lambda: box.update(state=device_state()))
