@@ -285,3 +285,28 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry.py"), "--gpus", "4", "--steps", "1"], env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
+
+
+def test_device_state_is_parsed_from_the_side_samplers_file(tmp_path):
+    """bench_support.sampled_state: the last rocm-smi block taken entirely inside the window, parsed into clocks / power / temperatures /
+    listed KFD processes (the sampler itself needs a GPU box; its file format does not)."""
+    import bench_support
+    block = """============================ ROCm System Management Interface ============================
+GPU[0]		: Temperature (Sensor junction) (C): 51.0
+GPU[0]		: Temperature (Sensor memory) (C): 68.0
+GPU[0]		: fclk clock level: 0: (1250Mhz)
+GPU[0]		: mclk clock level: 0: (2000Mhz)
+GPU[0]		: sclk clock level: 1: (2393Mhz)
+GPU[0]		: Current Socket Graphics Package Power (W): 1081.0
+KFD process information:
+PID   	PROCESS NAME	GPU(s)	VRAM USED	SDMA USED    	CU OCCUPANCY	
+523673	UNKNOWN     	0     	0        	0            	UNKNOWN     	
+517951	python3     	1     	188780544	1313156012359	0           	
+"""
+    p = tmp_path / "state.txt"
+    p.write_text("@@ 100.000 100.100\n" + block.replace("2393", "500") + "\n@@ 105.000 105.100\n" + block + "\n@@ 109.950 110.200\n" + block.replace("2393", "777") + "\n")
+    assert bench_support.sampled_state(str(p), 200.0, 300.0) is None              # nothing inside the window
+    s = bench_support.sampled_state(str(p), 104.0, 110.0)                           # the third block ends after the window
+    assert s["sclk_MHz"] == 2393 and s["mclk_MHz"] == 2000 and s["fclk_MHz"] == 1250 and s["power_W"] == "1081.0"
+    assert s["temp_junction_C"] == "51.0" and s["temp_memory_C"] == "68.0" and s["kfd_processes_listed"] == 2
+    assert bench_support.sampled_state(str(tmp_path / "missing.txt"), 0.0, 1e12) is None
