@@ -491,9 +491,12 @@ def main(argv=None, backend=None):
 
     # clocks / power / who else is on the GPU while the loop runs: a side process, started before this one touches the GPU
     sampler = (None, "not started: dry run, a rank other than 0, a PMC child run or no sustained leg")
+    # (not under rocprofv3: its preloaded tool library has initialised the GPU in THIS process before main() runs, so starting the
+    #  side process here would already be an exec from a GPU-initialised process)
+    profiler_attached = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "HSA_TOOLS")) for k in os.environ)
     if not (backend and backend.dry) and int(os.environ.get("RANK", "0")) == 0 and not args.traffic_child and args.sustained_steps > 0 \
             and args.workload not in ("policy_rollout", "dict_api"):
-        sampler = start_state_sampler()
+        sampler = (None, "not started: a profiler is attached to this process") if profiler_attached else start_state_sampler()
 
     import numpy as np
     import torch

@@ -33,6 +33,8 @@ struct ppg_handle {
     uint32_t *coop_tab_dev;   // library-owned: KParams::coop_tab
     int32_t drive;  // drive-conditioned variant of the base family (cfg.n_drive)
     int32_t envs_in_flight;  // scheduling hint (ppg_set_envs_in_flight); 0 = the handle's own batch
+    int32_t coop_wgs_per_cu;  // float64 / float32 rows: four-wave cooperative workgroups a CU takes at most (PPG_COOP_WGS_PER_CU, read at create)
+    int32_t step_lds_pad;     // experiment (PPG_STEP_LDS_PAD, read at create): unused LDS added to the multi-wave kernels' launches
     int32_t *order_dev;      // library-owned [batch]: env order of ppg_rebalance (NULL until first used)
     uint32_t *vis_dev;       // library-owned [batch, G*G, vis_words]: line-of-sight masks of the walls variant (ppg_walls_changed)
     unsigned char *fetch_dev;   // library-owned staging buffer of ppg_fetch (NULL until first used)
@@ -366,8 +368,11 @@ static void ppg_coop_layout(ppg_handle *h) {
     P.Gp = P.G + 2 * P.pad;
     P.map_n = (P.Gp * P.Gp + 7) / 8 * 8;
     if (3 * P.map_n + P.pad * P.Gp + P.pad > 32767) return;             // 16-bit map offsets
+    // THREE maps (predators, prey, grass): channel 0 is computed from the window position (Env::coop_pieces).  The device reset lays
+    // its two arrays over them: G*G cells + the K placed entities, 16 bits each (Env::do_reset)
+    if (2 * (((c.grid_size * c.grid_size + 7) & ~7) + c.n_initial_predators + c.n_initial_prey + c.n_grass) > 3 * P.map_n) return;
     int off = 0;
-    P.off_map = off; off += 4 * P.map_n;
+    P.off_map = off; off += 3 * P.map_n;
     off = (off + 15) / 16 * 16;
     P.off_val = off; off += (196 + c.n_grass) * 8;      // packed sections (Env::SEC_Q, SEC_G)
     off = (off + 15) / 16 * 16;
@@ -380,8 +385,9 @@ static void ppg_coop_layout(ppg_handle *h) {
     // (blk_p, blk_q: the base parameters' -- 4 R^2, or the cell layout's)
     P.bp_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_p - 1) / (uint64_t)P.blk_p);
     P.bq_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_q - 1) / (uint64_t)P.blk_q);
-    // KParams::coop_tab: the observation descriptors of both species, then the channel-0 map of an empty grid
-    h->coop_tab_host.assign((size_t)(P.blk_p + P.blk_q) + (size_t)P.map_n / 4, 0u);
+    // KParams::coop_tab: the observation descriptors of both species
+    h->coop_tab_host.assign((size_t)(P.blk_p + P.blk_q), 0u);
+    const uint32_t desc_zero = 0xFFFF0000u | (8u << 4) | 8u;   // channel 0 at the observer's own cell: inside the grid, 0.0
     for (int t = 0; t < 2; ++t) {
         const int R = t ? P.Rq : P.Rp, o = (R - 1) / 2;
         uint32_t *out = h->coop_tab_host.data() + (t ? P.blk_p : 0);
@@ -390,18 +396,16 @@ static void ppg_coop_layout(ppg_handle *h) {
             if (P.obs_tiles) {   // the cell layout: position (ch, w) x cell element k
                 const int ce = ppg_cell_elems(R), pos = e / ce, w = pos % R;
                 ch = pos / R;
-                if (!ppg_cell_source(R, w, e % ce, i, j)) { out[e] = 0u; continue; }   // a zero: channel 0 at the observer's own cell
+                if (!ppg_cell_source(R, w, e % ce, i, j)) { out[e] = desc_zero; continue; }   // a zero
             }
-            const int moff = ch * P.map_n + (i - o) * P.Gp + (j - o);
+            if (ch == 0) {   // "outside the grid" (BASE:520-523): the window offsets, no map
+                out[e] = 0xFFFF0000u | ((uint32_t)(i - o + 8) << 4) | (uint32_t)(j - o + 8);
+                continue;
+            }
+            const int moff = (ch - 1) * P.map_n + (i - o) * P.Gp + (j - o);
             const int section = ch == 2 ? 66 : ch == 3 ? 66 + 129 : 0;     // Env::map_base of the cooperative kernels (SEC_Q, SEC_G)
             out[e] = ((uint32_t)moff & 0xFFFFu) | ((uint32_t)section << 16);
         }
-    }
-    {
-        unsigned char *m0 = (unsigned char *)(h->coop_tab_host.data() + P.blk_p + P.blk_q);
-        for (int x = 0; x < P.Gp; ++x)
-            for (int y = 0; y < P.Gp; ++y)
-                if (x < P.pad || x >= P.pad + P.G || y < P.pad || y >= P.pad + P.G) m0[x * P.Gp + y] = 65;   // Env::ONE_IDX
     }
     h->coop = P;
     h->coop_ok = 1;
@@ -531,6 +535,11 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     h->coop_ok = 0; h->coop_tab_dev = nullptr;
     h->forced = {0, 0, 0};
     h->envs_in_flight = 0;
+    {   // scheduling knobs of the experiments, read ONCE per handle (never per step)
+        const char *ev = getenv("PPG_COOP_WGS_PER_CU"), *pad = getenv("PPG_STEP_LDS_PAD");
+        h->coop_wgs_per_cu = ev ? atoi(ev) : 5;
+        h->step_lds_pad = pad ? atoi(pad) : 0;
+    }
     h->order_dev = nullptr;
     h->vis_dev = nullptr;
     h->fetch_dev = nullptr; h->fetch_cap = 0; h->fetch_hint = 0;
@@ -655,9 +664,9 @@ static ppg::KParams ppg_planned_step_params(const ppg_handle *h) {
         // then has fewer scattered write streams open at a time: 66.8 -> 68.2 M env-steps/s on the headline workload, the driver's
         // command 62.1 -> 63.0 M (profiles/r05/n_coop_workgroups_per_cu.txt; four: the same; three: -13 %).  Done by asking for LDS
         // the kernel does not use.  bfloat16 rows go the other way (ppgch_step: eight per CU).  PPG_COOP_WGS_PER_CU=0: no limit.
-        if (wp.nw == 4 && h->cfg.obs_dtype < 2) {
-            const char *ev = getenv("PPG_COOP_WGS_PER_CU");
-            const int per_cu = ev ? atoi(ev) : 5;
+        // (obs_f32: the handle's normalised row dtype, both generations -- 0 float64, 1 float32, 2 / 3 bfloat16)
+        if (wp.nw == 4 && h->base.obs_f32 < 2) {
+            const int per_cu = h->coop_wgs_per_cu;
             if (per_cu > 0 && per_cu < 16) {
                 const int floor_bytes = 160 * 1024 / (per_cu + 1) + 16;
                 if (P.lds_bytes < floor_bytes) P.lds_bytes = floor_bytes;
@@ -666,9 +675,7 @@ static ppg::KParams ppg_planned_step_params(const ppg_handle *h) {
         P.env_order = h->base.env_order;
         P.vis_masks = h->base.vis_masks;
     }
-    else if (const char *pad = getenv("PPG_STEP_LDS_PAD")) {   // experiment (profiles/r05/s_*): fewer envs per CU for the multi-wave kernels
-        P.lds_bytes += atoi(pad);
-    }
+    else P.lds_bytes += h->step_lds_pad;   // experiment (profiles/r05/s_*): fewer envs per CU for the multi-wave kernels
     P.helper_min_rows = wp.min_rows;
     return P;
 }

@@ -109,7 +109,8 @@ struct KParams {
     double hunger_safe[2], norm_prey_opp, norm_pred_danger, norm_grass_opp;   // DRV:76-86
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
-    int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass
+    int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass.  Cooperative kernels: THREE maps
+                      // (predators, prey, grass) -- channel 0 is a function of the window position and has no map (Env::chmap)
     int32_t off_val;  // float64 value table: [0]=0, 1+row predators, 1+cap_pred+row prey, then grass
     int32_t off_scr;  // 8-byte scratch per row (permutation / reset random words)
     int32_t off_lut;  // observation element descriptors (see Env::obs_row), predators then prey
@@ -158,10 +159,11 @@ struct KParams {
     int32_t off_ctl;           // from the start of dynamic LDS: control words (Env::CTL_*)
     int32_t blk_p, blk_q;      // elements per observation block: channels x Rp^2, channels x Rq^2 (or the cell layout's: obs_tiles)
     uint32_t bp_magic, bq_magic;  // ceil(2^32 / blk): element / blk == mulhi(element, magic)
-    const uint32_t *coop_tab;  // library-owned: blk_p + blk_q observation descriptors (bits 0-15 the signed map offset of element
-                               // (channel, i, j) of a species' (4,R,R) block relative to the observer's padded cell, channel * map_n
-                               // + (i - off) * Gp + (j - off); bits 16-31 the value-table section of the channel), then map_n / 4
-                               // words: the padded channel-0 map of an empty grid (halo cells = Env::ONE_IDX)
+    const uint32_t *coop_tab;  // library-owned: blk_p + blk_q observation descriptors.  Element (channel, i, j) of a species' (4,R,R)
+                               // block, channels 1-3: bits 0-15 the signed map offset relative to the observer's padded cell,
+                               // (channel - 1) * map_n + (i - off) * Gp + (j - off); bits 16-31 the value-table section of the channel.
+                               // Channel 0 ("outside the grid", BASE:520-523) has no map: bits 16-31 = 0xFFFF, bits 4-7 (i - off) + 8,
+                               // bits 0-3 (j - off) + 8 -- the element is 1.0 iff (x + i - off, y + j - off) lies outside the grid
 };
 
 // ---------------------------------------------------------------------------------
@@ -283,7 +285,8 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // run of elements; piece p of the workgroup goes to wave p mod NW).  Every store instruction writes a full 1 KB, the rows of
 // the workgroup's envs are balanced over its waves at piece grain, every wave runs a transition (no idle helper waves on a full
 // GPU) and the waves of a workgroup write neighbouring addresses at the same time.  Cell maps are padded (KParams::pad), so no
-// window element needs a bounds check: channel 0's halo points at a constant 1.0 (BASE:522-523), the other halos at 0.0.
+// window element of channels 1-3 needs a bounds check (their halos read 0.0); channel 0 (BASE:520-523: 1.0 outside the grid) is
+// computed from the window position and has NO map -- three maps per env instead of four (round 6: 64x64 grids 24.1 -> 18.1 KB).
 template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, int NW, class KP, class KC, bool COOP = false>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
@@ -363,8 +366,8 @@ struct Env {
     // Index of an entity's energy in the LDS value table.  16-bit maps: [0] = 0.0, then all row slots, then the grass patches.
     // MAP8: one section per channel, each led by a zero entry so that "map entry + section base" needs no test for an empty cell:
     // [0] = 0.0 | predators 1..64 || [129] = 0.0 | prey 130..257 || [258] = 0.0 | grass 259..513  (section base = 129 * (channel - 1)).
-    // The cooperative kernels pack the sections (LDS decides how many envs a CU holds): [0] = 0.0 | predators 1..64 | [65] = 1.0 (the
-    // "outside the grid" value of channel 0's halo) || [66] = 0.0 | prey 67..194 || [195] = 0.0 | grass 196...
+    // The cooperative kernels pack the sections (LDS decides how many envs a CU holds): [0] = 0.0 | predators 1..64 | [65] unused ||
+    // [66] = 0.0 | prey 67..194 || [195] = 0.0 | grass 196...
     static constexpr int SEC_Q = COOP ? 66 : 129, SEC_G = SEC_Q + 129;
     PPG_MEMBER int validx(int r, int k) const { return MAP8 ? (r ? SEC_Q + 1 + row_of(r, k) : 1 + k) : 1 + slot_of(r, k); }
     PPG_MEMBER int validx_row(int type, int row) const { return MAP8 ? (type ? SEC_Q + 1 + row : 1 + row) : 1 + (type ? P.cap_pred + row : row); }
@@ -379,7 +382,9 @@ struct Env {
         const int x = (int)wv::mulhi((uint32_t)c, C.g_magic);
         return (x + P.pad) * P.Gp + (c - x * P.G) + P.pad;
     }
-    PPG_MEMBER map_t *chmap(int ch) const { return map + ch * P.map_n; }
+    // the cell map of channel ch (1 predators, 2 prey, 3 grass; 0 = the all-zero map of channel 0, which the cooperative kernels do not have)
+    PPG_MEMBER map_t *chmap(int ch) const { return map + (COOP ? ch - 1 : ch) * P.map_n; }
+    static constexpr int N_MAPS = COOP ? 3 : 4;
     // what a map entry of channel ch means as an index into the value table, and back (MAP8: channel-local 8-bit indices)
     PPG_MEMBER int map_base(int ch) const { return MAP8 ? (ch == 2 ? SEC_Q : ch == 3 ? SEC_G : 0) : 0; }
     PPG_MEMBER map_t to_map(int ch, int vidx) const { return (map_t)(vidx - map_base(ch)); }
@@ -595,11 +600,7 @@ struct Env {
 
     // maps -> all zero, observation descriptors -> LDS
     PPG_MEMBER void init_lds(const Pre &p) {
-        if (COOP) {   // (maps: coop_tab_store)
-            if (ln == 0) val[ONE_IDX] = 1.0;
-        } else {
-            init_maps();
-        }
+        if (!COOP) init_maps();   // (COOP: coop_tab_store)
         if (COOP) {
         } else if (FASTOBS) {
 #pragma unroll
@@ -615,43 +616,28 @@ struct Env {
             for (int i = ln; i < C.n_wall_words; i += 64) wallw[i] = C.wall_bits[(size_t)b * C.n_wall_words + i];
     }
 
-    // all four cell maps empty.  COOP: plus the halo of channel 0 -> the constant 1.0 of the value table ("outside the grid",
-    // BASE:520-523); the halos of channels 1-3 stay 0 -> the zero entry of their section.
-    static constexpr int ONE_IDX = 65;   // a free entry of the predator section (rows use 1..64)
+    // all cell maps empty (four; the cooperative kernels' three: the halos of channels 1-3 stay 0 -> the zero entry of their section)
     PPG_MEMBER void init_maps() {
         uint32_t *m32 = (uint32_t *)map;
-        const int n32 = 4 * P.map_n * (int)sizeof(map_t) / 4;
-        if (COOP) {   // (channel 0 from the template behind the descriptors in C.coop_tab; the start of a step has it prefetched: TabPre)
-            const uint32_t *tmpl = C.coop_tab + C.blk_p + C.blk_q;
-            const int n0 = P.map_n / 4;
-            for (int i = ln; i < n32; i += 64) m32[i] = i < n0 ? tmpl[i] : 0u;
-        } else {
-            for (int i = ln; i < n32; i += 64) m32[i] = 0u;
-        }
+        const int n32 = N_MAPS * P.map_n * (int)sizeof(map_t) / 4;
+        for (int i = ln; i < n32; i += 64) m32[i] = 0u;
     }
-    // COOP: the workgroup's descriptor table and this env's channel-0 map come from C.coop_tab.  Their loads are issued in front
-    // of everything else and held in registers (up to LUT_REGS / TMPL_REGS words per lane, enough for 7x7 / 9x9 windows on a
-    // 25x25 grid; larger geometries finish with plain copy loops), so the tables cost no memory round trip of their own.
-    static constexpr int LUT_REGS = 9, TMPL_REGS = 5;
-    struct TabPre { uint32_t l[LUT_REGS], m[TMPL_REGS]; };
+    // COOP: the workgroup's descriptor table comes from C.coop_tab.  Its loads are issued in front of everything else and held in
+    // registers (up to LUT_REGS words per lane, enough for 7x7 / 9x9 windows; larger geometries finish with a plain copy loop), so
+    // the table costs no memory round trip of its own.
+    static constexpr int LUT_REGS = 9;
+    struct TabPre { uint32_t l[LUT_REGS]; };
     PPG_MEMBER void coop_tab_issue(TabPre &t) const {
-        const int nl = C.blk_p + C.blk_q, nm = P.map_n / 4;
+        const int nl = C.blk_p + C.blk_q;
 #pragma unroll
         for (int u = 0; u < LUT_REGS; ++u) { t.l[u] = 0; if (u * 64 + ln < nl) t.l[u] = C.coop_tab[u * 64 + ln]; }
-#pragma unroll
-        for (int u = 0; u < TMPL_REGS; ++u) { t.m[u] = 0; if (u * 64 + ln < nm) t.m[u] = C.coop_tab[nl + u * 64 + ln]; }
     }
     PPG_MEMBER void coop_tab_store(const TabPre &t) {
-        const int nl = C.blk_p + C.blk_q, nm = P.map_n / 4;
-        uint32_t *m32 = (uint32_t *)map;
-        const int n32 = P.map_n;   // (four 8-bit maps of map_n entries)
-        for (int i = nm + ln; i < n32; i += 64) m32[i] = 0u;   // channels 1-3: empty
+        const int nl = C.blk_p + C.blk_q;
+        init_maps();
 #pragma unroll
         for (int u = 0; u < LUT_REGS; ++u) if (u * 64 + ln < nl) lut2[u * 64 + ln] = t.l[u];
-#pragma unroll
-        for (int u = 0; u < TMPL_REGS; ++u) if (u * 64 + ln < nm) m32[u * 64 + ln] = t.m[u];
         for (int i = LUT_REGS * 64 + ln; i < nl; i += 64) lut2[i] = C.coop_tab[i];
-        for (int i = TMPL_REGS * 64 + ln; i < nm; i += 64) m32[i] = C.coop_tab[nl + i];
     }
 
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
@@ -940,9 +926,10 @@ struct Env {
         uint32_t wish[T];
         uint64_t moved[T], sp[T];
         const bool costly = GEN2 && C.move_factor != 0.0;
-        // distance * factor per squared displacement (RQ:310-312), once per wavefront in the LDS scratch (behind the explicit-order
-        // path's row lists) instead of a chain of selects per row register
-        double *cost = (double *)scr + 32;
+        // distance * factor per squared displacement (RQ:310-312), once per wavefront in the LDS scratch instead of a chain of selects
+        // per row register.  BEHIND the explicit-order path's row lists (publish_order: predators at bytes 0..127, prey at
+        // 128..128 + 2 * cap_prey <= 640): bytes 640..895 of a scratch that is at least 1024 bytes in every layout (ppg_host.h).
+        double *cost = (double *)scr + 80;
         if (costly) {
             if (ln < 32) cost[ln] = ln < 19 ? move_distance(ln) * C.move_factor : 0.0;   // (rows not in use index anything below 32)
             wv::sync();
@@ -1503,11 +1490,12 @@ struct Env {
     }
 
     // ---- COOP: observations as whole 1 KB pieces of an env's run of live rows ---------------------------------
-    // The live rows of `type` of the env whose LDS region is `region` are listed in `list` (n_live words: row << 16 | padded
-    // cell of the agent); concatenated they are a run of n_live * blk elements.  Piece p is elements 128 p .. 128 p + 127 of
+    // The live rows of `type` of the env whose LDS region is `region` are listed in `list` (n_live words: row << 16 | x << 8 | y
+    // of the agent); concatenated they are a run of n_live * blk elements.  Piece p is elements 128 p .. 128 p + 127 of
     // the run: lane l produces elements 128 p + 2l and + 1 (blk is even: a pair never straddles two rows) -- BASE:511-526 per
-    // element: value = val[map[cell + offset of the element] + section of its channel]; the padded maps make the window
-    // clipping of _obs_clip (BASE:528-539) implicit.  This wavefront writes pieces first, first + stride, ...
+    // element: channels 1-3: value = val[map[cell + offset of the element] + section of its channel]; the padded maps make the window
+    // clipping of _obs_clip (BASE:528-539) implicit.  Channel 0: 1.0 iff the element's cell lies outside the grid (BASE:520-523),
+    // from the agent's position and the element's window offsets alone.  This wavefront writes pieces first, first + stride, ...
     PPG_MEMBER void coop_pieces(int type, const unsigned char *region, const uint32_t *list, int n_live, int eb, int first, int stride) {
         const map_t *m = (const map_t *)(region + P.off_map);
         const double *vt = (const double *)(region + P.off_val);
@@ -1517,26 +1505,34 @@ struct Env {
         const int total = n_live * blk;
         const size_t obase = (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;
         constexpr int U = 2;   // pieces in flight per wavefront: the three dependent LDS lookups of one hide behind the other's
-        const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
+        const uint32_t G = (uint32_t)P.G;
         for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
             uint32_t o[U], i0[U], i1[U];
-            bool on[U];
+            bool on[U], out0[U], out1[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s0 = (p0 + u * stride) * 128 + 2 * ln;
                 on[u] = s0 < total;
                 const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
                 const uint32_t i = wv::mulhi(sc, magic), w = sc - i * (uint32_t)blk;
-                const uint32_t ent = on[u] ? list[i] : safe_cell;
+                const uint32_t ent = on[u] ? list[i] : 0u;   // (lanes behind the end of the run look at cell (0,0): inside the maps)
                 const uint2 d = *(const uint2 *)(L + w);
-                const int pc = (int)(ent & 0xFFFFu);
-                i0[u] = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)] + (d.x >> 16);
-                i1[u] = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)] + (d.y >> 16);
+                const uint32_t ax = (ent >> 8) & 255u, ay = ent & 255u;
+                const int pc = ((int)ax + P.pad) * P.Gp + (int)ay + P.pad;
+                const bool z0 = (d.x >> 16) == 0xFFFFu, z1 = (d.y >> 16) == 0xFFFFu;   // channel 0: no map
+                // (a channel-0 descriptor's low bits as a map offset stay inside the three maps: no lane reads outside LDS)
+                const uint32_t m0 = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)], m1 = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)];
+                i0[u] = z0 ? 0u : m0 + (d.x >> 16);
+                i1[u] = z1 ? 0u : m1 + (d.y >> 16);
+                // unsigned compares: a coordinate below 0 wraps far above G
+                out0[u] = z0 && (ax + ((d.x >> 4) & 15u) - 8u >= G || ay + (d.x & 15u) - 8u >= G);
+                out1[u] = z1 && (ax + ((d.y >> 4) & 15u) - 8u >= G || ay + (d.y & 15u) - 8u >= G);
                 o[u] = (ent >> 16) * (uint32_t)blk + w;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double v0 = vt[i0[u]], v1 = vt[i1[u]];
+                const double t0 = vt[i0[u]], t1 = vt[i1[u]];   // (channel 0 inside the grid: entry 0 = 0.0)
+                const double v0 = out0[u] ? 1.0 : t0, v1 = out1[u] ? 1.0 : t1;
                 if (!on[u]) continue;
                 store_obs_pair(type ? P.obs_prey : P.obs_pred, P.obs_f32, obase + o[u], v0, v1);
             }
@@ -1546,7 +1542,7 @@ struct Env {
     PPG_MEMBER void obs_row_coop(int type, int j, uint32_t s_xy) {
         wv::sync();   // LDS writes of the sequential phases -> visible
         uint32_t *mid = ctl + CTL_MID + wave_idx;
-        if (ln == 0) mid[0] = ((uint32_t)j << 16) | (uint32_t)cell_of(s_xy);
+        if (ln == 0) mid[0] = ((uint32_t)j << 16) | s_xy;
         wv::sync();
         coop_pieces(type, (const unsigned char *)map - P.off_map, mid, 1, b, 0, 1);
         wv::sync();   // reads done before the caller touches the maps again
@@ -1560,7 +1556,7 @@ struct Env {
         for (int r = 0; r < T; ++r) {
             const int type = type_of(r);
             if ((alive[r] >> ln) & 1ull)
-                lst[(type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])] = ((uint32_t)row_of(r, ln) << 16) | (uint32_t)cell_of(xy[r]);
+                lst[(type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])] = ((uint32_t)row_of(r, ln) << 16) | xy[r];
             n[type] += wv::popc(alive[r]);
         }
         if (ln == 0) {
@@ -1912,17 +1908,24 @@ struct Env {
     PPG_MEMBER bool fallback_spawn(int type, int cid, uint32_t &child_xy) {
         // BASE:759-764.  The reference draws from the unseeded global np.random; the build's
         // contract (oracle/ppg_oracle.c:find_spawn) is the k-th free cell in x-major order.
-        map_t *occ = chmap(0);
+        // the occupancy board: the all-zero map of channel 0; the cooperative kernels (no such map) borrow bit 7 of the predator
+        // map's entries (8-bit maps, predator entries are <= 65) for the length of this function
+        static_assert(!COOP || MAP8, "the cooperative kernels run on 8-bit maps");
+        map_t *occ = COOP ? chmap(1) : chmap(0);
+        constexpr uint32_t OCC = COOP ? 0x80u : 1u;
         wv::sync();
 #pragma unroll
         for (int r = 0; r < T; ++r)
-            if ((alive[r] >> ln) & 1ull) occ[cell_of(xy[r])] = 1;
+            if ((alive[r] >> ln) & 1ull) {   // (two agents on one cell write the same byte value)
+                map_t *at = occ + cell_of(xy[r]);
+                *at = (map_t)(COOP ? ((uint32_t)*at | OCC) : OCC);
+            }
         wv::sync();
         const int n = P.G * P.G;
         int nfree = 0;
         for (int base = 0; base < n; base += 64) {
             const int c = base + ln;
-            nfree += wv::popc(wv::ballot(c < n && occ[cell_index(c < n ? c : 0)] == 0));
+            nfree += wv::popc(wv::ballot(c < n && ((uint32_t)occ[cell_index(c < n ? c : 0)] & OCC) == 0u));
         }
         bool ok = false;
         if (nfree > 0) {
@@ -1932,7 +1935,7 @@ struct Env {
             int kth = (int)wv::mulhi(wv::first(w[0]), (uint32_t)nfree);
             for (int base = 0; base < n; base += 64) {
                 const int c = base + ln;
-                uint64_t fm = wv::ballot(c < n && occ[cell_index(c < n ? c : 0)] == 0);
+                uint64_t fm = wv::ballot(c < n && ((uint32_t)occ[cell_index(c < n ? c : 0)] & OCC) == 0u);
                 const int cnt = wv::popc(fm);
                 if (kth < cnt) {
                     for (int s = 0; s < kth; ++s) fm &= fm - 1;
@@ -1948,7 +1951,10 @@ struct Env {
         wv::sync();
 #pragma unroll
         for (int r = 0; r < T; ++r)
-            if ((alive[r] >> ln) & 1ull) occ[cell_of(xy[r])] = 0;
+            if ((alive[r] >> ln) & 1ull) {
+                map_t *at = occ + cell_of(xy[r]);
+                *at = (map_t)(COOP ? ((uint32_t)*at & ~OCC) : 0u);
+            }
         wv::sync();
         return ok;
     }
@@ -2326,8 +2332,11 @@ struct Env {
         episode = new_episode;
         const int n = P.G * P.G;
         const int K = C.n_init_pred + C.n_init_prey + C.n_grass;
-        // two arrays of G*G 16-bit cell indices over the map area (MAP8: the four 8-bit maps together are exactly that large)
-        uint16_t *perm = MAP8 ? (uint16_t *)map : (uint16_t *)chmap(1), *ent = MAP8 ? (uint16_t *)map + P.map_n : (uint16_t *)chmap(2);
+        // two arrays of 16-bit cell indices over the map area: the G*G cells, and the K placed entities (MAP8: the four 8-bit maps
+        // together hold two arrays of map_n >= G*G entries; the cooperative kernels' three maps hold G*G + K entries -- ppg_coop_layout
+        // admits only configurations where they do)
+        uint16_t *perm = MAP8 ? (uint16_t *)map : (uint16_t *)chmap(1);
+        uint16_t *ent = COOP ? (uint16_t *)map + ((n + 7) & ~7) : MAP8 ? (uint16_t *)map + P.map_n : (uint16_t *)chmap(2);
         uint32_t *rnd = (uint32_t *)scr;  // 256 words per round
         wv::sync();
         int n_free = n;

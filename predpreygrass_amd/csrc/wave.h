@@ -73,8 +73,11 @@ PPG_DEVICE double shfl_xor_f64(double v, int mask) {
 // would also drain vmcnt(0), i.e. wait for every outstanding observation store to reach HBM.)
 PPG_DEVICE void sync() { __asm__ volatile("" ::: "memory"); }
 
-// Count one more on an 8- or 16-bit LDS counter that other lanes may be counting on too (ds_add_u32 on the word that holds it;
-// a counter never reaches its field's width: at most capacity + 1 agents touch a cell).
+// Count one more on an 8- or 16-bit LDS counter that other lanes may be counting on too (ds_add_u32 on the word that holds it).
+// A counter must never reach its field's width -- the add would carry into the neighbouring cell's counter, which the CPU wave
+// emulator (a plain increment of the field) cannot reproduce.  The one caller (Env::move) counts, per species channel, the live
+// agents standing on a cell plus the agents that want to move INTO it: disjoint sets of rows of one species, so at most its row
+// capacity -- <= 128 on 8-bit maps (Env::MAP8 = at most two prey row registers), <= 256 on 16-bit maps.
 PPG_DEVICE void lds_count(uint8_t *p) {
     const uint32_t low = (uint32_t)(uintptr_t)p & 3u;   // (the word's address stays derived from p: the access stays a DS instruction)
     __hip_atomic_fetch_add((uint32_t *)(p - low), 1u << (8u * low), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

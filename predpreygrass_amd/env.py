@@ -141,7 +141,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
 
     def _stage(self, action_dict):
         """Validate an action dict like the reference would and write it into this env's row of the
-        batch's action tensor.  Returns (ranks uint8 [S], dict order == row order)."""
+        batch's action tensor.  Returns (acting slots in dict order, dict order == row order)."""
         b, i = self._b, self._i
         where = self._where   # name -> (type, row) of the agents alive after the last call (_collect)
         a = b.stage_actions(i)     # this env's row of the pinned host mirror of the action tensor
@@ -168,28 +168,32 @@ class PredPreyGrass(_MultiAgentEnvBase):
             last[ty] = row
         if slots:
             a[slots] = acts
-        rk = None
-        if not in_row_order:   # position of each acting row within its type's action sequence (ppg_step_ordered)
-            ranks = np.zeros((b.S,), dtype=np.uint8)
-            count = [0, 0]
-            for s_ in slots:
-                ty = PREDATOR if s_ < cp else PREY
-                ranks[s_] = count[ty]
-                count[ty] += 1
-            rk = torch.from_numpy(ranks)
-        return rk, in_row_order
+        return slots, in_row_order
+
+    def _ranks(self, slots):
+        """Position of each acting row within its type's action sequence (ppg_step_ordered): uint8 [S].  Needed for EVERY env of a
+        launch that goes through the explicit-order kernel, also for the envs whose dict happens to be in row order."""
+        b = self._b
+        cp = b.pred_capacity
+        ranks = np.zeros((b.S,), dtype=np.uint8)
+        count = [0, 0]
+        for s_ in slots:
+            ty = PREDATOR if s_ < cp else PREY
+            ranks[s_] = count[ty]
+            count[ty] += 1
+        return torch.from_numpy(ranks)
 
     def step(self, action_dict):
         """predpreygrass_rllib_env.py:219-473."""
         b, i = self._b, self._i
         if b.batch_size != 1:
             raise RuntimeError("step() of a view into a shared batch: use VectorPredPreyGrass.step")
-        rk, in_row_order = self._stage(action_dict)
+        slots, in_row_order = self._stage(action_dict)
         b.upload_actions()   # one host->device copy; the step and the fetch behind it are ordered on the same stream
         if in_row_order:
             b.step()
         else:
-            b.step(act_rank=rk[None].to(b.device))
+            b.step(act_rank=self._ranks(slots)[None].to(b.device))
         return self._collect(after_reset=False)
 
     def close(self):
@@ -465,21 +469,23 @@ class VectorPredPreyGrass:
         if len(action_dicts) != self.num_envs:
             raise ValueError("one action dict per env")
         b = self.batch
-        ranks = torch.zeros((self.num_envs, b.S), dtype=torch.uint8)
+        staged = [None] * self.num_envs
         all_in_order = True
         for i, (e, ad) in enumerate(zip(self.envs, action_dicts)):
             done = bool(int(e._tables["env_state"][0][_abi.ENV_FLAGS]) & _abi.ENVF_DONE)
             if self.auto_reset and done:
                 b.stage_actions(i)[:] = _abi.ACTION_NONE  # ignored: this call resets the env
                 continue
-            rk, in_order = e._stage(ad)
-            if rk is not None:
-                ranks[i] = rk
+            staged[i], in_order = e._stage(ad)
             all_in_order = all_in_order and in_order
         b.upload_actions()   # ONE host->device copy for all envs
         if all_in_order:
             b.step(auto_reset=self.auto_reset)
-        else:
+        else:   # one env out of row order sends the whole launch through ppg_step_ordered: every env needs its ranks
+            ranks = torch.zeros((self.num_envs, b.S), dtype=torch.uint8)
+            for i, (e, slots) in enumerate(zip(self.envs, staged)):
+                if slots is not None:
+                    ranks[i] = e._ranks(slots)
             b.step(auto_reset=self.auto_reset, act_rank=ranks.to(b.device))
         return self._collect_all(after_reset=False)
 

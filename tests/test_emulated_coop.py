@@ -144,3 +144,18 @@ def test_allocation_choices_are_ignored_without_a_gpu():
             assert torch.equal(getattr(x, n), getattr(y, n)), n
     b.subs[0].close()
     b.subs[0].close()   # idempotent
+
+
+@pytest.mark.parametrize("waves,coop", [(4, 2), (4, 4)])
+def test_cooperative_spawn_fallback_on_a_crowded_grid(waves, coop):
+    """Round 6: the cooperative kernels have no channel-0 map; the spawn fallback (BASE:759-764: all four neighbours taken) marks
+    occupied cells in bit 7 of the predator map's entries instead and must leave that map as it found it.  A 6x6 grid that fills up:
+    every call against the oracle (observations included), with fallback spawns actually happening."""
+    cfg = {**config_env, "grid_size": 6, "n_initial_active_predator": 6, "n_initial_active_prey": 14, "initial_num_grass": 10,
+           "max_steps": 60, "energy_gain_per_step_grass": 1.5, "energy_loss_per_step_prey": 0.01, "energy_loss_per_step_predator": 0.02,
+           "prey_creation_energy_threshold": 3.5, "predator_creation_energy_threshold": 6.0,
+           "predator_obs_range": 5, "prey_obs_range": 7}
+    env = maker(waves, coop, prey_capacity=128)(cfg, 5)
+    rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=77, n_calls=90, check_grid=True)
+    es = env.env_state.cpu().numpy()
+    assert es[:, _abi.ENV_FALLBACK_SPAWNS].sum() > 0 or (es[:, _abi.ENV_STATUS] & _abi.STATUS_FALLBACK_SPAWN).any()

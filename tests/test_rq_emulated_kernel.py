@@ -155,3 +155,28 @@ def test_fused_rollout_needs_a_cooperative_plan_and_no_walls():
     wenv.reset()
     with pytest.raises(RuntimeError, match="cooperative"):
         wenv.rollout(3, random_actions=True)
+
+
+def test_identity_act_rank_equals_no_rank_with_more_than_64_acting_prey():
+    """the explicit-order path's prey row list (publish_order) reaches past byte 256 of the LDS scratch once more
+    than 64 prey act; the move-cost table must live behind it.  110 prey, capacity 128, move cost on: identity ranks through
+    ppg_step_ordered give what the plain step gives."""
+    cfg = dict(RQGoldenCase("rq_base_seed3").config, move_energy_cost_factor=0.01, n_initial_active_type_1_prey=110,
+               n_possible_type_1_prey=400, n_initial_active_type_2_prey=0, grid_size=25)
+    a, b = make_env(cfg, 2, seed=5, prey_capacity=128), make_env(cfg, 2, seed=5, prey_capacity=128)
+    a.reset()
+    b.reset()
+    gen = torch.Generator().manual_seed(4)
+    for t in range(6):
+        act = torch.randint(0, 9, (2, a.S), generator=gen, dtype=torch.int8)
+        rows = a.host_tables()
+        n_pred, n_prey = rows["env_state"][:, _abi.ENV_N_PRED_ROWS], rows["env_state"][:, _abi.ENV_N_PREY_ROWS]
+        assert int(n_prey.min()) > 64
+        rank = torch.zeros((2, a.S), dtype=torch.uint8)
+        for e in range(2):   # identity: rank = position among the acting (= live) rows of the type, in row order
+            for lo, n in ((0, int(n_pred[e])), (a.pred_capacity, int(n_prey[e]))):
+                live = (rows["row_flags"][e, lo: lo + n] & _abi.ROW_DIED) == 0
+                rank[e, lo: lo + n] = torch.from_numpy((np.cumsum(live) - 1).clip(0).astype(np.uint8))
+        a.step(act)
+        b.step(act, act_rank=rank)
+        _same_tables(a, b)

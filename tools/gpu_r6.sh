@@ -1,0 +1,30 @@
+#!/bin/bash
+# On the GPU box (round 6): one parameterised runner for the round's measurement steps.  usage: tools/gpu_r6.sh TAG STEP [STEP ...]
+#   tests            the GPU test suite
+#   ab:<workload>:<streams>:<plan>[,<plan>...]     tools/ab_plans.py, plans as name=waves.min_rows.coop (e.g. pair=2.0.0,coop42=4.0.2)
+#   lib:<workload>:<steps>:<rounds>:name=lib.so[,name=lib.so...]   alternating-process A/B of library builds (tools/gpu_lib_ab.sh)
+#   bench:<name>:<bench.py arguments, comma separated>      one bench.py run, its JSON line kept
+cd "$GRAFT_REPO_ROOT" || exit 1
+tag=$1; shift
+mkdir -p gpurun_out
+for step in "$@"; do
+  kind=${step%%:*}; rest=${step#*:}
+  case $kind in
+    tests)
+      python3 -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc $?" >> gpurun_out/${tag}_pytest_gpu.log
+      tail -3 gpurun_out/${tag}_pytest_gpu.log ;;
+    ab)
+      IFS=: read -r wl streams plans <<< "$rest"
+      args=$(echo "$plans" | tr ',' ' ' | sed 's/=/:/g; s/\./,/g')
+      python3 tools/ab_plans.py --workload $wl --streams $streams --rounds 5 --segment 200 $args > gpurun_out/${tag}_ab_${wl}_s${streams}.txt 2>&1
+      cat gpurun_out/${tag}_ab_${wl}_s${streams}.txt | tail -8 ;;
+    lib)
+      IFS=: read -r wl steps rounds libs <<< "$rest"
+      bash tools/gpu_lib_ab.sh $tag $rounds $wl $steps $(echo "$libs" | tr ',' ' ') | tail -12 ;;
+    bench)
+      IFS=: read -r name bargs <<< "$rest"
+      python3 bench.py $(echo "$bargs" | tr ',' ' ') > gpurun_out/${tag}_bench_${name}.json.log 2> gpurun_out/${tag}_bench_${name}.err
+      grep '^{' gpurun_out/${tag}_bench_${name}.json.log | tail -1 | cut -c1-600 ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
