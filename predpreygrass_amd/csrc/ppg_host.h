@@ -423,9 +423,9 @@ static int ppg_coop_lds_bytes(const ppg_handle *h, int e) {
 //  - walls / drive variants are bound by per-row work: 4 waves at every batch size (4096 envs: 1.7-1.9x), always all of
 //    them: a second, wave-0-only copy of their large observation code in the same kernel cost 10-15 % (Env::ADAPTIVE_HELPERS);
 //  - a FULL GPU (> 3072 envs in flight) runs as fast as the slowest env of a launch lets it, and that is always a heavy one.  Base
-//    family: the cooperative kernels (two envs per four-wave workgroup, Env's COOP) where the configuration has them and six
-//    workgroups fit a CU's LDS; else a PAIR of waves per env (64x64 grids: 8-bit maps admit 7-8 envs per CU and a pair fills the 16
-//    wave slots, +27 %); second generation (float32 observations: no longer store-bound): four waves, helpers only for envs
+//    family: the cooperative kernels (two envs per four-wave workgroup, Env's COOP) where the configuration has them and four
+//    workgroups fit a CU's LDS (64x64 grids with 7x7 windows just do); else a PAIR of waves per env (8-bit maps; a pair fills the 16
+//    wave slots, +27 % over one wave); second generation (float32 observations: no longer store-bound): four waves, helpers only for envs
 //    with >= 72 rows -- the stragglers -- +25 % (48.0 -> 60.2 M env-steps/s), where helpers for every env cost 6 %.
 // The plan is computed when the handle is created and when ppg_set_envs_in_flight / ppg_set_wave_plan change its inputs -- never
 // per step.  ppg_set_wave_plan overrides it (tests, A/B tools).
@@ -469,7 +469,10 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
     } else if (h->gen2 && !(h->coop_ok && ppg_coop_lds_bytes(h, 2) * 6 <= 160 * 1024)) {
         p.nw = 4;
         p.min_rows = 72;
-    } else if (h->coop_ok && ppg_coop_lds_bytes(h, 2) * 6 <= 160 * 1024) {
+    } else if (h->coop_ok && ppg_coop_lds_bytes(h, 2) * (h->gen2 ? 6 : 4) <= 160 * 1024) {
+        // (base family from FOUR workgroups per CU on -- round 6, 64x64 grids / BASELINE config 4: three cell maps per env instead of
+        // four make it 4 x 2 envs per CU, 60.0 us per 4096-env step against 63.8 for the pair kernel at the same eight envs per CU,
+        // interleaved in one process: profiles/r06/a_*)
         // (second generation, float32 observations, 3 sub-batches on one box: 56.5 us per 4096-env step against 68.1 for its
         // four-wave kernel with helpers from 72 rows; four envs per workgroup 71.7, three 63.7)
         // cooperative kernels, TWO envs per four-wave workgroup (six workgroups = 24 waves = 12 envs per CU): two waves run a

@@ -619,8 +619,11 @@ struct Env {
     // all cell maps empty (four; the cooperative kernels' three: the halos of channels 1-3 stay 0 -> the zero entry of their section)
     PPG_MEMBER void init_maps() {
         uint32_t *m32 = (uint32_t *)map;
-        const int n32 = N_MAPS * P.map_n * (int)sizeof(map_t) / 4;
-        for (int i = ln; i < n32; i += 64) m32[i] = 0u;
+        const int n32 = N_MAPS * P.map_n * (int)sizeof(map_t) / 4, n128 = n32 >> 2;
+        uint4 *m128 = (uint4 *)map;   // (the map area starts a 16-byte aligned LDS region: ds_write_b128 -- 64x64 grids zero 14.7 KB per step)
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = ln; i < n128; i += 64) m128[i] = zero;
+        for (int i = 4 * n128 + ln; i < n32; i += 64) m32[i] = 0u;
     }
     // COOP: the workgroup's descriptor table comes from C.coop_tab.  Its loads are issued in front of everything else and held in
     // registers (up to LUT_REGS words per lane, enough for 7x7 / 9x9 windows; larger geometries finish with a plain copy loop), so
@@ -1514,20 +1517,22 @@ struct Env {
                 const int s0 = (p0 + u * stride) * 128 + 2 * ln;
                 on[u] = s0 < total;
                 const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
-                const uint32_t i = wv::mulhi(sc, magic), w = sc - i * (uint32_t)blk;
+                const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
                 const uint32_t ent = on[u] ? list[i] : 0u;   // (lanes behind the end of the run look at cell (0,0): inside the maps)
                 const uint2 d = *(const uint2 *)(L + w);
                 const uint32_t ax = (ent >> 8) & 255u, ay = ent & 255u;
-                const int pc = ((int)ax + P.pad) * P.Gp + (int)ay + P.pad;
+                const int pc = (int)(wv::mul24(ax + (uint32_t)P.pad, (uint32_t)P.Gp) + ay + (uint32_t)P.pad);
                 const bool z0 = (d.x >> 16) == 0xFFFFu, z1 = (d.y >> 16) == 0xFFFFu;   // channel 0: no map
                 // (a channel-0 descriptor's low bits as a map offset stay inside the three maps: no lane reads outside LDS)
                 const uint32_t m0 = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)], m1 = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)];
                 i0[u] = z0 ? 0u : m0 + (d.x >> 16);
                 i1[u] = z1 ? 0u : m1 + (d.y >> 16);
-                // unsigned compares: a coordinate below 0 wraps far above G
-                out0[u] = z0 && (ax + ((d.x >> 4) & 15u) - 8u >= G || ay + (d.x & 15u) - 8u >= G);
-                out1[u] = z1 && (ax + ((d.y >> 4) & 15u) - 8u >= G || ay + (d.y & 15u) - 8u >= G);
-                o[u] = (ent >> 16) * (uint32_t)blk + w;
+                // outside the grid: unsigned compares (a coordinate below 0 wraps far above G); computed for every lane, no branches
+                const uint32_t tx0 = ax + ((d.x >> 4) & 15u) - 8u, ty0 = ay + (d.x & 15u) - 8u;
+                const uint32_t tx1 = ax + ((d.y >> 4) & 15u) - 8u, ty1 = ay + (d.y & 15u) - 8u;
+                out0[u] = z0 & ((tx0 > ty0 ? tx0 : ty0) >= G);
+                out1[u] = z1 & ((tx1 > ty1 ? tx1 : ty1) >= G);
+                o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

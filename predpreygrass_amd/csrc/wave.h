@@ -91,6 +91,8 @@ PPG_DEVICE void lds_count(uint16_t *p) {
 PPG_DEVICE void drain_loads() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 PPG_DEVICE uint32_t mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+// low 32 bits of the product of two values below 2^24 (v_mul_u32_u24: full rate, where v_mul_lo_u32 runs at a quarter of it)
+PPG_DEVICE uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 PPG_DEVICE int popc(uint64_t m) { return __popcll(m); }
 PPG_DEVICE int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }  // m != 0
 

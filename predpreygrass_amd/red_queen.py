@@ -363,13 +363,15 @@ class PredPreyGrass(_MultiAgentEnvBase):
     transition running on the GPU.  `reset(seed=s)` places the agents where the reference does and seeds the same
     PCG64 stream for the reproduction uniforms, so an episode driven with the same actions is identical.
 
-    Not carried over: the per-agent analytics the reference accumulates on the side (unique_agent_stats,
-    per_step_agent_data, death statistics, offspring lists, agent_ages)."""
+    The per-agent analytics the reference accumulates on the side (``unique_agent_stats``, ``death_agents_stats``,
+    ``per_step_agent_data``, ``agent_ages``, offspring lists ... RQ:99-116) are kept by a host-side mirror
+    (rq_analytics.AgentAnalytics) from the tables every call fetches anyway; ``analytics=False`` switches them off."""
 
     _walls = False                 # walls_occlusion.PredPreyGrass sets this
     _require_all_actions = True    # RQ:279 fails for a live agent without an action
 
-    def __init__(self, config=None, *, device=None, prey_capacity: int | None = None, _library=None):
+    def __init__(self, config=None, *, device=None, prey_capacity: int | None = None, analytics: bool = True,
+                 _check_analytics: bool = False, _library=None):
         super().__init__()
         cfg = resolve_config(config)
         self.config = config
@@ -396,6 +398,53 @@ class PredPreyGrass(_MultiAgentEnvBase):
         self._records = []
         self._insertion_order = []
         self._tables = None
+        from .rq_analytics import AgentAnalytics
+        self._an = AgentAnalytics(cfg, walls=self._walls, check=_check_analytics) if analytics else None
+
+    # the reference's analytics attributes (RQ:99-116), served by the host-side mirror
+    def _analytics_attr(self, name):
+        if self._an is None:
+            raise AttributeError(f"{name}: this env was built with analytics=False")
+        return getattr(self._an, name)
+
+    unique_agents = property(lambda self: self._analytics_attr("unique_agents"))
+    unique_agent_stats = property(lambda self: self._analytics_attr("unique_agent_stats"))
+    death_agents_stats = property(lambda self: self._analytics_attr("death_agents_stats"))
+    per_step_agent_data = property(lambda self: self._analytics_attr("per_step_agent_data"))
+    agent_ages = property(lambda self: self._analytics_attr("agent_ages"))
+    agent_parents = property(lambda self: self._analytics_attr("agent_parents"))
+    agent_offspring_counts = property(lambda self: self._analytics_attr("agent_offspring_counts"))
+    agent_live_offspring_ids = property(lambda self: self._analytics_attr("agent_live_offspring_ids"))
+    agent_activation_counts = property(lambda self: self._analytics_attr("agent_activation_counts"))
+    death_cause_prey = property(lambda self: self._analytics_attr("death_cause_prey"))
+
+    def _analytics_step(self, before, where, current_step, insertion_order, action_names):
+        """Feed the mirror one non-truncated call: the tables before it (`before`, `where`: live name -> (species, row)) and the
+        ones `_collect` just fetched."""
+        b, t = self._b, self._tables
+        cp = b.pred_capacity
+        xy = lambda tab, s: (int(tab["row_xy"][0][s]) >> 8, int(tab["row_xy"][0][s]) & 255)
+        slot0 = {n: cp * sp + row for n, (sp, row) in where.items()}
+        slot1 = {name: cp * sp + row for name, sp, row, *_ in self._records}
+        fl1 = t["row_flags"][0]
+        newborn = [name for name, *_ in self._records if fl1[slot1[name]] & _abi.ROW_NEWBORN]
+        ng = b.n_grass
+        pending = self._an.step(
+            current_step=current_step, action_names=action_names,
+            agents_in_order=[name for name, *_ in self._records if not fl1[slot1[name]] & _abi.ROW_NEWBORN],
+            insertion_order=insertion_order,
+            pos_before={n: xy(before, s) for n, s in slot0.items()},
+            pos_after={n: xy(t, s) for n, s in slot1.items()},
+            cum_before={n: float(before["row_cumrew"][0][s]) for n, s in slot0.items()},
+            grass_pos=[(int(v) >> 8, int(v) & 255) for v in before["grass_xy"][0][:ng].tolist()],
+            grass_energy_before=before["grass_energy"][0][:ng].tolist(),
+            terminated={name for name, _, _, _, te, _ in self._records if te},
+            ate={n for n, s in slot1.items() if fl1[s] & _abi.ROW_ATE},
+            newborn=newborn,
+            lastrep_after={n: int(t["row_lastrep"][0][s]) for n, s in slot1.items()},
+            energy_after={n: float(t["row_energy"][0][s]) for n, s in slot1.items()},
+            grass_energy_after=t["grass_energy"][0][:ng].tolist())
+        self._an.record_step(sorted(slot1), set(pending), {n: xy(t, s) for n, s in slot1.items()})
 
     # ------------------------------------------------------------------
     def reset(self, *, seed=None, options=None):
@@ -410,12 +459,17 @@ class PredPreyGrass(_MultiAgentEnvBase):
         b.set_placement(np.asarray(p).reshape(1, -1, 2), np.asarray(q).reshape(1, -1, 2), np.asarray(g).reshape(1, -1, 2))
         self.cumulative_rewards = {}
         self._insertion_order = []
-        return self._collect(after_reset=True)[0], {}
+        obs = self._collect(after_reset=True)[0]
+        if self._an is not None:
+            self._an.reset(self.possible_agents, self.agents, self.agent_energies)
+        return obs, {}
 
     def step(self, action_dict):
         """RQ:197-299."""
         b = self._b
         where = {name: (sp, row) for name, sp, row, _, te, _ in self._records if not te}
+        before, step_before = self._tables, self.current_step
+        order_before = [n for n in self._insertion_order if n in where]
         a = b.stage_actions(0)     # the pinned host mirror of the action tensor
         a[:] = _abi.ACTION_NONE
         rk = torch.zeros((b.S,), dtype=torch.uint8)
@@ -447,6 +501,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
         out = self._collect(after_reset=False)
         self.rng.bit_generator.state = state
         self.rng.bit_generator.advance(int(self._tables["env_state"][0][_abi.ENV_DRAWS]))
+        if self._an is not None and not truncated_call:
+            self._analytics_step(before, where, step_before, order_before, list(action_dict))
         return out
 
     def close(self):
@@ -571,6 +627,7 @@ class PredPreyGrass(_MultiAgentEnvBase):
             "pending_removal": list(self._pending_removal), "next_idx": dict(self._next_idx),
             "_device_state": b.export_state(0),   # ppg_export_state (incl. row_lastrep; walls: row_info + wall bitmap)
             "_insertion_order": list(self._insertion_order), "_rng_state": self.rng.bit_generator.state,
+            **(self._an.snapshot() if self._an is not None else {}),
         }
 
     def restore_state_snapshot(self, snapshot):
@@ -582,6 +639,8 @@ class PredPreyGrass(_MultiAgentEnvBase):
         self._collect(after_reset=False)
         self.agents = list(snapshot["agents"])
         self.cumulative_rewards = dict(snapshot["cumulative_rewards"])
+        if self._an is not None and "unique_agents" in snapshot:
+            self._an.restore(snapshot)
 
 
 def env_creator(config):

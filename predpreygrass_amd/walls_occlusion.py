@@ -126,7 +126,10 @@ class PredPreyGrass(_RedQueenPredPreyGrass):
         self.cumulative_rewards = {}
         self._insertion_order = []
         self._last_action_names = []
-        return self._collect(after_reset=True)[0], {}
+        obs = self._collect(after_reset=True)[0]
+        if self._an is not None:
+            self._an.reset(self.possible_agents, self.agents, self.agent_energies)   # WO:146-165
+        return obs, {}
 
     def _finish_outputs(self, recs, tables, rew, term, trunc, truncated_call):
         """WO:370-395: the scalar dicts also name every agent of the action dict (defaults 0.0 / False); infos carry

@@ -164,3 +164,22 @@ def test_random_walls_config_matches_oracle_on_gpu(seed):
     from predpreygrass_amd.walls_occlusion import PredPreyGrass as WallsEnv
     from tests.test_rq_random_configs import run_differential
     run_differential(lambda cfg: WallsEnv(cfg, device="cuda:0"), seed, walls=True)
+
+
+# ---- the per-agent analytics of the dict classes (RQ:99-116) ------------------------------------------------------
+
+def _make_dict_env_on_gpu(case):
+    if case.walls:
+        from predpreygrass_amd.walls_occlusion import PredPreyGrass as Env
+    else:
+        from predpreygrass_amd.red_queen import PredPreyGrass as Env
+    return Env(case.config, device="cuda:0", _check_analytics=True)
+
+
+@pytest.mark.parametrize("name", ["rq_mixed_types_seed7", "rq_pool_exhaust_seed2", "rq_shuffled_seed5", "rq_base_seed3",
+                                  "wo_los_two_types_seed5", "wo_mask_only_shuffled_seed6"])
+def test_analytics_books_equal_the_references_on_gpu(name):
+    """unique_agent_stats / death_agents_stats / per_step_agent_data / ages / offspring lists after whole golden episodes stepped by
+    the HIP kernels == the books of the reference itself (tests/golden/*/<name>.analytics.json.gz), floats bit for bit."""
+    from tests.test_rq_analytics import replay_analytics
+    replay_analytics(_make_dict_env_on_gpu, name)

@@ -142,10 +142,10 @@ def run_differential(make_env, seed, max_calls=45, walls=False):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_random_gen2_config_matches_oracle_emulated(seed):
-    run_differential(lambda cfg: PredPreyGrass(cfg, _library=library()), seed)
+    run_differential(lambda cfg: PredPreyGrass(cfg, _library=library(), _check_analytics=True), seed)   # (the analytics mirror cross-checks its energies)
 
 
 @pytest.mark.parametrize("seed", range(30))
 def test_random_walls_config_matches_oracle_emulated(seed):
     from predpreygrass_amd.walls_occlusion import PredPreyGrass as WallsEnv
-    run_differential(lambda cfg: WallsEnv(cfg, _library=library()), seed, walls=True)
+    run_differential(lambda cfg: WallsEnv(cfg, _library=library(), _check_analytics=True), seed, walls=True)

@@ -235,6 +235,10 @@ inline void lds_count(uint8_t *p) { *p = (uint8_t)(*p + 1); }
 inline void lds_count(uint16_t *p) { *p = (uint16_t)(*p + 1); }
 inline void drain_loads() { (void)exchange(0); }  // lanes run one after another here: a collective orders reads before writes
 inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+inline uint32_t mul24(uint32_t a, uint32_t b) {
+    if ((a | b) >> 24) { fprintf(stderr, "wave_emu: mul24 operand of 24 bits or more\n"); abort(); }
+    return a * b;
+}
 inline int popc(uint64_t m) { return __builtin_popcountll(m); }
 inline int ctz(uint64_t m) { return __builtin_ctzll(m); }
 
@@ -242,6 +246,8 @@ inline int ctz(uint64_t m) { return __builtin_ctzll(m); }
 
 struct double2 { double x, y; };
 struct uint2 { uint32_t x, y; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 struct float2 { float x, y; };
 static inline long long __double_as_longlong(double d) { long long r; memcpy(&r, &d, 8); return r; }
 static inline double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }
