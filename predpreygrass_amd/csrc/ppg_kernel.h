@@ -1507,32 +1507,59 @@ struct Env {
         const uint32_t *L = lut2 + (type ? C.blk_p : 0);
         const int total = n_live * blk;
         const size_t obase = (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;
-        constexpr int U = 2;   // pieces in flight per wavefront: the three dependent LDS lookups of one hide behind the other's
+#ifndef PPG_COOP_U
+#define PPG_COOP_U 2
+#endif
+#ifndef PPG_COOP_PREFETCH
+#define PPG_COOP_PREFETCH 0
+#endif
+        constexpr int U = PPG_COOP_U;   // pieces in flight per wavefront: the three dependent LDS lookups of one hide behind the others'
         const uint32_t G = (uint32_t)P.G;
-        for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
-            uint32_t o[U], i0[U], i1[U];
-            bool on[U], out0[U], out1[U];
+        // A group of U pieces takes three dependent LDS round trips: (row entry, element descriptors) -> map entries -> values.
+        // PPG_COOP_PREFETCH: the first of them is issued one group ahead, beside the map reads of the group in hand.
+        uint32_t ent_n[U], w_n[U];
+        uint2 d_n[U];
+        bool on_n[U];
+        auto issue = [&](int p0) {   // the reads that depend on the piece number alone
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s0 = (p0 + u * stride) * 128 + 2 * ln;
-                on[u] = s0 < total;
-                const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
-                const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
-                const uint32_t ent = on[u] ? list[i] : 0u;   // (lanes behind the end of the run look at cell (0,0): inside the maps)
-                const uint2 d = *(const uint2 *)(L + w);
-                const uint32_t ax = (ent >> 8) & 255u, ay = ent & 255u;
-                const int pc = (int)(wv::mul24(ax + (uint32_t)P.pad, (uint32_t)P.Gp) + ay + (uint32_t)P.pad);
-                const bool z0 = (d.x >> 16) == 0xFFFFu, z1 = (d.y >> 16) == 0xFFFFu;   // channel 0: no map
+                on_n[u] = s0 < total;
+                const uint32_t sc = on_n[u] ? (uint32_t)s0 : 0u;
+                const uint32_t i = wv::mulhi(sc, magic);
+                w_n[u] = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
+                ent_n[u] = on_n[u] ? list[i] : 0u;          // (lanes behind the end of the run look at cell (0,0): inside the maps)
+                d_n[u] = *(const uint2 *)(L + w_n[u]);
+            }
+        };
+        if (PPG_COOP_PREFETCH) issue(first);
+        for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
+            uint32_t o[U], i0[U], i1[U], m0[U], m1[U], ax[U], ay[U];
+            uint2 d[U];
+            bool on[U], out0[U], out1[U];
+            if (!PPG_COOP_PREFETCH) issue(p0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t ent = ent_n[u];
+                d[u] = d_n[u]; on[u] = on_n[u];
+                ax[u] = (ent >> 8) & 255u; ay[u] = ent & 255u;
+                const int pc = (int)(wv::mul24(ax[u] + (uint32_t)P.pad, (uint32_t)P.Gp) + ay[u] + (uint32_t)P.pad);
                 // (a channel-0 descriptor's low bits as a map offset stay inside the three maps: no lane reads outside LDS)
-                const uint32_t m0 = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)], m1 = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)];
-                i0[u] = z0 ? 0u : m0 + (d.x >> 16);
-                i1[u] = z1 ? 0u : m1 + (d.y >> 16);
+                m0[u] = (uint32_t)m[pc + (int)(int16_t)(d[u].x & 0xFFFFu)];
+                m1[u] = (uint32_t)m[pc + (int)(int16_t)(d[u].y & 0xFFFFu)];
+                o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w_n[u];
+            }
+            if (PPG_COOP_PREFETCH) issue(p0 + U * stride);   // (behind the end of the run: every lane off, two harmless reads of entry 0)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool z0 = (d[u].x >> 16) == 0xFFFFu, z1 = (d[u].y >> 16) == 0xFFFFu;   // channel 0: no map
+                i0[u] = z0 ? 0u : m0[u] + (d[u].x >> 16);
+                i1[u] = z1 ? 0u : m1[u] + (d[u].y >> 16);
                 // outside the grid: unsigned compares (a coordinate below 0 wraps far above G); computed for every lane, no branches
-                const uint32_t tx0 = ax + ((d.x >> 4) & 15u) - 8u, ty0 = ay + (d.x & 15u) - 8u;
-                const uint32_t tx1 = ax + ((d.y >> 4) & 15u) - 8u, ty1 = ay + (d.y & 15u) - 8u;
+                const uint32_t tx0 = ax[u] + ((d[u].x >> 4) & 15u) - 8u, ty0 = ay[u] + (d[u].x & 15u) - 8u;
+                const uint32_t tx1 = ax[u] + ((d[u].y >> 4) & 15u) - 8u, ty1 = ay[u] + (d[u].y & 15u) - 8u;
                 out0[u] = z0 & ((tx0 > ty0 ? tx0 : ty0) >= G);
                 out1[u] = z1 & ((tx1 > ty1 ? tx1 : ty1) >= G);
-                o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -359,13 +359,14 @@ def test_cooperative_fused_rollout_equals_single_steps_on_gpu():
 
 def test_default_wave_plans_give_identical_results():
     """What the library picks by itself -- sixteen waves per env at 200 envs, the cooperative kernel (two envs per four-wave
-    workgroup) for a full GPU of 25x25 grids, a pair of waves with 8-bit maps for a full GPU of 64x64 grids, the second
+    workgroup) for a full GPU of 25x25 and of 64x64 grids, a pair of waves with 8-bit maps for a full GPU of 80x80 grids, the second
     generation's cooperative kernel -- against the one-wave kernels, bit for bit."""
     from predpreygrass_amd.red_queen import BatchedRedQueen, config_env_base
     c4 = {**config_env, **C4}
     cases = [(lambda: make_env(dict(config_env), 200), b"ppgw16_step_q2", 120),
              (lambda: make_env(dict(config_env), 4096), b"ppgc_step_q2", 60),
-             (lambda: make_env(c4, 4096), b"ppgwp_step_q2", 40),
+             (lambda: make_env(c4, 4096), b"ppgc_step_q2", 40),        # (round 6: three cell maps per env -> four cooperative workgroups per CU)
+             (lambda: make_env({**c4, "grid_size": 80}, 4096), b"ppgwp_step_q2", 30),
              (lambda: BatchedRedQueen(config_env_base, batch_size=4096, device="cuda:0"), b"ppgc2_step_q2", 120)]
     names = ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state", "grass_energy", "obs_pred", "obs_prey")
     for mk, kernel, calls in cases:

@@ -980,3 +980,60 @@ def test_rows_in_the_cell_layout_give_the_same_rows_logits_and_actions(batch, st
         assert torch.equal(getattr(a, n), getattr(b, n)), n
     assert bool(la[1].abs().sum() > 0)
     assert (b.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["random_init_base_env", "rllib_checkpoint_walls_env"])
+def test_report_greedy_agreement_with_fp32_inference_over_a_closed_loop_rollout(which):
+    """A REPORT, not a tolerance (the figures are quoted in INTEGRATION.md): a population of envs is rolled out
+    for 1000 steps with the kernels' own sampled actions closing the loop (bfloat16 MFMA operands, `tune_ppo_*.py`'s rollout
+    setting), and on every 20th step the greedy action of the kernels is compared with the argmax of the float32 PyTorch module
+    (RLlib's inference arithmetic) on the same observation rows -- the observation distribution the policy itself produces,
+    not i.i.d. windows.  Asserted: the only sanity bounds the other tests already state (> 0.95)."""
+    from predpreygrass_amd.policy import FusedPolicy
+    if which == "random_init_base_env":
+        from predpreygrass_amd.batched import BatchedPredPreyGrass
+        nets = make_nets(seed=11)
+        env = BatchedPredPreyGrass(dict(config_env), batch_size=256, device="cuda:0", obs_dtype=torch.float64, seed=4)
+    else:
+        from predpreygrass_amd.policy import load_rllib_state_dict
+        from predpreygrass_amd.red_queen import BatchedRedQueen
+        from predpreygrass_amd.walls_occlusion import config_env_zigzag_walls
+        actor = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(FIXTURE, "type_1_predator_actor.npz")).items()}
+        net = load_rllib_state_dict(actor)
+        nets = (net, net)
+        cfg = {**config_env_zigzag_walls, "predator_obs_range": 9, "prey_obs_range": 9}
+        env = BatchedRedQueen(cfg, batch_size=256, device="cuda:0", walls=True, obs_dtype=torch.float32, seed=4)
+        env.set_walls(cfg["manual_wall_positions"])
+    fused = FusedPolicy(nets[0], nets[1])
+    refs = [n.to("cuda:0") for n in nets]
+    env.reset()
+    agree = total = 0
+    margins = []     # float32 top-1 minus top-2 logit where the two greedy actions differ
+    scale = 0.0
+    for t in range(1000):
+        if t % 20 == 0:
+            lg = fused.act(env, want_logits=True)
+            torch.cuda.synchronize()
+            mp, mq = rows_in_use(env)
+            for sp, m in enumerate((mp, mq)):
+                obs = (env.obs_prey if sp else env.obs_pred)[m]
+                if obs.shape[0] == 0:
+                    continue
+                with torch.no_grad():
+                    ref = refs[sp](obs)
+                got = lg[sp][: obs.shape[0]]
+                same = got.argmax(1) == ref.argmax(1)
+                agree += int(same.sum()); total += int(same.numel())
+                top2 = ref.topk(2, dim=1).values
+                margins.append((top2[:, 0] - top2[:, 1])[~same].float().cpu())
+                scale = max(scale, float(ref.abs().max()))
+        fused.act(env, sample=True, seed=t)
+        env.step(env.actions, auto_reset=True)
+    torch.cuda.synchronize()
+    mg = torch.cat(margins) if margins else torch.zeros(0)
+    rate = agree / max(total, 1)
+    print(f"\n[policy precision] {which}: greedy agreement bf16-MFMA vs float32 module {rate:.5f} over {total} observations of a 1000-step "
+          f"closed-loop rollout (256 envs, every 20th step); {total - agree} differ, float32 margin there: median "
+          f"{float(mg.median()) if len(mg) else 0.0:.2e}, max {float(mg.max()) if len(mg) else 0.0:.2e} (largest |logit| {scale:.2f})")
+    assert total > 20000 and rate > 0.95

@@ -4,6 +4,7 @@
 #   ab:<workload>:<streams>:<plan>[,<plan>...]     tools/ab_plans.py, plans as name=waves.min_rows.coop (e.g. pair=2.0.0,coop42=4.0.2)
 #   lib:<workload>:<steps>:<rounds>:name=lib.so[,name=lib.so...]   alternating-process A/B of library builds (tools/gpu_lib_ab.sh)
 #   bench:<name>:<bench.py arguments, comma separated>      one bench.py run, its JSON line kept
+#   pt:<name>:<file>:<-k expression>    selected GPU tests with their printed reports kept (pytest -s)
 #   phase:<name>:<tools/phase_profile.py arguments, comma separated>   phase shares of a wavefront's cycles (diagnostic build)
 cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; shift
@@ -26,6 +27,10 @@ for step in "$@"; do
       IFS=: read -r name bargs <<< "$rest"
       python3 bench.py $(echo "$bargs" | tr ',' ' ') > gpurun_out/${tag}_bench_${name}.json.log 2> gpurun_out/${tag}_bench_${name}.err
       grep '^{' gpurun_out/${tag}_bench_${name}.json.log | tail -1 | cut -c1-600 ;;
+    pt)
+      IFS=: read -r name file expr <<< "$rest"
+      python3 -m pytest "$file" -m gpu -q -s -k "$expr" > gpurun_out/${tag}_pt_${name}.log 2>&1
+      grep -E "^\[|passed|failed" gpurun_out/${tag}_pt_${name}.log | tail -12 ;;
     phase)
       IFS=: read -r name pargs <<< "$rest"
       python3 tools/phase_profile.py $(echo "$pargs" | tr ',' ' ') > gpurun_out/${tag}_phase_${name}.txt 2>&1
