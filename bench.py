@@ -137,10 +137,9 @@ def parse_args(argv):
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--obs-dtype", choices=["f64", "f32", "bf16", "cells"], default=None,
+    ap.add_argument("--obs-dtype", choices=["f64", "f32", "bf16"], default=None,
                     help="observation dtype (default: f64 for the base workload, f32 -- the reference's -- for red_queen, bf16 -- the "
-                         "compact rows the policy kernels stage without conversion -- for policy_rollout; cells = the same bf16 values in the cell "
-                         "layout the pipeline kernels copy into their image as they are, include/ppg.h obs_dtype 3: policy_rollout only)")
+                         "compact rows the policy kernels stage without conversion -- for policy_rollout)")
     ap.add_argument("--policy-arch", choices=["rllib", "fc256", "r3", "depth"], default="rllib",
                     help="policy_rollout: the network (rllib = what RLlib builds from the reference's model_config)")
     ap.add_argument("--workload", choices=["base", "c4", "red_queen", "drive", "walls", "policy_rollout", "dict_api"], default="base",
@@ -333,7 +332,7 @@ def policy_rollout(args, backend, device, distributed, rank, n_gpus):
     cfg = dict(config_env)
     B = args.envs
     args.obs_dtype = args.obs_dtype or "bf16"
-    obs_dtype = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16, "cells": "bf16_cells"}[args.obs_dtype]
+    obs_dtype = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[args.obs_dtype]
     env = BatchedPredPreyGrass(cfg, batch_size=B, device=device, obs_dtype=obs_dtype, seed=args.seed + rank * B)
     torch.manual_seed(1234)
     # --policy-arch rllib (default): what RLlib builds from tune_ppo_base_environment.py:106-141 -- channels-last reading, conv 3x3

@@ -101,7 +101,6 @@ extern "C" {
 
 /* The config dict of the reference (BASE:20-61; defaults CFG = config_env.py:1-38)
  * plus the capacities of this implementation. */
-#define PPG_OBS_BF16_CELLS 3   /* ppg_config.obs_dtype: bfloat16 rows in the policy kernels' cell layout */
 
 typedef struct ppg_config {
     int32_t abi_version;          /* PPG_ABI_VERSION */
@@ -119,13 +118,7 @@ typedef struct ppg_config {
     int32_t grass_capacity;       /* >= n_grass, multiple of 64 */
     int32_t obs_dtype;            /* 0: float64 (bit-exact with the reference), 1: float32, 2: bfloat16 (the float64 value rounded to
                                    * float32, then to bfloat16, both to nearest even: compact rows for ppg_policy_act, which stages them
-                                   * without conversion -- same logits as from the float64 rows, a quarter of the bytes);
-                                   * 3 (PPG_OBS_BF16_CELLS): the same bfloat16 values in the CELL layout the policy kernels stage from, for
-                                   * observation ranges R <= 9: the policy network reads the (4,R,R) Box channels-last -- 4 x R positions
-                                   * (plane c, window row w) of R channels -- and a row holds, position-major, per position one 16-byte
-                                   * cell {Box[c][w][0..7]} (values behind R-1: 0) and, for R = 9, a second cell {Box[c][w-1][8],
-                                   * Box[c][w][8], Box[c][w+1][8], 0, 0, 0, 0, 0} (0 where w-1 / w+1 leave the window): 4R x 8 or 4R x 16
-                                   * elements per row.  A policy rollout's rows only: the dict classes do not take it. */
+                                   * without conversion -- same logits as from the float64 rows, a quarter of the bytes) */
     double reward_predator_catch_prey;  /* BASE:29 */
     double reward_prey_eat_grass;       /* BASE:30 */
     double reward_predator_step;        /* BASE:31 */

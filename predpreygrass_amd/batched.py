@@ -138,18 +138,12 @@ class BatchedPredPreyGrass:
             self.device = torch.device("cpu")
         # float64 = the reference's observations bit for bit; float32; bfloat16 = compact rows for a policy that runs next to the env
         # (FusedPolicy stages them without conversion: its logits are bit-identical to those from the float64 rows)
-        # "bf16_cells" = bfloat16 rows in the cell layout FusedPolicy's kernels stage from (include/ppg.h: obs_dtype 3): per position
-        # (channel plane, window row) of the (4,R,R) Box one 16-byte cell of its first eight values and -- R = 9 -- a second cell with the
-        # ninth value of the position and its two neighbours: obs_pred / obs_prey are [B, rows, 4, R, 8 or 16].  Policy rollouts only.
-        self.obs_cells = isinstance(obs_dtype, str) and obs_dtype == "bf16_cells"
-        if self.obs_cells:
-            obs_dtype = torch.bfloat16
         if obs_dtype not in (torch.float64, torch.float32, torch.bfloat16):
-            raise ValueError("obs_dtype must be torch.float64, torch.float32, torch.bfloat16 or 'bf16_cells'")
+            raise ValueError("obs_dtype must be torch.float64, torch.float32 or torch.bfloat16")
         self.obs_dtype = obs_dtype
 
     def _abi_obs_dtype(self):
-        return 3 if self.obs_cells else {torch.float64: 0, torch.float32: 1, torch.bfloat16: 2}[self.obs_dtype]
+        return {torch.float64: 0, torch.float32: 1, torch.bfloat16: 2}[self.obs_dtype]
 
     def _alloc_buffers(self, prey_capacity):
         self.pred_capacity = PRED_CAPACITY
@@ -180,9 +174,8 @@ class BatchedPredPreyGrass:
         self.grass_energy = z((B, NG), torch.float64)
         nc = getattr(self, "obs_channels", 4)
         ncp, ncq = getattr(self, "obs_channels_pred", nc), getattr(self, "obs_channels_prey", nc)
-        cells = lambda R: 8 if R <= 8 else 16
-        self.obs_pred = self._obs_tensor((B, self.pred_capacity, ncp, self.Rp, cells(self.Rp) if self.obs_cells else self.Rp), seed_salt=1)
-        self.obs_prey = self._obs_tensor((B, self.prey_capacity, ncq, self.Rq, cells(self.Rq) if self.obs_cells else self.Rq), seed_salt=2)
+        self.obs_pred = self._obs_tensor((B, self.pred_capacity, ncp, self.Rp, self.Rp), seed_salt=1)
+        self.obs_prey = self._obs_tensor((B, self.prey_capacity, ncq, self.Rq, self.Rq), seed_salt=2)
         self.actions = torch.full((B, S), _abi.ACTION_NONE, dtype=torch.int8, device=dev)
 
     def _obs_tensor(self, shape, seed_salt=0):

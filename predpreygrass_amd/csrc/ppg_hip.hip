@@ -228,7 +228,7 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
     // one workgroup = one wavefront = one environment
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != h->device) PPG_HIP_TRY(h, hipSetDevice(h->device));
-    const bool fast = P.nch_p <= 2 && P.nch_q <= 3 && !P.obs_tiles;
+    const bool fast = P.nch_p <= 2 && P.nch_q <= 3;
     if (h->gen2 && mode > ppg::MODE_STEP_ORDERED && !(mode == ppg::MODE_VIS && h->cfg2.walls) &&
         !(mode == ppg::MODE_ROLLOUT && !h->cfg2.walls && P.coop_e > 0))
         return ppg_fail(h, PPG_EINVAL, "mode %d is not available for second-generation handles", mode);

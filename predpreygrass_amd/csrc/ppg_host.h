@@ -108,40 +108,6 @@ static void ppg_build_lut(int R, int G, int map_n, uint32_t *out, int channels =
     }
 }
 
-// obs_dtype 3 (PPG_OBS_BF16_CELLS, include/ppg.h): a row in the cell layout the policy kernels stage from.  The policy network reads the
-// (4,R,R) Box channels-last -- 4 x R positions of R channels -- and its staging wants, per position, the channels 0-7 as one
-// 16-byte cell and (R = 9) a second cell with the ninth channel of the position's three taps {c8(w-1), c8(w), c8(w+1), 0 ...}: the
-// row is exactly those cells, position-major, so a position is one or two aligned 16-byte loads.
-static int ppg_cell_elems(int R) { return R <= 8 ? 8 : 16; }
-static int ppg_cells_block_elems(int R) { return 4 * R * ppg_cell_elems(R); }
-// source of element k of the cell(s) of position (h, w): the Box element (h, w2, j), or none (a zero)
-static bool ppg_cell_source(int R, int w, int k, int &w2, int &j) {
-    if (k < 8) { w2 = w; j = k; return k < R; }
-    if (R <= 8 || k > 10) return false;
-    w2 = w + (k - 9); j = 8;
-    return w2 >= 0 && w2 < R;
-}
-// the element descriptors of ppg_build_lut for such a row (a zero = an existing element outside every window, of channel 1)
-static void ppg_build_lut_cells(int R, int G, int map_n, uint32_t *out) {
-    const int ce = ppg_cell_elems(R), blk = 4 * R * ce, off = (R - 1) / 2, W = 2 * off + 1;
-    const int nwords = (blk + 127) / 128 * 128;
-    for (int e = 0; e < nwords; ++e) {
-        uint32_t d = 0;
-        if (e < blk) {
-            const int pos = e / ce, k = e % ce, c = pos / R, w = pos % R;
-            int i, j;
-            if (ppg_cell_source(R, w, k, i, j)) {
-                const int moff = c * map_n + (i - off) * G + (j - off);
-                d = ((uint32_t)moff & 0xFFFFu) | ((uint32_t)(i - off + 8) << 16) | ((uint32_t)(j - off + 8) << 20) | ((uint32_t)c << 24) |
-                    0x4000000u | ((i < W && j < W) ? 0x8000000u : 0u) | ((uint32_t)(c >= 2 ? c - 1 : 0) << 30);
-            } else {
-                d = (8u << 16) | (8u << 20) | (1u << 24) | 0x4000000u;   // moff 0: the observer's own cell in the all-zero map 0
-            }
-        }
-        out[e] = d;
-    }
-}
-
 static int ppg_validate_and_layout(ppg_handle *h) {
     const ppg_config &c = h->cfg;
     if (c.abi_version != PPG_ABI_VERSION) return ppg_fail(h, PPG_EINVAL, "abi_version %d != %d", c.abi_version, PPG_ABI_VERSION);
@@ -161,11 +127,9 @@ static int ppg_validate_and_layout(ppg_handle *h) {
         return ppg_fail(h, PPG_EINVAL, "Cannot place more unique positions than grid cells.");  // BASE:167-168
     if (c.n_possible_predators < 0 || c.n_possible_predators > 999999 || c.n_possible_prey < 0 || c.n_possible_prey > 999999)
         return ppg_fail(h, PPG_EINVAL, "n_possible_* must be in 0..999999");
-    if (c.obs_dtype < 0 || c.obs_dtype > 3) return ppg_fail(h, PPG_EINVAL, "obs_dtype must be 0 (f64), 1 (f32), 2 (bf16) or 3 (bf16 in the policy kernels' cell layout)");
-    if (c.obs_dtype >= 2 && ((h->gen2 && h->cfg2.walls) || c.n_drive[0] > 0 || c.n_drive[1] > 0))
-        return ppg_fail(h, PPG_EINVAL, "bfloat16 observations (obs_dtype 2, 3) are for the 4-channel observations of the base family and the second generation");
-    if (c.obs_dtype == 3 && (c.predator_obs_range > 9 || c.prey_obs_range > 9))
-        return ppg_fail(h, PPG_EINVAL, "the cell layout (obs_dtype 3) is defined for observation ranges up to 9 (nine input channels of the policy's first convolution)");
+    if (c.obs_dtype < 0 || c.obs_dtype > 2) return ppg_fail(h, PPG_EINVAL, "obs_dtype must be 0 (f64), 1 (f32) or 2 (bf16)");
+    if (c.obs_dtype == 2 && ((h->gen2 && h->cfg2.walls) || c.n_drive[0] > 0 || c.n_drive[1] > 0))
+        return ppg_fail(h, PPG_EINVAL, "bfloat16 observations (obs_dtype 2) are for the 4-channel observations of the base family and the second generation");
     if (c.max_steps < 0) return ppg_fail(h, PPG_EINVAL, "max_steps < 0");
     const ppg_buffers &b = h->bufs;
     if (!b.row_xy || !b.row_energy || !b.row_id || !b.row_key || !b.row_cumrew || !b.row_flags || !b.row_reward ||
@@ -179,8 +143,7 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     P.n_init_pred = c.n_initial_predators; P.n_init_prey = c.n_initial_prey; P.n_grass = c.n_grass;
     P.cap_pred = c.pred_capacity; P.cap_prey = c.prey_capacity; P.cap_grass = c.grass_capacity;
     P.S = c.pred_capacity + c.prey_capacity;
-    P.obs_f32 = c.obs_dtype == 3 ? 2 : c.obs_dtype;
-    P.obs_tiles = c.obs_dtype == 3 ? 1 : 0;
+    P.obs_f32 = c.obs_dtype;
     P.g_magic = (uint32_t)((0x100000000ull + (uint64_t)c.grid_size - 1) / (uint64_t)c.grid_size);
     P.rp_magic = (uint32_t)((0x100000000ull + (uint64_t)c.predator_obs_range - 1) / (uint64_t)c.predator_obs_range);
     P.rq_magic = (uint32_t)((0x100000000ull + (uint64_t)c.prey_obs_range - 1) / (uint64_t)c.prey_obs_range);
@@ -234,12 +197,11 @@ static int ppg_validate_and_layout(ppg_handle *h) {
     const int channels = (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
     const int ch_p = drive ? 4 + c.n_drive[0] : channels, ch_q = drive ? 4 + c.n_drive[1] : channels;
     P.blk_p = ch_p * P.Rp * P.Rp; P.blk_q = ch_q * P.Rq * P.Rq;   // elements per observation block
-    if (P.obs_tiles) { P.blk_p = ppg_cells_block_elems(P.Rp); P.blk_q = ppg_cells_block_elems(P.Rq); }
     P.nch_p = (P.blk_p + 127) / 128; P.nch_q = (P.blk_q + 127) / 128;
     // the descriptor table lives in LDS only for the kernels that read it from there: the FASTOBS kernels (base family / second
     // generation with <= 2 predator and <= 3 prey chunks: the same rule as the backends' kernel selection) keep it in registers.
     // (64x64 grid, 7x7 windows: 24080 -> 22032 bytes per env = 7 instead of 6 envs per CU.)
-    const bool lut_in_registers = P.nch_p <= 2 && P.nch_q <= 3 && !drive && !(h->gen2 && h->cfg2.walls) && !P.obs_tiles
+    const bool lut_in_registers = P.nch_p <= 2 && P.nch_q <= 3 && !drive && !(h->gen2 && h->cfg2.walls)
 #ifdef PPG_WAVE_EMU   // (tests: exercise the LDS-descriptor observation path on configurations that would keep it in registers)
                                   && !getenv("PPG_EMU_FORCE_GENERIC_OBS")
 #endif
@@ -276,11 +238,6 @@ static int ppg_validate_and_layout(ppg_handle *h) {
 
     if (3 * P.map_n + 8 * c.grid_size + 8 > 32767) return ppg_fail(h, PPG_EINVAL, "grid too large for 16-bit map offsets");
     h->lut_host.assign((size_t)(P.nch_p + P.nch_q) * 128, 0u);
-    if (P.obs_tiles) {
-        ppg_build_lut_cells(P.Rp, P.G, P.map_n, h->lut_host.data());
-        ppg_build_lut_cells(P.Rq, P.G, P.map_n, h->lut_host.data() + (size_t)P.nch_p * 128);
-        return PPG_OK;
-    }
     ppg_build_lut(P.Rp, P.G, P.map_n, h->lut_host.data(), ch_p, drive);
     ppg_build_lut(P.Rq, P.G, P.map_n, h->lut_host.data() + (size_t)P.nch_p * 128, ch_q, drive);
     return PPG_OK;
@@ -387,17 +344,11 @@ static void ppg_coop_layout(ppg_handle *h) {
     P.bq_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_q - 1) / (uint64_t)P.blk_q);
     // KParams::coop_tab: the observation descriptors of both species
     h->coop_tab_host.assign((size_t)(P.blk_p + P.blk_q), 0u);
-    const uint32_t desc_zero = 0xFFFF0000u | (8u << 4) | 8u;   // channel 0 at the observer's own cell: inside the grid, 0.0
     for (int t = 0; t < 2; ++t) {
         const int R = t ? P.Rq : P.Rp, o = (R - 1) / 2;
         uint32_t *out = h->coop_tab_host.data() + (t ? P.blk_p : 0);
         for (int e = 0; e < (t ? P.blk_q : P.blk_p); ++e) {
-            int ch = e / (R * R), i = (e % (R * R)) / R, j = e % R;
-            if (P.obs_tiles) {   // the cell layout: position (ch, w) x cell element k
-                const int ce = ppg_cell_elems(R), pos = e / ce, w = pos % R;
-                ch = pos / R;
-                if (!ppg_cell_source(R, w, e % ce, i, j)) { out[e] = desc_zero; continue; }   // a zero
-            }
+            const int ch = e / (R * R), i = (e % (R * R)) / R, j = e % R;
             if (ch == 0) {   // "outside the grid" (BASE:520-523): the window offsets, no map
                 out[e] = 0xFFFF0000u | ((uint32_t)(i - o + 8) << 4) | (uint32_t)(j - o + 8);
                 continue;
@@ -447,7 +398,7 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         } else {
             if (p.nw != 1 && p.nw != 2 && p.nw != 4 && p.nw != 8 && p.nw != 16) p.nw = 4;
             if (p.nw == 2 && h->gen2 && !walls) p.nw = 4;                                      // no pair kernels for the second generation without walls
-            if (p.nw == 16 && (h->gen2 || h->base.nch_p > 2 || h->base.nch_q > 3 || h->nq > 2 || h->base.obs_tiles)) p.nw = 8;  // sixteen waves: base family, register descriptors, <= 128 prey rows
+            if (p.nw == 16 && (h->gen2 || h->base.nch_p > 2 || h->base.nch_q > 3 || h->nq > 2)) p.nw = 8;  // sixteen waves: base family, register descriptors, <= 128 prey rows
         }
         return p;
     }
@@ -463,7 +414,7 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         // up to 256 envs one workgroup per CU is all there is: sixteen waves (base family, register-descriptor observation path):
         // 256 envs 11.3 -> 12.1 M env-steps/s; at 512 envs eight are faster (20.5 vs 17.8 M)
         // (not with 256 prey rows: a 1024-thread workgroup caps the registers at 128 and four prey row registers spill there)
-        if (in_flight <= 256 && !h->gen2 && h->base.nch_p <= 2 && h->base.nch_q <= 3 && h->nq <= 2 && !h->base.obs_tiles) p.nw = 16;
+        if (in_flight <= 256 && !h->gen2 && h->base.nch_p <= 2 && h->base.nch_q <= 3 && h->nq <= 2) p.nw = 16;
     } else if (in_flight <= 3072) {
         p.nw = 4;
     } else if (h->gen2 && !(h->coop_ok && ppg_coop_lds_bytes(h, 2) * 6 <= 160 * 1024)) {
@@ -822,7 +773,7 @@ const char *ppg_step_kernel_name(ppg_handle *h) {
                  h->gen2 ? "2" : wp.nw == 8 ? "8" : wp.nw == 16 ? "16" : wp.nw == 6 ? "6" : ppg_coop_high_occupancy(h, wp.coop_e) ? "h" : "", h->nq);
         return h->kernel_name;
     }
-    const bool walls = h->gen2 && h->cfg2.walls, fast = h->base.nch_p <= 2 && h->base.nch_q <= 3 && !walls && !h->drive && !h->base.obs_tiles;
+    const bool walls = h->gen2 && h->cfg2.walls, fast = h->base.nch_p <= 2 && h->base.nch_q <= 3 && !walls && !h->drive;
     const char *family = h->drive ? "4" : walls ? "3" : h->gen2 ? "2" : "";
     // ppg[w|w8|wp]<family>_step... the names of ppg_kernel_list.h: ppgw_step / ppgw8_step / ppgwp_step, ppgw2_step / ppgw28_step, ppgw3_step, ppgw4_step
     const char *waves = wp.nw == 1 ? "" : wp.nw == 2 ? "wp" : wp.nw == 8 ? "w8" : wp.nw == 16 ? "w16" : "w";
@@ -908,7 +859,6 @@ static int ppg_pack_geometry(const ppg_handle *h, uint32_t flags, int &blk_p, in
     const int channels = (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
     blk_p = (drive ? 4 + P.n_drive[0] : channels) * P.Rp * P.Rp;
     blk_q = (drive ? 4 + P.n_drive[1] : channels) * P.Rq * P.Rq;
-    if (P.obs_tiles) { blk_p = P.blk_p; blk_q = P.blk_q; }
     if (flags & PPG_PACK_NO_OBS) blk_p = blk_q = 0;   // an image without observation sections
     src_elem = P.obs_f32 == 2 ? 2 : P.obs_f32 ? 4 : 8;
     dst_elem = ((flags & PPG_PACK_F32) && src_elem == 8) ? 4 : src_elem;

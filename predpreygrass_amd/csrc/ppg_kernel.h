@@ -96,7 +96,7 @@ struct KParams {
     // per-cell line-of-sight masks, precomputed from the (static) walls by ppg_walls_changed: bit (dx + vis_neg) * vis_w + (dy + vis_neg)
     // of cell (x, y)'s vis_words words = "(x + dx, y + dy) is in the grid and no wall lies strictly between" (WO:492-525, 577-589)
     int32_t vis_neg, vis_w, vis_words;
-    int32_t obs_tiles;            // 1: observation rows in the policy kernels' cell layout (ppg_config.obs_dtype 3; blk_p / blk_q elements)
+    int32_t pad4_;
     uint32_t rp_magic, rq_magic;  // ceil(2^32 / Rp), ceil(2^32 / Rq): cell / R == mulhi(cell, magic) for cell < R*R
     uint32_t np_magic, nq_magic;  // ceil(2^32 / Rp^2), ceil(2^32 / Rq^2): element / R^2 for element < 8 R^2
     uint32_t *vis_masks;          // library-owned [B, G*G, vis_words]; NULL = not computed: observations walk the lines themselves
@@ -157,7 +157,7 @@ struct KParams {
     int32_t lds_env_bytes;     // LDS region of one env (map / val / scr offsets above are relative to it)
     int32_t off_lut2;          // from the start of dynamic LDS: the workgroup's copy of obs_lut2
     int32_t off_ctl;           // from the start of dynamic LDS: control words (Env::CTL_*)
-    int32_t blk_p, blk_q;      // elements per observation block: channels x Rp^2, channels x Rq^2 (or the cell layout's: obs_tiles)
+    int32_t blk_p, blk_q;      // elements per observation block: channels x Rp^2, channels x Rq^2
     uint32_t bp_magic, bq_magic;  // ceil(2^32 / blk): element / blk == mulhi(element, magic)
     const uint32_t *coop_tab;  // library-owned: blk_p + blk_q observation descriptors.  Element (channel, i, j) of a species' (4,R,R)
                                // block, channels 1-3: bits 0-15 the signed map offset relative to the observer's padded cell,
@@ -1507,59 +1507,36 @@ struct Env {
         const uint32_t *L = lut2 + (type ? C.blk_p : 0);
         const int total = n_live * blk;
         const size_t obase = (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;
-#ifndef PPG_COOP_U
-#define PPG_COOP_U 2
-#endif
-#ifndef PPG_COOP_PREFETCH
-#define PPG_COOP_PREFETCH 0
-#endif
-        constexpr int U = PPG_COOP_U;   // pieces in flight per wavefront: the three dependent LDS lookups of one hide behind the others'
+        // pieces in flight per wavefront: the three dependent LDS lookups of one hide behind the other's.  (Round 6, measured and not
+        // kept: four in flight, and the first lookup of the next group issued beside the map reads of the group in hand -- 53.8 / 55.4
+        // against 53.0 us per 4096-env step on 64x64 grids, 63.5 / 67.4 against 62.3 on the headline: the write phase is bound by how
+        // fast the memory system takes the stores, not by this chain.  profiles/r06/b_*)
+        constexpr int U = 2;
         const uint32_t G = (uint32_t)P.G;
-        // A group of U pieces takes three dependent LDS round trips: (row entry, element descriptors) -> map entries -> values.
-        // PPG_COOP_PREFETCH: the first of them is issued one group ahead, beside the map reads of the group in hand.
-        uint32_t ent_n[U], w_n[U];
-        uint2 d_n[U];
-        bool on_n[U];
-        auto issue = [&](int p0) {   // the reads that depend on the piece number alone
+        for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
+            uint32_t o[U], i0[U], i1[U];
+            bool on[U], out0[U], out1[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s0 = (p0 + u * stride) * 128 + 2 * ln;
-                on_n[u] = s0 < total;
-                const uint32_t sc = on_n[u] ? (uint32_t)s0 : 0u;
-                const uint32_t i = wv::mulhi(sc, magic);
-                w_n[u] = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
-                ent_n[u] = on_n[u] ? list[i] : 0u;          // (lanes behind the end of the run look at cell (0,0): inside the maps)
-                d_n[u] = *(const uint2 *)(L + w_n[u]);
-            }
-        };
-        if (PPG_COOP_PREFETCH) issue(first);
-        for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
-            uint32_t o[U], i0[U], i1[U], m0[U], m1[U], ax[U], ay[U];
-            uint2 d[U];
-            bool on[U], out0[U], out1[U];
-            if (!PPG_COOP_PREFETCH) issue(p0);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t ent = ent_n[u];
-                d[u] = d_n[u]; on[u] = on_n[u];
-                ax[u] = (ent >> 8) & 255u; ay[u] = ent & 255u;
-                const int pc = (int)(wv::mul24(ax[u] + (uint32_t)P.pad, (uint32_t)P.Gp) + ay[u] + (uint32_t)P.pad);
+                on[u] = s0 < total;
+                const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
+                const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
+                const uint32_t ent = on[u] ? list[i] : 0u;   // (lanes behind the end of the run look at cell (0,0): inside the maps)
+                const uint2 d = *(const uint2 *)(L + w);
+                const uint32_t ax = (ent >> 8) & 255u, ay = ent & 255u;
+                const int pc = (int)(wv::mul24(ax + (uint32_t)P.pad, (uint32_t)P.Gp) + ay + (uint32_t)P.pad);
+                const bool z0 = (d.x >> 16) == 0xFFFFu, z1 = (d.y >> 16) == 0xFFFFu;   // channel 0: no map
                 // (a channel-0 descriptor's low bits as a map offset stay inside the three maps: no lane reads outside LDS)
-                m0[u] = (uint32_t)m[pc + (int)(int16_t)(d[u].x & 0xFFFFu)];
-                m1[u] = (uint32_t)m[pc + (int)(int16_t)(d[u].y & 0xFFFFu)];
-                o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w_n[u];
-            }
-            if (PPG_COOP_PREFETCH) issue(p0 + U * stride);   // (behind the end of the run: every lane off, two harmless reads of entry 0)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool z0 = (d[u].x >> 16) == 0xFFFFu, z1 = (d[u].y >> 16) == 0xFFFFu;   // channel 0: no map
-                i0[u] = z0 ? 0u : m0[u] + (d[u].x >> 16);
-                i1[u] = z1 ? 0u : m1[u] + (d[u].y >> 16);
+                const uint32_t m0 = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)], m1 = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)];
+                i0[u] = z0 ? 0u : m0 + (d.x >> 16);
+                i1[u] = z1 ? 0u : m1 + (d.y >> 16);
                 // outside the grid: unsigned compares (a coordinate below 0 wraps far above G); computed for every lane, no branches
-                const uint32_t tx0 = ax[u] + ((d[u].x >> 4) & 15u) - 8u, ty0 = ay[u] + (d[u].x & 15u) - 8u;
-                const uint32_t tx1 = ax[u] + ((d[u].y >> 4) & 15u) - 8u, ty1 = ay[u] + (d[u].y & 15u) - 8u;
+                const uint32_t tx0 = ax + ((d.x >> 4) & 15u) - 8u, ty0 = ay + (d.x & 15u) - 8u;
+                const uint32_t tx1 = ax + ((d.y >> 4) & 15u) - 8u, ty1 = ay + (d.y & 15u) - 8u;
                 out0[u] = z0 & ((tx0 > ty0 ? tx0 : ty0) >= G);
                 out1[u] = z1 & ((tx1 > ty1 ? tx1 : ty1) >= G);
+                o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1635,7 +1612,7 @@ struct Env {
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0);   // (arithmetic, not a select of fields: see window_sum)
         double dv[4] = {0.0, 0.0, 0.0, 0.0};
         if (DRIVE) drive_features(type, s_e, s_xy, dv);
-        const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);   // channels x R x R, or the cell layout's elements (KParams::obs_tiles)
+        const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);   // channels x R x R
         const int off = (R - 1) / 2;
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int s_cell = x * P.G + y;

@@ -705,15 +705,15 @@ __device__ __forceinline__ KPtr uniform(KPtr p) { return (KPtr)uniform((uintptr_
 // written to LDS, one sub-group later); the 16-channel float64 variant converts to float at once (64 registers otherwise).
 template <int OBS, int NCH>
 struct ObsRaw {
-    typedef typename std::conditional<OBS >= 2, uint16_t, typename std::conditional<OBS == 1, float, double>::type>::type elem;
+    typedef typename std::conditional<OBS == 2, uint16_t, typename std::conditional<OBS == 1, float, double>::type>::type elem;
     // (bfloat16 rows travel as the zero-extended 16 bits in a register of their own: two 16-bit values in one register would be
     //  packed as soon as they are loaded, i.e. waited for)
-    typedef typename std::conditional<OBS >= 2, uint32_t, typename std::conditional<OBS == 0 && (NCH > 8), float, elem>::type>::type type;
+    typedef typename std::conditional<OBS == 2, uint32_t, typename std::conditional<OBS == 0 && (NCH > 8), float, elem>::type>::type type;
     // (the empty asm pins the conversion -- and with it the wait for the load -- to the place where the value is staged: a pure
     //  function of a loaded value is otherwise scheduled right behind its load)
     static __device__ __forceinline__ __bf16 to_bf16(type v) {
         __asm__ volatile("" : "+v"(v));
-        if constexpr (OBS >= 2) return __builtin_bit_cast(__bf16, (uint16_t)v);
+        if constexpr (OBS == 2) return __builtin_bit_cast(__bf16, (uint16_t)v);
         else return (__bf16)(float)v;
     }
 };
@@ -1007,9 +1007,6 @@ PPG_POLICY_KERNEL(ppg_policy_forward_hwc16_bf16, 2, 16)
 
 #include "ppg_policy_direct.h"
 #include "ppg_policy_pipe.h"
-#ifdef PPG_WITH_PIPE4   // (an experiment that lost: see the file's header; not part of the product build)
-#include "ppg_policy_pipe4.h"
-#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side
@@ -1714,11 +1711,7 @@ static int ppg_policy_fill(ppg_policy *p, int species, ppg_handle *const *handle
     if (p->n_actions != 9 && !h0->gen2) return ppg_policy_fail(p, PPG_EINVAL, "the base env has 9 actions, the policy %d", p->n_actions);
     K = p->base;
     memset(&L, 0, sizeof L);
-    K.species = species; K.obs_f32 = h0->base.obs_tiles ? 3 : h0->base.obs_f32; K.sample = (flags & PPG_POLICY_SAMPLE) ? 1 : 0;
-    if (h0->base.obs_tiles) {   // rows in the cell layout (ppg_config.obs_dtype 3): the pipeline kernels' own staging format
-        if (!p->pipe) return ppg_policy_fail(p, PPG_EINVAL, "observation rows in the cell layout (obs_dtype 3) are read by the pipeline kernels only; this network runs the %s kernels", p->direct ? "one-role" : "fully connected");
-        K.obs_elems = species ? h0->base.blk_q : h0->base.blk_p;
-    }
+    K.species = species; K.obs_f32 = h0->base.obs_f32; K.sample = (flags & PPG_POLICY_SAMPLE) ? 1 : 0;
     K.seed_lo = (uint32_t)seed ^ (species ? 0x9E3779B9u : 0u); K.seed_hi = (uint32_t)(seed >> 32);
     K.seed_dev = (flags & PPG_POLICY_SEED_ON_DEVICE) ? (const uint64_t *)(uintptr_t)seed : nullptr;
     K.S = h0->base.S; K.cap = species ? h0->base.cap_prey : h0->base.cap_pred; K.slot0 = species ? h0->base.cap_pred : 0;
@@ -1731,7 +1724,7 @@ static int ppg_policy_fill(ppg_policy *p, int species, ppg_handle *const *handle
         const int channels = h->drive ? 4 + h->cfg.n_drive[species] : (h->gen2 && h->cfg2.walls && h->cfg2.include_visibility_channel) ? 5 : 4;
         if (channels != p->obs_channels)
             return ppg_policy_fail(p, PPG_EINVAL, "the policy reads %d-channel observations, handle %d writes %d channels", p->obs_channels, k, channels);
-        if ((species ? h->base.Rq : h->base.Rp) != R || h->base.S != K.S || h->base.obs_f32 != h0->base.obs_f32 || h->base.obs_tiles != h0->base.obs_tiles || h->device != p->device)
+        if ((species ? h->base.Rq : h->base.Rp) != R || h->base.S != K.S || h->base.obs_f32 != h0->base.obs_f32 || h->device != p->device)
             return ppg_policy_fail(p, PPG_EINVAL, "handle %d has another geometry / dtype / device than handle 0", k);
         if (!actions[k]) return ppg_policy_fail(p, PPG_EINVAL, "actions[%d] is NULL", k);
         K.env_base[k] = L.env_base[k] = total;
@@ -1914,33 +1907,19 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
     K2.iter_q = ppg_env_int("PPG_POLICY_ITER_Q", 7500);
     K2.iter_p = ppg_env_int("PPG_POLICY_ITER_P", 8500);
     typedef void (*fused_fn)(const ppgpol::PolParams2);
-    const fused_fn fn[2][2][4] = {
-        {{ppgpol::ppg_policy_pipe2_8_8_f64, ppgpol::ppg_policy_pipe2_8_8_f32, ppgpol::ppg_policy_pipe2_8_8_bf16, ppgpol::ppg_policy_pipe2_8_8_cells},
-         {ppgpol::ppg_policy_pipe2_8_16_f64, ppgpol::ppg_policy_pipe2_8_16_f32, ppgpol::ppg_policy_pipe2_8_16_bf16, ppgpol::ppg_policy_pipe2_8_16_cells}},
-        {{ppgpol::ppg_policy_pipe2_16_8_f64, ppgpol::ppg_policy_pipe2_16_8_f32, ppgpol::ppg_policy_pipe2_16_8_bf16, ppgpol::ppg_policy_pipe2_16_8_cells},
-         {ppgpol::ppg_policy_pipe2_16_16_f64, ppgpol::ppg_policy_pipe2_16_16_f32, ppgpol::ppg_policy_pipe2_16_16_bf16, ppgpol::ppg_policy_pipe2_16_16_cells}}};
-    const int dt = K2.q.obs_f32 == 3 ? 3 : K2.q.obs_f32 == 2 ? 2 : K2.q.obs_f32 ? 1 : 0;
-#ifdef PPG_WITH_PIPE4
-    // the four-role pipeline (ppg_policy_pipe4.h: sixteen wavefronts per workgroup; same LDS layout, bit-identical results, 18 % slower:
-    // profiles/r05/i_*) -- experiment builds only; PPG_POLICY_PIPE4=0 selects the two-role kernels there
-    const fused_fn fn4[2][2][3] = {
-        {{ppgpol::ppg_policy_pipe4_8_8_f64, ppgpol::ppg_policy_pipe4_8_8_f32, ppgpol::ppg_policy_pipe4_8_8_bf16},
-         {ppgpol::ppg_policy_pipe4_8_16_f64, ppgpol::ppg_policy_pipe4_8_16_f32, ppgpol::ppg_policy_pipe4_8_16_bf16}},
-        {{ppgpol::ppg_policy_pipe4_16_8_f64, ppgpol::ppg_policy_pipe4_16_8_f32, ppgpol::ppg_policy_pipe4_16_8_bf16},
-         {ppgpol::ppg_policy_pipe4_16_16_f64, ppgpol::ppg_policy_pipe4_16_16_f32, ppgpol::ppg_policy_pipe4_16_16_bf16}}};
-    const char *p4 = getenv("PPG_POLICY_PIPE4");
-    const bool pipe4 = !(p4 && p4[0] == '0' && p4[1] == 0) && dt < 3;
-    const fused_fn f = pipe4 ? fn4[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt < 3 ? dt : 2] : fn[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt];
-#else
-    const bool pipe4 = false;
+    const fused_fn fn[2][2][3] = {
+        {{ppgpol::ppg_policy_pipe2_8_8_f64, ppgpol::ppg_policy_pipe2_8_8_f32, ppgpol::ppg_policy_pipe2_8_8_bf16},
+         {ppgpol::ppg_policy_pipe2_8_16_f64, ppgpol::ppg_policy_pipe2_8_16_f32, ppgpol::ppg_policy_pipe2_8_16_bf16}},
+        {{ppgpol::ppg_policy_pipe2_16_8_f64, ppgpol::ppg_policy_pipe2_16_8_f32, ppgpol::ppg_policy_pipe2_16_8_bf16},
+         {ppgpol::ppg_policy_pipe2_16_16_f64, ppgpol::ppg_policy_pipe2_16_16_f32, ppgpol::ppg_policy_pipe2_16_16_bf16}}};
+    const int dt = K2.q.obs_f32 == 2 ? 2 : K2.q.obs_f32 ? 1 : 0;
     const fused_fn f = fn[prey->nch16 ? 1 : 0][pred->nch16 ? 1 : 0][dt];
-#endif
 #ifdef PPG_DIRECT_PROFILE   // diagnostic build: per-wavefront phase cycles of launch number PPG_DIRECT_PROFILE_RUN (default 300) -> $PPG_DIRECT_PROFILE_FILE.fused
     static int dp_runs = 0;
     static unsigned long long *dp_buf = nullptr;
     const char *dp_path = getenv("PPG_DIRECT_PROFILE_FILE");
     const int dp_at = getenv("PPG_DIRECT_PROFILE_RUN") ? atoi(getenv("PPG_DIRECT_PROFILE_RUN")) : 300;
-    const size_t dp_bytes = (size_t)prey->grid * 16 * 16 * 8;   // (sixteen wavefronts per workgroup in the four-role kernels)
+    const size_t dp_bytes = (size_t)prey->grid * 8 * 16 * 8;   // (eight wavefronts per workgroup, sixteen words each)
     if (dp_path && !dp_buf) {
         PPG_POL_TRY(prey, hipMalloc((void **)&dp_buf, dp_bytes));
         PPG_POL_TRY(prey, hipMemset(dp_buf, 0, dp_bytes));
@@ -1955,7 +1934,7 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
     rc = ppg_pipe_debug_arm(prey);
     if (rc != PPG_OK) { memcpy(g_ppg_policy_error, prey->err, sizeof g_ppg_policy_error); return rc; }
 #endif
-    hipLaunchKernelGGL(f, dim3((unsigned)prey->grid), dim3(pipe4 ? 1024 : 512), (size_t)lds, (hipStream_t)stream, K2);
+    hipLaunchKernelGGL(f, dim3((unsigned)prey->grid), dim3(512), (size_t)lds, (hipStream_t)stream, K2);
     PPG_POL_TRY(prey, hipGetLastError());
 #ifdef PPG_PIPE_DEBUG
     rc = ppg_pipe_debug_check(prey);
@@ -1967,7 +1946,7 @@ static int ppg_policy_run_fused(ppg_policy *pred, ppg_policy *prey, ppg_handle *
         std::vector<unsigned long long> host(dp_bytes / 8);
         PPG_POL_TRY(prey, hipMemcpy(host.data(), dp_buf, dp_bytes, hipMemcpyDeviceToHost));
         char name[512];
-        snprintf(name, sizeof name, "%s.%s", dp_path, pipe4 ? "fused4" : "fused");
+        snprintf(name, sizeof name, "%s.fused", dp_path);
         if (FILE *fo = fopen(name, "wb")) { fwrite(host.data(), 8, host.size(), fo); fclose(fo); }
     }
 #endif

@@ -49,7 +49,7 @@
 #define PPG_PIPE_FETCH_EARLY 0   // 1: the chunk loads of sub-group it + 2 go out right behind the staging of sub-group it + 1 (experiment, profiles/r05/r_*)
 #endif
 #ifndef PPG_PIPE_ABLATE
-#define PPG_PIPE_ABLATE 0   // timing-only ablation builds (tools/gpu_r5_pipe_ablate.sh; never the product -- the results are then meaningless):
+#define PPG_PIPE_ABLATE 0   // timing-only ablation builds (rounds 4-5, profiles/r05/h_*; never the product -- the results are then meaningless):
                             // 1 no head, 2 no staging, 4 no conv1, 8 no conv2, 16 no conv3, 32 no logits / actions, 64 no Gumbel noise,
                             // 128 no row fetch / park
 #endif
@@ -182,7 +182,7 @@ __device__ __forceinline__ u32x2_t relu_pack4(const f32x4_t &a) {
     return w;
 }
 // One sub-group's conv1: X (input blocks at element offset xo) -> Y.  CB1 = 2: a second input block (the ninth channel's taps).
-// LOOP: tile after tile (12 registers of operands; the four-role kernels' 128-register budget) instead of the straight line below.
+// LOOP: tile after tile (12 registers of operands) instead of the straight line below.
 template <int CB1, bool LOOP = (PPG_PIPE_CONV1X_LOOP != 0), class KP>
 __device__ __forceinline__ void conv1x(const KP &K, const Conv1X &W, __bf16 *img, int xo, int ns, int bw, int lane, int dummy) {
     const int kq = lane >> 4;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void conv2_pair(const KP &K, const ConvW<2, 1> &W, __
 // envs' predator / prey row counts (env words 0, 1: one 8-byte load per env) over the concatenated envs of all handles, in LDS:
 // scratch = [512 threads][2] partial sums | pre_pred[n_envs] | pre_prey[n_envs].  512 threads; ends with a workgroup barrier.
 constexpr int FUSED_PART_WORDS = 1024, FUSED_MAX_ENVS = 8192;
-template <int NT, class KP>   // NT threads (512: the two-role kernels, 1024: ppg_policy_pipe4.h)
+template <int NT, class KP>   // NT threads (512: the two-role kernels)
 __device__ __forceinline__ void fused_prefix_sums(const KP &K, uint32_t *scratch, int tid, uint32_t &tot_pred, uint32_t &tot_prey) {
     static_assert(PPG_ENV_N_PRED_ROWS == 0 && PPG_ENV_N_PREY_ROWS == 1, "the two row counts are one 8-byte load");
     constexpr int FUSED_RUN = FUSED_MAX_ENVS / NT, NWAVES = NT / 64;
@@ -427,7 +427,7 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
             const int row = (int)(n - (!FUSED ? K.plan[PLAN_HDR + e] : n0 == begin ? pre[e] : __builtin_nontemporal_load(&pre_g[e])));
             const unsigned char *base;
             const int b = pipe_pick_handle(K, K.obs, e, base);
-            tab[2 * i] = (unsigned long long)(uintptr_t)(base + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS >= 2 ? 2 : OBS == 1 ? 4 : 8));
+            tab[2 * i] = (unsigned long long)(uintptr_t)(base + ((size_t)b * K.cap + row) * (size_t)K.obs_elems * (OBS == 2 ? 2 : OBS == 1 ? 4 : 8));
             tab[2 * i + 1] = (unsigned long long)(uint32_t)e | ((unsigned long long)(uint32_t)row << 32);
         }
         __syncthreads();
@@ -611,7 +611,6 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         auto group_ns = [&](int g) { const int left = nt_samples - g * K.ST; return left < K.ST ? left : K.ST; };
         raw_t pre[NCH];
         u32x2_t chunk[PIPE_CHUNKS];
-        u32x4_t cellv[2];   // OBS == 3 (rows in the cell layout, ppg_config.obs_dtype 3): this thread's position as it will lie in the image
         auto fetch = [&](int g) {   // row chunks: chunk ch_w of this thread's samples of sub-group g -> registers
             // (every load unconditional, the sample clamped: a load under a condition is merged with its default value by a register
             //  copy right behind it -- a wait for the whole memory round trip, 1500-3700 cycles per sub-group: profiles/r04)
@@ -632,15 +631,6 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         };
         auto request = [&](int g) {   // (a B thread stages one position: ST * P <= 256, ppg_policy_create_spec)
             const int ns = group_ns(g);
-            if constexpr (OBS == 3) {
-                // the row IS the staged layout: the position's cell(s), one or two aligned 16-byte loads (unconditional, the sample
-                // clamped -- see fetch), written to the image one iteration later as they are: no `raw` area, no LDS read, no packing
-                const int last = ns - 1, s = st_s < last ? st_s : last;
-                const GLOBAL_AS unsigned char *src = row_of(g * K.ST + s) + st_p * (CB1 > 1 ? 32 : 16);
-                cellv[0] = *(const GLOBAL_AS u32x4_t *)src;
-                if constexpr (CB1 > 1) cellv[1] = *(const GLOBAL_AS u32x4_t *)(src + 16);
-                return;
-            }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) pre[c] = (raw_t)0;
             if (st_sv < ns) {
@@ -655,20 +645,6 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
         };
         auto stage = [&](int g) {
             const int ns = group_ns(g);
-            if constexpr (OBS == 3) {
-                if (st_sv < ns) {
-                    __bf16 *cell = img + st_img + ((g & 1) ? K.pipe_x1 : 0);
-                    u32x4_t v0 = cellv[0];
-                    __asm__ volatile("" : "+v"(v0));   // (the wait for the load stays here)
-                    *(u32x4_t *)cell = v0;
-                    if constexpr (CB1 > 1) {
-                        u32x4_t v1 = cellv[1];
-                        __asm__ volatile("" : "+v"(v1));
-                        *(u32x4_t *)(cell + K.Wp2 * 8) = v1;
-                    }
-                }
-                return;
-            }
             if (st_sv < ns) {
                 if constexpr (CH) {
                     const uint16_t *rh = (const uint16_t *)raw + st_raw;
@@ -712,11 +688,8 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
                 if (!(PPG_PIPE_ABLATE & 2)) stage(it + 1);
                 b_target += 4;
                 pipe_arrive(ctr, lane);
-                // (cells: the next sub-group's loads go out NOW and have the whole iteration to land -- the __syncthreads at its end waits
-                //  for every outstanding load of the workgroup)
-                if constexpr (OBS == 3) request(it + 2 < G ? it + 2 : G - 1);
 #if PPG_PIPE_FETCH_EARLY
-                else if constexpr (CH) fetch(it + 2 < G ? it + 2 : G - 1);
+                if constexpr (CH) fetch(it + 2 < G ? it + 2 : G - 1);
 #endif
             }
             PPG_DP(11);
@@ -766,7 +739,6 @@ __device__ __forceinline__ void pipe_main(KPtr Kp, unsigned char *lds, int wg = 
 #else
                 else if constexpr (CH) fetch(g + 1 < G ? g + 1 : g);   // (unconditional, like the loads in it; the last one is not parked)
 #endif
-                else if constexpr (OBS == 3) { }
                 else if (g + 1 < G) request(g + 1);
                 PPG_DP(5);
                 pipe_wait(ctr, b_target);
@@ -906,10 +878,5 @@ PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_16_f64, 0, 16, 16)
 PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_bf16, 2, 8, 16)
 PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_f32, 1, 8, 16)
 PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_f64, 0, 8, 16)
-// rows in the cell layout (ppg_config.obs_dtype 3)
-PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_8_cells, 3, 16, 8)
-PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_8_cells, 3, 8, 8)
-PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_16_16_cells, 3, 16, 16)
-PPG_POLICY_PIPE2_KERNEL(ppg_policy_pipe2_8_16_cells, 3, 8, 16)
 
 }  // namespace ppgpol

@@ -284,41 +284,3 @@ def test_rebalance_changes_scheduling_only():
     for n in ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
         assert torch.equal(getattr(envs[0], n), getattr(envs[1], n)), n
     assert torch.equal(envs[0].env_state[:, : _abi.ENV_CALLS], envs[1].env_state[:, : _abi.ENV_CALLS])
-
-
-def _rows_as_cells(chw, R):
-    ce = 8 if R <= 8 else 16
-    out = torch.zeros(chw.shape[:-1] + (ce,), dtype=chw.dtype)
-    out[..., :min(R, 8)] = chw[..., :min(R, 8)]
-    if R == 9:
-        out[..., 1:, 8] = chw[..., :-1, 8]
-        out[..., :, 9] = chw[..., :, 8]
-        out[..., :-1, 10] = chw[..., 1:, 8]
-    return out
-
-
-@pytest.mark.parametrize("plan", [None, (4, 0, 2), (1, 0, 0), (4, 0, 0)])
-@pytest.mark.parametrize("over", [{}, {"predator_obs_range": 5, "prey_obs_range": 8, "grid_size": 12}])
-def test_rows_in_the_cell_layout_are_the_bfloat16_rows_reordered(plan, over):
-    """ppg_config.obs_dtype 3 (include/ppg.h: PPG_OBS_BF16_CELLS): per position of the channels-last reading of the (4,R,R) Box one
-    16-byte cell, for R = 9 a second one with the ninth value of the position and its two neighbours.  Descriptor tables only: the
-    single-wave, multi-wave and cooperative kernels, reset and auto-reset all write it; every live row against the bfloat16 row of an
-    env stepped alongside."""
-    cfg = {**config_env, **over}
-    a = BatchedPredPreyGrass(cfg, batch_size=3, _library=library(), obs_dtype=torch.bfloat16)
-    b = BatchedPredPreyGrass(cfg, batch_size=3, _library=library(), obs_dtype="bf16_cells")
-    assert b.obs_prey.shape[-2:] == (b.Rq, 16 if b.Rq == 9 else 8)
-    for e in (a, b):
-        if plan:
-            e.set_wave_plan(*plan)
-        e.reset(seed=5)
-    for t in range(25):
-        for e in (a, b):
-            e.step(random_actions=True, auto_reset=True)
-        for n in ("row_xy", "row_energy", "row_flags", "row_reward"):
-            assert torch.equal(getattr(a, n), getattr(b, n)), (n, t)
-        es = a.env_state.numpy()
-        for i in range(3):
-            npd, npy = int(es[i, _abi.ENV_N_PRED_ROWS]), int(es[i, _abi.ENV_N_PREY_ROWS])
-            assert torch.equal(_rows_as_cells(a.obs_pred[i, :npd], a.Rp).view(torch.int16), b.obs_pred[i, :npd].view(torch.int16)), ("pred", t, i)
-            assert torch.equal(_rows_as_cells(a.obs_prey[i, :npy], a.Rq).view(torch.int16), b.obs_prey[i, :npy].view(torch.int16)), ("prey", t, i)

@@ -505,41 +505,6 @@ def test_one_fused_launch_gives_what_the_separate_launches_give(batch, steps, dt
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch,steps,dt", [(4096, 150, torch.bfloat16), (700, 60, torch.float64), (700, 60, torch.float32),
-                                            (6500, 500, torch.bfloat16), (3, 30, torch.bfloat16), (1, 5, torch.bfloat16)])
-def test_four_role_pipeline_gives_what_the_two_role_pipeline_gives(batch, steps, dt, monkeypatch):
-    """The four-role kernels (ppg_policy_pipe4.h: sixteen wavefronts per workgroup, conv3 split by output channel halves, the head and
-    the row fetch on wavefronts of their own) run every output's instructions in the two-role kernels' order: identical logits, greedy
-    AND sampled actions (PPG_POLICY_PIPE4=0 selects the two-role fused launch) -- the benchmark's size, float64 / float32 rows, shares of
-    several tiles, fewer rows than workgroups, one env."""
-    from predpreygrass_amd.batched import BatchedPredPreyGrass
-    from predpreygrass_amd.policy import FusedPolicy
-    if b"ppg_policy_pipe4_16_8_bf16" not in open(_abi.LIB_PATH, "rb").read():
-        pytest.skip("the four-role kernels are an experiment build (-DPPG_WITH_PIPE4): measured 18 % slower, profiles/r05/i_*")
-    nets = make_nets(seed=54)
-    env = BatchedPredPreyGrass(dict(config_env), batch_size=batch, device="cuda:0", obs_dtype=dt, seed=16)
-    env.reset()
-    for _ in range(steps):
-        env.step(random_actions=True, auto_reset=True)
-    fused = FusedPolicy(nets[0], nets[1])
-    out = []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("PPG_POLICY_PIPE4", mode)
-        env.actions.fill_(_abi.ACTION_NONE)
-        lg = fused.act(env, want_logits=True)
-        greedy = env.actions.clone()
-        fused.act(env, sample=True, seed=79)
-        torch.cuda.synchronize()
-        out.append((lg[0].clone(), lg[1].clone(), greedy, env.actions.clone()))
-    for a, b in zip(*out):
-        assert torch.equal(a, b)
-    assert bool(out[0][1].abs().sum() > 0) and (batch < 10 or not torch.equal(out[0][2], out[0][3]))
-    env.step(env.actions, auto_reset=True)
-    torch.cuda.synchronize()
-    assert (env.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()
-
-
-@pytest.mark.gpu
 def test_fused_launch_over_several_sub_batches_and_an_extinct_species(monkeypatch):
     """The fused launch over three handles (the envs of a GPU as sub-batches), and with one species extinct everywhere (every
     workgroup then serves the other one)."""
@@ -927,59 +892,6 @@ def test_a_step_replayed_from_a_hip_graph_equals_the_launches_it_was_captured_fr
     for name in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "row_cumrew", "env_state", "grass_energy", "obs_pred", "obs_prey", "actions"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert (a.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all() and (a.env_state[:, _abi.ENV_CALLS] == 30 + n).all()
-
-
-def _rows_as_cells(chw, R):
-    """(…, 4, R, R) bfloat16 rows -> the cell layout of include/ppg.h (obs_dtype 3): per position (plane, window row) the first eight
-    values, and for R = 9 a second cell {value 8 of the row before, of this row, of the row after, 0 ...}."""
-    ce = 8 if R <= 8 else 16
-    out = torch.zeros(chw.shape[:-1] + (ce,), dtype=chw.dtype, device=chw.device)
-    out[..., :min(R, 8)] = chw[..., :min(R, 8)]
-    if R == 9:
-        out[..., 1:, 8] = chw[..., :-1, 8]
-        out[..., :, 9] = chw[..., :, 8]
-        out[..., :-1, 10] = chw[..., 1:, 8]
-    return out
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("batch,steps,over", [(4096, 150, {}), (300, 80, {}), (6500, 300, {}), (2, 20, {}),
-                                              (500, 100, {"predator_obs_range": 5, "prey_obs_range": 7, "grid_size": 15})])
-def test_rows_in_the_cell_layout_give_the_same_rows_logits_and_actions(batch, steps, over):
-    """obs_dtype 3 (its cheap form): the step writes every row as the policy pipeline's staging wants it -- 16-byte
-    cells per position -- and the pipeline copies the cells into its image instead of picking the row apart.  Two envs with the same
-    seed, one on bfloat16 (4,R,R) rows, one on cells, closed around the same policy: the rows are the same values in the other order
-    (every live row of every env compared), logits, greedy and sampled actions identical, call by call."""
-    from predpreygrass_amd.batched import BatchedPredPreyGrass
-    from predpreygrass_amd.policy import FusedPolicy
-    cfg = {**config_env, **over}
-    nets = make_nets(Rp=cfg["predator_obs_range"], Rq=cfg["prey_obs_range"], seed=61)
-    a = BatchedPredPreyGrass(cfg, batch_size=batch, device="cuda:0", obs_dtype=torch.bfloat16, seed=19)
-    b = BatchedPredPreyGrass(cfg, batch_size=batch, device="cuda:0", obs_dtype="bf16_cells", seed=19)
-    assert b.obs_prey.shape[-1] == (16 if b.Rq == 9 else 8)
-    fused = FusedPolicy(nets[0], nets[1])
-    for e in (a, b):
-        e.reset()
-    for t in range(steps):
-        sample = t % 3 != 0
-        la = fused.act(a, want_logits=True, sample=sample, seed=1000 + t)
-        lb = fused.act(b, want_logits=True, sample=sample, seed=1000 + t)
-        torch.cuda.synchronize()
-        assert torch.equal(a.actions, b.actions), t
-        for x, y in zip(la, lb):
-            assert torch.equal(x, y), t
-        if t % 10 == 0:
-            live_p = torch.arange(a.pred_capacity, device="cuda:0")[None, :] < a.env_state[:, _abi.ENV_N_PRED_ROWS, None]
-            live_q = torch.arange(a.prey_capacity, device="cuda:0")[None, :] < a.env_state[:, _abi.ENV_N_PREY_ROWS, None]
-            assert torch.equal(_rows_as_cells(a.obs_pred, a.Rp)[live_p].view(torch.int16), b.obs_pred[live_p].view(torch.int16)), t
-            assert torch.equal(_rows_as_cells(a.obs_prey, a.Rq)[live_q].view(torch.int16), b.obs_prey[live_q].view(torch.int16)), t
-        for e in (a, b):
-            e.step(e.actions, auto_reset=True)
-    torch.cuda.synchronize()
-    for n in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "grass_energy"):
-        assert torch.equal(getattr(a, n), getattr(b, n)), n
-    assert bool(la[1].abs().sum() > 0)
-    assert (b.env_state[:, _abi.ENV_STATUS] & _abi.STATUS_BAD_ACTION == 0).all()
 
 
 @pytest.mark.gpu

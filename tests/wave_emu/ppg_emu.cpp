@@ -47,7 +47,7 @@ static void lane_entry(void *arg) {
     const EmuLaunch *L = (const EmuLaunch *)arg;
     // same selection rule as the HIP backend; PPG_EMU_FORCE_GENERIC_OBS=1 exercises the LDS-descriptor path
     static const bool force_generic = getenv("PPG_EMU_FORCE_GENERIC_OBS") != nullptr;
-    run_part(L, L->P->nch_p <= 2 && L->P->nch_q <= 3 && !force_generic && L->gen2 < 2 && !L->P->obs_tiles);
+    run_part(L, L->P->nch_p <= 2 && L->P->nch_q <= 3 && !force_generic && L->gen2 < 2);
 }
 
 static int backend_init(ppg_handle *h, int) {

@@ -4,6 +4,7 @@
 #   ab:<workload>:<streams>:<plan>[,<plan>...]     tools/ab_plans.py, plans as name=waves.min_rows.coop (e.g. pair=2.0.0,coop42=4.0.2)
 #   lib:<workload>:<steps>:<rounds>:name=lib.so[,name=lib.so...]   alternating-process A/B of library builds (tools/gpu_lib_ab.sh)
 #   bench:<name>:<bench.py arguments, comma separated>      one bench.py run, its JSON line kept
+#   benv:<name>:<VAR=value>:<bench.py arguments>    the same with one environment variable set for that run
 #   pt:<name>:<file>:<-k expression>    selected GPU tests with their printed reports kept (pytest -s)
 #   phase:<name>:<tools/phase_profile.py arguments, comma separated>   phase shares of a wavefront's cycles (diagnostic build)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -27,6 +28,10 @@ for step in "$@"; do
       IFS=: read -r name bargs <<< "$rest"
       python3 bench.py $(echo "$bargs" | tr ',' ' ') > gpurun_out/${tag}_bench_${name}.json.log 2> gpurun_out/${tag}_bench_${name}.err
       grep '^{' gpurun_out/${tag}_bench_${name}.json.log | tail -1 | cut -c1-600 ;;
+    benv)
+      IFS=: read -r name var bargs <<< "$rest"
+      env "$var" python3 bench.py $(echo "$bargs" | tr ',' ' ') > gpurun_out/${tag}_bench_${name}.json.log 2> gpurun_out/${tag}_bench_${name}.err
+      grep '^{' gpurun_out/${tag}_bench_${name}.json.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$name', r.get('kernel'), 'kernel %.2f us frac %.4f value %.3f M' % (r['kernel_ms']*1e3, r['frac'], d['value']/1e6))" ;;
     pt)
       IFS=: read -r name file expr <<< "$rest"
       python3 -m pytest "$file" -m gpu -q -s -k "$expr" > gpurun_out/${tag}_pt_${name}.log 2>&1
