@@ -313,23 +313,22 @@ static int ppg_validate_and_layout_gen2(ppg_handle *h) {
 
 // Cooperative step kernels (Env's COOP): eligibility and LDS layout of one env's region.  The maps are padded by the larger
 // window's reach, so the map offsets of an observation block's elements are position-independent (Env::coop_build_lut).
-static void ppg_coop_layout(ppg_handle *h) {
-    h->coop_ok = 0;
+// One layout of the cooperative kernels' env region: with a channel-0 map (four maps) or without (three; Env::coop_pieces computes
+// channel 0).  false: the configuration cannot have it.
+static bool ppg_coop_layout_with(ppg_handle *h, int ch0_map, ppg::KParams &P, std::vector<uint32_t> &tab) {
     const ppg_config &c = h->cfg;
-    const bool walls = h->gen2 && h->cfg2.walls;
-    if (walls || h->drive || c.kickback || h->nq > 2) return;           // (8-bit maps; generic 4-channel observations only)
-    if (!(c.predator_obs_range & 1) || !(c.prey_obs_range & 1)) return;  // even windows keep the element-descriptor kernels
-    ppg::KParams P = h->base;
+    P = h->base;
     const int offp = (P.Rp - 1) / 2, offq = (P.Rq - 1) / 2;
+    P.ch0_map = ch0_map;
     P.pad = offp > offq ? offp : offq;
     P.Gp = P.G + 2 * P.pad;
     P.map_n = (P.Gp * P.Gp + 7) / 8 * 8;
-    if (3 * P.map_n + P.pad * P.Gp + P.pad > 32767) return;             // 16-bit map offsets
-    // THREE maps (predators, prey, grass): channel 0 is computed from the window position (Env::coop_pieces).  The device reset lays
-    // its two arrays over them: G*G cells + the K placed entities, 16 bits each (Env::do_reset)
-    if (2 * (((c.grid_size * c.grid_size + 7) & ~7) + c.n_initial_predators + c.n_initial_prey + c.n_grass) > 3 * P.map_n) return;
+    const int n_maps = 3 + ch0_map;
+    if (3 * P.map_n + P.pad * P.Gp + P.pad > 32767) return false;       // 16-bit map offsets
+    // The device reset lays its two arrays over the maps: three maps must hold G*G cells + the K placed entities, 16 bits each (Env::do_reset)
+    if (!ch0_map && 2 * (((c.grid_size * c.grid_size + 7) & ~7) + c.n_initial_predators + c.n_initial_prey + c.n_grass) > 3 * P.map_n) return false;
     int off = 0;
-    P.off_map = off; off += 3 * P.map_n;
+    P.off_map = off; off += n_maps * P.map_n;
     off = (off + 15) / 16 * 16;
     P.off_val = off; off += (196 + c.n_grass) * 8;      // packed sections (Env::SEC_Q, SEC_G)
     off = (off + 15) / 16 * 16;
@@ -339,33 +338,61 @@ static void ppg_coop_layout(ppg_handle *h) {
     P.off_scr = off; off += scr_bytes;
     P.off_lut = off;
     P.lds_env_bytes = (off + 15) / 16 * 16;
-    // (blk_p, blk_q: the base parameters' -- 4 R^2, or the cell layout's)
     P.bp_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_p - 1) / (uint64_t)P.blk_p);
     P.bq_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_q - 1) / (uint64_t)P.blk_q);
-    // KParams::coop_tab: the observation descriptors of both species
-    h->coop_tab_host.assign((size_t)(P.blk_p + P.blk_q), 0u);
+    // KParams::coop_tab: the observation descriptors of both species (then, with a channel-0 map, that map for an empty grid)
+    tab.assign((size_t)(P.blk_p + P.blk_q) + (ch0_map ? (size_t)P.map_n / 4 : 0), 0u);
     for (int t = 0; t < 2; ++t) {
         const int R = t ? P.Rq : P.Rp, o = (R - 1) / 2;
-        uint32_t *out = h->coop_tab_host.data() + (t ? P.blk_p : 0);
+        uint32_t *out = tab.data() + (t ? P.blk_p : 0);
         for (int e = 0; e < (t ? P.blk_q : P.blk_p); ++e) {
             const int ch = e / (R * R), i = (e % (R * R)) / R, j = e % R;
-            if (ch == 0) {   // "outside the grid" (BASE:520-523): the window offsets, no map
+            if (ch == 0 && !ch0_map) {   // "outside the grid" (BASE:520-523): the window offsets, no map
                 out[e] = 0xFFFF0000u | ((uint32_t)(i - o + 8) << 4) | (uint32_t)(j - o + 8);
                 continue;
             }
-            const int moff = (ch - 1) * P.map_n + (i - o) * P.Gp + (j - o);
+            const int moff = (ch - 1 + ch0_map) * P.map_n + (i - o) * P.Gp + (j - o);
             const int section = ch == 2 ? 66 : ch == 3 ? 66 + 129 : 0;     // Env::map_base of the cooperative kernels (SEC_Q, SEC_G)
             out[e] = ((uint32_t)moff & 0xFFFFu) | ((uint32_t)section << 16);
         }
     }
-    h->coop = P;
+    if (ch0_map) {
+        unsigned char *m0 = (unsigned char *)(tab.data() + P.blk_p + P.blk_q);
+        for (int x = 0; x < P.Gp; ++x)
+            for (int y = 0; y < P.Gp; ++y)
+                if (x < P.pad || x >= P.pad + P.G || y < P.pad || y >= P.pad + P.G) m0[x * P.Gp + y] = 65;   // Env::ONE_IDX
+    }
+    return true;
+}
+static int ppg_coop_lds_bytes_of(const ppg::KParams &P, int e) {
+    return e * P.lds_env_bytes + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16 + 80 * 4;   // env regions, descriptor table, Env::CTL_WORDS
+}
+// Cooperative step kernels (Env's COOP): eligibility and LDS layout of one env's region.  The maps are padded by the larger
+// window's reach, so the map offsets of an observation block's elements are position-independent.  Four maps (channel 0's halo points
+// at a constant 1.0: every element is one uniform lookup) where four two-env workgroups then fit a CU's LDS -- every grid up to
+// about 45x45; else three maps and channel 0 computed per element (64x64 grids: 24.1 -> 18.1 KB per env, three -> four workgroups per
+// CU, +10 % -- profiles/r06/a_*; the arithmetic costs the second generation's float32 rows on a 25x25 grid 11 %, so they keep the map).
+// PPG_COOP_MAPS=3 / 4 (read at create): force either (tests, A/B runs).
+static void ppg_coop_layout(ppg_handle *h) {
+    h->coop_ok = 0;
+    const ppg_config &c = h->cfg;
+    const bool walls = h->gen2 && h->cfg2.walls;
+    if (walls || h->drive || c.kickback || h->nq > 2) return;           // (8-bit maps; generic 4-channel observations only)
+    if (!(c.predator_obs_range & 1) || !(c.prey_obs_range & 1)) return;  // even windows keep the element-descriptor kernels
+    ppg::KParams P4, P3;
+    std::vector<uint32_t> t4, t3;
+    const bool ok4 = ppg_coop_layout_with(h, 1, P4, t4), ok3 = ppg_coop_layout_with(h, 0, P3, t3);
+    const char *force = getenv("PPG_COOP_MAPS");
+    bool use4 = ok4 && (ppg_coop_lds_bytes_of(P4, 2) * 4 <= 160 * 1024 || !ok3);
+    if (force && force[0] == '3' && ok3) use4 = false;
+    if (force && force[0] == '4' && ok4) use4 = true;
+    if (!use4 && !ok3) return;
+    h->coop = use4 ? P4 : P3;
+    h->coop_tab_host = use4 ? t4 : t3;
     h->coop_ok = 1;
 }
 // dynamic LDS of a cooperative workgroup of `e` envs: env regions, descriptor table, control words
-static int ppg_coop_lds_bytes(const ppg_handle *h, int e) {
-    const ppg::KParams &P = h->coop;
-    return e * P.lds_env_bytes + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16 + 80 * 4;   // (Env::CTL_WORDS)
-}
+static int ppg_coop_lds_bytes(const ppg_handle *h, int e) { return ppg_coop_lds_bytes_of(h->coop, e); }
 
 // How many wavefronts step one env (wave 0 runs the transition; all of them write the final observations), and from how many
 // agent rows on the helper wavefronts of an env stay (lighter envs are left to wave 0: Env::helpers).  Measured on MI355X:

@@ -96,7 +96,9 @@ struct KParams {
     // per-cell line-of-sight masks, precomputed from the (static) walls by ppg_walls_changed: bit (dx + vis_neg) * vis_w + (dy + vis_neg)
     // of cell (x, y)'s vis_words words = "(x + dx, y + dy) is in the grid and no wall lies strictly between" (WO:492-525, 577-589)
     int32_t vis_neg, vis_w, vis_words;
-    int32_t pad4_;
+    int32_t ch0_map;              // cooperative kernels: 1 = four cell maps per env, channel 0's among them (its halo points at the constant 1.0);
+                                  // 0 = THREE maps, channel 0 computed from the window position -- for grids whose LDS footprint
+                                  // decides how many workgroups a CU holds (64x64: 24.1 -> 18.1 KB per env).  ppg_coop_layout chooses.
     uint32_t rp_magic, rq_magic;  // ceil(2^32 / Rp), ceil(2^32 / Rq): cell / R == mulhi(cell, magic) for cell < R*R
     uint32_t np_magic, nq_magic;  // ceil(2^32 / Rp^2), ceil(2^32 / Rq^2): element / R^2 for element < 8 R^2
     uint32_t *vis_masks;          // library-owned [B, G*G, vis_words]; NULL = not computed: observations walk the lines themselves
@@ -109,8 +111,8 @@ struct KParams {
     double hunger_safe[2], norm_prey_opp, norm_pred_danger, norm_grass_opp;   // DRV:76-86
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
-    int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass.  Cooperative kernels: THREE maps
-                      // (predators, prey, grass) -- channel 0 is a function of the window position and has no map (Env::chmap)
+    int32_t off_map;  // 4 maps: [0] always zero (channel 0), [1] predators, [2] prey, [3] grass.  Cooperative kernels with ch0_map 0:
+                      // THREE maps (predators, prey, grass) -- channel 0 is a function of the window position (Env::chmap)
     int32_t off_val;  // float64 value table: [0]=0, 1+row predators, 1+cap_pred+row prey, then grass
     int32_t off_scr;  // 8-byte scratch per row (permutation / reset random words)
     int32_t off_lut;  // observation element descriptors (see Env::obs_row), predators then prey
@@ -160,9 +162,10 @@ struct KParams {
     int32_t blk_p, blk_q;      // elements per observation block: channels x Rp^2, channels x Rq^2
     uint32_t bp_magic, bq_magic;  // ceil(2^32 / blk): element / blk == mulhi(element, magic)
     const uint32_t *coop_tab;  // library-owned: blk_p + blk_q observation descriptors.  Element (channel, i, j) of a species' (4,R,R)
-                               // block, channels 1-3: bits 0-15 the signed map offset relative to the observer's padded cell,
-                               // (channel - 1) * map_n + (i - off) * Gp + (j - off); bits 16-31 the value-table section of the channel.
-                               // Channel 0 ("outside the grid", BASE:520-523) has no map: bits 16-31 = 0xFFFF, bits 4-7 (i - off) + 8,
+                               // block: bits 0-15 the signed map offset relative to the observer's padded cell, map index * map_n
+                               // + (i - off) * Gp + (j - off); bits 16-31 the value-table section of the channel.  ch0_map 1: then
+                               // map_n / 4 words, the padded channel-0 map of an empty grid (halo cells = Env::ONE_IDX).  ch0_map 0:
+                               // channel 0 ("outside the grid", BASE:520-523) has no map: bits 16-31 = 0xFFFF, bits 4-7 (i - off) + 8,
                                // bits 0-3 (j - off) + 8 -- the element is 1.0 iff (x + i - off, y + j - off) lies outside the grid
 };
 
@@ -285,8 +288,10 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // run of elements; piece p of the workgroup goes to wave p mod NW).  Every store instruction writes a full 1 KB, the rows of
 // the workgroup's envs are balanced over its waves at piece grain, every wave runs a transition (no idle helper waves on a full
 // GPU) and the waves of a workgroup write neighbouring addresses at the same time.  Cell maps are padded (KParams::pad), so no
-// window element of channels 1-3 needs a bounds check (their halos read 0.0); channel 0 (BASE:520-523: 1.0 outside the grid) is
-// computed from the window position and has NO map -- three maps per env instead of four (round 6: 64x64 grids 24.1 -> 18.1 KB).
+// window element needs a bounds check: channel 0's halo points at a constant 1.0 (BASE:522-523), the other halos at 0.0.  Where
+// LDS decides the occupancy (round 6: 64x64 grids 24.1 -> 18.1 KB per env = four instead of three workgroups per CU) channel 0 has
+// NO map and is computed from the window position (KParams::ch0_map 0; the extra arithmetic per element costs the float32 rows of
+// the second generation 11 %, so the small grids keep their fourth map).
 template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, int NW, class KP, class KC, bool COOP = false>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
@@ -366,8 +371,8 @@ struct Env {
     // Index of an entity's energy in the LDS value table.  16-bit maps: [0] = 0.0, then all row slots, then the grass patches.
     // MAP8: one section per channel, each led by a zero entry so that "map entry + section base" needs no test for an empty cell:
     // [0] = 0.0 | predators 1..64 || [129] = 0.0 | prey 130..257 || [258] = 0.0 | grass 259..513  (section base = 129 * (channel - 1)).
-    // The cooperative kernels pack the sections (LDS decides how many envs a CU holds): [0] = 0.0 | predators 1..64 | [65] unused ||
-    // [66] = 0.0 | prey 67..194 || [195] = 0.0 | grass 196...
+    // The cooperative kernels pack the sections (LDS decides how many envs a CU holds): [0] = 0.0 | predators 1..64 | [65] = 1.0 (the
+    // "outside the grid" value of channel 0's halo, ch0_map 1) || [66] = 0.0 | prey 67..194 || [195] = 0.0 | grass 196...
     static constexpr int SEC_Q = COOP ? 66 : 129, SEC_G = SEC_Q + 129;
     PPG_MEMBER int validx(int r, int k) const { return MAP8 ? (r ? SEC_Q + 1 + row_of(r, k) : 1 + k) : 1 + slot_of(r, k); }
     PPG_MEMBER int validx_row(int type, int row) const { return MAP8 ? (type ? SEC_Q + 1 + row : 1 + row) : 1 + (type ? P.cap_pred + row : row); }
@@ -383,8 +388,9 @@ struct Env {
         return (x + P.pad) * P.Gp + (c - x * P.G) + P.pad;
     }
     // the cell map of channel ch (1 predators, 2 prey, 3 grass; 0 = the all-zero map of channel 0, which the cooperative kernels do not have)
-    PPG_MEMBER map_t *chmap(int ch) const { return map + (COOP ? ch - 1 : ch) * P.map_n; }
-    static constexpr int N_MAPS = COOP ? 3 : 4;
+    PPG_MEMBER bool three_maps() const { return COOP && !P.ch0_map; }
+    PPG_MEMBER map_t *chmap(int ch) const { return map + (COOP ? ch - 1 + P.ch0_map : ch) * P.map_n; }
+    PPG_MEMBER int n_maps() const { return COOP ? 3 + P.ch0_map : 4; }
     // what a map entry of channel ch means as an index into the value table, and back (MAP8: channel-local 8-bit indices)
     PPG_MEMBER int map_base(int ch) const { return MAP8 ? (ch == 2 ? SEC_Q : ch == 3 ? SEC_G : 0) : 0; }
     PPG_MEMBER map_t to_map(int ch, int vidx) const { return (map_t)(vidx - map_base(ch)); }
@@ -602,6 +608,7 @@ struct Env {
     PPG_MEMBER void init_lds(const Pre &p) {
         if (!COOP) init_maps();   // (COOP: coop_tab_store)
         if (COOP) {
+            if (P.ch0_map && ln == 0) val[ONE_IDX] = 1.0;
         } else if (FASTOBS) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) { lutr[2 * c] = p.lutd[c].x; lutr[2 * c + 1] = p.lutd[c].y; }
@@ -616,31 +623,53 @@ struct Env {
             for (int i = ln; i < C.n_wall_words; i += 64) wallw[i] = C.wall_bits[(size_t)b * C.n_wall_words + i];
     }
 
-    // all cell maps empty (four; the cooperative kernels' three: the halos of channels 1-3 stay 0 -> the zero entry of their section)
-    PPG_MEMBER void init_maps() {
+    // all cell maps empty.  COOP with a channel-0 map: plus that map's halo -> the constant 1.0 of the value table ("outside the grid",
+    // BASE:520-523); the halos of channels 1-3 stay 0 -> the zero entry of their section.
+    static constexpr int ONE_IDX = 65;   // a free entry of the predator section (rows use 1..64)
+    PPG_MEMBER void zero_maps(int first_word) {   // words first_word.. of the map area
         uint32_t *m32 = (uint32_t *)map;
-        const int n32 = N_MAPS * P.map_n * (int)sizeof(map_t) / 4, n128 = n32 >> 2;
-        uint4 *m128 = (uint4 *)map;   // (the map area starts a 16-byte aligned LDS region: ds_write_b128 -- 64x64 grids zero 14.7 KB per step)
+        const int n32 = n_maps() * P.map_n * (int)sizeof(map_t) / 4;
+        // (16-byte stores where the range allows: 64x64 grids zero 14.7 KB per step)
+        const int lo16 = (first_word + 3) >> 2, n128 = n32 >> 2;
+        uint4 *m128 = (uint4 *)map;
         const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = ln; i < n128; i += 64) m128[i] = zero;
-        for (int i = 4 * n128 + ln; i < n32; i += 64) m32[i] = 0u;
+        for (int i = first_word + ln; i < 4 * lo16 && i < n32; i += 64) m32[i] = 0u;
+        for (int i = lo16 + ln; i < n128; i += 64) m128[i] = zero;
+        for (int i = (4 * n128 > first_word ? 4 * n128 : first_word) + ln; i < n32; i += 64) m32[i] = 0u;
     }
-    // COOP: the workgroup's descriptor table comes from C.coop_tab.  Its loads are issued in front of everything else and held in
-    // registers (up to LUT_REGS words per lane, enough for 7x7 / 9x9 windows; larger geometries finish with a plain copy loop), so
-    // the table costs no memory round trip of its own.
-    static constexpr int LUT_REGS = 9;
-    struct TabPre { uint32_t l[LUT_REGS]; };
+    PPG_MEMBER void init_maps() {
+        if (COOP && P.ch0_map) {   // (channel 0 from the template behind the descriptors in C.coop_tab; a step has it prefetched: TabPre)
+            const uint32_t *tmpl = C.coop_tab + C.blk_p + C.blk_q;
+            const int n0 = P.map_n / 4;
+            uint32_t *m32 = (uint32_t *)map;
+            for (int i = ln; i < n0; i += 64) m32[i] = tmpl[i];
+            zero_maps(n0);
+        } else {
+            zero_maps(0);
+        }
+    }
+    // COOP: the workgroup's descriptor table and (ch0_map) this env's channel-0 map come from C.coop_tab.  Their loads are issued in
+    // front of everything else and held in registers (up to LUT_REGS / TMPL_REGS words per lane, enough for 7x7 / 9x9 windows on a
+    // 25x25 grid; larger geometries finish with plain copy loops), so the tables cost no memory round trip of their own.
+    static constexpr int LUT_REGS = 9, TMPL_REGS = 5;
+    struct TabPre { uint32_t l[LUT_REGS], m[TMPL_REGS]; };
     PPG_MEMBER void coop_tab_issue(TabPre &t) const {
-        const int nl = C.blk_p + C.blk_q;
+        const int nl = C.blk_p + C.blk_q, nm = P.ch0_map ? P.map_n / 4 : 0;
 #pragma unroll
         for (int u = 0; u < LUT_REGS; ++u) { t.l[u] = 0; if (u * 64 + ln < nl) t.l[u] = C.coop_tab[u * 64 + ln]; }
+#pragma unroll
+        for (int u = 0; u < TMPL_REGS; ++u) { t.m[u] = 0; if (u * 64 + ln < nm) t.m[u] = C.coop_tab[nl + u * 64 + ln]; }
     }
     PPG_MEMBER void coop_tab_store(const TabPre &t) {
-        const int nl = C.blk_p + C.blk_q;
-        init_maps();
+        const int nl = C.blk_p + C.blk_q, nm = P.ch0_map ? P.map_n / 4 : 0;
+        uint32_t *m32 = (uint32_t *)map;
+        zero_maps(nm);   // channels 1-3: empty
 #pragma unroll
         for (int u = 0; u < LUT_REGS; ++u) if (u * 64 + ln < nl) lut2[u * 64 + ln] = t.l[u];
+#pragma unroll
+        for (int u = 0; u < TMPL_REGS; ++u) if (u * 64 + ln < nm) m32[u * 64 + ln] = t.m[u];
         for (int i = LUT_REGS * 64 + ln; i < nl; i += 64) lut2[i] = C.coop_tab[i];
+        for (int i = TMPL_REGS * 64 + ln; i < nm; i += 64) m32[i] = C.coop_tab[nl + i];
     }
 
     // grass table -> LDS (value table + channel-3 map).  regrow: BASE:252-256.
@@ -1493,12 +1522,13 @@ struct Env {
     }
 
     // ---- COOP: observations as whole 1 KB pieces of an env's run of live rows ---------------------------------
-    // The live rows of `type` of the env whose LDS region is `region` are listed in `list` (n_live words: row << 16 | x << 8 | y
-    // of the agent); concatenated they are a run of n_live * blk elements.  Piece p is elements 128 p .. 128 p + 127 of
-    // the run: lane l produces elements 128 p + 2l and + 1 (blk is even: a pair never straddles two rows) -- BASE:511-526 per
-    // element: channels 1-3: value = val[map[cell + offset of the element] + section of its channel]; the padded maps make the window
-    // clipping of _obs_clip (BASE:528-539) implicit.  Channel 0: 1.0 iff the element's cell lies outside the grid (BASE:520-523),
-    // from the agent's position and the element's window offsets alone.  This wavefront writes pieces first, first + stride, ...
+    // The live rows of `type` of the env whose LDS region is `region` are listed in `list` (n_live words: row << 16 | the agent's
+    // padded cell -- ch0_map 0: | x << 8 | y); concatenated they are a run of n_live * blk elements.  Piece p is elements 128 p ..
+    // 128 p + 127 of the run: lane l produces elements 128 p + 2l and + 1 (blk is even: a pair never straddles two rows) --
+    // BASE:511-526 per element: value = val[map[cell + offset of the element] + section of its channel]; the padded maps make the
+    // window clipping of _obs_clip (BASE:528-539) implicit.  ch0_map 0: channel 0 is 1.0 iff the element's cell lies outside the grid
+    // (BASE:520-523), from the agent's position and the element's window offsets alone.  This wavefront writes pieces first,
+    // first + stride, ...
     PPG_MEMBER void coop_pieces(int type, const unsigned char *region, const uint32_t *list, int n_live, int eb, int first, int stride) {
         const map_t *m = (const map_t *)(region + P.off_map);
         const double *vt = (const double *)(region + P.off_val);
@@ -1512,6 +1542,33 @@ struct Env {
         // against 53.0 us per 4096-env step on 64x64 grids, 63.5 / 67.4 against 62.3 on the headline: the write phase is bound by how
         // fast the memory system takes the stores, not by this chain.  profiles/r06/b_*)
         constexpr int U = 2;
+        if (P.ch0_map) {   // four maps: every element is a map lookup
+            const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
+            for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
+                uint32_t o[U], i0[U], i1[U];
+                bool on[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int s0 = (p0 + u * stride) * 128 + 2 * ln;
+                    on[u] = s0 < total;
+                    const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
+                    const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
+                    const uint32_t ent = on[u] ? list[i] : safe_cell;
+                    const uint2 d = *(const uint2 *)(L + w);
+                    const int pc = (int)(ent & 0xFFFFu);
+                    i0[u] = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)] + (d.x >> 16);
+                    i1[u] = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)] + (d.y >> 16);
+                    o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double v0 = vt[i0[u]], v1 = vt[i1[u]];
+                    if (!on[u]) continue;
+                    store_obs_pair(type ? P.obs_prey : P.obs_pred, P.obs_f32, obase + o[u], v0, v1);
+                }
+            }
+            return;
+        }
         const uint32_t G = (uint32_t)P.G;
         for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
             uint32_t o[U], i0[U], i1[U];
@@ -1521,7 +1578,7 @@ struct Env {
                 const int s0 = (p0 + u * stride) * 128 + 2 * ln;
                 on[u] = s0 < total;
                 const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
-                const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
+                const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);
                 const uint32_t ent = on[u] ? list[i] : 0u;   // (lanes behind the end of the run look at cell (0,0): inside the maps)
                 const uint2 d = *(const uint2 *)(L + w);
                 const uint32_t ax = (ent >> 8) & 255u, ay = ent & 255u;
@@ -1551,7 +1608,7 @@ struct Env {
     PPG_MEMBER void obs_row_coop(int type, int j, uint32_t s_xy) {
         wv::sync();   // LDS writes of the sequential phases -> visible
         uint32_t *mid = ctl + CTL_MID + wave_idx;
-        if (ln == 0) mid[0] = ((uint32_t)j << 16) | s_xy;
+        if (ln == 0) mid[0] = ((uint32_t)j << 16) | (P.ch0_map ? (uint32_t)cell_of(s_xy) : s_xy);
         wv::sync();
         coop_pieces(type, (const unsigned char *)map - P.off_map, mid, 1, b, 0, 1);
         wv::sync();   // reads done before the caller touches the maps again
@@ -1565,7 +1622,7 @@ struct Env {
         for (int r = 0; r < T; ++r) {
             const int type = type_of(r);
             if ((alive[r] >> ln) & 1ull)
-                lst[(type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])] = ((uint32_t)row_of(r, ln) << 16) | xy[r];
+                lst[(type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])] = ((uint32_t)row_of(r, ln) << 16) | (P.ch0_map ? (uint32_t)cell_of(xy[r]) : xy[r]);
             n[type] += wv::popc(alive[r]);
         }
         if (ln == 0) {
@@ -1917,17 +1974,18 @@ struct Env {
     PPG_MEMBER bool fallback_spawn(int type, int cid, uint32_t &child_xy) {
         // BASE:759-764.  The reference draws from the unseeded global np.random; the build's
         // contract (oracle/ppg_oracle.c:find_spawn) is the k-th free cell in x-major order.
-        // the occupancy board: the all-zero map of channel 0; the cooperative kernels (no such map) borrow bit 7 of the predator
-        // map's entries (8-bit maps, predator entries are <= 65) for the length of this function
+        // the occupancy board: the map of channel 0 (all-zero inside the grid); the cooperative kernels without such a map borrow bit 7
+        // of the predator map's entries (8-bit maps, predator entries are <= 65) for the length of this function
         static_assert(!COOP || MAP8, "the cooperative kernels run on 8-bit maps");
-        map_t *occ = COOP ? chmap(1) : chmap(0);
-        constexpr uint32_t OCC = COOP ? 0x80u : 1u;
+        const bool borrow = three_maps();
+        map_t *occ = borrow ? chmap(1) : chmap(0);
+        const uint32_t OCC = borrow ? 0x80u : 1u;
         wv::sync();
 #pragma unroll
         for (int r = 0; r < T; ++r)
             if ((alive[r] >> ln) & 1ull) {   // (two agents on one cell write the same byte value)
                 map_t *at = occ + cell_of(xy[r]);
-                *at = (map_t)(COOP ? ((uint32_t)*at | OCC) : OCC);
+                *at = (map_t)(borrow ? ((uint32_t)*at | OCC) : OCC);
             }
         wv::sync();
         const int n = P.G * P.G;
@@ -1962,7 +2020,7 @@ struct Env {
         for (int r = 0; r < T; ++r)
             if ((alive[r] >> ln) & 1ull) {
                 map_t *at = occ + cell_of(xy[r]);
-                *at = (map_t)(COOP ? ((uint32_t)*at & ~OCC) : 0u);
+                *at = (map_t)(borrow ? ((uint32_t)*at & ~OCC) : 0u);
             }
         wv::sync();
         return ok;
@@ -2342,10 +2400,10 @@ struct Env {
         const int n = P.G * P.G;
         const int K = C.n_init_pred + C.n_init_prey + C.n_grass;
         // two arrays of 16-bit cell indices over the map area: the G*G cells, and the K placed entities (MAP8: the four 8-bit maps
-        // together hold two arrays of map_n >= G*G entries; the cooperative kernels' three maps hold G*G + K entries -- ppg_coop_layout
-        // admits only configurations where they do)
+        // together hold two arrays of map_n >= G*G entries; three maps hold G*G + K entries -- ppg_coop_layout admits only
+        // configurations where they do)
         uint16_t *perm = MAP8 ? (uint16_t *)map : (uint16_t *)chmap(1);
-        uint16_t *ent = COOP ? (uint16_t *)map + ((n + 7) & ~7) : MAP8 ? (uint16_t *)map + P.map_n : (uint16_t *)chmap(2);
+        uint16_t *ent = three_maps() ? (uint16_t *)map + ((n + 7) & ~7) : MAP8 ? (uint16_t *)map + P.map_n : (uint16_t *)chmap(2);
         uint32_t *rnd = (uint32_t *)scr;  // 256 words per round
         wv::sync();
         int n_free = n;

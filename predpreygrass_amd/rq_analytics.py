@@ -61,7 +61,11 @@ class AgentAnalytics:
         self.agent_offspring_counts[agent_id] = 0
         self.agent_live_offspring_ids[agent_id] = []
         self.agent_parents[agent_id] = parent_unique_id
-        self.unique_agent_stats[unique_id] = {
+        self.unique_agent_stats[unique_id] = self._fresh_stats(agent_id, current_step, parent_unique_id)
+
+    @staticmethod
+    def _fresh_stats(agent_id, current_step, parent_unique_id):
+        return {
             "birth_step": current_step,
             "parent": parent_unique_id,
             "offspring_count": 0,
@@ -297,3 +301,13 @@ class AgentAnalytics:
         self.death_cause_prey = snap["death_cause_prey"].copy()
         self.per_step_agent_data = snap["per_step_agent_data"].copy()
         self._energy = dict(snap["_analytics_energy"])
+        # The books the reference does NOT snapshot (unique_agent_stats, parents, offspring lists: RQ:906-913) stay as they are.  After
+        # a reset() in between they no longer know the restored agents -- the reference then fails at its next step (RQ:530); here
+        # such agents get fresh entries so that a restored env keeps stepping.
+        for agent_id, uid in self.unique_agents.items():
+            if uid not in self.unique_agent_stats:
+                self.unique_agent_stats[uid] = self._fresh_stats(agent_id, None, None)
+            self.agent_parents.setdefault(agent_id, None)
+            self.agent_offspring_counts.setdefault(agent_id, 0)
+            self.agent_live_offspring_ids.setdefault(agent_id, [])
+            self.agent_ages.setdefault(agent_id, 0)

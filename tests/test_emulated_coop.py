@@ -37,6 +37,19 @@ def test_base_family_golden_cases_cooperative(waves, coop, names, max_calls):
     replay_golden_cases(maker(waves, coop), names, config_env, max_calls=max_calls)
 
 
+@pytest.mark.parametrize("waves,coop,names,max_calls", [
+    (4, 4, ["default_seed0", "default_seed1"], 150),
+    (4, 4, ["dense_seed0", "dense_seed3"], None),       # ghost cells / co-occupancy, many mid-step observations
+    (4, 2, ["pool_seed3"], None),
+])
+def test_golden_cases_cooperative_without_a_channel_0_map(waves, coop, names, max_calls, monkeypatch):
+    """Round 6: the cooperative kernels have two env-region layouts -- four cell maps (every window element one lookup; what 25x25
+    grids get) and THREE, channel 0 computed from the window position (what 64x64 grids get: c4_seed0 above).  PPG_COOP_MAPS=3
+    forces the second one on the small grids' golden episodes."""
+    monkeypatch.setenv("PPG_COOP_MAPS", "3")
+    replay_golden_cases(maker(waves, coop), names, config_env, max_calls=max_calls)
+
+
 def test_cooperative_launch_shape():
     lib = emu_backend.library()
     env = maker(4, 4)(dict(config_env), 6)
@@ -72,9 +85,12 @@ def test_cooperative_big_windows_and_float32():
 
 
 @pytest.mark.parametrize("name", ["rq_mixed_types_seed7", "rq_base_seed3", "rq_pool_exhaust_seed2"])
-def test_second_generation_golden_cases_cooperative(name):
-    """The red_queen env's golden episodes (recorded PCG64 uniforms through ppg_step_uniforms) on the cooperative kernels."""
+def test_second_generation_golden_cases_cooperative(name, monkeypatch):
+    """The red_queen env's golden episodes (recorded PCG64 uniforms through ppg_step_uniforms) on the cooperative kernels
+    (rq_mixed_types_seed7: also without a channel-0 map)."""
     from predpreygrass_amd.red_queen import BatchedRedQueen
+    if name == "rq_mixed_types_seed7":
+        monkeypatch.setenv("PPG_COOP_MAPS", "3")
     from tests.parity_utils_rq import replay_golden_case
 
     def make(cfg, B, **kw):
@@ -146,11 +162,14 @@ def test_allocation_choices_are_ignored_without_a_gpu():
     b.subs[0].close()   # idempotent
 
 
+@pytest.mark.parametrize("maps", ["3", "4"])
 @pytest.mark.parametrize("waves,coop", [(4, 2), (4, 4)])
-def test_cooperative_spawn_fallback_on_a_crowded_grid(waves, coop):
-    """Round 6: the cooperative kernels have no channel-0 map; the spawn fallback (BASE:759-764: all four neighbours taken) marks
-    occupied cells in bit 7 of the predator map's entries instead and must leave that map as it found it.  A 6x6 grid that fills up:
+def test_cooperative_spawn_fallback_on_a_crowded_grid(waves, coop, maps, monkeypatch):
+    """Round 6: without a channel-0 map (PPG_COOP_MAPS=3; by default only grids too large for four maps) the spawn fallback
+    (BASE:759-764: all four neighbours taken) marks occupied cells in bit 7 of the predator map's entries instead and must leave that
+    map as it found it; with four maps the board is the channel-0 map.  A 6x6 grid that fills up:
     every call against the oracle (observations included), with fallback spawns actually happening."""
+    monkeypatch.setenv("PPG_COOP_MAPS", maps)
     cfg = {**config_env, "grid_size": 6, "n_initial_active_predator": 6, "n_initial_active_prey": 14, "initial_num_grass": 10,
            "max_steps": 60, "energy_gain_per_step_grass": 1.5, "energy_loss_per_step_prey": 0.01, "energy_loss_per_step_predator": 0.02,
            "prey_creation_energy_threshold": 3.5, "predator_creation_energy_threshold": 6.0,
