@@ -27,10 +27,14 @@ struct ppg_wave_plan_t { int nw; int min_rows; int coop_e; };
 struct ppg_handle {
     ppg_wave_plan_t plan;     // what ppg_step launches: decided at ppg_create / ppg_set_envs_in_flight / ppg_set_wave_plan
     ppg_wave_plan_t forced;   // ppg_set_wave_plan: nw = 0 -> automatic
-    ppg::KParams coop;        // parameter block of the cooperative step kernels (their own LDS layout: padded cell maps)
+    ppg::KParams coop;        // parameter block of the cooperative step kernels (their own LDS layout: padded cell maps, four per env)
     int32_t coop_ok;          // the configuration has cooperative kernels (ppg_coop_layout)
+    ppg::KParams coop3;       // the same with THREE cell maps per env (KParams::ch0_map 0: kernels ppgcm_*, four-wave step launches only)
+    int32_t coop3_ok;         // that layout exists for the configuration ...
+    int32_t coop_prefers3;    // ... and is the one a four-wave cooperative step uses (large grids; PPG_COOP_MAPS)
+    uint32_t coop3_tab_off;   // words in front of its descriptor table inside coop_tab
     std::vector<uint32_t> coop_tab_host;
-    uint32_t *coop_tab_dev;   // library-owned: KParams::coop_tab
+    uint32_t *coop_tab_dev;   // library-owned: KParams::coop_tab of both layouts
     int32_t drive;  // drive-conditioned variant of the base family (cfg.n_drive)
     int32_t envs_in_flight;  // scheduling hint (ppg_set_envs_in_flight); 0 = the handle's own batch
     int32_t coop_wgs_per_cu;  // float64 / float32 rows: four-wave cooperative workgroups a CU takes at most (PPG_COOP_WGS_PER_CU, read at create)
@@ -372,27 +376,30 @@ static int ppg_coop_lds_bytes_of(const ppg::KParams &P, int e) {
 // at a constant 1.0: every element is one uniform lookup) where four two-env workgroups then fit a CU's LDS -- every grid up to
 // about 45x45; else three maps and channel 0 computed per element (64x64 grids: 24.1 -> 18.1 KB per env, three -> four workgroups per
 // CU, +10 % -- profiles/r06/a_*; the arithmetic costs the second generation's float32 rows on a 25x25 grid 11 %, so they keep the map).
-// PPG_COOP_MAPS=3 / 4 (read at create): force either (tests, A/B runs).
+// Both layouts are kept: the three-map one serves four-wave step launches only (kernels ppgcm_*); rollouts, the 6 / 8 / 16-wave and
+// the 64-register builds use the four-map layout whatever the grid.  PPG_COOP_MAPS=3 / 4 (read at create): force either (tests, A/B runs).
 static void ppg_coop_layout(ppg_handle *h) {
-    h->coop_ok = 0;
+    h->coop_ok = 0; h->coop3_ok = 0; h->coop_prefers3 = 0; h->coop3_tab_off = 0;
     const ppg_config &c = h->cfg;
     const bool walls = h->gen2 && h->cfg2.walls;
     if (walls || h->drive || c.kickback || h->nq > 2) return;           // (8-bit maps; generic 4-channel observations only)
     if (!(c.predator_obs_range & 1) || !(c.prey_obs_range & 1)) return;  // even windows keep the element-descriptor kernels
-    ppg::KParams P4, P3;
-    std::vector<uint32_t> t4, t3;
-    const bool ok4 = ppg_coop_layout_with(h, 1, P4, t4), ok3 = ppg_coop_layout_with(h, 0, P3, t3);
-    const char *force = getenv("PPG_COOP_MAPS");
-    bool use4 = ok4 && (ppg_coop_lds_bytes_of(P4, 2) * 4 <= 160 * 1024 || !ok3);
-    if (force && force[0] == '3' && ok3) use4 = false;
-    if (force && force[0] == '4' && ok4) use4 = true;
-    if (!use4 && !ok3) return;
-    h->coop = use4 ? P4 : P3;
-    h->coop_tab_host = use4 ? t4 : t3;
+    std::vector<uint32_t> t3;
+    if (!ppg_coop_layout_with(h, 1, h->coop, h->coop_tab_host)) return;
     h->coop_ok = 1;
+    if (ppg_coop_layout_with(h, 0, h->coop3, t3)) {
+        h->coop3_ok = 1;
+        h->coop3_tab_off = (uint32_t)h->coop_tab_host.size();
+        h->coop_tab_host.insert(h->coop_tab_host.end(), t3.begin(), t3.end());
+        const char *force = getenv("PPG_COOP_MAPS");
+        h->coop_prefers3 = ppg_coop_lds_bytes_of(h->coop, 2) * 4 > 160 * 1024;
+        if (force && force[0] == '3') h->coop_prefers3 = 1;
+        if (force && force[0] == '4') h->coop_prefers3 = 0;
+    }
 }
 // dynamic LDS of a cooperative workgroup of `e` envs: env regions, descriptor table, control words
-static int ppg_coop_lds_bytes(const ppg_handle *h, int e) { return ppg_coop_lds_bytes_of(h->coop, e); }
+// (of the layout a four-wave cooperative step launch uses: what the plan's occupancy rules are about)
+static int ppg_coop_lds_bytes(const ppg_handle *h, int e) { return ppg_coop_lds_bytes_of(h->coop_prefers3 ? h->coop3 : h->coop, e); }
 
 // How many wavefronts step one env (wave 0 runs the transition; all of them write the final observations), and from how many
 // agent rows on the helper wavefronts of an env stay (lighter envs are left to wave 0: Env::helpers).  Measured on MI355X:
@@ -513,7 +520,7 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     if (cfg) h->cfg = *cfg; else h->cfg2 = *cfg2;
     h->bufs = *bufs; h->batch = batch; h->device = device;
     h->lut_dev = nullptr; h->backend = nullptr; h->prof_dev = nullptr; h->err[0] = 0;
-    h->coop_ok = 0; h->coop_tab_dev = nullptr;
+    h->coop_ok = 0; h->coop3_ok = 0; h->coop_prefers3 = 0; h->coop3_tab_off = 0; h->coop_tab_dev = nullptr;
     h->forced = {0, 0, 0};
     h->envs_in_flight = 0;
     {   // scheduling knobs of the experiments, read ONCE per handle (never per step)
@@ -537,6 +544,8 @@ static int ppg_create_common(const ppg_config *cfg, const ppg_config_gen2 *cfg2,
     h->base.obs_lut = h->lut_dev;
     h->coop.obs_lut = h->lut_dev;
     h->coop.coop_tab = h->coop_tab_dev;
+    h->coop3.obs_lut = h->lut_dev;
+    h->coop3.coop_tab = h->coop_tab_dev ? h->coop_tab_dev + h->coop3_tab_off : nullptr;
     h->plan = ppg_wave_plan(h);
     *out = h;
     return PPG_OK;
@@ -633,14 +642,17 @@ int ppg_observe(ppg_handle *h, void *stream) {
 }
 
 // the parameter block of a row-order step as the handle's wave plan wants it launched
-static ppg::KParams ppg_planned_step_params(const ppg_handle *h) {
+static bool ppg_coop_high_occupancy(const ppg_handle *h, int coop_e);
+// (fused: ppg_rollout -- the fused kernels exist for the four-map layout only, like the 6 / 8 / 16-wave and the 64-register builds)
+static ppg::KParams ppg_planned_step_params(const ppg_handle *h, bool fused = false) {
     const ppg_wave_plan_t &wp = h->plan;
-    ppg::KParams P = wp.coop_e > 0 ? h->coop : h->base;
+    const bool three = wp.coop_e > 0 && h->coop_prefers3 && wp.nw == 4 && !fused && !ppg_coop_high_occupancy(h, wp.coop_e);
+    ppg::KParams P = wp.coop_e > 0 ? (three ? h->coop3 : h->coop) : h->base;
     if (wp.coop_e > 0) {   // cooperative kernels: wp.coop_e env regions, then the workgroup's descriptor table and control words
         P.coop_e = wp.coop_e;
         P.off_lut2 = wp.coop_e * P.lds_env_bytes;
         P.off_ctl = P.off_lut2 + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16;
-        P.lds_bytes = ppg_coop_lds_bytes(h, wp.coop_e);
+        P.lds_bytes = ppg_coop_lds_bytes_of(P, wp.coop_e);
         // float64 / float32 rows: at most FIVE four-wave workgroups (ten envs) per CU although registers and LDS admit six -- a CU
         // then has fewer scattered write streams open at a time: 66.8 -> 68.2 M env-steps/s on the headline workload, the driver's
         // command 62.1 -> 63.0 M (profiles/r05/n_coop_workgroups_per_cu.txt; four: the same; three: -13 %).  Done by asking for LDS
@@ -683,7 +695,7 @@ int ppg_rollout(ppg_handle *h, int32_t n_steps, const int8_t *actions, uint32_t 
     if (!actions && !(flags & PPG_STEP_RANDOM_ACTIONS)) return ppg_fail(h, PPG_EINVAL, "actions is NULL without PPG_STEP_RANDOM_ACTIONS");
     if (flags & ~(PPG_STEP_RANDOM_ACTIONS | PPG_STEP_AUTO_RESET)) return ppg_fail(h, PPG_EINVAL, "unknown step flags 0x%x", flags);
     // a handle whose plan is cooperative with four-wave workgroups runs the fused form of that kernel; else one wave per env
-    ppg::KParams P = (h->plan.coop_e > 0 && h->plan.nw == 4) ? ppg_planned_step_params(h) : h->base;
+    ppg::KParams P = (h->plan.coop_e > 0 && h->plan.nw == 4) ? ppg_planned_step_params(h, true) : h->base;
     P.mode = ppg::MODE_ROLLOUT; P.actions = actions; P.flags = flags; P.prof = h->prof_dev; P.n_steps = n_steps;
     return backend_launch(h, ppg::MODE_ROLLOUT, P, stream);
 }
@@ -789,14 +801,15 @@ int32_t ppg_lds_bytes(const ppg_handle *h) { return h ? h->base.lds_bytes : 0; }
 
 // bfloat16 rows on the four-wave cooperative kernel: its 64-register build when eight workgroups fit a CU's LDS
 static bool ppg_coop_high_occupancy(const ppg_handle *h, int coop_e) {
-    return !h->gen2 && h->cfg.obs_dtype >= 2 && ppg_coop_lds_bytes(h, coop_e) * 8 <= 160 * 1024 && !getenv("PPG_COOP_NO_HIGH_OCCUPANCY");
+    return !h->gen2 && h->cfg.obs_dtype >= 2 && ppg_coop_lds_bytes_of(h->coop, coop_e) * 8 <= 160 * 1024 && !getenv("PPG_COOP_NO_HIGH_OCCUPANCY");
 }
 
 const char *ppg_step_kernel_name(ppg_handle *h) {
     if (!h) return "";
     const ppg_wave_plan_t wp = h->plan;
     if (wp.coop_e > 0) {   // ppgc_step_q<NQ> (4 waves) / ppgc8_ / ppgc16_
-        snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc%s_step_q%d",
+        const bool three = !ppg_planned_step_params(h).ch0_map;
+        snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc%s%s_step_q%d", three ? "m" : "",
                  h->gen2 ? "2" : wp.nw == 8 ? "8" : wp.nw == 16 ? "16" : wp.nw == 6 ? "6" : ppg_coop_high_occupancy(h, wp.coop_e) ? "h" : "", h->nq);
         return h->kernel_name;
     }

@@ -97,8 +97,8 @@ struct KParams {
     // of cell (x, y)'s vis_words words = "(x + dx, y + dy) is in the grid and no wall lies strictly between" (WO:492-525, 577-589)
     int32_t vis_neg, vis_w, vis_words;
     int32_t ch0_map;              // cooperative kernels: 1 = four cell maps per env, channel 0's among them (its halo points at the constant 1.0);
-                                  // 0 = THREE maps, channel 0 computed from the window position -- for grids whose LDS footprint
-                                  // decides how many workgroups a CU holds (64x64: 24.1 -> 18.1 KB per env).  ppg_coop_layout chooses.
+                                  // 0 = THREE maps, channel 0 computed from the window position (kernels ppgcm_*, Env's CH0MAP = false) --
+                                  // for grids whose LDS footprint decides how many workgroups a CU holds (64x64: 24.1 -> 18.1 KB per env)
     uint32_t rp_magic, rq_magic;  // ceil(2^32 / Rp), ceil(2^32 / Rq): cell / R == mulhi(cell, magic) for cell < R*R
     uint32_t np_magic, nq_magic;  // ceil(2^32 / Rp^2), ceil(2^32 / Rq^2): element / R^2 for element < 8 R^2
     uint32_t *vis_masks;          // library-owned [B, G*G, vis_words]; NULL = not computed: observations walk the lines themselves
@@ -292,7 +292,7 @@ PPG_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // LDS decides the occupancy (round 6: 64x64 grids 24.1 -> 18.1 KB per env = four instead of three workgroups per CU) channel 0 has
 // NO map and is computed from the window position (KParams::ch0_map 0; the extra arithmetic per element costs the float32 rows of
 // the second generation 11 %, so the small grids keep their fourth map).
-template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, int NW, class KP, class KC, bool COOP = false>
+template <int NQ, bool ORDERED, bool FASTOBS, bool FUSED, bool KICK, bool GEN2, bool WALLS, bool DRIVE, int NW, class KP, class KC, bool COOP = false, bool CH0MAP = true>
 struct Env {
     static constexpr int T = 1 + NQ;  // row registers: 0 = predators, 1.. = prey
     static constexpr bool MAP8 = NQ <= 2;
@@ -388,9 +388,12 @@ struct Env {
         return (x + P.pad) * P.Gp + (c - x * P.G) + P.pad;
     }
     // the cell map of channel ch (1 predators, 2 prey, 3 grass; 0 = the all-zero map of channel 0, which the cooperative kernels do not have)
-    PPG_MEMBER bool three_maps() const { return COOP && !P.ch0_map; }
-    PPG_MEMBER map_t *chmap(int ch) const { return map + (COOP ? ch - 1 + P.ch0_map : ch) * P.map_n; }
-    PPG_MEMBER int n_maps() const { return COOP ? 3 + P.ch0_map : 4; }
+    // (CH0MAP = false, cooperative kernels only: three maps -- KParams::ch0_map 0; a kernel of its own, ppgcm_*: both forms in one
+    // kernel made every inlined copy of coop_pieces carry two loops, +25 % code, and cost the small grids 1-2 %)
+    static_assert(CH0MAP || COOP, "only the cooperative kernels come without a channel-0 map");
+    static constexpr bool THREE = !CH0MAP;
+    PPG_MEMBER map_t *chmap(int ch) const { return map + (THREE ? ch - 1 : ch) * P.map_n; }
+    static constexpr int N_MAPS = THREE ? 3 : 4;
     // what a map entry of channel ch means as an index into the value table, and back (MAP8: channel-local 8-bit indices)
     PPG_MEMBER int map_base(int ch) const { return MAP8 ? (ch == 2 ? SEC_Q : ch == 3 ? SEC_G : 0) : 0; }
     PPG_MEMBER map_t to_map(int ch, int vidx) const { return (map_t)(vidx - map_base(ch)); }
@@ -608,7 +611,7 @@ struct Env {
     PPG_MEMBER void init_lds(const Pre &p) {
         if (!COOP) init_maps();   // (COOP: coop_tab_store)
         if (COOP) {
-            if (P.ch0_map && ln == 0) val[ONE_IDX] = 1.0;
+            if (CH0MAP && ln == 0) val[ONE_IDX] = 1.0;
         } else if (FASTOBS) {
 #pragma unroll
             for (int c = 0; c < 5; ++c) { lutr[2 * c] = p.lutd[c].x; lutr[2 * c + 1] = p.lutd[c].y; }
@@ -628,7 +631,7 @@ struct Env {
     static constexpr int ONE_IDX = 65;   // a free entry of the predator section (rows use 1..64)
     PPG_MEMBER void zero_maps(int first_word) {   // words first_word.. of the map area
         uint32_t *m32 = (uint32_t *)map;
-        const int n32 = n_maps() * P.map_n * (int)sizeof(map_t) / 4;
+        const int n32 = N_MAPS * P.map_n * (int)sizeof(map_t) / 4;
         // (16-byte stores where the range allows: 64x64 grids zero 14.7 KB per step)
         const int lo16 = (first_word + 3) >> 2, n128 = n32 >> 2;
         uint4 *m128 = (uint4 *)map;
@@ -638,7 +641,7 @@ struct Env {
         for (int i = (4 * n128 > first_word ? 4 * n128 : first_word) + ln; i < n32; i += 64) m32[i] = 0u;
     }
     PPG_MEMBER void init_maps() {
-        if (COOP && P.ch0_map) {   // (channel 0 from the template behind the descriptors in C.coop_tab; a step has it prefetched: TabPre)
+        if (COOP && CH0MAP) {   // (channel 0 from the template behind the descriptors in C.coop_tab; a step has it prefetched: TabPre)
             const uint32_t *tmpl = C.coop_tab + C.blk_p + C.blk_q;
             const int n0 = P.map_n / 4;
             uint32_t *m32 = (uint32_t *)map;
@@ -654,14 +657,14 @@ struct Env {
     static constexpr int LUT_REGS = 9, TMPL_REGS = 5;
     struct TabPre { uint32_t l[LUT_REGS], m[TMPL_REGS]; };
     PPG_MEMBER void coop_tab_issue(TabPre &t) const {
-        const int nl = C.blk_p + C.blk_q, nm = P.ch0_map ? P.map_n / 4 : 0;
+        const int nl = C.blk_p + C.blk_q, nm = CH0MAP ? P.map_n / 4 : 0;
 #pragma unroll
         for (int u = 0; u < LUT_REGS; ++u) { t.l[u] = 0; if (u * 64 + ln < nl) t.l[u] = C.coop_tab[u * 64 + ln]; }
 #pragma unroll
         for (int u = 0; u < TMPL_REGS; ++u) { t.m[u] = 0; if (u * 64 + ln < nm) t.m[u] = C.coop_tab[nl + u * 64 + ln]; }
     }
     PPG_MEMBER void coop_tab_store(const TabPre &t) {
-        const int nl = C.blk_p + C.blk_q, nm = P.ch0_map ? P.map_n / 4 : 0;
+        const int nl = C.blk_p + C.blk_q, nm = CH0MAP ? P.map_n / 4 : 0;
         uint32_t *m32 = (uint32_t *)map;
         zero_maps(nm);   // channels 1-3: empty
 #pragma unroll
@@ -1542,7 +1545,7 @@ struct Env {
         // against 53.0 us per 4096-env step on 64x64 grids, 63.5 / 67.4 against 62.3 on the headline: the write phase is bound by how
         // fast the memory system takes the stores, not by this chain.  profiles/r06/b_*)
         constexpr int U = 2;
-        if (P.ch0_map) {   // four maps: every element is a map lookup
+        if (CH0MAP) {   // four maps: every element is a map lookup
             const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
             for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
                 uint32_t o[U], i0[U], i1[U];
@@ -1608,7 +1611,7 @@ struct Env {
     PPG_MEMBER void obs_row_coop(int type, int j, uint32_t s_xy) {
         wv::sync();   // LDS writes of the sequential phases -> visible
         uint32_t *mid = ctl + CTL_MID + wave_idx;
-        if (ln == 0) mid[0] = ((uint32_t)j << 16) | (P.ch0_map ? (uint32_t)cell_of(s_xy) : s_xy);
+        if (ln == 0) mid[0] = ((uint32_t)j << 16) | (CH0MAP ? (uint32_t)cell_of(s_xy) : s_xy);
         wv::sync();
         coop_pieces(type, (const unsigned char *)map - P.off_map, mid, 1, b, 0, 1);
         wv::sync();   // reads done before the caller touches the maps again
@@ -1622,7 +1625,7 @@ struct Env {
         for (int r = 0; r < T; ++r) {
             const int type = type_of(r);
             if ((alive[r] >> ln) & 1ull)
-                lst[(type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])] = ((uint32_t)row_of(r, ln) << 16) | (P.ch0_map ? (uint32_t)cell_of(xy[r]) : xy[r]);
+                lst[(type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])] = ((uint32_t)row_of(r, ln) << 16) | (CH0MAP ? (uint32_t)cell_of(xy[r]) : xy[r]);
             n[type] += wv::popc(alive[r]);
         }
         if (ln == 0) {
@@ -1977,7 +1980,7 @@ struct Env {
         // the occupancy board: the map of channel 0 (all-zero inside the grid); the cooperative kernels without such a map borrow bit 7
         // of the predator map's entries (8-bit maps, predator entries are <= 65) for the length of this function
         static_assert(!COOP || MAP8, "the cooperative kernels run on 8-bit maps");
-        const bool borrow = three_maps();
+        constexpr bool borrow = THREE;
         map_t *occ = borrow ? chmap(1) : chmap(0);
         const uint32_t OCC = borrow ? 0x80u : 1u;
         wv::sync();
@@ -2403,7 +2406,7 @@ struct Env {
         // together hold two arrays of map_n >= G*G entries; three maps hold G*G + K entries -- ppg_coop_layout admits only
         // configurations where they do)
         uint16_t *perm = MAP8 ? (uint16_t *)map : (uint16_t *)chmap(1);
-        uint16_t *ent = three_maps() ? (uint16_t *)map + ((n + 7) & ~7) : MAP8 ? (uint16_t *)map + P.map_n : (uint16_t *)chmap(2);
+        uint16_t *ent = THREE ? (uint16_t *)map + ((n + 7) & ~7) : MAP8 ? (uint16_t *)map + P.map_n : (uint16_t *)chmap(2);
         uint32_t *rnd = (uint32_t *)scr;  // 256 words per round
         wv::sync();
         int n_free = n;
@@ -2726,10 +2729,10 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
 }
 
 // The cooperative step kernels (ppgc_*): see Env's COOP.  Workgroup g steps envs g * coop_e ... g * coop_e + coop_e - 1.
-template <int NQ, bool GEN2, int NW>
+template <int NQ, bool GEN2, int NW, bool CH0MAP = true>
 PPG_DEVICE void coop_main(const KParams &P, unsigned char *lds) {
     const PPG_CONSTANT_AS KParams *Pc = PPG_KERNARG_PTR(KParams, P);
-    typedef Env<NQ, false, false, false, false, GEN2, false, false, NW, const KParams, const PPG_CONSTANT_AS KParams, true> CoopEnv;
+    typedef Env<NQ, false, false, false, false, GEN2, false, false, NW, const KParams, const PPG_CONSTANT_AS KParams, true, CH0MAP> CoopEnv;
     const int w = wv::wave_index(), ln = wv::lane();
     const int ne = Pc->coop_e;
     uint32_t *lut2 = (uint32_t *)(lds + Pc->off_lut2), *ctl = (uint32_t *)(lds + Pc->off_ctl);

@@ -30,7 +30,8 @@
     PPG_KW(ppgwp_step_q##NQ##g, NQ, false, 2)                         \
     PPG_KW(ppgw16_step_q##NQ, NQ, true, 16)
 
-// cooperative step kernels of the base family (Env's COOP): coop_e envs per workgroup of 4 / 8 / 16 wavefronts
+// cooperative step kernels (Env's COOP): coop_e envs per workgroup of 4 / 8 / 16 wavefronts; ppgc2_*: second generation; ppgcm_* / ppgcm2_*:
+// the four-wave kernels without a channel-0 cell map (large grids)
 #define PPG_DEFINE_KERNELSC(NQ)                                       \
     PPG_KC(ppgc_step_q##NQ, NQ, false, 4)                             \
     PPG_KCH(ppgch_step_q##NQ, NQ)                                     \
@@ -38,6 +39,8 @@
     PPG_KC(ppgc8_step_q##NQ, NQ, false, 8)                            \
     PPG_KC(ppgc16_step_q##NQ, NQ, false, 16)                          \
     PPG_KC(ppgc2_step_q##NQ, NQ, true, 4)                             \
+    PPG_KCM(ppgcm_step_q##NQ, NQ, false)                              \
+    PPG_KCM(ppgcm2_step_q##NQ, NQ, true)                              \
     PPG_KCR(ppgc_rollout_q##NQ, NQ, false, 4)                         \
     PPG_KCR(ppgc2_rollout_q##NQ, NQ, true, 4)
 

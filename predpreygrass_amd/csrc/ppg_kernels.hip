@@ -45,6 +45,9 @@
 #endif
 #define PPG_KC(name, NQ, GEN2, NW)                                                           \
     PPG_KERNEL_NW(name, PPG_WPE_COOP, NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_main<NQ, GEN2, NW>(P, lds); }
+// the four-wave cooperative kernels without a channel-0 cell map (three maps per env: KParams::ch0_map 0, large grids)
+#define PPG_KCM(name, NQ, GEN2)                                                              \
+    PPG_KERNEL_NW(name, PPG_WPE_COOP, 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_main<NQ, GEN2, 4, false>(P, lds); }
 // the same four-wave cooperative kernel at 64 registers (8 wavefronts per SIMD, all 16 envs of a CU resident): for bfloat16 rows, where
 // the transitions and not the write streams decide (policy rollouts: 51 -> 44 us per 4096-env step; float64 rows: 62 -> 70 us)
 #define PPG_KCH(name, NQ)                                                                    \

@@ -25,7 +25,8 @@ def maker(waves, coop, **kw):
 @pytest.mark.parametrize("waves,coop,names,max_calls", [
     (4, 4, ["default_seed0", "default_seed1"], 150),   # two envs in a workgroup with room for four: two empty env slots
     (4, 1, ["default_seed0"], 120),                     # one env, three pure helper waves
-    (8, 2, ["c4_seed0"], 100),                          # 64x64 grid
+    (8, 2, ["c4_seed0"], 100),                          # 64x64 grid (eight waves: the four-map layout)
+    (4, 2, ["c4_seed0"], 100),                          # 64x64 grid, four waves: THREE cell maps per env (ppgcm_step), the default there
     (4, 4, ["dense_seed0", "dense_seed3"], None),       # ghost cells / co-occupancy, many mid-step observations
     (16, 1, ["c1_seed0"], None),                        # sixteen waves on one env (small batches)
     (4, 2, ["pool_seed3"], None),                       # id pools run dry
@@ -34,7 +35,14 @@ def maker(waves, coop, **kw):
     (4, 4, ["dense_rewards_seed0"], 100),               # dense reward mode reads the start-of-step energies back
 ])
 def test_base_family_golden_cases_cooperative(waves, coop, names, max_calls):
-    replay_golden_cases(maker(waves, coop), names, config_env, max_calls=max_calls)
+    made = []
+
+    def make(cfg, B, **kw):
+        made.append(maker(waves, coop)(cfg, B, **kw))
+        return made[-1]
+    replay_golden_cases(make, names, config_env, max_calls=max_calls)
+    if names == ["c4_seed0"]:
+        assert made[-1].step_kernel_name() == ("ppgcm_step_q2" if waves == 4 else "ppgc8_step_q2")
 
 
 @pytest.mark.parametrize("waves,coop,names,max_calls", [
@@ -96,7 +104,7 @@ def test_second_generation_golden_cases_cooperative(name, monkeypatch):
     def make(cfg, B, **kw):
         env = BatchedRedQueen(cfg, batch_size=B, _library=emu_backend.library(), **kw)
         env.set_wave_plan(4, 0, 2)
-        assert env.wave_plan() == (4, 0, 2) and env.step_kernel_name() == "ppgc2_step_q2"
+        assert env.wave_plan() == (4, 0, 2) and env.step_kernel_name() == ("ppgcm2_step_q2" if name == "rq_mixed_types_seed7" else "ppgc2_step_q2")
         return env
     replay_golden_case(make, name, max_calls=120)
 

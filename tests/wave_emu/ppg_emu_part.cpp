@@ -29,6 +29,7 @@ void run_nw(const ppg::KParams &P) {
 template <int NW>
 void run_coop(const ppg::KParams &P) {
     PPG_DYNAMIC_LDS(lds);
+    if (NW == 4 && !P.ch0_map) { ppg::coop_main<NQ, GEN2, 4, false>(P, lds); return; }   // three cell maps per env (ppgcm_*)
     ppg::coop_main<NQ, GEN2, NW>(P, lds);
 }
 #endif
