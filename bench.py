@@ -977,6 +977,10 @@ def main(argv=None, backend=None):
                 "sub_batches_per_gpu": n_sub,
                 "preroll_steps": preroll, "device_warm_steps": warm_steps,
                 "device_state_under_load": dev_state,
+                # the same as ONE scalar string (a consumer that flattens nested values keeps it)
+                "device_state_summary": ("unavailable: " + str(dev_state["unavailable"])[:120]) if "unavailable" in dev_state else
+                                        " ".join(f"{k}={dev_state[k]}" for k in ("sclk_MHz", "mclk_MHz", "power_W", "kfd_processes_listed", "gpu_uuid")
+                                                 if k in dev_state),
                 "obs_spread": args.obs_spread, **({"obs_spread_note": spread_note} if spread_note else {}),
                 "placement_candidates_us_per_step": None if group.placement_probe_us is None else [round(v, 1) for v in group.placement_probe_us],
                 # which placement mode this run drew (60 ms probes of each candidate buffer set; good placements of the headline workload

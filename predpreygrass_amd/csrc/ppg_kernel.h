@@ -308,6 +308,8 @@ struct Env {
 #ifndef PPG_CARRY_CUM_MULTIWAVE
 #define PPG_CARRY_CUM_MULTIWAVE 1
 #endif
+    // (round 6, measured and not kept: the walls variant's four-wave kernel too -- 94.3 against 92.3 us per 4096-env step at its
+    // 64-register cap, six more row registers spill; 102 us at 80 registers: profiles/r06/g_*)
     static constexpr bool CARRY_CUM = COOP || (PPG_CARRY_CUM_MULTIWAVE && NW > 1 && !GEN2 && !WALLS && !DRIVE && !KICK && NQ <= 2);
     template <bool B8, class Dummy = void> struct MapElem { typedef uint16_t type; };
     template <class Dummy> struct MapElem<true, Dummy> { typedef uint8_t type; };

@@ -365,7 +365,7 @@ def test_default_wave_plans_give_identical_results():
     c4 = {**config_env, **C4}
     cases = [(lambda: make_env(dict(config_env), 200), b"ppgw16_step_q2", 120),
              (lambda: make_env(dict(config_env), 4096), b"ppgc_step_q2", 60),
-             (lambda: make_env(c4, 4096), b"ppgc_step_q2", 40),        # (round 6: three cell maps per env -> four cooperative workgroups per CU)
+             (lambda: make_env(c4, 4096), b"ppgcm_step_q2", 40),       # (round 6: THREE cell maps per env -> four cooperative workgroups per CU)
              (lambda: make_env({**c4, "grid_size": 80}, 4096), b"ppgwp_step_q2", 30),
              (lambda: BatchedRedQueen(config_env_base, batch_size=4096, device="cuda:0"), b"ppgc2_step_q2", 120)]
     names = ("row_xy", "row_energy", "row_id", "row_cumrew", "row_flags", "row_reward", "env_state", "grass_energy", "obs_pred", "obs_prey")

@@ -6,6 +6,7 @@
 #   bench:<name>:<bench.py arguments, comma separated>      one bench.py run, its JSON line kept
 #   benv:<name>:<VAR=value>:<bench.py arguments>    the same with one environment variable set for that run
 #   pt:<name>:<file>:<-k expression>    selected GPU tests with their printed reports kept (pytest -s)
+#   soak:<envs>:<calls>      tools/gpu_soak_coop.py: every cooperative kernel and layout, every env against its oracle on every call
 #   phase:<name>:<tools/phase_profile.py arguments, comma separated>   phase shares of a wavefront's cycles (diagnostic build)
 cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; shift
@@ -36,6 +37,10 @@ for step in "$@"; do
       IFS=: read -r name file expr <<< "$rest"
       python3 -m pytest "$file" -m gpu -q -s -k "$expr" > gpurun_out/${tag}_pt_${name}.log 2>&1
       grep -E "^\[|passed|failed" gpurun_out/${tag}_pt_${name}.log | tail -12 ;;
+    soak)
+      IFS=: read -r envs calls <<< "$rest"
+      python3 tools/gpu_soak_coop.py $envs $calls > gpurun_out/${tag}_soak_coop.txt 2>&1
+      grep -v amdgpu.ids gpurun_out/${tag}_soak_coop.txt | tail -8 ;;
     phase)
       IFS=: read -r name pargs <<< "$rest"
       python3 tools/phase_profile.py $(echo "$pargs" | tr ',' ' ') > gpurun_out/${tag}_phase_${name}.txt 2>&1

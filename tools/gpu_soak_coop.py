@@ -29,7 +29,31 @@ for plan in ((4, 0, 2), (4, 0, 4), (6, 0, 3), (8, 0, 2), (16, 0, 1)):
         r = P1.rollout_vs_oracle(env, lambda cfg=cfg: OracleEnv(cfg), seed0=1000 + plan[0] * 10 + plan[2], n_calls=calls, check_grid=True)
         print("base", plan, env.step_kernel_name(), cfg["grid_size"], str(dt)[6:], "resets", r, f"{time.time() - t0:.0f} s", flush=True)
         env.close()
+# round 6: the cooperative kernels WITHOUT a channel-0 cell map (ppgcm_*): what 64x64 grids get by default, and forced on small grids
+c4 = {**short, "grid_size": 64, "n_initial_active_predator": 16, "n_initial_active_prey": 32, "predator_obs_range": 7, "prey_obs_range": 7}
+for maps, cfg, dt in ((None, c4, torch.float64), ("3", short, torch.float64), ("3", {**short, "grid_size": 12, "initial_num_grass": 50}, torch.float32),
+                      ("3", {**short, "grid_size": 9, "n_initial_active_predator": 10, "n_initial_active_prey": 30, "initial_num_grass": 30,
+                             "energy_gain_per_step_grass": 0.8, "prey_creation_energy_threshold": 4.0}, torch.float64)):   # (crowded: spawn fallbacks)
+    if maps:
+        os.environ["PPG_COOP_MAPS"] = maps
+    for plan in ((4, 0, 2), (4, 0, 4)):
+        env = BatchedPredPreyGrass(cfg, batch_size=B, device="cuda:0", obs_dtype=dt, obs_spread=4)
+        env.set_wave_plan(*plan)
+        assert env.step_kernel_name().startswith("ppgcm_step"), env.step_kernel_name()
+        r = P1.rollout_vs_oracle(env, lambda cfg=cfg: OracleEnv(cfg), seed0=3000 + plan[2], n_calls=calls, check_grid=True)
+        fb = int(env.env_state[:, 12].sum()) if hasattr(env, "env_state") else -1
+        print("base three maps", plan, env.step_kernel_name(), cfg["grid_size"], str(dt)[6:], "resets", r, f"{time.time() - t0:.0f} s", flush=True)
+        env.close()
+    os.environ.pop("PPG_COOP_MAPS", None)
 mixed = dict(RQGoldenCase("rq_mixed_types_seed7").config, max_steps=120)
+os.environ["PPG_COOP_MAPS"] = "3"
+env = BatchedRedQueen(mixed, batch_size=B, device="cuda:0", obs_spread=4)
+env.set_wave_plan(4, 0, 2)
+assert env.step_kernel_name() == "ppgcm2_step_q2", env.step_kernel_name()
+r = P2.rollout_vs_oracle(env, lambda: RQOracleEnv(mixed), seed0=91, n_calls=calls, check_every=1, check_grid=True)
+print("gen2 three maps", env.step_kernel_name(), "resets/stats", r, f"{time.time() - t0:.0f} s", flush=True)
+env.close()
+os.environ.pop("PPG_COOP_MAPS", None)
 for plan in ((4, 0, 2), (4, 0, 4)):
     for cfg in (dict(config_env_base, max_steps=150), mixed):
         env = BatchedRedQueen(cfg, batch_size=B, device="cuda:0", obs_spread=4)
