@@ -32,8 +32,8 @@ for plan in ((4, 0, 2), (4, 0, 4), (6, 0, 3), (8, 0, 2), (16, 0, 1)):
 # round 6: the cooperative kernels WITHOUT a channel-0 cell map (ppgcm_*): what 64x64 grids get by default, and forced on small grids
 c4 = {**short, "grid_size": 64, "n_initial_active_predator": 16, "n_initial_active_prey": 32, "predator_obs_range": 7, "prey_obs_range": 7}
 for maps, cfg, dt in ((None, c4, torch.float64), ("3", short, torch.float64), ("3", {**short, "grid_size": 12, "initial_num_grass": 50}, torch.float32),
-                      ("3", {**short, "grid_size": 9, "n_initial_active_predator": 10, "n_initial_active_prey": 30, "initial_num_grass": 30,
-                             "energy_gain_per_step_grass": 0.8, "prey_creation_energy_threshold": 4.0}, torch.float64)):   # (crowded: spawn fallbacks)
+                      ("3", {**short, "grid_size": 8, "n_initial_active_predator": 6, "n_initial_active_prey": 18, "initial_num_grass": 30,
+                             "energy_gain_per_step_grass": 0.5}, torch.float64)):   # (crowded: spawn fallbacks, never a full grid)
     if maps:
         os.environ["PPG_COOP_MAPS"] = maps
     for plan in ((4, 0, 2), (4, 0, 4)):
