@@ -6,6 +6,8 @@
 #   bench:<name>:<bench.py arguments, comma separated>      one bench.py run, its JSON line kept
 #   benv:<name>:<VAR=value>:<bench.py arguments>    the same with one environment variable set for that run
 #   pt:<name>:<file>:<-k expression>    selected GPU tests with their printed reports kept (pytest -s)
+#   prof:<name>:<kernel>:<bench.py arguments>   rocprofv3 --kernel-trace --stats and the two PMC passes (WRITE_SIZE | FETCH_SIZE, counters only, the
+#                            program directly behind `--`) of one bench.py command; mean duration / bytes per launch of <kernel>
 #   soak:<envs>:<calls>      tools/gpu_soak_coop.py: every cooperative kernel and layout, every env against its oracle on every call
 #   phase:<name>:<tools/phase_profile.py arguments, comma separated>   phase shares of a wavefront's cycles (diagnostic build)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -37,6 +39,39 @@ for step in "$@"; do
       IFS=: read -r name file expr <<< "$rest"
       python3 -m pytest "$file" -m gpu -q -s -k "$expr" > gpurun_out/${tag}_pt_${name}.log 2>&1
       grep -E "^\[|passed|failed" gpurun_out/${tag}_pt_${name}.log | tail -12 ;;
+    prof)
+      IFS=: read -r name kern bargs <<< "$rest"
+      export TMPDIR=/tmp
+      A=$(echo "$bargs" | tr ',' ' ')
+      rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_pt_$name -o t -- python3 bench.py $A > gpurun_out/${tag}_prof_${name}_under_trace.json.log 2> gpurun_out/${tag}_prof_${name}.err
+      find gpurun_out/${tag}_pt_$name -name '*kernel_stats.csv' -exec cp {} gpurun_out/${tag}_prof_${name}_kernel_stats.csv \;
+      rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pw_$name -o w -- python3 bench.py $A > /dev/null 2>> gpurun_out/${tag}_prof_${name}.err
+      rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pf_$name -o f -- python3 bench.py $A > /dev/null 2>> gpurun_out/${tag}_prof_${name}.err
+      python3 - "$tag" "$name" "$kern" > gpurun_out/${tag}_prof_${name}_summary.txt <<'PY'
+import csv, glob, json, sys
+tag, name, kern = sys.argv[1:4]
+out = {"kernel": kern}
+for f in glob.glob(f"gpurun_out/{tag}_prof_{name}_kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if r["Name"] == kern:
+            out["rocprofv3_calls"] = int(r["Calls"]); out["rocprofv3_mean_us"] = float(r["AverageNs"]) / 1e3
+for key, pat in (("WRITE_SIZE", f"gpurun_out/{tag}_pw_{name}/**/*counter_collection.csv"), ("FETCH_SIZE", f"gpurun_out/{tag}_pf_{name}/**/*counter_collection.csv")):
+    vals = [float(r["Counter_Value"]) for f in glob.glob(pat, recursive=True) for r in csv.DictReader(open(f))
+            if r.get("Kernel_Name", "").split("(")[0] == kern and r.get("Counter_Name") == key]
+    if vals:
+        out[key + "_mean_KB_per_launch"] = sum(vals) / len(vals); out[key + "_launches"] = len(vals)
+if "WRITE_SIZE_mean_KB_per_launch" in out and "FETCH_SIZE_mean_KB_per_launch" in out:
+    # MI355X_MICROARCH.md, HBM section: counters in KB; FETCH_SIZE reads half of a wide coalesced read on gfx950 (doubled)
+    out["hbm_bytes_per_launch_corrected"] = 1024 * (out["WRITE_SIZE_mean_KB_per_launch"] + 2 * out["FETCH_SIZE_mean_KB_per_launch"])
+for l in open(f"gpurun_out/{tag}_prof_{name}_under_trace.json.log"):
+    if l.startswith("{"):
+        d = json.loads(l); r = d["roofline"]
+        out["bench_py_under_trace"] = {"value": d["value"], "kernel_ms": r.get("kernel_ms"), "frac": r.get("frac"), "achieved": r.get("achieved"),
+                                       "counted_bytes_per_launch": r.get("counted_bytes_per_launch"), "concurrent_launches": r.get("concurrent_launches")}
+print(json.dumps(out, indent=1))
+PY
+      rm -rf gpurun_out/${tag}_pt_$name gpurun_out/${tag}_pw_$name gpurun_out/${tag}_pf_$name
+      cat gpurun_out/${tag}_prof_${name}_summary.txt ;;
     soak)
       IFS=: read -r envs calls <<< "$rest"
       python3 tools/gpu_soak_coop.py $envs $calls > gpurun_out/${tag}_soak_coop.txt 2>&1
