@@ -44,7 +44,7 @@ from bench_support import (device_state, gather_per_rank, gpu_uuid, measure_traf
                            self_launch, start_state_sampler)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r05", "bench_driver_summary.json")
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r06", "bench_driver_summary.json")
 
 
 def cpu_baseline(cfg, seed0, seconds=12.0, threads=None, workload="base"):
@@ -902,7 +902,7 @@ def main(argv=None, backend=None):
             scale = (run_bytes / args.steps / n_sub) / prof["counted_bytes_per_launch"]
             traffic = int(prof["hbm_traffic_per_launch_bytes"]["total_corrected"] * scale)
             traffic_origin = "profiles_fallback"
-            traffic_src = (f"profiles/r05/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+            traffic_src = (f"profiles/r06/bench_driver_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            f"{prof['hbm_traffic_per_launch_bytes']['total_corrected']} B per launch at "
                            f"{prof['mean_agents_per_env']} agents/env, scaled x{scale:.4f} by this run's counted bytes")
     except Exception:
