@@ -127,8 +127,8 @@ def test_kernel_source_is_clean_under_ubsan():
 def test_kernel_source_is_clean_under_address_sanitizer():
     """The kernel source built with -fsanitize=address (CPU wave-emulator build), the bytes behind every workgroup's LDS poisoned
     (wave_emu.h): out-of-bounds reads and writes of LDS, of the "device" tensors (torch's CPU allocations, intercepted through the
-    preloaded runtime) and of the host code's own buffers abort the process.  Single-wave, multi-wave and cooperative kernels, the
-    second generation, the pack and fetch launches."""
+    preloaded runtime) and of the host code's own buffers abort the process.  Single-wave, multi-wave and cooperative kernels (both env-region
+    layouts), the second generation, the pack and fetch launches."""
     import subprocess, sys, os
     from tests.emu_backend import asan_runtime, build
     rt = asan_runtime()
@@ -161,6 +161,11 @@ def test_kernel_source_is_clean_under_address_sanitizer():
         "replay_golden_cases(coop, ['default_seed0'], config_env, max_calls=60)\n"
         "cfg7 = {**config_env, 'grid_size': 9, 'predator_obs_range': 13, 'prey_obs_range': 15, 'initial_num_grass': 20, 'max_steps': 40}\n"
         "rollout_vs_oracle(coop(cfg7, 3), lambda: OracleEnv(cfg7), seed0=4, n_calls=50)\n"
+        "os.environ['PPG_COOP_MAPS'] = '3'\n"    # the cooperative kernels WITHOUT a channel-0 map and without halos (ppgcm_*): every window
+        "replay_golden_cases(coop, ['default_seed0'], config_env, max_calls=60)\n"   # element outside the grid must stay inside LDS
+        "replay_golden_cases(coop, ['c4_seed0'], config_env, max_calls=40)\n"
+        "rollout_vs_oracle(coop(cfg, 3), lambda: OracleEnv(cfg), seed0=12, n_calls=80)\n"
+        "os.environ.pop('PPG_COOP_MAPS')\n"
         "e = mk(config_env, 3); e.reset(seed=1)\n"
         "for _ in range(5):\n"
         "    e.step(random_actions=True, auto_reset=True); e.fetch(); e.fetch(1, 1)\n"
