@@ -1,0 +1,134 @@
+// ppg_env_coop.h -- part of struct ppg::Env (ppg_kernel.h includes it INSIDE the struct's body: member functions, no include guard,
+// not a header of its own): the cooperative kernels' observation writing: whole 1 KB pieces of an env's run of live rows, both env-region layouts.
+    // ---- COOP: observations as whole 1 KB pieces of an env's run of live rows ---------------------------------
+    // The live rows of `type` of the env whose LDS region is `region` are listed in `list` (n_live words: row << 16 | the agent's
+    // padded cell -- ch0_map 0: | x << 8 | y); concatenated they are a run of n_live * blk elements.  Piece p is elements 128 p ..
+    // 128 p + 127 of the run: lane l produces elements 128 p + 2l and + 1 (blk is even: a pair never straddles two rows) --
+    // BASE:511-526 per element: value = val[map[cell + offset of the element] + section of its channel]; the padded maps make the
+    // window clipping of _obs_clip (BASE:528-539) implicit.  ch0_map 0: channel 0 is 1.0 iff the element's cell lies outside the grid
+    // (BASE:520-523), from the agent's position and the element's window offsets alone.  This wavefront writes pieces first,
+    // first + stride, ...
+    PPG_MEMBER void coop_pieces(int type, const unsigned char *region, const uint32_t *list, int n_live, int eb, int first, int stride) {
+        const map_t *m = (const map_t *)(region + P.off_map);
+        const double *vt = (const double *)(region + P.off_val);
+        const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);   // (arithmetic, not a select of fields: see window_sum)
+        const uint32_t magic = C.bp_magic + (type ? C.bq_magic - C.bp_magic : 0u);
+        const uint32_t *L = lut2 + (type ? C.blk_p : 0);
+        const int total = n_live * blk;
+        const size_t obase = (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;
+        // pieces in flight per wavefront: the three dependent LDS lookups of one hide behind the other's.  (Round 6, measured and not
+        // kept: four in flight, and the first lookup of the next group issued beside the map reads of the group in hand -- 53.8 / 55.4
+        // against 53.0 us per 4096-env step on 64x64 grids, 63.5 / 67.4 against 62.3 on the headline: the write phase is bound by how
+        // fast the memory system takes the stores, not by this chain.  profiles/r06/b_*)
+        constexpr int U = 2;
+        if (CH0MAP) {   // four maps: every element is a map lookup
+            const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
+            for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
+                uint32_t o[U], i0[U], i1[U];
+                bool on[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int s0 = (p0 + u * stride) * 128 + 2 * ln;
+                    on[u] = s0 < total;
+                    const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
+                    const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
+                    const uint32_t ent = on[u] ? list[i] : safe_cell;
+                    const uint2 d = *(const uint2 *)(L + w);
+                    const int pc = (int)(ent & 0xFFFFu);
+                    i0[u] = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)] + (d.x >> 16);
+                    i1[u] = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)] + (d.y >> 16);
+                    o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double v0 = vt[i0[u]], v1 = vt[i1[u]];
+                    if (!on[u]) continue;
+                    store_obs_pair(type ? P.obs_prey : P.obs_pred, P.obs_f32, obase + o[u], v0, v1);
+                }
+            }
+            return;
+        }
+        const uint32_t G = (uint32_t)P.G;
+        for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
+            uint32_t o[U], i0[U], i1[U];
+            bool on[U], out0[U], out1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s0 = (p0 + u * stride) * 128 + 2 * ln;
+                on[u] = s0 < total;
+                const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
+                const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);
+                const uint32_t ent = on[u] ? list[i] : 0u;   // (lanes behind the end of the run look at cell (0,0): inside the maps)
+                const uint2 d = *(const uint2 *)(L + w);
+                const uint32_t ax = (ent >> 8) & 255u, ay = ent & 255u;
+                const int pc = (int)(wv::mul24(ax + (uint32_t)P.pad, (uint32_t)P.Gp) + ay + (uint32_t)P.pad);
+                const bool z0 = (d.x >> 16) == 0xFFFFu, z1 = (d.y >> 16) == 0xFFFFu;   // channel 0: no map
+                // (a channel-0 descriptor's low bits as a map offset stay inside the three maps: no lane reads outside LDS)
+                const uint32_t m0 = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)], m1 = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)];
+                i0[u] = z0 ? 0u : m0 + (d.x >> 16);
+                i1[u] = z1 ? 0u : m1 + (d.y >> 16);
+                // outside the grid: unsigned compares (a coordinate below 0 wraps far above G); computed for every lane, no branches
+                const uint32_t tx0 = ax + ((d.x >> 4) & 15u) - 8u, ty0 = ay + (d.x & 15u) - 8u;
+                const uint32_t tx1 = ax + ((d.y >> 4) & 15u) - 8u, ty1 = ay + (d.y & 15u) - 8u;
+                out0[u] = z0 & ((tx0 > ty0 ? tx0 : ty0) >= G);
+                out1[u] = z1 & ((tx1 > ty1 ? tx1 : ty1) >= G);
+                o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double t0 = vt[i0[u]], t1 = vt[i1[u]];   // (channel 0 inside the grid: entry 0 = 0.0)
+                const double v0 = out0[u] ? 1.0 : t0, v1 = out1[u] ? 1.0 : t1;
+                if (!on[u]) continue;
+                store_obs_pair(type ? P.obs_prey : P.obs_pred, P.obs_f32, obase + o[u], v0, v1);
+            }
+        }
+    }
+    // a mid-step observation (an agent that starves or is caught, BASE:287,327): its block alone, at this point of the sequence
+    PPG_MEMBER void obs_row_coop(int type, int j, uint32_t s_xy) {
+        wv::sync();   // LDS writes of the sequential phases -> visible
+        uint32_t *mid = ctl + CTL_MID + wave_idx;
+        if (ln == 0) mid[0] = ((uint32_t)j << 16) | (CH0MAP ? (uint32_t)cell_of(s_xy) : s_xy);
+        wv::sync();
+        coop_pieces(type, (const unsigned char *)map - P.off_map, mid, 1, b, 0, 1);
+        wv::sync();   // reads done before the caller touches the maps again
+    }
+    // the rows to observe at the end of the call, per species, in the env's scratch: [0] predators, [64] prey
+    PPG_MEMBER void coop_publish() {
+        uint32_t *lst = (uint32_t *)scr;
+        int n[2] = {0, 0};
+        wv::sync();
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int type = type_of(r);
+            if ((alive[r] >> ln) & 1ull)
+                lst[(type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])] = ((uint32_t)row_of(r, ln) << 16) | (CH0MAP ? (uint32_t)cell_of(xy[r]) : xy[r]);
+            n[type] += wv::popc(alive[r]);
+        }
+        if (ln == 0) {
+            uint32_t *slot = ctl + CTL_SLOT + 4 * wave_idx;
+            slot[0] = (uint32_t)n[0]; slot[1] = (uint32_t)n[1]; slot[2] = (uint32_t)b;
+        }
+        wv::sync();
+    }
+    // after the workgroup barrier: all the workgroup's envs, piece p of the workgroup to wavefront p mod NW
+    PPG_MEMBER void coop_write_all(const unsigned char *wg_lds) {
+        int at = 0;   // pieces handed out so far, mod NW
+        for (int k = 0; k < C.coop_e; ++k) {
+            const uint32_t *slot = ctl + CTL_SLOT + 4 * k;
+            const int eb = (int)wv::first(slot[2]);
+            if (eb < 0) continue;
+            const unsigned char *region = wg_lds + (size_t)k * C.lds_env_bytes;
+            const uint32_t *lst = (const uint32_t *)(region + P.off_scr);
+#pragma unroll
+            for (int type = 0; type < 2; ++type) {
+                const int n_live = (int)wv::first(slot[type]);
+                const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);
+                const int pieces = (n_live * blk + 127) >> 7;
+                int first = wave_idx - at;
+                if (first < 0) first += NW;
+                coop_pieces(type, region, lst + (type ? 64 : 0), n_live, eb, first, NW);
+                at = (at + pieces) % NW;
+            }
+        }
+    }
+

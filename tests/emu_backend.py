@@ -12,6 +12,8 @@ EMU_LIB = os.path.join(EMU_DIR, "libppg_emu.so")
 _KERNEL_SOURCES = [
     os.path.join(EMU_DIR, "ppg_emu_part.cpp"), os.path.join(EMU_DIR, "wave_emu.h"),
     os.path.join(ROOT, "predpreygrass_amd", "csrc", "ppg_kernel.h"),
+    *[os.path.join(ROOT, "predpreygrass_amd", "csrc", f"ppg_env_{p}.h")   # struct Env's member functions, one file per phase
+      for p in ("load", "move", "sort", "observe", "coop", "engage", "reproduce", "step")],
     os.path.join(ROOT, "include", "ppg.h"),
 ]
 _SOURCES = _KERNEL_SOURCES + [os.path.join(EMU_DIR, "ppg_emu.cpp"), os.path.join(ROOT, "predpreygrass_amd", "csrc", "ppg_host.h"),
