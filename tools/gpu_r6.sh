@@ -8,6 +8,7 @@
 #   pt:<name>:<file>:<-k expression>    selected GPU tests with their printed reports kept (pytest -s)
 #   prof:<name>:<kernel>:<bench.py arguments>   rocprofv3 --kernel-trace --stats and the two PMC passes (WRITE_SIZE | FETCH_SIZE, counters only, the
 #                            program directly behind `--`) of one bench.py command; mean duration / bytes per launch of <kernel>
+#   sweep:<first seed>:<n>   tools/gpu_sweep.py: random configurations of every variant through the dict APIs against the oracles
 #   soak:<envs>:<calls>      tools/gpu_soak_coop.py: every cooperative kernel and layout, every env against its oracle on every call
 #   phase:<name>:<tools/phase_profile.py arguments, comma separated>   phase shares of a wavefront's cycles (diagnostic build)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -72,6 +73,10 @@ print(json.dumps(out, indent=1))
 PY
       rm -rf gpurun_out/${tag}_pt_$name gpurun_out/${tag}_pw_$name gpurun_out/${tag}_pf_$name
       cat gpurun_out/${tag}_prof_${name}_summary.txt ;;
+    sweep)
+      IFS=: read -r first n <<< "$rest"
+      python3 tools/gpu_sweep.py $first $n > gpurun_out/${tag}_sweep_${first}.txt 2>&1
+      grep -v amdgpu.ids gpurun_out/${tag}_sweep_${first}.txt | tail -3 ;;
     soak)
       IFS=: read -r envs calls <<< "$rest"
       python3 tools/gpu_soak_coop.py $envs $calls > gpurun_out/${tag}_soak_coop.txt 2>&1

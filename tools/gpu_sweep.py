@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long randomised differential sweep on the GPU: random configurations of the base family, the second generation and
-the walls variant, dict API vs the CPU oracles, call by call, bit for bit.  usage: gpu_sweep.py <first seed> <n seeds>"""
+the walls variant, dict API vs the CPU oracles, call by call, bit for bit (round 6: the second-generation classes run with their analytics
+mirror cross-checking every energy it derives against the device's).  usage: gpu_sweep.py <first seed> <n seeds>"""
 import os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from predpreygrass_amd.env import PredPreyGrass
@@ -14,8 +15,8 @@ fails, t0 = [], time.time()
 counts = {"base": 0, "gen2": 0, "walls": 0}
 for seed in range(first, first + n):
     for kind, fn in (("base", lambda: T1.run_differential(lambda cfg: PredPreyGrass(cfg, device="cuda:0"), seed)),
-                     ("gen2", lambda: T2.run_differential(lambda cfg: RQEnv(cfg, device="cuda:0"), seed)),
-                     ("walls", lambda: T2.run_differential(lambda cfg: WOEnv(cfg, device="cuda:0"), seed, walls=True))):
+                     ("gen2", lambda: T2.run_differential(lambda cfg: RQEnv(cfg, device="cuda:0", _check_analytics=True), seed)),
+                     ("walls", lambda: T2.run_differential(lambda cfg: WOEnv(cfg, device="cuda:0", _check_analytics=True), seed, walls=True))):
         try:
             fn()
             counts[kind] += 1
