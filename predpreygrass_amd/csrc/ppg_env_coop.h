@@ -21,6 +21,12 @@
         // against 53.0 us per 4096-env step on 64x64 grids, 63.5 / 67.4 against 62.3 on the headline: the write phase is bound by how
         // fast the memory system takes the stores, not by this chain.  profiles/r06/b_*)
         constexpr int U = 2;
+        // The three-map kernels decide the dtype dispatch of the stores (float64 / float32 / bfloat16: wave-uniform branches per piece) ONCE
+        // per call -- a loop of its own for float64 rows: 64x64 grids 54.6-55.6 -> 52.7-53.3 us per 4096-env step.  The four-map kernels
+        // keep the one generic loop: there the second copy cost the headline 0.5-2 % (code size) -- profiles/r06/o_*.
+        void *const obuf = type ? P.obs_prey : P.obs_pred;
+        auto pieces = [&](auto f64_tag) {
+        constexpr bool F64 = decltype(f64_tag)::value;
         if (CH0MAP) {   // four maps: every element is a map lookup
             const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
             for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
@@ -43,7 +49,8 @@
                 for (int u = 0; u < U; ++u) {
                     const double v0 = vt[i0[u]], v1 = vt[i1[u]];
                     if (!on[u]) continue;
-                    store_obs_pair(type ? P.obs_prey : P.obs_pred, P.obs_f32, obase + o[u], v0, v1);
+                    if (F64) { double2 g; g.x = v0; g.y = v1; *(double2 *)((double *)obuf + obase + o[u]) = g; }
+                    else store_obs_pair(obuf, P.obs_f32, obase + o[u], v0, v1);
                 }
             }
             return;
@@ -79,9 +86,13 @@
                 const double t0 = vt[i0[u]], t1 = vt[i1[u]];   // (channel 0 inside the grid: entry 0 = 0.0)
                 const double v0 = out0[u] ? 1.0 : t0, v1 = out1[u] ? 1.0 : t1;
                 if (!on[u]) continue;
-                store_obs_pair(type ? P.obs_prey : P.obs_pred, P.obs_f32, obase + o[u], v0, v1);
+                if (F64) { double2 g; g.x = v0; g.y = v1; *(double2 *)((double *)obuf + obase + o[u]) = g; }
+                else store_obs_pair(obuf, P.obs_f32, obase + o[u], v0, v1);
             }
         }
+        };
+        if (THREE && P.obs_f32 == 0) pieces(TagTrue{});
+        else pieces(TagFalse{});
     }
     // a mid-step observation (an agent that starves or is caught, BASE:287,327): its block alone, at this point of the sequence
     PPG_MEMBER void obs_row_coop(int type, int j, uint32_t s_xy) {

@@ -173,6 +173,9 @@ struct KParams {
 // small helpers
 // ---------------------------------------------------------------------------------
 
+struct TagTrue { static constexpr bool value = true; };    // compile-time switches handed to generic lambdas
+struct TagFalse { static constexpr bool value = false; };
+
 PPG_DEVICE uint64_t bit64(int k) { return 1ull << k; }
 PPG_DEVICE uint64_t lowmask(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull)); }
 
