@@ -402,10 +402,21 @@ def test_bench_rccl_gather_legs_with_one_rank():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "50",
-           "--envs", "1024", "--force-dist", "--no-cpu-baseline", "--gather-steps", "5", "--preroll-max", "400"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    def run(port, timeout):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "50",
+               "--envs", "1024", "--force-dist", "--no-cpu-baseline", "--gather-steps", "5", "--preroll-max", "400"]
+        return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
+    try:
+        out = run(29533, 420)   # (takes ~10 s)
+    except subprocess.TimeoutExpired as first:
+        # Seen ONCE in round 6, on a lease whose every figure was off (the pool's slow state): the launcher did not come back.  One
+        # retry on another port; a second time-out fails the test with what the first attempt had printed.
+        try:
+            out = run(29541, 420)
+        except subprocess.TimeoutExpired as second:
+            tail = lambda e: ((e.stderr or b"")[-1500:].decode(errors="replace") if isinstance(e.stderr, bytes) else str(e.stderr or "")[-1500:])
+            pytest.fail("torchrun + bench.py with one rank timed out twice; stderr tails:\n" + tail(first) + "\n----\n" + tail(second))
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["value"] > 1e6
