@@ -423,28 +423,30 @@ class PredPreyGrass(_MultiAgentEnvBase):
         ones `_collect` just fetched."""
         b, t = self._b, self._tables
         cp = b.pred_capacity
-        xy = lambda tab, s: (int(tab["row_xy"][0][s]) >> 8, int(tab["row_xy"][0][s]) & 255)
+        # (whole columns as Python lists once: NumPy scalars one by one are what such a pass costs)
+        xy0, xy1 = before["row_xy"][0].tolist(), t["row_xy"][0].tolist()
+        cum0, fl1 = before["row_cumrew"][0].tolist(), t["row_flags"][0].tolist()
+        lr1, e1 = t["row_lastrep"][0].tolist(), t["row_energy"][0].tolist()
         slot0 = {n: cp * sp + row for n, (sp, row) in where.items()}
         slot1 = {name: cp * sp + row for name, sp, row, *_ in self._records}
-        fl1 = t["row_flags"][0]
-        newborn = [name for name, *_ in self._records if fl1[slot1[name]] & _abi.ROW_NEWBORN]
+        pos1 = {n: (xy1[s] >> 8 & 255, xy1[s] & 255) for n, s in slot1.items()}
         ng = b.n_grass
         pending = self._an.step(
             current_step=current_step, action_names=action_names,
             agents_in_order=[name for name, *_ in self._records if not fl1[slot1[name]] & _abi.ROW_NEWBORN],
             insertion_order=insertion_order,
-            pos_before={n: xy(before, s) for n, s in slot0.items()},
-            pos_after={n: xy(t, s) for n, s in slot1.items()},
-            cum_before={n: float(before["row_cumrew"][0][s]) for n, s in slot0.items()},
-            grass_pos=[(int(v) >> 8, int(v) & 255) for v in before["grass_xy"][0][:ng].tolist()],
+            pos_before={n: (xy0[s] >> 8 & 255, xy0[s] & 255) for n, s in slot0.items()},
+            pos_after=pos1,
+            cum_before={n: cum0[s] for n, s in slot0.items()},
+            grass_pos=[(v >> 8 & 255, v & 255) for v in before["grass_xy"][0][:ng].tolist()],
             grass_energy_before=before["grass_energy"][0][:ng].tolist(),
             terminated={name for name, _, _, _, te, _ in self._records if te},
             ate={n for n, s in slot1.items() if fl1[s] & _abi.ROW_ATE},
-            newborn=newborn,
-            lastrep_after={n: int(t["row_lastrep"][0][s]) for n, s in slot1.items()},
-            energy_after={n: float(t["row_energy"][0][s]) for n, s in slot1.items()},
+            newborn=[name for name, *_ in self._records if fl1[slot1[name]] & _abi.ROW_NEWBORN],
+            lastrep_after={n: lr1[s] for n, s in slot1.items()},
+            energy_after={n: e1[s] for n, s in slot1.items()},
             grass_energy_after=t["grass_energy"][0][:ng].tolist())
-        self._an.record_step(sorted(slot1), set(pending), {n: xy(t, s) for n, s in slot1.items()})
+        self._an.record_step(sorted(slot1), set(pending), pos1)
 
     # ------------------------------------------------------------------
     def reset(self, *, seed=None, options=None):

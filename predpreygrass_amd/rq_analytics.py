@@ -160,7 +160,9 @@ class AgentAnalytics:
             E[a] -= move_cost
             deltas[a]["move"] = -move_cost
             st = self.unique_agent_stats[self.unique_agents[a]]
-            st["distance_traveled"] += np.linalg.norm(np.array(new) - np.array(old))   # RQ:530
+            # RQ:530 adds np.linalg.norm(new - old) of two integer vectors: the correctly rounded square root of the same exact integer
+            # as RQ:310's math.sqrt -- the same float64, as a numpy scalar like the reference's (a tenth of the norm call's cost)
+            st["distance_traveled"] += np.float64(distance)
             st["energy_spent"] += move_cost
             st["avg_energy_sum"] += E[a]
             st["avg_energy_steps"] += 1
