@@ -25,8 +25,10 @@
         // per call -- a loop of its own for float64 rows: 64x64 grids 54.6-55.6 -> 52.7-53.3 us per 4096-env step.  The four-map kernels
         // keep the one generic loop: there the second copy cost the headline 0.5-2 % (code size) -- profiles/r06/o_*.
         void *const obuf = type ? P.obs_prey : P.obs_pred;
-        auto pieces = [&](auto f64_tag) {
-        constexpr bool F64 = decltype(f64_tag)::value;
+        // The second generation's kernels do the same for float32 rows, the reference's dtype there (RQ:137-139): its branch chain is the
+        // longest of the three -- 57.5 -> 53.5 us per 4096-env step, +7 % (profiles/r06/r_*).
+        auto pieces = [&](auto f64_tag, auto f32_tag) {
+        constexpr bool F64 = decltype(f64_tag)::value, F32 = decltype(f32_tag)::value;
         if (CH0MAP) {   // four maps: every element is a map lookup
             const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
             for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
@@ -50,6 +52,7 @@
                     const double v0 = vt[i0[u]], v1 = vt[i1[u]];
                     if (!on[u]) continue;
                     if (F64) { double2 g; g.x = v0; g.y = v1; *(double2 *)((double *)obuf + obase + o[u]) = g; }
+                    else if (F32) { float2 f; f.x = (float)v0; f.y = (float)v1; *(float2 *)((float *)obuf + obase + o[u]) = f; }
                     else store_obs_pair(obuf, P.obs_f32, obase + o[u], v0, v1);
                 }
             }
@@ -87,12 +90,14 @@
                 const double v0 = out0[u] ? 1.0 : t0, v1 = out1[u] ? 1.0 : t1;
                 if (!on[u]) continue;
                 if (F64) { double2 g; g.x = v0; g.y = v1; *(double2 *)((double *)obuf + obase + o[u]) = g; }
+                else if (F32) { float2 f; f.x = (float)v0; f.y = (float)v1; *(float2 *)((float *)obuf + obase + o[u]) = f; }
                 else store_obs_pair(obuf, P.obs_f32, obase + o[u], v0, v1);
             }
         }
         };
-        if (THREE && P.obs_f32 == 0) pieces(TagTrue{});
-        else pieces(TagFalse{});
+        if (THREE && P.obs_f32 == 0) pieces(TagTrue{}, TagFalse{});
+        else if (GEN2 && P.obs_f32 == 1) pieces(TagFalse{}, TagTrue{});
+        else pieces(TagFalse{}, TagFalse{});
     }
     // a mid-step observation (an agent that starves or is caught, BASE:287,327): its block alone, at this point of the sequence
     PPG_MEMBER void obs_row_coop(int type, int j, uint32_t s_xy) {
