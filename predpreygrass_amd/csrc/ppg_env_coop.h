@@ -124,17 +124,42 @@
             uint32_t *slot = ctl + CTL_SLOT + 4 * wave_idx;
             slot[0] = (uint32_t)n[0]; slot[1] = (uint32_t)n[1]; slot[2] = (uint32_t)b;
         }
+        if (WALLS) walls_stage_masks();
         wv::sync();
     }
     // after the workgroup barrier: all the workgroup's envs, piece p of the workgroup to wavefront p mod NW
-    PPG_MEMBER void coop_write_all(const unsigned char *wg_lds) {
-        int at = 0;   // pieces handed out so far, mod NW
+    // WALLS (ppgc3_step): whole rows instead of pieces -- row i of the workgroup to wavefront i mod NW, each through obs_row_walls_in
+    // (its per-cell work -- wall bit, line-of-sight bit, three lookups -- feeds all 4 / 5 channels of the cell)
+    PPG_MEMBER void coop_write_all(unsigned char *wg_lds) {
+        int at = 0;   // pieces (WALLS: rows) handed out so far, mod NW
         for (int k = 0; k < C.coop_e; ++k) {
             const uint32_t *slot = ctl + CTL_SLOT + 4 * k;
             const int eb = (int)wv::first(slot[2]);
             if (eb < 0) continue;
-            const unsigned char *region = wg_lds + (size_t)k * C.lds_env_bytes;
+            unsigned char *region = wg_lds + (size_t)k * C.lds_env_bytes;
             const uint32_t *lst = (const uint32_t *)(region + P.off_scr);
+            if (WALLS) {
+                const bool flat = walls_flat();
+                const uint32_t *vm = (const uint32_t *)(region + C.off_vm);
+#pragma unroll
+                for (int type = 0; type < 2; ++type) {
+                    const int n_live = (int)wv::first(slot[type]);
+                    int first = wave_idx - at;
+                    if (first < 0) first += NW;
+                    if (flat) {   // runs of window cells, 64 per pass (obs_cells_walls)
+                        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
+                        obs_cells_walls(type, lst + (type ? 64 : 0), n_live, vm + (type ? 64 * C.vis_words : 0), region, eb, first, NW);
+                        at = (at + ((n_live * R * R + 63) >> 6)) % NW;
+                        continue;
+                    }
+                    for (int i = first; i < n_live; i += NW) {   // (no precomputed masks: whole rows, each walks its lines)
+                        const uint32_t en = wv::first(lst[(type ? 64 : 0) + i]);
+                        obs_row_walls_in(type, (int)(en >> 16), en & 0xFFFFu, region, eb);
+                    }
+                    at = (at + n_live) % NW;
+                }
+                continue;
+            }
 #pragma unroll
             for (int type = 0; type < 2; ++type) {
                 const int n_live = (int)wv::first(slot[type]);

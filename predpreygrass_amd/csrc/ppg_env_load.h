@@ -158,15 +158,15 @@
     // 25x25 grid; larger geometries finish with plain copy loops), so the tables cost no memory round trip of their own.
     static constexpr int LUT_REGS = 9, TMPL_REGS = 5;
     struct TabPre { uint32_t l[LUT_REGS], m[TMPL_REGS]; };
-    PPG_MEMBER void coop_tab_issue(TabPre &t) const {
-        const int nl = C.blk_p + C.blk_q, nm = CH0MAP ? P.map_n / 4 : 0;
+    PPG_MEMBER void coop_tab_issue(TabPre &t) const {   // (WALLS: no descriptors -- its rows go through obs_row_walls_in)
+        const int nl = WALLS ? 0 : C.blk_p + C.blk_q, nm = CH0MAP ? P.map_n / 4 : 0;
 #pragma unroll
         for (int u = 0; u < LUT_REGS; ++u) { t.l[u] = 0; if (u * 64 + ln < nl) t.l[u] = C.coop_tab[u * 64 + ln]; }
 #pragma unroll
         for (int u = 0; u < TMPL_REGS; ++u) { t.m[u] = 0; if (u * 64 + ln < nm) t.m[u] = C.coop_tab[nl + u * 64 + ln]; }
     }
     PPG_MEMBER void coop_tab_store(const TabPre &t) {
-        const int nl = C.blk_p + C.blk_q, nm = CH0MAP ? P.map_n / 4 : 0;
+        const int nl = WALLS ? 0 : C.blk_p + C.blk_q, nm = CH0MAP ? P.map_n / 4 : 0;
         uint32_t *m32 = (uint32_t *)map;
         zero_maps(nm);   // channels 1-3: empty
 #pragma unroll

@@ -169,7 +169,11 @@
     // 1-3 optionally multiplied, in float32 like the reference, by the mask; optional last channel = the mask itself, which is
     // computed for every cell of the R x R array that maps into the grid (also the last row / column of an even R, which the
     // window copy WO:543 leaves untouched).  Consecutive lanes write consecutive elements of a channel plane.
-    PPG_MEMBER void obs_row_walls(int type, int j, uint32_t s_xy) {
+    // COOP (ppgc3_step: the cooperative walls kernel): `region` = the LDS region of the env the row belongs to -- after the workgroup's
+    // barrier every wavefront writes rows of all the workgroup's envs -- and eb its index; every wavefront stages the mask in ITS area
+    // of that region.
+    PPG_MEMBER void obs_row_walls(int type, int j, uint32_t s_xy) { obs_row_walls_in(type, j, s_xy, (unsigned char *)map - P.off_map, b); }
+    PPG_MEMBER void obs_row_walls_in(int type, int j, uint32_t s_xy, unsigned char *region, int eb) {
         wv::sync();  // LDS writes of the sequential phases -> visible
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0);   // (arithmetic, not a select of fields: see window_sum)
         const uint32_t rmagic = C.rp_magic + (type ? C.rq_magic - C.rp_magic : 0u);
@@ -177,25 +181,28 @@
         const int nchan = C.vis_channel ? 5 : 4;
         const int x = (int)(s_xy >> 8), y = (int)(s_xy & 255u);
         const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;   // (areas are strided by the larger window: waves work on both species)
-        float *visb = (float *)((unsigned char *)map + C.off_win - P.off_map) + wave_idx * rmax * rmax;
+        float *visb = (float *)(region + C.off_win) + wave_idx * rmax * rmax;
         const uint32_t *visw = (const uint32_t *)visb;
+        const map_t *const m = (const map_t *)(region + P.off_map);
+        const double *const vt = (const double *)(region + P.off_val);
+        const uint32_t *const ww = (const uint32_t *)(region + C.off_wall);
         const bool want_vis = C.mask_obs || C.vis_channel;
         const bool have_masks = C.vis_masks != nullptr;
         if (want_vis && have_masks) {
             // walls are static: the mask of this agent's cell was computed when they were set (ppg_walls_changed) -- a few words
             // instead of one Bresenham walk per window cell
-            if (ln < C.vis_words) ((uint32_t *)visb)[ln] = C.vis_masks[((size_t)b * P.G * P.G + x * P.G + y) * C.vis_words + ln];
+            if (ln < C.vis_words) ((uint32_t *)visb)[ln] = C.vis_masks[((size_t)eb * P.G * P.G + x * P.G + y) * C.vis_words + ln];
             wv::sync();
         } else if (want_vis) {
             for (int i = ln; i < n; i += 64) {
                 const int ci = (int)wv::mulhi((uint32_t)i, rmagic), cj = i - ci * R;
                 const int gx = x - off + ci, gy = y - off + cj;
                 const bool in_grid = (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
-                visb[i] = (in_grid && los_clear(x, y, gx, gy)) ? 1.0f : 0.0f;
+                visb[i] = (in_grid && los_clear_in(ww, x, y, gx, gy)) ? 1.0f : 0.0f;
             }
             wv::sync();
         }
-        const size_t obase = ((size_t)b * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)(nchan * n);
+        const size_t obase = ((size_t)eb * (type ? P.cap_prey : P.cap_pred) + (size_t)j) * (size_t)(nchan * n);
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int cell = c0 + ln;
             const bool valid = cell < n;
@@ -204,8 +211,9 @@
             const bool in_grid = valid && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
             const bool inb = in_grid && ci < Wc && cj < Wc;
             const int a = inb ? gx * P.G + gy : 0;
+            const int am = COOP ? (inb ? (gx + P.pad) * P.Gp + gy + P.pad : 0) : a;   // (COOP: padded maps)
             double v[5];
-            v[0] = (inb && ((wallw[a >> 5] >> (a & 31)) & 1u)) ? 1.0 : 0.0;
+            v[0] = (inb && ((ww[a >> 5] >> (a & 31)) & 1u)) ? 1.0 : 0.0;
             float vis = 0.0f;
             if (want_vis && in_grid) {
                 if (have_masks) {
@@ -217,7 +225,7 @@
             }
 #pragma unroll
             for (int ch = 1; ch < 4; ++ch) {
-                double t = val[from_map(ch, chmap(ch)[a])];
+                double t = vt[from_map(ch, (m + (THREE ? ch - 1 : ch) * P.map_n)[am])];
                 if (!inb) t = 0.0;
                 if (C.mask_obs) t = (double)((float)t * (inb ? vis : 0.0f));
                 v[ch] = t;
@@ -234,6 +242,94 @@
             }
         }
         wv::sync();  // reads done before the caller touches the maps again
+    }
+
+    // The same for a LIST of rows of one species (round 6; multi-wave and cooperative kernels, masks precomputed or not needed): the
+    // rows' window cells are ONE run of n_live * R*R cells, 64 per pass with every lane busy -- a 9x9 window alone fills 1.27 passes,
+    // the per-row form above spends 2 -- and their line-of-sight masks were staged for all rows at once (walls_stage_masks: one
+    // memory round trip per env instead of one per row).  list[i] = row << 16 | x << 8 | y (bit 31 ignored); vm = the staged masks of
+    // this species' list; chunk c of the run (64 cells) is written by the wavefront with c = first (mod stride).
+    PPG_MEMBER bool walls_flat() const { return !(C.mask_obs || C.vis_channel) || C.vis_masks != nullptr; }
+    PPG_MEMBER void obs_cells_walls(int type, const uint32_t *list, int n_live, const uint32_t *vm, const unsigned char *region, int eb,
+                                    int first, int stride) {
+        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
+        const uint32_t rmagic = C.rp_magic + (type ? C.rq_magic - C.rp_magic : 0u);
+        const uint32_t nmagic = C.np_magic + (type ? C.nq_magic - C.np_magic : 0u);
+        const int n = R * R, off = (R - 1) / 2, Wc = 2 * off + 1;
+        const int nchan = C.vis_channel ? 5 : 4;
+        const bool want_vis = C.mask_obs || C.vis_channel;
+        const map_t *const m = (const map_t *)(region + P.off_map);
+        const double *const vt = (const double *)(region + P.off_val);
+        const uint32_t *const ww = (const uint32_t *)(region + C.off_wall);
+        const int total = n_live * n, blk = nchan * n;
+        const size_t obase = (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;   // (wave-uniform; the lane's part is 32-bit)
+        // float32 rows -- the reference's dtype (WO:137-139) -- have a loop of their own: no dtype branch per store, no float64 detour
+        auto cells = [&](auto f32_tag) {
+        constexpr bool F32 = decltype(f32_tag)::value;
+        for (int c0 = first * 64; c0 < total; c0 += stride * 64) {
+            const int g = c0 + ln;
+            const bool valid = g < total;
+            const uint32_t gs = valid ? (uint32_t)g : 0u;
+            const int i = (int)wv::mulhi(gs, nmagic), cell = (int)gs - i * n;
+            const uint32_t en = list[i];
+            const int j = (int)((en >> 16) & 0x7FFFu), x = (int)((en >> 8) & 255u), y = (int)(en & 255u);
+            const int ci = (int)wv::mulhi((uint32_t)cell, rmagic), cj = cell - ci * R;
+            const int gx = x - off + ci, gy = y - off + cj;
+            const bool in_grid = valid && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+            const bool inb = in_grid && ci < Wc && cj < Wc;
+            const int a = inb ? gx * P.G + gy : 0;
+            const int am = COOP ? (inb ? (gx + P.pad) * P.Gp + gy + P.pad : 0) : a;   // (COOP: padded maps)
+            double v[5];
+            v[0] = (inb && ((ww[a >> 5] >> (a & 31)) & 1u)) ? 1.0 : 0.0;
+            float vis = 0.0f;
+            if (want_vis) {
+                const int bi = (ci - off + C.vis_neg) * C.vis_w + (cj - off + C.vis_neg);
+                const uint32_t word = vm[i * C.vis_words + (bi >> 5)];
+                vis = (in_grid && ((word >> (bi & 31)) & 1u)) ? 1.0f : 0.0f;
+            }
+            float f[5];
+            f[0] = (float)v[0];
+#pragma unroll
+            for (int ch = 1; ch < 4; ++ch) {
+                double t = vt[from_map(ch, (m + (THREE ? ch - 1 : ch) * P.map_n)[am])];
+                if (!inb) t = 0.0;
+                f[ch] = (float)t;
+                if (C.mask_obs) { f[ch] = f[ch] * (inb ? vis : 0.0f); t = (double)f[ch]; }   // (in float32, like the reference: WO:591-594)
+                v[ch] = t;
+            }
+            v[4] = (double)vis; f[4] = vis;
+            if (valid) {
+                const uint32_t o0 = (uint32_t)(j * blk + cell);
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) {
+                    if (ch >= nchan) continue;
+                    const uint32_t o = o0 + (uint32_t)(ch * n);
+                    if (F32) ((float *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = f[ch];
+                    else if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = f[ch];
+                    else ((double *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = v[ch];
+                }
+            }
+        }
+        };
+        if (P.obs_f32 == 1) cells(TagTrue{});
+        else cells(TagFalse{});
+    }
+    // the line-of-sight masks of all live rows, straight from the row registers into their list positions (predator list entry i at
+    // i, prey list entry i at 64 + i): every load is independent of every other
+    PPG_MEMBER void walls_stage_masks() {
+        if (!(C.mask_obs || C.vis_channel) || C.vis_masks == nullptr) return;
+        uint32_t *vm = (uint32_t *)((unsigned char *)map - P.off_map + C.off_vm);
+        int n[2] = {0, 0};
+#pragma unroll
+        for (int r = 0; r < T; ++r) {
+            const int type = type_of(r);
+            if ((alive[r] >> ln) & 1ull) {
+                const int i = (type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r]);
+                const uint32_t *src = C.vis_masks + ((size_t)b * P.G * P.G + (xy[r] >> 8) * P.G + (xy[r] & 255u)) * C.vis_words;
+                for (int w = 0; w < C.vis_words; ++w) vm[i * C.vis_words + w] = src[w];
+            }
+            n[type] += wv::popc(alive[r]);
+        }
     }
 
     // _get_observation of the drive-conditioned env (DRV:551-616), one window CELL per lane: the three world channels of a cell
@@ -336,7 +432,7 @@
     }
 
     PPG_MEMBER void obs_row(int type, int j, uint32_t s_xy, double s_e = 0.0) {
-        if (COOP) { obs_row_coop(type, j, s_xy); return; }
+        if (COOP && !WALLS) { obs_row_coop(type, j, s_xy); return; }
         if (FASTOBS) {
             if (type) obs_row_fast<1>(j, s_xy);
             else obs_row_fast<0>(j, s_xy);
@@ -468,6 +564,18 @@
             }
             return;
         }
+        if (WALLS && walls_flat()) {   // the listed rows as runs of window cells, chunk c to wavefront c mod stride
+            const int n_pred = (int)(head >> 16);
+            const unsigned char *region = (const unsigned char *)map - P.off_map;
+            const uint32_t *vm = (const uint32_t *)(region + C.off_vm);
+            wv::sync();
+            obs_cells_walls(0, lst + 1, n_pred, vm, region, b, w, stride);
+            const int chunks = (n_pred * P.Rp * P.Rp + 63) >> 6;
+            int first = (w - chunks) % stride;
+            if (first < 0) first += stride;
+            obs_cells_walls(1, lst + 1 + n_pred, n - n_pred, vm + 64 * C.vis_words, region, b, first, stride);
+            return;
+        }
         for (int i = w; i < n; i += stride) {
             const uint32_t en = wv::first(lst[1 + i]);
             const int ty = (int)(en >> 31), row = (int)((en >> 16) & 0x7FFFu);
@@ -514,6 +622,7 @@
                 n += wv::popc(alive[r]);
             }
             if (ln == 0) lst[0] = (uint32_t)n | ((uint32_t)wv::popc(alive[0]) << 16);
+            if (WALLS) walls_stage_masks();
             if (write_now) obs_finish();
             return;
         }

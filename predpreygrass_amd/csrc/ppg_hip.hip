@@ -21,6 +21,7 @@
 #define PPG_KW(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KW2(name, NQ, FAST, NW) PPG_KERNEL_NW(name, (NQ <= 2 ? 4 : 2), NW)(const ppg::KParams P);
 #define PPG_KC(name, NQ, GEN2, NW) PPG_KERNEL_NW(name, 4, NW)(const ppg::KParams P);
+#define PPG_KC3(name, NQ) PPG_KERNEL_NW(name, 4, 4)(const ppg::KParams P);
 #define PPG_KCM(name, NQ, GEN2) PPG_KERNEL_NW(name, 4, 4)(const ppg::KParams P);
 #define PPG_KCH(name, NQ) PPG_KERNEL_NW(name, 8, 4)(const ppg::KParams P);
 #define PPG_KCR(name, NQ, GEN2, NW) PPG_KERNEL_NW(name, 4, NW)(const ppg::KParams P);
@@ -247,6 +248,7 @@ static int backend_launch(ppg_handle *h, int mode, const ppg::KParams &P, void *
         if (h->gen2) fn = h->nq == 1 ? ppgc2_step_q1 : ppgc2_step_q2;   // (second generation: four-wave cooperative kernels)
         if (!P.ch0_map)   // three cell maps per env (ppg_planned_step_params chose that layout: four-wave step launches only)
             fn = h->gen2 ? (h->nq == 1 ? ppgcm2_step_q1 : ppgcm2_step_q2) : (h->nq == 1 ? ppgcm_step_q1 : ppgcm_step_q2);
+        if (h->gen2 && h->cfg2.walls) fn = h->nq == 1 ? ppgc3_step_q1 : ppgc3_step_q2;   // (walls: three maps, rows written whole)
         if (mode == ppg::MODE_ROLLOUT)   // (ppg_rollout: the fused form of the four-wave cooperative kernels)
             fn = h->gen2 ? (h->nq == 1 ? ppgc2_rollout_q1 : ppgc2_rollout_q2) : (h->nq == 1 ? ppgc_rollout_q1 : ppgc_rollout_q2);
         block = 64u * (unsigned)wp.nw;

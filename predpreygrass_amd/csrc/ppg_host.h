@@ -230,6 +230,10 @@ static int ppg_validate_and_layout(ppg_handle *h) {
         const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;
         off = (off + 15) / 16 * 16;
         P.off_win = off; off += 4 * rmax * rmax * 4;
+        // the line-of-sight masks of the rows listed for the shared observation writing (Env::walls_stage_masks)
+        const int offp = (P.Rp - 1) / 2, offq = (P.Rq - 1) / 2, posp = P.Rp - 1 - offp, posq = P.Rq - 1 - offq;
+        const int vw = (offp > offq ? offp : offq) + (posp > posq ? posp : posq) + 1;   // KParams::vis_w (ppg_validate_and_layout_gen2)
+        P.off_vm = off; off += (64 + P.cap_prey) * ((vw * vw + 31) / 32) * 4;
     }
     P.lds_bytes = off;
     if (P.lds_bytes > 64 * 1024) return ppg_fail(h, PPG_EINVAL, "configuration needs %d bytes of LDS per wave (> 64 KiB)", P.lds_bytes);
@@ -341,6 +345,14 @@ static bool ppg_coop_layout_with(ppg_handle *h, int ch0_map, ppg::KParams &P, st
     if (scr_bytes < 1024) scr_bytes = 1024;                                                       // (reset: 256 random words)
     P.off_scr = off; off += scr_bytes;
     P.off_lut = off;
+    if (h->gen2 && h->cfg2.walls) {   // walls (ppgc3_step): each env region carries its wall bitmap and four line-of-sight staging areas
+        off = (off + 15) / 16 * 16;
+        P.off_wall = off; off += P.n_wall_words * 4;
+        const int rmax = P.Rp > P.Rq ? P.Rp : P.Rq;
+        off = (off + 15) / 16 * 16;
+        P.off_win = off; off += 4 * rmax * rmax * 4;
+        P.off_vm = off; off += (64 + P.cap_prey) * P.vis_words * 4;
+    }
     P.lds_env_bytes = (off + 15) / 16 * 16;
     P.bp_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_p - 1) / (uint64_t)P.blk_p);
     P.bq_magic = (uint32_t)((0x100000000ull + (uint64_t)P.blk_q - 1) / (uint64_t)P.blk_q);
@@ -368,8 +380,10 @@ static bool ppg_coop_layout_with(ppg_handle *h, int ch0_map, ppg::KParams &P, st
     }
     return true;
 }
+// bytes of the workgroup's descriptor table (the walls variant writes whole rows through obs_row_walls_in: none)
+static int ppg_coop_table_bytes(const ppg::KParams &P) { return P.walls ? 0 : ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16; }
 static int ppg_coop_lds_bytes_of(const ppg::KParams &P, int e) {
-    return e * P.lds_env_bytes + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16 + 80 * 4;   // env regions, descriptor table, Env::CTL_WORDS
+    return e * P.lds_env_bytes + ppg_coop_table_bytes(P) + 80 * 4;   // env regions, descriptor table, Env::CTL_WORDS
 }
 // Cooperative step kernels (Env's COOP): eligibility and LDS layout of one env's region.  The maps are padded by the larger
 // window's reach, so the map offsets of an observation block's elements are position-independent.  Four maps (channel 0's halo points
@@ -382,9 +396,14 @@ static void ppg_coop_layout(ppg_handle *h) {
     h->coop_ok = 0; h->coop3_ok = 0; h->coop_prefers3 = 0; h->coop3_tab_off = 0;
     const ppg_config &c = h->cfg;
     const bool walls = h->gen2 && h->cfg2.walls;
-    if (walls || h->drive || c.kickback || h->nq > 2) return;           // (8-bit maps; generic 4-channel observations only)
-    if (!(c.predator_obs_range & 1) || !(c.prey_obs_range & 1)) return;  // even windows keep the element-descriptor kernels
+    if (h->drive || c.kickback || h->nq > 2) return;                    // (8-bit maps; generic 4-channel observations only)
     std::vector<uint32_t> t3;
+    if (walls) {   // (round 6) ppgc3_step: the three-map layout only -- channel 0 of its observations is the wall bitmap; whole rows
+                   // through obs_row_walls_in, which reads the maps for in-grid cells only: even windows too
+        h->coop_ok = ppg_coop_layout_with(h, 0, h->coop, h->coop_tab_host) ? 1 : 0;
+        return;
+    }
+    if (!(c.predator_obs_range & 1) || !(c.prey_obs_range & 1)) return;  // even windows keep the element-descriptor kernels
     if (!ppg_coop_layout_with(h, 1, h->coop, h->coop_tab_host)) return;
     h->coop_ok = 1;
     if (ppg_coop_layout_with(h, 0, h->coop3, t3)) {
@@ -421,7 +440,10 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
     ppg_wave_plan_t p = {1, 0, 0};
     if (h->forced.nw > 0) {
         p = h->forced;
-        if (walls || h->drive) { p.nw = p.nw == 2 ? 2 : p.nw > 1 ? 4 : 1; p.min_rows = 0; p.coop_e = 0; }   // (pair and four-wave kernels, helpers always stay)
+        if (walls || h->drive) {   // (pair and four-wave kernels, helpers always stay; walls: the four-wave cooperative kernel)
+            p.nw = p.nw == 2 ? 2 : p.nw > 1 ? 4 : 1; p.min_rows = 0;
+            if (!(walls && p.nw == 4)) p.coop_e = 0;
+        }
         if (h->cfg.kickback) { p.nw = 1; p.coop_e = 0; }
         if (p.coop_e > 0 && !h->coop_ok) p.coop_e = 0;
         if (p.coop_e > 0) {
@@ -443,6 +465,11 @@ static ppg_wave_plan_t ppg_wave_plan(const ppg_handle *h) {
         p.nw = in_flight > 3072 ? 2 : 4;
     } else if (walls) {
         p.nw = 4;
+        // (round 6) a full GPU: the cooperative walls kernel, two envs per four-wave workgroup at 113 registers without scratch (the
+        // four-wave kernel runs at a 64-register cap with 37 spilled) -- 77.3 against 86.5 us per 4096-env step, alternating processes
+        // on one box; three envs per workgroup 79.6, four 88.7; at 96 registers (five workgroups per CU) 79.8 (profiles/r06/u_*).  Both
+        // with the rows' window cells written as one run (Env::obs_cells_walls), which alone took the four-wave kernel from 92.1 to 86.5.
+        if (in_flight > 3072 && h->coop_ok && ppg_coop_lds_bytes(h, 2) * 4 <= 160 * 1024) p.coop_e = 2;
     } else if (in_flight <= 512) {
         p.nw = 8;
         // up to 256 envs one workgroup per CU is all there is: sixteen waves (base family, register-descriptor observation path):
@@ -651,7 +678,7 @@ static ppg::KParams ppg_planned_step_params(const ppg_handle *h, bool fused = fa
     if (wp.coop_e > 0) {   // cooperative kernels: wp.coop_e env regions, then the workgroup's descriptor table and control words
         P.coop_e = wp.coop_e;
         P.off_lut2 = wp.coop_e * P.lds_env_bytes;
-        P.off_ctl = P.off_lut2 + ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16;
+        P.off_ctl = P.off_lut2 + ppg_coop_table_bytes(P);
         P.lds_bytes = ppg_coop_lds_bytes_of(P, wp.coop_e);
         // float64 / float32 rows: at most FIVE four-wave workgroups (ten envs) per CU although registers and LDS admit six -- a CU
         // then has fewer scattered write streams open at a time: 66.8 -> 68.2 M env-steps/s on the headline workload, the driver's
@@ -808,6 +835,7 @@ const char *ppg_step_kernel_name(ppg_handle *h) {
     if (!h) return "";
     const ppg_wave_plan_t wp = h->plan;
     if (wp.coop_e > 0) {   // ppgc_step_q<NQ> (4 waves) / ppgc8_ / ppgc16_
+        if (h->gen2 && h->cfg2.walls) { snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc3_step_q%d", h->nq); return h->kernel_name; }
         const bool three = !ppg_planned_step_params(h).ch0_map;
         snprintf(h->kernel_name, sizeof h->kernel_name, "ppgc%s%s_step_q%d", three ? "m" : "",
                  h->gen2 ? "2" : wp.nw == 8 ? "8" : wp.nw == 16 ? "16" : wp.nw == 6 ? "6" : ppg_coop_high_occupancy(h, wp.coop_e) ? "h" : "", h->nq);

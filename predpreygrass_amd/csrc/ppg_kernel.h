@@ -107,7 +107,8 @@ struct KParams {
     int32_t drive_kind[2][4];     // 0 hunger_pressure, 1 reproductive_readiness, 2 prey_opportunity, 3 predator_danger_pressure,
                                   // 4 grass_opportunity (DRV:587-608)
     int32_t off_win;              // LDS offset of the window staging area (one float64 per window cell)
-    int32_t pad3_;
+    int32_t off_vm;               // walls variant: LDS offset of the listed rows' line-of-sight masks, (64 + cap_prey) x vis_words words
+                                  // (entry i of the predator list at i, of the prey list at 64 + i: Env::walls_stage_masks)
     double hunger_safe[2], norm_prey_opp, norm_pred_danger, norm_grass_opp;   // DRV:76-86
     // LDS layout (bytes from the start of dynamic LDS)
     int32_t map_n;    // u16 entries per channel map (>= G*G, multiple of 8)
@@ -405,13 +406,15 @@ struct Env {
     PPG_MEMBER int from_map(int ch, uint32_t m) const { return (int)m + map_base(ch); }   // (an empty cell lands on the section's zero entry)
 
     // ---- walls (WO) ----------------------------------------------------------------------
-    PPG_MEMBER bool wall_at(int x, int y) const {
+    PPG_MEMBER bool wall_at(int x, int y) const { return wall_in(wallw, x, y); }
+    PPG_MEMBER bool wall_in(const uint32_t *ww, int x, int y) const {   // (ww: the bitmap of an env's LDS region)
         const int c = x * P.G + y;
-        return (wallw[c >> 5] >> (c & 31)) & 1u;
+        return (ww[c >> 5] >> (c & 31)) & 1u;
     }
     // _line_of_sight_clear (WO:492-525) == the bresenham walk of _get_observation (WO:550-589): no wall strictly between
     // the two cells.  The reference's float error term dx/2.0 is carried doubled, as an integer.
-    PPG_MEMBER bool los_clear(int x0, int y0, int x1, int y1) const {
+    PPG_MEMBER bool los_clear(int x0, int y0, int x1, int y1) const { return los_clear_in(wallw, x0, y0, x1, y1); }
+    PPG_MEMBER bool los_clear_in(const uint32_t *ww, int x0, int y0, int x1, int y1) const {
         const int dx = x1 > x0 ? x1 - x0 : x0 - x1, dy = y1 > y0 ? y1 - y0 : y0 - y1;
         const int sx = x1 > x0 ? 1 : -1, sy = y1 > y0 ? 1 : -1;
         int x = x0, y = y0;
@@ -419,7 +422,7 @@ struct Env {
         if (dx >= dy) {
             int err2 = dx;
             while (x != x1) {
-                if (!(x == x0 && y == y0) && !(x == x1 && y == y1) && wall_at(x, y)) clear = false;
+                if (!(x == x0 && y == y0) && !(x == x1 && y == y1) && wall_in(ww, x, y)) clear = false;
                 err2 -= 2 * dy;
                 if (err2 < 0) { y += sy; err2 += 2 * dx; }
                 x += sx;
@@ -427,7 +430,7 @@ struct Env {
         } else {
             int err2 = dy;
             while (y != y1) {
-                if (!(x == x0 && y == y0) && !(x == x1 && y == y1) && wall_at(x, y)) clear = false;
+                if (!(x == x0 && y == y0) && !(x == x1 && y == y1) && wall_in(ww, x, y)) clear = false;
                 err2 -= 2 * dx;
                 if (err2 < 0) { x += sx; err2 += 2 * dy; }
                 y += sy;
@@ -575,10 +578,12 @@ PPG_DEVICE void env_main(const KParams &P, unsigned char *lds) {
 }
 
 // The cooperative step kernels (ppgc_*): see Env's COOP.  Workgroup g steps envs g * coop_e ... g * coop_e + coop_e - 1.
-template <int NQ, bool GEN2, int NW, bool CH0MAP = true>
+// WALLS (ppgc3_step): the walls variant of the second generation -- three cell maps (its channel 0 is the wall bitmap), rows written whole.
+template <int NQ, bool GEN2, int NW, bool CH0MAP = true, bool WALLS = false>
 PPG_DEVICE void coop_main(const KParams &P, unsigned char *lds) {
+    static_assert(!WALLS || (GEN2 && !CH0MAP), "the cooperative walls kernel: second generation, three maps");
     const PPG_CONSTANT_AS KParams *Pc = PPG_KERNARG_PTR(KParams, P);
-    typedef Env<NQ, false, false, false, false, GEN2, false, false, NW, const KParams, const PPG_CONSTANT_AS KParams, true, CH0MAP> CoopEnv;
+    typedef Env<NQ, false, false, false, false, GEN2, WALLS, false, NW, const KParams, const PPG_CONSTANT_AS KParams, true, CH0MAP> CoopEnv;
     const int w = wv::wave_index(), ln = wv::lane();
     const int ne = Pc->coop_e;
     uint32_t *lut2 = (uint32_t *)(lds + Pc->off_lut2), *ctl = (uint32_t *)(lds + Pc->off_ctl);
@@ -604,6 +609,11 @@ PPG_DEVICE void coop_main(const KParams &P, unsigned char *lds) {
     env.coop_write_all(lds);
     PPG_COOP_STAMP(14);
     if (has_env) env.finish_stores();
+}
+
+template <int NQ>
+PPG_DEVICE void coop_walls_main(const KParams &P, unsigned char *lds) {
+    if constexpr (NQ <= 2) coop_main<NQ, true, 4, false, true>(P, lds);   // (8-bit maps: up to 128 prey rows)
 }
 
 // ppg_rollout on a handle whose plan is cooperative: P.n_steps transitions in one launch.  A workgroup's envs never interact with any

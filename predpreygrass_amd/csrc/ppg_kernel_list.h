@@ -50,9 +50,11 @@
     PPG_KW2(ppgw28_step_q##NQ, NQ, true, 8)                           \
     PPG_KW2(ppgw28_step_q##NQ##g, NQ, false, 8)
 
-// walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>; ppgw3_step: 4 waves per env, ppgwp3_step: 2)
+// walls variant of the second generation: generic observation geometry only (ppg3_<mode>_q<NQ>; ppgw3_step: 4 waves per env, ppgwp3_step: 2;
+// ppgc3_step: cooperative, two envs per four-wave workgroup -- up to 128 prey rows)
 #define PPG_DEFINE_KERNELS3(NQ)                                       \
     PPG_KW3(ppgw3_step_q##NQ, NQ, 4)                                  \
+    PPG_KC3(ppgc3_step_q##NQ, NQ)                                     \
     PPG_KW3(ppgwp3_step_q##NQ, NQ, 2)                                 \
     PPG_K3(ppg3_step_q##NQ, NQ, ppg::MODE_STEP)                       \
     PPG_K3(ppg3_reset_q##NQ, NQ, ppg::MODE_RESET)                     \

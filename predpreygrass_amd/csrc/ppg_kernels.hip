@@ -52,6 +52,12 @@
 // the transitions and not the write streams decide (policy rollouts: 51 -> 44 us per 4096-env step; float64 rows: 62 -> 70 us)
 #define PPG_KCH(name, NQ)                                                                    \
     PPG_KERNEL_NW(name, 8, 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_main<NQ, false, 4>(P, lds); }
+// the cooperative walls kernel (8-bit maps: up to two prey row registers; the four-register unit gets an empty kernel nothing launches)
+#ifndef PPG_WPE_COOP_WALLS
+#define PPG_WPE_COOP_WALLS PPG_WPE_COOP
+#endif
+#define PPG_KC3(name, NQ)                                                                    \
+    PPG_KERNEL_NW(name, PPG_WPE_COOP_WALLS, 4)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_walls_main<NQ>(P, lds); }
 #define PPG_KCR(name, NQ, GEN2, NW)                                                          \
     PPG_KERNEL_NW(name, PPG_WPE, NW)(const ppg::KParams P) { PPG_DYNAMIC_LDS(lds); ppg::coop_main_fused<NQ, GEN2, NW>(P, lds); }
 #include "ppg_kernel_list.h"

@@ -186,3 +186,53 @@ def test_cooperative_spawn_fallback_on_a_crowded_grid(waves, coop, maps, monkeyp
     rollout_vs_oracle(env, lambda: OracleEnv(cfg), seed0=77, n_calls=90, check_grid=True)
     es = env.env_state.cpu().numpy()
     assert es[:, _abi.ENV_FALLBACK_SPAWNS].sum() > 0 or (es[:, _abi.ENV_STATUS] & _abi.STATUS_FALLBACK_SPAWN).any()
+
+
+# ---- round 6: the cooperative walls kernel (ppgc3_step: two envs per four-wave workgroup, rows written whole) -------------------
+def _walls_maker(coop):
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+
+    def make(cfg, B, **kw):
+        env = BatchedRedQueen(cfg, batch_size=B, _library=emu_backend.library(), **{"walls": True, **kw})
+        env.set_wave_plan(4, 0, coop)
+        assert env.wave_plan() == (4, 0, coop), env.wave_plan()
+        assert env.step_kernel_name() == "ppgc3_step_q%d" % (1 if env.prey_capacity <= 64 else 2)
+        return env
+    return make
+
+
+@pytest.mark.parametrize("name", ["wo_zigzag_seed1", "wo_los_two_types_seed5", "wo_mask_only_shuffled_seed6"])
+def test_walls_golden_cases_cooperative(name):
+    """The walls env's golden episodes (walls, corner cutting, line-of-sight moves, masked observations, the visibility channel;
+    recorded PCG64 uniforms) on the cooperative kernel: mid-step observations by the env's own wavefront, final rows by all four."""
+    from tests.parity_utils_rq import replay_golden_case
+    replay_golden_case(_walls_maker(2), name, max_calls=100)
+
+
+@pytest.mark.parametrize("coop,batch", [(2, 5), (4, 6), (1, 2)])
+def test_walls_cooperative_rollout_matches_oracle_with_different_walls_per_env(coop, batch):
+    """Device reset around the walls + Philox actions + auto-reset; every env has its OWN walls (after the barrier a wavefront writes
+    rows of envs whose bitmap is not the one of its own region), a batch that does not fill the last workgroup; every call against
+    the oracle."""
+    import numpy as np
+    from oracle.rq_oracle import RQOracleEnv
+    from tests.golden_io_rq import RQGoldenCase
+    from tests.parity_utils_rq import rollout_vs_oracle as rq_rollout_vs_oracle
+    case = RQGoldenCase("wo_zigzag_seed1")
+    cfg = case.config
+    env = _walls_maker(coop)(cfg, batch, walls=True)
+    G = cfg["grid_size"]
+    rng = np.random.default_rng(5)
+    per_env = []
+    for b in range(batch):
+        extra = rng.integers(0, G, size=(6 + b, 2))
+        per_env.append(np.unique(np.concatenate([np.asarray(case.wall_xy).reshape(-1, 2)[b::2], extra]), axis=0))
+    env.set_walls(per_env, per_env=True)
+    made = []
+
+    def oracle():
+        o = RQOracleEnv(cfg, walls=True)
+        o.set_walls(per_env[len(made)])
+        made.append(o)
+        return o
+    rq_rollout_vs_oracle(env, oracle, seed0=11, n_calls=70, check_every=1, check_grid=True)

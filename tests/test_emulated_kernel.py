@@ -128,7 +128,7 @@ def test_kernel_source_is_clean_under_address_sanitizer():
     """The kernel source built with -fsanitize=address (CPU wave-emulator build), the bytes behind every workgroup's LDS poisoned
     (wave_emu.h): out-of-bounds reads and writes of LDS, of the "device" tensors (torch's CPU allocations, intercepted through the
     preloaded runtime) and of the host code's own buffers abort the process.  Single-wave, multi-wave and cooperative kernels (both env-region
-    layouts), the second generation, the pack and fetch launches."""
+    layouts), the second generation, the cooperative walls kernel, the pack and fetch launches."""
     import subprocess, sys, os
     from tests.emu_backend import asan_runtime, build
     rt = asan_runtime()
@@ -173,6 +173,14 @@ def test_kernel_source_is_clean_under_address_sanitizer():
         "from oracle.rq_oracle import RQOracleEnv\n"
         "from tests.parity_utils_rq import rollout_vs_oracle as rq_rollout\n"
         "rq_rollout(BatchedRedQueen(config_env_base, batch_size=2, _library=lib), lambda: RQOracleEnv(config_env_base), seed0=3, n_calls=40)\n"
+        "from tests.golden_io_rq import RQGoldenCase\n"   # the cooperative walls kernel (ppgc3_step): whole rows, bitmaps and staging areas of other envs' regions
+        "for name in ('wo_los_two_types_seed5', 'wo_mask_only_shuffled_seed6'):\n"
+        "    case = RQGoldenCase(name)\n"
+        "    w = BatchedRedQueen(case.config, batch_size=3, walls=True, _library=lib); w.set_wave_plan(4, 0, 2); w.set_walls(case.wall_xy)\n"
+        "    assert w.step_kernel_name().startswith('ppgc3_step'), w.step_kernel_name()\n"
+        "    def wo(case=case):\n"
+        "        o = RQOracleEnv(case.config, walls=True); o.set_walls(case.wall_xy); return o\n"
+        "    rq_rollout(w, wo, seed0=6, n_calls=40)\n"
         "print('ASAN-CLEAN')\n" % root)
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", PYTHONMALLOC="malloc")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800, env=env)

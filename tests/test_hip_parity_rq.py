@@ -159,6 +159,75 @@ def test_walls_random_rollout_matches_oracle_on_gpu(waves):
     assert stats["births"] > 20 and n_resets > 10
 
 
+def make_walls_coop(coop):
+    def make(cfg, B, **kw):
+        env = make_env(cfg, B, **{"walls": True, **kw})
+        env.set_wave_plan(4, 0, coop)
+        assert env.wave_plan() == (4, 0, coop) and env.step_kernel_name().startswith("ppgc3_step_q"), (env.wave_plan(), env.step_kernel_name())
+        return env
+    return make
+
+
+@pytest.mark.parametrize("name", case_names(walls=True))
+def test_walls_golden_cases_through_the_cooperative_kernel(name):
+    """Round 6: the walls env's golden episodes on ppgc3_step -- two envs per four-wave workgroup, mid-step observations by the env's
+    own wavefront, the final rows by all four (even windows included: wo_mask_only_shuffled_seed6)."""
+    replay_golden_case(make_walls_coop(2), name)
+
+
+@pytest.mark.parametrize("coop,B", [(2, 63), (4, 64), (3, 31)])
+def test_walls_cooperative_random_rollout_with_walls_of_its_own_per_env(coop, B):
+    """Every env with its OWN walls: after the workgroup's barrier a wavefront writes rows of envs whose bitmap, line-of-sight masks and
+    staging areas are not those of the env it stepped.  Every fifth call against the oracle (tables, observations, grid)."""
+    case = RQGoldenCase("wo_zigzag_seed1")
+    cfg, G = case.config, case.config["grid_size"]
+    rng = np.random.default_rng(17)
+    base = np.asarray(case.wall_xy).reshape(-1, 2)
+    per_env = [np.unique(np.concatenate([base[b % 3::3], rng.integers(0, G, size=(5 + b % 11, 2))]), axis=0) for b in range(B)]
+    env = make_walls_coop(coop)(cfg, B)
+    env.set_walls(per_env, per_env=True)
+    made = []
+
+    def oracle():
+        o = RQOracleEnv(cfg, walls=True)
+        o.set_walls(per_env[len(made)])
+        made.append(o)
+        return o
+    n_resets, stats = rollout_vs_oracle(env, oracle, seed0=77, n_calls=200, check_every=5, check_grid=True)
+    assert stats["births"] > 20
+
+
+def test_walls_cooperative_kernel_gives_what_the_four_wave_kernel_gives_at_full_size():
+    """4096 envs of the reference's zigzag layout, every line-of-sight option on: 150 calls on ppgc3_step and on ppgw3_step, every table
+    and every observation row in use bit-identical."""
+    from predpreygrass_amd.walls_occlusion import config_env_zigzag_walls as cfg
+    states = []
+    for coop in (0, 2):
+        env = make_env(cfg, 4096, walls=True)
+        env.set_wave_plan(4, 0, coop)
+        assert env.step_kernel_name() == ("ppgc3_step_q2" if coop else "ppgw3_step_q2")
+        env.set_walls(cfg["manual_wall_positions"])
+        env.set_seeds(99)
+        env.env_state.zero_()
+        env.env_state[:, _abi.ENV_FLAGS] = _abi.ENVF_DONE   # (the first call is the device reset)
+        env.env_state[:, _abi.ENV_EPISODE] = -1
+        for _ in range(150):
+            env.step(random_actions=True, auto_reset=True)
+        torch.cuda.synchronize()
+        states.append(env)
+    a, b = states
+    assert torch.equal(a.env_state[:, : _abi.ENV_CALLS], b.env_state[:, : _abi.ENV_CALLS])
+    nP, nQ = a.env_state[:, _abi.ENV_N_PRED_ROWS], a.env_state[:, _abi.ENV_N_PREY_ROWS]
+    cp = a.pred_capacity
+    rows = torch.arange(a.S, device="cuda:0")[None, :]
+    used = (rows < nP[:, None]) | ((rows >= cp) & (rows < cp + nQ[:, None]))
+    for n in ("row_xy", "row_energy", "row_id", "row_key", "row_cumrew", "row_flags", "row_reward", "row_info"):
+        assert torch.equal(getattr(a, n)[used], getattr(b, n)[used]), n
+    assert torch.equal(a.obs_pred[used[:, :cp]], b.obs_pred[used[:, :cp]])
+    assert torch.equal(a.obs_prey[used[:, cp:]], b.obs_prey[used[:, cp:]])
+    assert int(used.sum()) > 4096 * 10
+
+
 @pytest.mark.parametrize("seed", range(200, 220))
 def test_random_walls_config_matches_oracle_on_gpu(seed):
     from predpreygrass_amd.walls_occlusion import PredPreyGrass as WallsEnv

@@ -25,10 +25,11 @@ void run_nw(const ppg::KParams &P) {
     ppg::env_main<NQ, ppg::MODE_STEP, FAST, GEN2, WALLS, DRIVE, NW>(P, lds);
 }
 
-#if PPG_EMU_FAMILY <= 1 && PPG_EMU_NQ <= 2
+#if PPG_EMU_FAMILY <= 2 && PPG_EMU_NQ <= 2
 template <int NW>
 void run_coop(const ppg::KParams &P) {
     PPG_DYNAMIC_LDS(lds);
+    if constexpr (WALLS) { ppg::coop_walls_main<NQ>(P, lds); return; }                      // ppgc3_step
     if (NW == 4 && !P.ch0_map) { ppg::coop_main<NQ, GEN2, 4, false>(P, lds); return; }   // three cell maps per env (ppgcm_*)
     ppg::coop_main<NQ, GEN2, NW>(P, lds);
 }
@@ -48,6 +49,8 @@ void run(const ppg::KParams &P, int mode, int nw) {
         run_coop<4>(P);
         return;
     }
+#elif PPG_EMU_FAMILY == 2 && PPG_EMU_NQ <= 2
+    if (P.coop_e > 0) { run_coop<4>(P); return; }   // ppgc3_step
 #endif
     if (nw == 4) { run_nw<FAST, 4>(P); return; }
 #if PPG_EMU_FAMILY != 1

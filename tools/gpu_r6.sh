@@ -9,7 +9,7 @@
 #   prof:<name>:<kernel>:<bench.py arguments>   rocprofv3 --kernel-trace --stats and the two PMC passes (WRITE_SIZE | FETCH_SIZE, counters only, the
 #                            program directly behind `--`) of one bench.py command; mean duration / bytes per launch of <kernel>
 #   sweep:<first seed>:<n>   tools/gpu_sweep.py: random configurations of every variant through the dict APIs against the oracles
-#   soak:<envs>:<calls>      tools/gpu_soak_coop.py: every cooperative kernel and layout, every env against its oracle on every call
+#   soak:<envs>:<calls>[:walls]      tools/gpu_soak_coop.py: every cooperative kernel and layout, every env against its oracle on every call
 #   phase:<name>:<tools/phase_profile.py arguments, comma separated>   phase shares of a wavefront's cycles (diagnostic build)
 cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; shift
@@ -78,8 +78,8 @@ PY
       python3 tools/gpu_sweep.py $first $n > gpurun_out/${tag}_sweep_${first}.txt 2>&1
       grep -v amdgpu.ids gpurun_out/${tag}_sweep_${first}.txt | tail -3 ;;
     soak)
-      IFS=: read -r envs calls <<< "$rest"
-      python3 tools/gpu_soak_coop.py $envs $calls > gpurun_out/${tag}_soak_coop.txt 2>&1
+      IFS=: read -r envs calls only <<< "$rest"
+      python3 tools/gpu_soak_coop.py $envs $calls $only > gpurun_out/${tag}_soak_coop.txt 2>&1
       grep -v amdgpu.ids gpurun_out/${tag}_soak_coop.txt | tail -8 ;;
     phase)
       IFS=: read -r name pargs <<< "$rest"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak run on a GPU: the cooperative step kernels (every wave plan the library ships), with the observation tensors on spread
 physical pages, long random rollouts with device reset / Philox actions / auto-reset, EVERY env compared with its CPU oracle on
-EVERY call; then ppg_rollout against the same number of steps.   usage: gpu_soak_coop.py [envs=96] [calls=400]"""
+EVERY call; then ppg_rollout against the same number of steps.   usage: gpu_soak_coop.py [envs=96] [calls=400] [walls]
+(walls: only the walls variant's kernels, cooperative and not)"""
 import os
 import sys
 import time
@@ -20,6 +21,40 @@ from tests.golden_io_rq import RQGoldenCase  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 t0 = time.time()
+
+
+def soak_walls():
+    """round 6: the cooperative walls kernel (ppgc3_step) and the four-wave / pair kernels, all writing the listed rows' window cells as one
+    run (Env::obs_cells_walls); every env with walls of its own, every golden configuration of the walls env, float32 and float64 rows."""
+    import numpy as np
+    from tests.golden_io_rq import case_names
+    rng = np.random.default_rng(2)
+    for name in case_names(walls=True):
+        case = RQGoldenCase(name)
+        cfg, G = dict(case.config, max_steps=120), case.config["grid_size"]
+        base = np.asarray(case.wall_xy).reshape(-1, 2)
+        walls = [np.unique(np.concatenate([base[b % 4::4], rng.integers(0, G, size=(3 + b % 9, 2))]), axis=0) for b in range(B)]
+        for plan, dt in (((4, 0, 2), torch.float32), ((4, 0, 4), torch.float64), ((4, 0, 0), torch.float32), ((2, 0, 0), torch.float64)):
+            env = BatchedRedQueen(cfg, batch_size=B, device="cuda:0", walls=True, obs_dtype=dt)
+            env.set_wave_plan(*plan)
+            assert env.wave_plan() == plan, (plan, env.wave_plan())
+            env.set_walls(walls, per_env=True)
+            made = []
+
+            def oracle():
+                o = RQOracleEnv(cfg, walls=True)
+                o.set_walls(walls[len(made)])
+                made.append(o)
+                return o
+            r = P2.rollout_vs_oracle(env, oracle, seed0=500 + plan[2], n_calls=calls, check_every=1, check_grid=True)
+            print("walls", name, plan, env.step_kernel_name(), str(dt)[6:], "resets/stats", r, f"{time.time() - t0:.0f} s", flush=True)
+            env.close()
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "walls":
+    soak_walls()
+    print("soak walls ok", f"{time.time() - t0:.0f} s")
+    sys.exit(0)
 short = {**config_env, "max_steps": 150}
 for plan in ((4, 0, 2), (4, 0, 4), (6, 0, 3), (8, 0, 2), (16, 0, 1)):
     for cfg, dt in ((short, torch.float64), ({**short, "grid_size": 12, "initial_num_grass": 50}, torch.float32)):
@@ -76,4 +111,5 @@ for cls, cfg, name in ((BatchedPredPreyGrass, {**config_env, "max_steps": 200}, 
     for n in ("row_xy", "row_energy", "row_id", "row_flags", "row_reward", "grass_energy", "obs_pred", "obs_prey"):
         assert torch.equal(getattr(a, n), getattr(b, n)), (name, n)
     print(name, "4096 envs: 600 steps == 6 x ppg_rollout(100) on spread pages", f"{time.time() - t0:.0f} s", flush=True)
+soak_walls()
 print("soak ok", f"{time.time() - t0:.0f} s")
