@@ -266,47 +266,67 @@
         // float32 rows -- the reference's dtype (WO:137-139) -- have a loop of their own: no dtype branch per store, no float64 detour
         auto cells = [&](auto f32_tag) {
         constexpr bool F32 = decltype(f32_tag)::value;
-        for (int c0 = first * 64; c0 < total; c0 += stride * 64) {
-            const int g = c0 + ln;
-            const bool valid = g < total;
-            const uint32_t gs = valid ? (uint32_t)g : 0u;
-            const int i = (int)wv::mulhi(gs, nmagic), cell = (int)gs - i * n;
-            const uint32_t en = list[i];
-            const int j = (int)((en >> 16) & 0x7FFFu), x = (int)((en >> 8) & 255u), y = (int)(en & 255u);
-            const int ci = (int)wv::mulhi((uint32_t)cell, rmagic), cj = cell - ci * R;
-            const int gx = x - off + ci, gy = y - off + cj;
-            const bool in_grid = valid && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
-            const bool inb = in_grid && ci < Wc && cj < Wc;
-            const int a = inb ? gx * P.G + gy : 0;
-            const int am = COOP ? (inb ? (gx + P.pad) * P.Gp + gy + P.pad : 0) : a;   // (COOP: padded maps)
-            double v[5];
-            v[0] = (inb && ((ww[a >> 5] >> (a & 31)) & 1u)) ? 1.0 : 0.0;
-            float vis = 0.0f;
-            if (want_vis) {
-                const int bi = (ci - off + C.vis_neg) * C.vis_w + (cj - off + C.vis_neg);
-                const uint32_t word = vm[i * C.vis_words + (bi >> 5)];
-                vis = (in_grid && ((word >> (bi & 31)) & 1u)) ? 1.0f : 0.0f;
-            }
-            float f[5];
-            f[0] = (float)v[0];
+        // chunks in flight per wavefront: the dependent LDS reads of one (list entry -> map bytes -> values) hide behind the other's
+        constexpr int U = 2;
+        for (int c0 = first * 64; c0 < total; c0 += U * stride * 64) {
+            bool valid[U], in_grid[U], inb[U];
+            int cell[U], i[U], ci[U], cj[U];
+            uint32_t en[U];
 #pragma unroll
-            for (int ch = 1; ch < 4; ++ch) {
-                double t = vt[from_map(ch, (m + (THREE ? ch - 1 : ch) * P.map_n)[am])];
-                if (!inb) t = 0.0;
-                f[ch] = (float)t;
-                if (C.mask_obs) { f[ch] = f[ch] * (inb ? vis : 0.0f); t = (double)f[ch]; }   // (in float32, like the reference: WO:591-594)
-                v[ch] = t;
+            for (int u = 0; u < U; ++u) {
+                const int g = c0 + u * stride * 64 + ln;
+                valid[u] = g < total;
+                const uint32_t gs = valid[u] ? (uint32_t)g : 0u;
+                i[u] = (int)wv::mulhi(gs, nmagic); cell[u] = (int)gs - i[u] * n;
+                en[u] = list[i[u]];
+                ci[u] = (int)wv::mulhi((uint32_t)cell[u], rmagic); cj[u] = cell[u] - ci[u] * R;
             }
-            v[4] = (double)vis; f[4] = vis;
-            if (valid) {
-                const uint32_t o0 = (uint32_t)(j * blk + cell);
+            uint32_t wallw_[U], visw_[U], mb[U][3];
+            int a[U], bi[U];
 #pragma unroll
-                for (int ch = 0; ch < 5; ++ch) {
-                    if (ch >= nchan) continue;
-                    const uint32_t o = o0 + (uint32_t)(ch * n);
-                    if (F32) ((float *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = f[ch];
-                    else if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = f[ch];
-                    else ((double *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = v[ch];
+            for (int u = 0; u < U; ++u) {
+                const int x = (int)((en[u] >> 8) & 255u), y = (int)(en[u] & 255u);
+                const int gx = x - off + ci[u], gy = y - off + cj[u];
+                in_grid[u] = valid[u] && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+                inb[u] = in_grid[u] && ci[u] < Wc && cj[u] < Wc;
+                a[u] = inb[u] ? gx * P.G + gy : 0;
+                const int am = COOP ? (inb[u] ? (gx + P.pad) * P.Gp + gy + P.pad : 0) : a[u];   // (COOP: padded maps)
+                wallw_[u] = ww[a[u] >> 5];
+                bi[u] = (ci[u] - off + C.vis_neg) * C.vis_w + (cj[u] - off + C.vis_neg);
+                visw_[u] = want_vis ? vm[i[u] * C.vis_words + (bi[u] >> 5)] : 0u;
+#pragma unroll
+                for (int ch = 1; ch < 4; ++ch) mb[u][ch - 1] = (uint32_t)(m + (THREE ? ch - 1 : ch) * P.map_n)[am];
+            }
+            double t[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int ch = 1; ch < 4; ++ch) t[u][ch - 1] = vt[from_map(ch, mb[u][ch - 1])];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double v[5];
+                float f[5];
+                v[0] = (inb[u] && ((wallw_[u] >> (a[u] & 31)) & 1u)) ? 1.0 : 0.0;
+                f[0] = (float)v[0];
+                const float vis = (want_vis && in_grid[u] && ((visw_[u] >> (bi[u] & 31)) & 1u)) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int ch = 1; ch < 4; ++ch) {
+                    double tt = inb[u] ? t[u][ch - 1] : 0.0;
+                    f[ch] = (float)tt;
+                    if (C.mask_obs) { f[ch] = f[ch] * (inb[u] ? vis : 0.0f); tt = (double)f[ch]; }   // (in float32, like the reference: WO:591-594)
+                    v[ch] = tt;
+                }
+                v[4] = (double)vis; f[4] = vis;
+                if (valid[u]) {
+                    const uint32_t o0 = (uint32_t)((int)((en[u] >> 16) & 0x7FFFu) * blk + cell[u]);
+#pragma unroll
+                    for (int ch = 0; ch < 5; ++ch) {
+                        if (ch >= nchan) continue;
+                        const uint32_t o = o0 + (uint32_t)(ch * n);
+                        if (F32) ((float *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = f[ch];
+                        else if (P.obs_f32) ((float *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = f[ch];
+                        else ((double *)(type ? P.obs_prey : P.obs_pred) + obase)[o] = v[ch];
+                    }
                 }
             }
         }
@@ -319,16 +339,29 @@
     PPG_MEMBER void walls_stage_masks() {
         if (!(C.mask_obs || C.vis_channel) || C.vis_masks == nullptr) return;
         uint32_t *vm = (uint32_t *)((unsigned char *)map - P.off_map + C.off_vm);
-        int n[2] = {0, 0};
+        constexpr int MW = 4;   // words fetched side by side (windows up to 11x11; the rest in a loop)
+        const int vw = C.vis_words;
+        uint32_t mw[T][MW];
+        int pos[T], n[2] = {0, 0};
+#pragma unroll
+        for (int r = 0; r < T; ++r) {   // all loads first: one memory round trip
+            const int type = type_of(r);
+            const bool on = (alive[r] >> ln) & 1ull;
+            pos[r] = ((type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])) * vw;
+            n[type] += wv::popc(alive[r]);
+            const uint32_t *src = C.vis_masks + ((size_t)b * P.G * P.G + (on ? (xy[r] >> 8) * P.G + (xy[r] & 255u) : 0u)) * vw;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) { mw[r][w] = 0; if (on && w < vw) mw[r][w] = src[w]; }
+        }
 #pragma unroll
         for (int r = 0; r < T; ++r) {
-            const int type = type_of(r);
-            if ((alive[r] >> ln) & 1ull) {
-                const int i = (type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r]);
-                const uint32_t *src = C.vis_masks + ((size_t)b * P.G * P.G + (xy[r] >> 8) * P.G + (xy[r] & 255u)) * C.vis_words;
-                for (int w = 0; w < C.vis_words; ++w) vm[i * C.vis_words + w] = src[w];
+            if (!((alive[r] >> ln) & 1ull)) continue;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) if (w < vw) vm[pos[r] + w] = mw[r][w];
+            if (vw > MW) {
+                const uint32_t *src = C.vis_masks + ((size_t)b * P.G * P.G + (xy[r] >> 8) * P.G + (xy[r] & 255u)) * vw;
+                for (int w = MW; w < vw; ++w) vm[pos[r] + w] = src[w];
             }
-            n[type] += wv::popc(alive[r]);
         }
     }
 
