@@ -1,3 +1,6 @@
+#ifndef PPG_COOP_QUAD32
+#define PPG_COOP_QUAD32 1
+#endif
 // ppg_env_coop.h -- part of struct ppg::Env (ppg_kernel.h includes it INSIDE the struct's body: member functions, no include guard,
 // not a header of its own): the cooperative kernels' observation writing: whole 1 KB pieces of an env's run of live rows, both env-region layouts.
     // ---- COOP: observations as whole 1 KB pieces of an env's run of live rows ---------------------------------
@@ -8,6 +11,9 @@
     // window clipping of _obs_clip (BASE:528-539) implicit.  ch0_map 0: channel 0 is 1.0 iff the element's cell lies outside the grid
     // (BASE:520-523), from the agent's position and the element's window offsets alone.  This wavefront writes pieces first,
     // first + stride, ...
+    // elements per piece: 128 (two per lane); 256 for the second generation's float32 rows on the four-map layout (four per lane)
+    static constexpr bool QUAD32 = PPG_COOP_QUAD32 && GEN2 && CH0MAP && COOP && !WALLS;
+    PPG_MEMBER int piece_shift() const { return (QUAD32 && P.obs_f32 == 1) ? 8 : 7; }
     PPG_MEMBER void coop_pieces(int type, const unsigned char *region, const uint32_t *list, int n_live, int eb, int first, int stride) {
         const map_t *m = (const map_t *)(region + P.off_map);
         const double *vt = (const double *)(region + P.off_val);
@@ -29,6 +35,38 @@
         // longest of the three -- 57.5 -> 53.5 us per 4096-env step, +7 % (profiles/r06/r_*).
         auto pieces = [&](auto f64_tag, auto f32_tag) {
         constexpr bool F64 = decltype(f64_tag)::value, F32 = decltype(f32_tag)::value;
+        if (QUAD32 && F32) {
+            // float32 rows, four maps: FOUR elements per lane -- a 16-byte store per lane like a float64 pair, a piece is 256 elements.
+            // The write phase is bound by the store INSTRUCTIONS the memory pipeline takes, not by bytes or lookups (round 6: window cells
+            // with 4-byte stores and 40 % fewer LDS reads ran no faster, profiles/r06/v_*): half the instructions for the same rows.
+            const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);
+            for (int p0 = first; p0 * 256 < total; p0 += U * stride) {
+                uint32_t o[U], ix[U][4];
+                bool on[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int s0 = (p0 + u * stride) * 256 + 4 * ln;
+                    on[u] = s0 < total;
+                    const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
+                    const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (blk = 4 R^2: a quad never straddles two rows)
+                    const uint32_t ent = on[u] ? list[i] : safe_cell;
+                    const uint4 d = *(const uint4 *)(L + w);
+                    const int pc = (int)(ent & 0xFFFFu);
+                    ix[u][0] = (uint32_t)m[pc + (int)(int16_t)(d.x & 0xFFFFu)] + (d.x >> 16);
+                    ix[u][1] = (uint32_t)m[pc + (int)(int16_t)(d.y & 0xFFFFu)] + (d.y >> 16);
+                    ix[u][2] = (uint32_t)m[pc + (int)(int16_t)(d.z & 0xFFFFu)] + (d.z >> 16);
+                    ix[u][3] = (uint32_t)m[pc + (int)(int16_t)(d.w & 0xFFFFu)] + (d.w >> 16);
+                    o[u] = wv::mul24(ent >> 16, (uint32_t)blk) + w;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float4 f;
+                    f.x = (float)vt[ix[u][0]]; f.y = (float)vt[ix[u][1]]; f.z = (float)vt[ix[u][2]]; f.w = (float)vt[ix[u][3]];
+                    if (on[u]) *(float4 *)((float *)obuf + obase + o[u]) = f;
+                }
+            }
+            return;
+        }
         if (CH0MAP) {   // four maps: every element is a map lookup
             const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
             for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
@@ -164,7 +202,8 @@
             for (int type = 0; type < 2; ++type) {
                 const int n_live = (int)wv::first(slot[type]);
                 const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);
-                const int pieces = (n_live * blk + 127) >> 7;
+                const int psh = piece_shift();
+                const int pieces = (n_live * blk + (1 << psh) - 1) >> psh;
                 int first = wave_idx - at;
                 if (first < 0) first += NW;
                 coop_pieces(type, region, lst + (type ? 64 : 0), n_live, eb, first, NW);

@@ -249,5 +249,6 @@ struct uint2 { uint32_t x, y; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
 static inline long long __double_as_longlong(double d) { long long r; memcpy(&r, &d, 8); return r; }
 static inline double __longlong_as_double(long long v) { double r; memcpy(&r, &v, 8); return r; }
