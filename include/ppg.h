@@ -360,7 +360,9 @@ int ppg_get_wave_plan(const ppg_handle *h, int32_t *waves, int32_t *helper_min_r
 /* Walls variant: tell the library that the caller has (re)written wall_bits.  It recomputes, for every cell of every env, the
  * line-of-sight mask over the observation window (one HIP launch; library-owned [B, G*G, words] in HBM) -- from then on
  * observations read a few mask words per agent instead of walking one Bresenham line per window cell (WO:492-525, 577-589).
- * Results are identical with or without it as long as it is called after every change of wall_bits (ppg_import_state does). */
+ * Results are identical with or without it as long as it is called after every change of wall_bits (ppg_import_state does).
+ * It also copies the bitmaps to the host and WAITS for the stream: when every env's bitmap equals env 0's (one wall layout for the
+ * batch) all envs read env 0's masks from then on (a few KB that stay in L2). */
 int ppg_walls_changed(ppg_handle *h, void *stream);
 
 /* Scheduling only, results are unaffected: recompute the order in which the handle's envs are assigned to workgroups --

@@ -191,7 +191,7 @@
         if (want_vis && have_masks) {
             // walls are static: the mask of this agent's cell was computed when they were set (ppg_walls_changed) -- a few words
             // instead of one Bresenham walk per window cell
-            if (ln < C.vis_words) ((uint32_t *)visb)[ln] = C.vis_masks[((size_t)eb * P.G * P.G + x * P.G + y) * C.vis_words + ln];
+            if (ln < C.vis_words) ((uint32_t *)visb)[ln] = C.vis_masks[((size_t)eb * C.vis_env_stride + x * P.G + y) * C.vis_words + ln];
             wv::sync();
         } else if (want_vis) {
             for (int i = ln; i < n; i += 64) {
@@ -349,7 +349,7 @@
             const bool on = (alive[r] >> ln) & 1ull;
             pos[r] = ((type ? 64 : 0) + n[type] + (int)wv::prefix(alive[r])) * vw;
             n[type] += wv::popc(alive[r]);
-            const uint32_t *src = C.vis_masks + ((size_t)b * P.G * P.G + (on ? (xy[r] >> 8) * P.G + (xy[r] & 255u) : 0u)) * vw;
+            const uint32_t *src = C.vis_masks + ((size_t)b * C.vis_env_stride + (on ? (xy[r] >> 8) * P.G + (xy[r] & 255u) : 0u)) * vw;
 #pragma unroll
             for (int w = 0; w < MW; ++w) { mw[r][w] = 0; if (on && w < vw) mw[r][w] = src[w]; }
         }
@@ -359,7 +359,7 @@
 #pragma unroll
             for (int w = 0; w < MW; ++w) if (w < vw) vm[pos[r] + w] = mw[r][w];
             if (vw > MW) {
-                const uint32_t *src = C.vis_masks + ((size_t)b * P.G * P.G + (xy[r] >> 8) * P.G + (xy[r] & 255u)) * vw;
+                const uint32_t *src = C.vis_masks + ((size_t)b * C.vis_env_stride + (xy[r] >> 8) * P.G + (xy[r] & 255u)) * vw;
                 for (int w = MW; w < vw; ++w) vm[pos[r] + w] = src[w];
             }
         }
@@ -497,7 +497,7 @@
         if (want_vis && have_masks) {
             // walls are static: the mask of this agent's cell was computed when they were set (ppg_walls_changed) -- a few words
             // instead of one Bresenham walk per window cell
-            if (ln < C.vis_words) ((uint32_t *)visb)[ln] = C.vis_masks[((size_t)b * P.G * P.G + s_cell) * C.vis_words + ln];
+            if (ln < C.vis_words) ((uint32_t *)visb)[ln] = C.vis_masks[((size_t)b * C.vis_env_stride + s_cell) * C.vis_words + ln];
             wv::sync();
         } else if (want_vis) {
             for (int i = ln; i < R * R; i += 64) {

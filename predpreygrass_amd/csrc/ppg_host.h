@@ -694,6 +694,7 @@ static ppg::KParams ppg_planned_step_params(const ppg_handle *h, bool fused = fa
         }
         P.env_order = h->base.env_order;
         P.vis_masks = h->base.vis_masks;
+        P.vis_env_stride = h->base.vis_env_stride;
     }
     else P.lds_bytes += h->step_lds_pad;   // experiment (profiles/r05/s_*): fewer envs per CU for the multi-wave kernels
     P.helper_min_rows = wp.min_rows;
@@ -781,8 +782,23 @@ int ppg_walls_changed(ppg_handle *h, void *stream) {
     }
     ppg::KParams P = h->base;
     P.mode = ppg::MODE_VIS; P.vis_masks = h->vis_dev;
-    const int rc = backend_launch(h, ppg::MODE_VIS, P, stream);
-    if (rc == PPG_OK) h->base.vis_masks = h->vis_dev;   // every later launch reads the masks instead of walking the lines
+    int rc = backend_launch(h, ppg::MODE_VIS, P, stream);
+    if (rc != PPG_OK) return rc;
+    // One wall layout for the whole batch (the usual case)?  Then every env reads env 0's masks: a table of a few KB that stays in
+    // L2 instead of a scattered read from [batch, G*G, vis_words] in HBM.  Decided here, on the host, from the bitmaps themselves
+    // (batch x n_wall_words words: 320 KB for 4096 envs of 25x25) -- setting walls is not on the step path.
+    const size_t words = (size_t)B.n_wall_words;
+    uint32_t *bits = (uint32_t *)malloc((size_t)h->batch * words * sizeof(uint32_t));
+    if (!bits) return ppg_fail(h, PPG_ENOMEM, "ppg_walls_changed: no host memory for the bitmap comparison");
+    rc = backend_copy(h, bits, h->bufs.wall_bits, (size_t)h->batch * words * sizeof(uint32_t), false, stream);
+    if (rc == PPG_OK) rc = backend_sync(h, stream);
+    bool same = rc == PPG_OK;
+    for (int b = 1; same && b < h->batch; ++b) same = memcmp(bits, bits + (size_t)b * words, words * sizeof(uint32_t)) == 0;
+    free(bits);
+    if (rc != PPG_OK) return rc;
+    h->base.vis_masks = h->vis_dev;   // every later launch reads the masks instead of walking the lines
+    if (getenv("PPG_VIS_PER_ENV")) same = false;   // (A/B switch: every env reads its own table whatever the bitmaps say)
+    h->base.vis_env_stride = same ? 0 : B.G * B.G;
     return rc;
 }
 

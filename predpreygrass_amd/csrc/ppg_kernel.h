@@ -102,6 +102,9 @@ struct KParams {
     uint32_t rp_magic, rq_magic;  // ceil(2^32 / Rp), ceil(2^32 / Rq): cell / R == mulhi(cell, magic) for cell < R*R
     uint32_t np_magic, nq_magic;  // ceil(2^32 / Rp^2), ceil(2^32 / Rq^2): element / R^2 for element < 8 R^2
     uint32_t *vis_masks;          // library-owned [B, G*G, vis_words]; NULL = not computed: observations walk the lines themselves
+    int32_t vis_env_stride;       // cells between the mask tables of env b and env b + 1: G*G, or 0 when ppg_walls_changed found every env's
+                                  // wall bitmap equal to env 0's (the usual case: one wall layout for the batch) -- all envs then read
+                                  // env 0's table, a few KB that stay in L2 instead of a scattered read of [B, G*G, vis_words] from HBM
     // drive-conditioned variant of the base family (drive_conditioned_environment/predpreygrass_rllib_env.py, "DRV")
     int32_t n_drive[2];           // extra constant-filled observation channels per species (DRV:70-75), <= 4
     int32_t drive_kind[2][4];     // 0 hunger_pressure, 1 reproductive_readiness, 2 prey_opportunity, 3 predator_danger_pressure,

@@ -197,6 +197,32 @@ def test_walls_cooperative_random_rollout_with_walls_of_its_own_per_env(coop, B)
     assert stats["births"] > 20
 
 
+@pytest.mark.parametrize("coop", [0, 2])
+def test_shared_and_per_env_visibility_masks_across_wall_changes_on_gpu(coop):
+    """ppg_walls_changed: one wall layout for the batch = every env reads env 0's masks; one env's walls changed = per-env tables again
+    (and back): at every stage the same bits as a handle that walks the lines itself (no precomputed masks)."""
+    case = RQGoldenCase("wo_los_two_types_seed5")
+    B = 130
+    half = case.wall_xy[: len(case.wall_xy) // 2]
+    layouts = ([case.wall_xy] * B, [case.wall_xy if b != 77 else half for b in range(B)], [case.wall_xy[:7]] * B)
+    envs = []
+    for pre in (True, False):
+        e = make_walls_coop(coop)(case.config, B, seed=11) if coop else make_env(case.config, B, walls=True, seed=11)
+        e.set_walls(layouts[0], per_env=True, precompute_visibility=pre)
+        e.reset()
+        envs.append(e)
+    for stage, layout in enumerate(layouts):
+        if stage:
+            for e, pre in zip(envs, (True, False)):
+                e.set_walls(layout, per_env=True, precompute_visibility=pre)
+                e.reset()
+        for _ in range(25):
+            for e in envs:
+                e.step(random_actions=True, auto_reset=True)
+            for n in ("obs_pred", "obs_prey", "row_xy", "row_energy", "row_info", "env_state"):
+                assert torch.equal(getattr(envs[0], n), getattr(envs[1], n)), (stage, n)
+
+
 def test_walls_cooperative_kernel_gives_what_the_four_wave_kernel_gives_at_full_size():
     """4096 envs of the reference's zigzag layout, every line-of-sight option on: 150 calls on ppgc3_step and on ppgw3_step, every table
     and every observation row in use bit-identical."""

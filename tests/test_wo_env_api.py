@@ -138,3 +138,31 @@ def test_precomputed_visibility_masks_equal_the_walked_lines():
                 e.step(random_actions=True, auto_reset=True)
             for n in ("obs_pred", "obs_prey", "row_xy", "row_energy", "row_info", "env_state"):
                 assert torch.equal(getattr(envs[0], n), getattr(envs[1], n)), n
+
+
+def test_shared_and_per_env_visibility_masks_across_wall_changes():
+    """ppg_walls_changed lets every env read env 0's masks when all bitmaps are equal, and goes back to per-env tables when one env's
+    walls change (and forth again): at every stage the observations equal those of a handle that walks the lines itself."""
+    import torch
+    from predpreygrass_amd.red_queen import BatchedRedQueen
+    case = RQGoldenCase("wo_los_two_types_seed5")
+    B = 4
+    layouts = ([case.wall_xy] * B,                                                  # one layout: shared masks
+               [case.wall_xy, case.wall_xy, case.wall_xy[: len(case.wall_xy) // 2], case.wall_xy],   # env 2 differs: per-env tables
+               [case.wall_xy[:7]] * B)                                              # one (other) layout again
+    envs = []
+    for pre in (True, False):
+        e = BatchedRedQueen(case.config, batch_size=B, walls=True, _library=library(), seed=11)
+        e.set_walls(layouts[0], per_env=True, precompute_visibility=pre)
+        e.reset()
+        envs.append(e)
+    for stage, layout in enumerate(layouts):
+        if stage:
+            for e, pre in zip(envs, (True, False)):
+                e.set_walls(layout, per_env=True, precompute_visibility=pre)
+                e.reset()
+        for _ in range(12):
+            for e in envs:
+                e.step(random_actions=True, auto_reset=True)
+            for n in ("obs_pred", "obs_prey", "row_xy", "row_energy", "row_info", "env_state"):
+                assert torch.equal(getattr(envs[0], n), getattr(envs[1], n)), (stage, n)
