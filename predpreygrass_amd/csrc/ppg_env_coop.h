@@ -185,9 +185,8 @@
                     int first = wave_idx - at;
                     if (first < 0) first += NW;
                     if (flat) {   // runs of window cells, 64 per pass (obs_cells_walls)
-                        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
                         obs_cells_walls(type, lst + (type ? 64 : 0), n_live, vm + (type ? 64 * C.vis_words : 0), region, eb, first, NW);
-                        at = (at + ((n_live * R * R + 63) >> 6)) % NW;
+                        at = (at + walls_chunks(type, n_live)) % NW;
                         continue;
                     }
                     for (int i = first; i < n_live; i += NW) {   // (no precomputed masks: whole rows, each walks its lines)

@@ -250,8 +250,96 @@
     // memory round trip per env instead of one per row).  list[i] = row << 16 | x << 8 | y (bit 31 ignored); vm = the staged masks of
     // this species' list; chunk c of the run (64 cells) is written by the wavefront with c = first (mod stride).
     PPG_MEMBER bool walls_flat() const { return !(C.mask_obs || C.vis_channel) || C.vis_masks != nullptr; }
+    // float32 rows (the reference's dtype, WO:137-139): WQ ADJACENT window cells per lane -- per channel ONE 16-byte store per lane
+    // (4-byte aligned: global_store_dwordx4 takes that) instead of four 4-byte stores; the write phase is bound by the store
+    // instructions the memory pipeline takes (profiles/r06/v_*).  A row's R*R cells are cut into ceil(R*R / WQ) quads; the last quad
+    // of a row starts at R*R - WQ, i.e. overlaps its neighbour and writes up to WQ - 1 cells a second time with the same values, so
+    // every quad is whole and there is one store path.
+#ifndef PPG_WALLS_QUAD
+#define PPG_WALLS_QUAD 4
+#endif
+    static constexpr int WQ = PPG_WALLS_QUAD;
+    PPG_MEMBER bool walls_quads(int type) const {
+        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
+        return WQ > 1 && P.obs_f32 == 1 && R * R >= WQ;
+    }
+    // 64-lane chunks of a species' run of n_live rows (what obs_cells_walls hands out to the wavefronts)
+    PPG_MEMBER int walls_chunks(int type, int n_live) const {
+        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
+        const int per_row = walls_quads(type) ? (R * R + WQ - 1) / WQ : R * R;
+        return (n_live * per_row + 63) >> 6;
+    }
+    PPG_MEMBER void obs_quads_walls(int type, const uint32_t *list, int n_live, const uint32_t *vm, const unsigned char *region, int eb,
+                                    int first, int stride) {
+        typedef float fq_t __attribute__((vector_size((WQ > 1 ? WQ : 2) * 4), aligned(4)));   // (4-byte aligned: rows of R*R cells start anywhere)
+        const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
+        const uint32_t rmagic = C.rp_magic + (type ? C.rq_magic - C.rp_magic : 0u);
+        const int n = R * R, off = (R - 1) / 2, Wc = 2 * off + 1;
+        const int nchan = C.vis_channel ? 5 : 4;
+        const bool want_vis = C.mask_obs || C.vis_channel;
+        const map_t *const m = (const map_t *)(region + P.off_map);
+        const double *const vt = (const double *)(region + P.off_val);
+        const uint32_t *const ww = (const uint32_t *)(region + C.off_wall);
+        const int QR = (n + WQ - 1) / WQ;                                  // quads per row
+        const uint32_t qmagic = 0xFFFFFFFFu / (uint32_t)QR + 1u;           // ceil(2^32 / QR) (QR == 1: unused)
+        const int total = n_live * QR, blk = nchan * n;
+        float *const out = (float *)(type ? P.obs_prey : P.obs_pred) + (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;
+        for (int c0 = first * 64; c0 < total; c0 += stride * 64) {
+            const int g = c0 + ln;
+            const bool valid = g < total;
+            const uint32_t gs = valid ? (uint32_t)g : 0u;
+            const int i = QR == 1 ? (int)gs : (int)wv::mulhi(gs, qmagic);
+            int cell0 = ((int)gs - i * QR) * WQ;
+            cell0 = cell0 > n - WQ ? n - WQ : cell0;                       // the row's last quad overlaps its neighbour
+            const uint32_t en = list[i];
+            const int x = (int)((en >> 8) & 255u), y = (int)(en & 255u);
+            int ci = (int)wv::mulhi((uint32_t)cell0, rmagic), cj = cell0 - ci * R;
+            bool in_grid[WQ], inb[WQ];
+            int a[WQ], bi[WQ];
+            uint32_t wallw_[WQ], visw_[WQ], mb[WQ][3];
+#pragma unroll
+            for (int k = 0; k < WQ; ++k) {
+                const int gx = x - off + ci, gy = y - off + cj;
+                in_grid[k] = valid && (unsigned)gx < (unsigned)P.G && (unsigned)gy < (unsigned)P.G;
+                inb[k] = in_grid[k] && ci < Wc && cj < Wc;
+                a[k] = inb[k] ? gx * P.G + gy : 0;
+                const int am = COOP ? (inb[k] ? (gx + P.pad) * P.Gp + gy + P.pad : 0) : a[k];   // (COOP: padded maps)
+                wallw_[k] = ww[a[k] >> 5];
+                bi[k] = (ci - off + C.vis_neg) * C.vis_w + (cj - off + C.vis_neg);
+                visw_[k] = want_vis ? vm[i * C.vis_words + (bi[k] >> 5)] : 0u;
+#pragma unroll
+                for (int ch = 1; ch < 4; ++ch) mb[k][ch - 1] = (uint32_t)(m + (THREE ? ch - 1 : ch) * P.map_n)[am];
+                if (++cj == R) { cj = 0; ++ci; }
+            }
+            float f[5][WQ];
+#pragma unroll
+            for (int k = 0; k < WQ; ++k) {
+                f[0][k] = (inb[k] && ((wallw_[k] >> (a[k] & 31)) & 1u)) ? 1.0f : 0.0f;
+                const float vis = (want_vis && in_grid[k] && ((visw_[k] >> (bi[k] & 31)) & 1u)) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int ch = 1; ch < 4; ++ch) {
+                    const double tt = vt[from_map(ch, mb[k][ch - 1])];
+                    f[ch][k] = inb[k] ? (float)tt : 0.0f;
+                    if (C.mask_obs) f[ch][k] = f[ch][k] * (inb[k] ? vis : 0.0f);   // (in float32, like the reference: WO:591-594)
+                }
+                f[4][k] = vis;
+            }
+            if (valid) {
+                const uint32_t o0 = (uint32_t)((int)((en >> 16) & 0x7FFFu) * blk + cell0);
+#pragma unroll
+                for (int ch = 0; ch < 5; ++ch) {
+                    if (ch >= nchan) continue;
+                    fq_t v;
+#pragma unroll
+                    for (int k = 0; k < WQ; ++k) v[k] = f[ch][k];
+                    *(fq_t *)(out + o0 + (uint32_t)(ch * n)) = v;
+                }
+            }
+        }
+    }
     PPG_MEMBER void obs_cells_walls(int type, const uint32_t *list, int n_live, const uint32_t *vm, const unsigned char *region, int eb,
                                     int first, int stride) {
+        if (walls_quads(type)) { obs_quads_walls(type, list, n_live, vm, region, eb, first, stride); return; }
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
         const uint32_t rmagic = C.rp_magic + (type ? C.rq_magic - C.rp_magic : 0u);
         const uint32_t nmagic = C.np_magic + (type ? C.nq_magic - C.np_magic : 0u);
@@ -603,7 +691,7 @@
             const uint32_t *vm = (const uint32_t *)(region + C.off_vm);
             wv::sync();
             obs_cells_walls(0, lst + 1, n_pred, vm, region, b, w, stride);
-            const int chunks = (n_pred * P.Rp * P.Rp + 63) >> 6;
+            const int chunks = walls_chunks(0, n_pred);
             int first = (w - chunks) % stride;
             if (first < 0) first += stride;
             obs_cells_walls(1, lst + 1 + n_pred, n - n_pred, vm + 64 * C.vis_words, region, b, first, stride);
