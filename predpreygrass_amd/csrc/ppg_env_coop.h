@@ -14,7 +14,32 @@
     // elements per piece: 128 (two per lane); 256 for the second generation's float32 rows on the four-map layout (four per lane)
     static constexpr bool QUAD32 = PPG_COOP_QUAD32 && GEN2 && CH0MAP && COOP && !WALLS;
     PPG_MEMBER int piece_shift() const { return (QUAD32 && P.obs_f32 == 1) ? 8 : 7; }
-    PPG_MEMBER void coop_pieces(int type, const unsigned char *region, const uint32_t *list, int n_live, int eb, int first, int stride) {
+    // Who writes which piece: statically -- this wavefront writes pieces first, first + stride, ... (tk == nullptr: mid-step
+    // observations, the fused kernels) -- or through an LDS ticket word (DYN): a ticket is U consecutive pieces, and the next ticket is
+    // issued before the pieces in hand are produced, so its round trip hides behind them.
+    struct Turn {
+        uint32_t *tk; int stride, us; uint32_t pend;
+    };
+    PPG_MEMBER int turn_begin(Turn &t, uint32_t *tk, int first, int stride, int U) const {
+        t.tk = tk; t.stride = stride; t.us = stride; t.pend = 0;
+        if (DYN && tk) {
+            t.us = 1;
+            const uint32_t mine = wv::lds_take_issue(tk, (uint32_t)U);
+            t.pend = wv::lds_take_issue(tk, (uint32_t)U);
+            return (int)wv::lds_take_value(mine);
+        }
+        return first;
+    }
+    PPG_MEMBER int turn_next(Turn &t, int p0, int U) const {
+        if (DYN && t.tk) {
+            const int p = (int)wv::lds_take_value(t.pend);
+            t.pend = wv::lds_take_issue(t.tk, (uint32_t)U);
+            return p;
+        }
+        return p0 + U * t.stride;
+    }
+    PPG_MEMBER void coop_pieces(int type, const unsigned char *region, const uint32_t *list, int n_live, int eb, int first, int stride,
+                                uint32_t *tk = nullptr) {
         const map_t *m = (const map_t *)(region + P.off_map);
         const double *vt = (const double *)(region + P.off_val);
         const int blk = C.blk_p + (type ? C.blk_q - C.blk_p : 0);   // (arithmetic, not a select of fields: see window_sum)
@@ -40,12 +65,13 @@
             // The write phase is bound by the store INSTRUCTIONS the memory pipeline takes, not by bytes or lookups (round 6: window cells
             // with 4-byte stores and 40 % fewer LDS reads ran no faster, profiles/r06/v_*): half the instructions for the same rows.
             const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);
-            for (int p0 = first; p0 * 256 < total; p0 += U * stride) {
+            Turn t;
+            for (int p0 = turn_begin(t, tk, first, stride, U); p0 * 256 < total; p0 = turn_next(t, p0, U)) {
                 uint32_t o[U], ix[U][4];
                 bool on[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int s0 = (p0 + u * stride) * 256 + 4 * ln;
+                    const int s0 = (p0 + u * t.us) * 256 + 4 * ln;
                     on[u] = s0 < total;
                     const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
                     const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (blk = 4 R^2: a quad never straddles two rows)
@@ -69,12 +95,13 @@
         }
         if (CH0MAP) {   // four maps: every element is a map lookup
             const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
-            for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
+            Turn t;
+            for (int p0 = turn_begin(t, tk, first, stride, U); p0 * 128 < total; p0 = turn_next(t, p0, U)) {
                 uint32_t o[U], i0[U], i1[U];
                 bool on[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int s0 = (p0 + u * stride) * 128 + 2 * ln;
+                    const int s0 = (p0 + u * t.us) * 128 + 2 * ln;
                     on[u] = s0 < total;
                     const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
                     const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);   // (rows x block elements < 2^24)
@@ -97,12 +124,13 @@
             return;
         }
         const uint32_t G = (uint32_t)P.G;
-        for (int p0 = first; p0 * 128 < total; p0 += U * stride) {
+        Turn t;
+        for (int p0 = turn_begin(t, tk, first, stride, U); p0 * 128 < total; p0 = turn_next(t, p0, U)) {
             uint32_t o[U], i0[U], i1[U];
             bool on[U], out0[U], out1[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int s0 = (p0 + u * stride) * 128 + 2 * ln;
+                const int s0 = (p0 + u * t.us) * 128 + 2 * ln;
                 on[u] = s0 < total;
                 const uint32_t sc = on[u] ? (uint32_t)s0 : 0u;
                 const uint32_t i = wv::mulhi(sc, magic), w = sc - wv::mul24(i, (uint32_t)blk);
@@ -164,6 +192,42 @@
         }
         if (WALLS) walls_stage_masks();
         wv::sync();
+    }
+    // DYN, no workgroup barrier: the envs of the workgroup in the order in which their READY bits appear; the pieces (WALLS: chunks of
+    // window cells) of a ready env's two runs go to whichever wavefront asks next (tickets CTL_TICKET + 2 k + species).
+    PPG_MEMBER void coop_write_dynamic(unsigned char *wg_lds) {
+        const uint32_t all = (1u << C.coop_e) - 1u;
+        uint32_t done = 0;
+        while (done != all) {
+            const uint32_t rdy = wv::lds_poll(ctl + CTL_READY) & ~done;
+            if (!rdy) { wv::poll_sleep(); continue; }
+            const int k = wv::ctz((uint64_t)rdy);
+            done |= 1u << k;
+            const uint32_t *slot = ctl + CTL_SLOT + 4 * k;
+            const int eb = (int)wv::first(slot[2]);
+            if (eb < 0) continue;
+            unsigned char *region = wg_lds + (size_t)k * C.lds_env_bytes;
+            const uint32_t *lst = (const uint32_t *)(region + P.off_scr);
+            const bool flat = WALLS && walls_flat();
+#pragma unroll
+            for (int type = 0; type < 2; ++type) {
+                const int n_live = (int)wv::first(slot[type]);
+                uint32_t *tk = ctl + CTL_TICKET + 2 * k + type;
+                if (WALLS) {
+                    const uint32_t *vm = (const uint32_t *)(region + C.off_vm);
+                    if (flat) { obs_cells_walls(type, lst + (type ? 64 : 0), n_live, vm + (type ? 64 * C.vis_words : 0), region, eb, 0, 1, tk); continue; }
+                    // (no precomputed masks: whole rows, each walks its lines -- a ticket is one row)
+                    uint32_t pend = wv::lds_take_issue(tk, 1u);
+                    for (int i = (int)wv::lds_take_value(pend); i < n_live; i = (int)wv::lds_take_value(pend)) {
+                        pend = wv::lds_take_issue(tk, 1u);
+                        const uint32_t en = wv::first(lst[(type ? 64 : 0) + i]);
+                        obs_row_walls_in(type, (int)(en >> 16), en & 0xFFFFu, region, eb);
+                    }
+                    continue;
+                }
+                coop_pieces(type, region, lst + (type ? 64 : 0), n_live, eb, 0, 1, tk);
+            }
+        }
     }
     // after the workgroup barrier: all the workgroup's envs, piece p of the workgroup to wavefront p mod NW
     // WALLS (ppgc3_step): whole rows instead of pieces -- row i of the workgroup to wavefront i mod NW, each through obs_row_walls_in

@@ -270,7 +270,7 @@
         return (n_live * per_row + 63) >> 6;
     }
     PPG_MEMBER void obs_quads_walls(int type, const uint32_t *list, int n_live, const uint32_t *vm, const unsigned char *region, int eb,
-                                    int first, int stride) {
+                                    int first, int stride, uint32_t *tk = nullptr) {
         typedef float fq_t __attribute__((vector_size((WQ > 1 ? WQ : 2) * 4), aligned(4)));   // (4-byte aligned: rows of R*R cells start anywhere)
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
         const uint32_t rmagic = C.rp_magic + (type ? C.rq_magic - C.rp_magic : 0u);
@@ -284,8 +284,9 @@
         const uint32_t qmagic = 0xFFFFFFFFu / (uint32_t)QR + 1u;           // ceil(2^32 / QR) (QR == 1: unused)
         const int total = n_live * QR, blk = nchan * n;
         float *const out = (float *)(type ? P.obs_prey : P.obs_pred) + (size_t)eb * (size_t)(type ? P.cap_prey : P.cap_pred) * (size_t)blk;
-        for (int c0 = first * 64; c0 < total; c0 += stride * 64) {
-            const int g = c0 + ln;
+        Turn t;   // (chunks of 64 quads: handed out statically, or through the ticket word tk -- ppg_env_coop.h)
+        for (int p0 = turn_begin(t, tk, first, stride, 1); p0 * 64 < total; p0 = turn_next(t, p0, 1)) {
+            const int g = p0 * 64 + ln;
             const bool valid = g < total;
             const uint32_t gs = valid ? (uint32_t)g : 0u;
             const int i = QR == 1 ? (int)gs : (int)wv::mulhi(gs, qmagic);
@@ -338,8 +339,8 @@
         }
     }
     PPG_MEMBER void obs_cells_walls(int type, const uint32_t *list, int n_live, const uint32_t *vm, const unsigned char *region, int eb,
-                                    int first, int stride) {
-        if (walls_quads(type)) { obs_quads_walls(type, list, n_live, vm, region, eb, first, stride); return; }
+                                    int first, int stride, uint32_t *tk = nullptr) {
+        if (walls_quads(type)) { obs_quads_walls(type, list, n_live, vm, region, eb, first, stride, tk); return; }
         const int R = P.Rp + (type ? P.Rq - P.Rp : 0);
         const uint32_t rmagic = C.rp_magic + (type ? C.rq_magic - C.rp_magic : 0u);
         const uint32_t nmagic = C.np_magic + (type ? C.nq_magic - C.np_magic : 0u);
@@ -356,16 +357,18 @@
         constexpr bool F32 = decltype(f32_tag)::value;
         // chunks in flight per wavefront: the dependent LDS reads of one (list entry -> map bytes -> values) hide behind the other's
         constexpr int U = 2;
-        for (int c0 = first * 64; c0 < total; c0 += U * stride * 64) {
+        Turn t;
+        for (int p0 = turn_begin(t, tk, first, stride, U); p0 * 64 < total; p0 = turn_next(t, p0, U)) {
             bool valid[U], in_grid[U], inb[U];
             int cell[U], i[U], ci[U], cj[U];
             uint32_t en[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int g = c0 + u * stride * 64 + ln;
+                const int g = (p0 + u * t.us) * 64 + ln;
                 valid[u] = g < total;
                 const uint32_t gs = valid[u] ? (uint32_t)g : 0u;
-                i[u] = (int)wv::mulhi(gs, nmagic); cell[u] = (int)gs - i[u] * n;
+                i[u] = n == 1 ? (int)gs : (int)wv::mulhi(gs, nmagic);   // (a 1x1 window: ceil(2^32 / 1) does not fit the magic word)
+                cell[u] = (int)gs - i[u] * n;
                 en[u] = list[i[u]];
                 ci[u] = (int)wv::mulhi((uint32_t)cell[u], rmagic); cj[u] = cell[u] - ci[u] * R;
             }

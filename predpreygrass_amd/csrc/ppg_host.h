@@ -383,7 +383,7 @@ static bool ppg_coop_layout_with(ppg_handle *h, int ch0_map, ppg::KParams &P, st
 // bytes of the workgroup's descriptor table (the walls variant writes whole rows through obs_row_walls_in: none)
 static int ppg_coop_table_bytes(const ppg::KParams &P) { return P.walls ? 0 : ((P.blk_p + P.blk_q) * 4 + 15) / 16 * 16; }
 static int ppg_coop_lds_bytes_of(const ppg::KParams &P, int e) {
-    return e * P.lds_env_bytes + ppg_coop_table_bytes(P) + 80 * 4;   // env regions, descriptor table, Env::CTL_WORDS
+    return e * P.lds_env_bytes + ppg_coop_table_bytes(P) + 128 * 4;   // env regions, descriptor table, Env::CTL_WORDS
 }
 // Cooperative step kernels (Env's COOP): eligibility and LDS layout of one env's region.  The maps are padded by the larger
 // window's reach, so the map offsets of an observation block's elements are position-independent.  Four maps (channel 0's halo points

@@ -340,7 +340,17 @@ struct Env {
     uint32_t *ctl = nullptr;
     // control words: per env slot k of the workgroup CTL_SLOT + 4k: live predator rows, live prey rows, env index (-1 = no env);
     // per wavefront w CTL_MID + w: the (row, cell) entry of a mid-step observation
-    enum { CTL_SLOT = 0, CTL_MID = 64, CTL_WORDS = 80 };
+    // CTL_READY: bit k = env slot k's transition is over, its rows are published; CTL_TICKET + 2k + species: the next piece of that
+    // run nobody has taken yet (DYN)
+    enum { CTL_SLOT = 0, CTL_MID = 64, CTL_READY = 80, CTL_TICKET = 84, CTL_WORDS = 128 };
+    // DYN: the shared write phase without a workgroup barrier.  A wavefront whose transition is over sets its env's READY bit and
+    // every wavefront of the workgroup takes pieces of the envs that are ready through LDS tickets: while one of the workgroup's
+    // transitions is still running, the other env's observations are already being written by the three wavefronts that are free
+    // (behind a barrier they waited -- 5-7 % of a wavefront's cycles on average, far more in the slow tail).
+#ifndef PPG_COOP_DYNAMIC
+#define PPG_COOP_DYNAMIC 1
+#endif
+    static constexpr bool DYN = PPG_COOP_DYNAMIC && COOP && !FUSED;
 
     // per-lane row fields
     uint32_t xy[T];
@@ -599,6 +609,10 @@ PPG_DEVICE void coop_main(const KParams &P, unsigned char *lds) {
     env.ctl = ctl;
     // (every wavefront that steps an env writes the whole descriptor table, identical words: it may need it for a mid-step
     // observation long before the workgroup's barrier; a workgroup always has at least one env)
+    if (CoopEnv::DYN) {   // READY bits and tickets start at zero (all wavefronts are still here: this barrier costs nothing)
+        if (w == NW - 1 && ln < CoopEnv::CTL_WORDS - CoopEnv::CTL_READY) ctl[CoopEnv::CTL_READY + ln] = 0u;
+        wv::wg_barrier_lds();
+    }
     if (has_env) env.run_step();
     else if (w < ne && ln == 0) ctl[CoopEnv::CTL_SLOT + 4 * w + 2] = 0xFFFFFFFFu;   // an env slot beyond the batch
 #ifdef PPG_PROFILE_PHASES
@@ -607,9 +621,15 @@ PPG_DEVICE void coop_main(const KParams &P, unsigned char *lds) {
 #else
 #define PPG_COOP_STAMP(i) do { } while (0)
 #endif
-    wv::wg_barrier_lds();   // (LDS only: the table stores of this wave need not have reached memory)
-    PPG_COOP_STAMP(13);
-    env.coop_write_all(lds);
+    if (CoopEnv::DYN) {
+        if (w < ne) wv::lds_or(ctl + CoopEnv::CTL_READY, 1u << w);
+        PPG_COOP_STAMP(13);
+        env.coop_write_dynamic(lds);
+    } else {
+        wv::wg_barrier_lds();   // (LDS only: the table stores of this wave need not have reached memory)
+        PPG_COOP_STAMP(13);
+        env.coop_write_all(lds);
+    }
     PPG_COOP_STAMP(14);
     if (has_env) env.finish_stores();
 }

@@ -87,6 +87,29 @@ PPG_DEVICE void lds_count(uint16_t *p) {
     __hip_atomic_fetch_add((uint32_t *)((unsigned char *)p - low), 1u << (8u * low), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// ---- hand-over between the wavefronts of ONE workgroup through LDS words (the cooperative kernels' dynamic write phase) ----
+// Fetch-add on an LDS word for the whole wavefront: lane 0 adds (ds_add_rtn_u32), lds_take_value() hands its old value to every lane.
+// Two calls so that the round trip of the NEXT ticket hides behind the work on the ticket in hand.
+PPG_DEVICE uint32_t lds_take_issue(uint32_t *p, uint32_t n) {
+    uint32_t old = 0;
+    if (lane() == 0) old = __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return old;
+}
+PPG_DEVICE uint32_t lds_take_value(uint32_t issued) { return readlane(issued, 0); }
+// set bits of an LDS word AFTER everything this wavefront wrote to LDS before (DS instructions of a wave execute in issue order; the
+// s_waitcnt only keeps the compiler and the counters honest)
+PPG_DEVICE void lds_or(uint32_t *p, uint32_t bits) {
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane() == 0) __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// an LDS word another wavefront may set, as a scalar; LDS reads behind it are not moved in front of it
+PPG_DEVICE uint32_t lds_poll(const uint32_t *p) {
+    const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __asm__ volatile("" ::: "memory");
+    return first(v);
+}
+PPG_DEVICE void poll_sleep() { __builtin_amdgcn_s_sleep(8); }
+
 // all of this wave's outstanding global loads have returned (used before overwriting memory other lanes just read)
 PPG_DEVICE void drain_loads() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -233,6 +233,13 @@ inline void sync() { (void)exchange(0); }
 // (lanes are fibers that only switch at collectives: a plain increment is atomic here)
 inline void lds_count(uint8_t *p) { *p = (uint8_t)(*p + 1); }
 inline void lds_count(uint16_t *p) { *p = (uint16_t)(*p + 1); }
+// hand-over between the wavefronts of a workgroup through LDS words.  Lanes run one after another here, so lane 0's read-modify-write
+// is atomic; the collectives make the result wave-uniform and let the other wavefronts run while this one polls.
+inline uint32_t lds_take_issue(uint32_t *p, uint32_t n) { uint32_t old = 0; if (lane() == 0) { old = *p; *p = old + n; } return old; }
+inline uint32_t lds_take_value(uint32_t issued) { return readlane(issued, 0); }
+inline void lds_or(uint32_t *p, uint32_t bits) { (void)exchange(0); if (lane() == 0) *p |= bits; }   // (every lane's LDS writes first)
+inline uint32_t lds_poll(const uint32_t *p) { return readlane(*(const volatile uint32_t *)p, 0); }
+inline void poll_sleep() { }
 inline void drain_loads() { (void)exchange(0); }  // lanes run one after another here: a collective orders reads before writes
 inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline uint32_t mul24(uint32_t a, uint32_t b) {
