@@ -17,23 +17,34 @@
     // Who writes which piece: statically -- this wavefront writes pieces first, first + stride, ... (tk == nullptr: mid-step
     // observations, the fused kernels) -- or through an LDS ticket word (DYN): a ticket is U consecutive pieces, and the next ticket is
     // issued before the pieces in hand are produced, so its round trip hides behind them.
+#ifndef PPG_COOP_TICKET_GROUPS
+#define PPG_COOP_TICKET_GROUPS 4
+#endif
+    // a ticket of the piece writer is TG groups of U consecutive pieces (one LDS round trip per 1-2 K elements: second generation
+    // +1.5-2 %, 64x64 grids +1.2 % against one group per ticket, headline equal; the walls variant's chunks of 256 window cells are
+    // large enough as they are -- there larger tickets cost 2 % of balance: profiles/r06/y_*)
+    static constexpr int TG = PPG_COOP_TICKET_GROUPS;
     struct Turn {
-        uint32_t *tk; int stride, us; uint32_t pend;
+        uint32_t *tk; int stride, us, end, take; uint32_t pend;
     };
-    PPG_MEMBER int turn_begin(Turn &t, uint32_t *tk, int first, int stride, int U) const {
-        t.tk = tk; t.stride = stride; t.us = stride; t.pend = 0;
+    PPG_MEMBER int turn_begin(Turn &t, uint32_t *tk, int first, int stride, int U, int groups = 1) const {
+        t.tk = tk; t.stride = stride; t.us = stride; t.pend = 0; t.end = 0; t.take = U * groups;
         if (DYN && tk) {
             t.us = 1;
-            const uint32_t mine = wv::lds_take_issue(tk, (uint32_t)U);
-            t.pend = wv::lds_take_issue(tk, (uint32_t)U);
-            return (int)wv::lds_take_value(mine);
+            const uint32_t mine = wv::lds_take_issue(tk, (uint32_t)t.take);
+            t.pend = wv::lds_take_issue(tk, (uint32_t)t.take);
+            const int p = (int)wv::lds_take_value(mine);
+            t.end = p + t.take;
+            return p;
         }
         return first;
     }
     PPG_MEMBER int turn_next(Turn &t, int p0, int U) const {
         if (DYN && t.tk) {
+            if (p0 + U < t.end) return p0 + U;
             const int p = (int)wv::lds_take_value(t.pend);
-            t.pend = wv::lds_take_issue(t.tk, (uint32_t)U);
+            t.pend = wv::lds_take_issue(t.tk, (uint32_t)t.take);
+            t.end = p + t.take;
             return p;
         }
         return p0 + U * t.stride;
@@ -66,7 +77,7 @@
             // with 4-byte stores and 40 % fewer LDS reads ran no faster, profiles/r06/v_*): half the instructions for the same rows.
             const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);
             Turn t;
-            for (int p0 = turn_begin(t, tk, first, stride, U); p0 * 256 < total; p0 = turn_next(t, p0, U)) {
+            for (int p0 = turn_begin(t, tk, first, stride, U, TG); p0 * 256 < total; p0 = turn_next(t, p0, U)) {
                 uint32_t o[U], ix[U][4];
                 bool on[U];
 #pragma unroll
@@ -96,7 +107,7 @@
         if (CH0MAP) {   // four maps: every element is a map lookup
             const uint32_t safe_cell = (uint32_t)(P.pad * P.Gp + P.pad);   // lanes behind the end of the run look at cell (0,0): inside the maps
             Turn t;
-            for (int p0 = turn_begin(t, tk, first, stride, U); p0 * 128 < total; p0 = turn_next(t, p0, U)) {
+            for (int p0 = turn_begin(t, tk, first, stride, U, TG); p0 * 128 < total; p0 = turn_next(t, p0, U)) {
                 uint32_t o[U], i0[U], i1[U];
                 bool on[U];
 #pragma unroll
@@ -125,7 +136,7 @@
         }
         const uint32_t G = (uint32_t)P.G;
         Turn t;
-        for (int p0 = turn_begin(t, tk, first, stride, U); p0 * 128 < total; p0 = turn_next(t, p0, U)) {
+        for (int p0 = turn_begin(t, tk, first, stride, U, TG); p0 * 128 < total; p0 = turn_next(t, p0, U)) {
             uint32_t o[U], i0[U], i1[U];
             bool on[U], out0[U], out1[U];
 #pragma unroll

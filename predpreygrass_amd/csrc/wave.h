@@ -108,7 +108,10 @@ PPG_DEVICE uint32_t lds_poll(const uint32_t *p) {
     __asm__ volatile("" ::: "memory");
     return first(v);
 }
-PPG_DEVICE void poll_sleep() { __builtin_amdgcn_s_sleep(8); }
+#ifndef PPG_COOP_POLL_SLEEP
+#define PPG_COOP_POLL_SLEEP 8
+#endif
+PPG_DEVICE void poll_sleep() { __builtin_amdgcn_s_sleep(PPG_COOP_POLL_SLEEP); }
 
 // all of this wave's outstanding global loads have returned (used before overwriting memory other lanes just read)
 PPG_DEVICE void drain_loads() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
