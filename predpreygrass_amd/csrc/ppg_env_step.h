@@ -1,9 +1,10 @@
 // ppg_env_step.h -- part of struct ppg::Env (ppg_kernel.h includes it INSIDE the struct's body: member functions, no include guard,
 // not a header of its own): rewards + table stores (BASE:288-411), the device reset (BASE:129-217), the transition's phase order (step_body) and the kernel modes' entry points.
     // ---- rewards, cumulative rewards (BASE:288,322-323,328-329,341-344,365-366,375-378,408-411) ----
-    // COOP: the table stores come AFTER the shared observation writing (coop_main calls finish_stores()).  Under a saturated store
-    // pipe the ~25 store instructions of the tables take 9 k cycles to issue; in front of the workgroup barrier that is 9 k cycles in
-    // which the helper waves cannot start writing (interleaved A/B of two builds: 66.4 -> 65.1 us per 4096-env step).
+    // COOP: the table stores are issued by coop_main (finish_stores()), not here.  Under a saturated store pipe the ~25 store
+    // instructions of the tables take 9 k cycles to issue; in front of a workgroup barrier that was 9 k cycles in which the helper
+    // waves could not start writing (66.4 -> 65.1 us per 4096-env step when they moved behind the writing).  Without the barrier
+    // (Env::DYN) they go right behind the READY bit; the fused rollout kernels keep them behind the writing.
     bool pend = false, pend_grass = false, pend_transition = false, pend_done = false;
     PPG_MEMBER void finish_stores() {
         if (pend) { pend = false; rewards_and_store(pend_grass, pend_transition); }
